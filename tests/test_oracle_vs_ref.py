@@ -1,0 +1,116 @@
+"""Pins oracle/ngp_oracle.c (plain-C restatement) against oracle/_ref (the reference's OWN kernel headers compiled for
+the host).  Runs wherever oracle/_ref/*.so exists (this container; the files also travel to the GPU box)."""
+import numpy as np
+import pytest
+from oracle import oracle as O, ref as R
+import synth
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+def test_pcg32_stream():
+    a, b = O.PCG32(1337), R.PCG32(1337)
+    assert [a.next_uint() for _ in range(64)] == [b.next_uint() for _ in range(64)]
+    a.advance(8 * 1234567); b.advance(8 * 1234567)
+    assert a.next_float() == b.next_float()
+    a.advance(); b.advance()
+    assert (a.st == b.st).all()
+
+
+@pytest.mark.parametrize("aabb_scale", [1, 4])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_hash_encode(aabb_scale, dtype):
+    table, offsets, n_params = O.level_table(aabb_scale)
+    rng = np.random.default_rng(0)
+    n = 2048
+    x = synth.uniform_positions(n)
+    x[:8] = [[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0.5, 0.5, 0.5], [0.999999, 0.3, 0.7], [1e-7, 1, 0], [0.25, 0.75, 1], [1, 1, 0]]
+    grid = rng.uniform(-1, 1, n_params).astype(dtype)
+    a = O.hash_encode_fwd(x, grid, table)
+    b = R.hash_fwd(x, grid, offsets, aabb_scale)
+    # same indices, same weights => identical up to the 1-ulp freedom of exp2f in the per-level scale
+    assert np.allclose(a.astype(np.float32), b.astype(np.float32), rtol=0, atol=2e-3 if dtype == np.float16 else 2e-5)
+    assert (a == b).mean() > 0.98
+    dy = (rng.normal(size=(n, 32)) * 1e-2).astype(dtype)
+    ga = O.hash_encode_bwd(x, dy, table, n_params)
+    gb = R.hash_bwd(x, dy, offsets, aabb_scale, n_params)
+    assert ((ga != 0) == (gb != 0)).mean() > 0.9999
+    assert np.allclose(ga.astype(np.float32), gb.astype(np.float32), rtol=0, atol=2e-3 if dtype == np.float16 else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_sh(dtype):
+    d = synth.unit_dirs01(4096)
+    assert (O.sh_encode(d, dtype) == R.sh(d, dtype)).all()
+
+
+@pytest.mark.parametrize("const_dt,aabb", [(True, (0.0, 1.0)), (False, (-1.5, 2.5)), (False, (0.0, 1.0))])
+def test_march_compact_composite(const_dt, aabb):
+    xf, focal, meta = synth.camera_ring(8, radius=1.3)
+    img, o, d, _ = synth.rays_from_cameras(xf, focal, meta, 64, 48, 512)
+    d[0] = [0, 0, 1]; o[0] = [0.5, 0.5, -1.0]          # axis-aligned ray (inf idir components)
+    o[1] = [5, 5, 5]; d[1] = [1, 0, 0]                  # misses the box
+    bits = synth.shell_bitfield()
+    cap = 512 * 1024
+    ra, rb = O.PCG32(1337), R.PCG32(1337)
+    ca, na, cnta, ia = O.march_rays(o, d, bits, aabb, ra, cap, const_dt=const_dt)
+    cb, nb, cntb, ib = R.march(o, d, bits, aabb, rb.st, cap, meta, img, xf, const_dt=const_dt)
+    assert (ra.st == rb.st).all()
+    assert (na == nb).all() and (cnta == cntb).all() and (ia == ib).all()
+    assert cnta[1] > 1000
+    assert (ca == cb).all()                              # bit-exact records
+    # overflow behaviour: capacity smaller than the demand
+    small = int(cnta[1]) // 2
+    ca2, na2, cnt2, _ = O.march_rays(o, d, bits, aabb, O.PCG32(1337), small, const_dt=const_dt)
+    cb2, nb2, cntb2, _ = R.march(o, d, bits, aabb, R.PCG32(1337).st, small, meta, img, xf, const_dt=const_dt)
+    assert (na2 == nb2).all() and (ca2 == cb2).all() and (cnt2 == cntb2).all() and (na2[:, 0] == 0).any()
+    # compaction
+    M = int(cnta[1])
+    rng = np.random.default_rng(5)
+    for dtype in (np.float32, np.float16):
+        net = rng.normal(size=(M, 4)).astype(dtype)
+        for ccap in (M + 100, M // 3):
+            xa = O.compact_coords(ca[:M], na, ccap)
+            xb = R.compact(net, cb[:M], nb, ccap, aabb)
+            for u, v in zip(xa, xb):
+                assert (u == v).all()
+        cc, nc, _ = O.compact_coords(ca[:M], na, M // 3)
+        netc = rng.normal(size=(M // 3, 4)).astype(dtype)
+        bg = rng.random((512, 3), dtype=np.float32)
+        fa = O.composite_fwd(netc, cc, na, nc, bg)
+        fb = R.rgb_fwd(netc, cc, na, nc, bg, aabb)
+        assert np.array_equal(fa, fb)
+        G = rng.normal(size=(512, 3)).astype(np.float32)
+        for mean in (0.001, 0.5):
+            da = O.composite_bwd(netc, cc, nc, G, fa, mean)
+            db = R.rgb_bwd(netc, cc, nc, G, fb, mean, aabb)
+            assert np.array_equal(da, db)
+        ia_, aa = O.composite_inference(net, ca[:M], na)
+        ib_, ab = R.rgb_inference(net, cb[:M], nb, aabb)
+        assert np.array_equal(ia_, ib_) and np.array_equal(aa, ab)
+
+
+def test_density_grid_ops():
+    xf, focal, meta = synth.camera_ring(6, radius=1.1)
+    n_el = 5 * 128 ** 3
+    ga = O.grid_mark_untrained(n_el, focal, xf, 64, 48)
+    gb = R.grid_mark(n_el, focal, xf, 64, 48)
+    assert np.array_equal(ga, gb) and (ga < 0).any() and (ga == 0).any()
+    rng = np.random.default_rng(7)
+    grid = np.where(ga < 0, ga, rng.random(n_el, dtype=np.float32) * 0.05).astype(np.float32)
+    for n_casc, thresh, step in ((1, -0.01, 0), (3, 0.01, 7)):
+        ra, rb = O.PCG32(1337), R.PCG32(1337)
+        pa, ia = O.grid_generate_samples(100000, ra, step, (-1.5, 2.5), grid, n_casc, thresh)
+        pb, ib = R.grid_gen(100000, rb.st, step, (-1.5, 2.5), grid, n_casc, thresh)
+        assert np.array_equal(pa, pb) and np.array_equal(ia, ib) and (ra.st == rb.st).all()
+    for dtype in (np.float32, np.float16):
+        mlp = (rng.normal(size=100000) * 3).astype(dtype)
+        ta = O.grid_splat_max(ia, mlp, np.zeros(n_el, np.float32))
+        tb = R.grid_splat(ib, mlp, np.zeros(n_el, np.float32))
+        assert np.array_equal(ta, tb)
+    ea = O.grid_ema(grid.copy(), ta)
+    eb = R.grid_ema(grid.copy(), tb)
+    assert np.array_equal(ea, eb)
+    ba, ma = O.grid_update_bitfield(ea)
+    bb, mb = R.grid_bitfield(eb)
+    assert ma[0] == mb[0] and np.array_equal(ba, bb) and ba.any()
