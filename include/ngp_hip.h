@@ -1,0 +1,123 @@
+/*
+ * ngp_hip.h — C ABI of libngp_hip.so: the MI355X (gfx950) Instant-NGP hot path for JNeRF.
+ *
+ * One entry point per `jt.code(...)` site of the reference's hot path plus the
+ * fused variants the MI355X design adds.  Conventions (mirroring the reference's operator interface,
+ * SURVEY.md §8b "Ownership / Errors / Threading"):
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (PyTorch-ROCm allocator here,
+ *     Jittor's allocator in the reference) unless the name ends in `_host`;
+ *   - nothing is allocated or freed inside; scratch is passed in by the caller;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it, no call synchronises;
+ *   - return value: 0 = launched, <0 = argument error (NGP_E_*), >0 = hipError_t from the launch;
+ *     ngp_last_error() gives a message for the calling thread;
+ *   - `dtype` is the table / network-output element type T of the reference (`grad_t`): NGP_F32 or NGP_F16;
+ *   - capacity overflow keeps the reference's silent-saturation semantics (ray_sampler.h:74-80,
+ *     compacted_coord.h:63) — it is never an error.
+ * File:line citations are relative to /root/reference/python/jnerf/.
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGP_ABI_VERSION 1
+enum { NGP_F32 = 0, NGP_F16 = 1 };
+enum { NGP_E_ARG = -1, NGP_E_DTYPE = -2, NGP_E_ALIGN = -3, NGP_E_CAPACITY = -4 };
+/* feature-tensor layouts between the encoder and the MLP */
+enum { NGP_LAYOUT_AOS = 0 /* [n,32] as HashEncoder returns it */, NGP_LAYOUT_SOA = 1 /* [16][n] pairs, level-major */ };
+
+int ngp_abi_version(void);
+const char *ngp_last_error(void);
+/* device query used by bench.py: fills {CU count, max clock kHz, L2 bytes, total global MiB}; returns 0 */
+int ngp_device_info(int device, int64_t *out4_host);
+/* self-test of the MFMA fragment-layout assumptions the fused MLP relies on (A=I with asymmetric B); result u32[4] device, [0]==0 ok */
+int ngp_selftest_mfma(void *stream, uint32_t *result);
+
+/* ---- hash grid ------------------------------------------------------------------------------------------------
+ * level_table_host: u32[16][4] = {offset (entries), size (entries), resolution, scale (f32 bits)} per level, built by the host
+ * exactly as position_encoders/hash_encoder/grid_encode.py:17-40 + op_header/HashEncode.h:149-151 prescribe. */
+/* replaces GridEncode.execute (grid_encode.py:71-125: extract_position + kernel_grid + transpose_encoded_position) */
+int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *table,
+                        const uint32_t *level_table_host, void *out, int dtype, int out_layout, const uint32_t *n_valid /*device u32 or NULL*/);
+/* replaces GridEncode.grad (grid_encode.py:137-184: memset + transpose_gradients + kernel_grid_backward).
+ * grad_dtype may be NGP_F32 with dtype NGP_F16 (fp32 accumulation of fp16 gradients). zero_first!=0 clears `grad` (n_params elements). */
+int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, const uint32_t *level_table_host,
+                        void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid);
+
+/* ---- direction encoding: replaces SHEncoder.execute (position_encoders/sh_encoder/sh_encoder.py:29-51, SphericalEncode.h:45-95) */
+int ngp_sh_encode(void *stream, uint32_t n, const float *dir, uint32_t dir_stride_floats, void *out /*[n,16]*/, int dtype);
+
+/* ---- field network -------------------------------------------------------------------------------------------------
+ * Both MLPs of NGPNetworks.execute_ (models/networks/ngp_network.py:77-84) in one fp16-MFMA kernel, weights resident in LDS:
+ * replaces mlp_fused_forward_func x2 (ops/code_ops/fully_fused_mlp.py:52-86) + SHEncoder + the three concats.
+ * wd: f16[3072] = W0[64x32] W1[16x64];  wc: f16[7168] = V0[64x32] V1[64x64] V2[16x64]  — the FMLP pack (ngp_network.py:21-29).
+ * feat: f16 features in `feat_layout`; dir: f32 warped directions; out: [n,4] T = (r,g,b logits, log-density). */
+int ngp_field_fwd(void *stream, uint32_t n, const void *feat, int feat_layout, const float *dir, uint32_t dir_stride_floats,
+                  const void *wd, const void *wc, void *out, int out_dtype, const uint32_t *n_valid);
+/* NGPNetworks.density (ngp_network.py:86-89): density MLP only, out [n] T (column 0) */
+int ngp_density_fwd(void *stream, uint32_t n, const void *feat, int feat_layout, const void *wd, void *out, int out_dtype);
+/* replaces mlp_fused_backward_func x2 + the 5 cublas_acc_matmul wgrads (fully_fused_mlp.py:93-145): forward is recomputed in-kernel.
+ * dLdout [n,4] T -> dLdfeat f16 (feat_layout) ; weight-gradient partial slabs f32[n_slabs][10240] (wd part first), reduced by ngp_reduce_slabs. */
+int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int feat_layout, const float *dir, uint32_t dir_stride_floats,
+                  const void *wd, const void *wc, const void *dLdout, int out_dtype, void *dLdfeat, float *wgrad_slabs, uint32_t n_slabs,
+                  const uint32_t *n_valid);
+int ngp_field_bwd_slabs(uint32_t n);                       /* number of slabs ngp_field_bwd writes for capacity n */
+int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out /*[width]*/);
+
+/* ---- sampler ------------------------------------------------------------------------------------------------------
+ * rng_state_host: u64[2] = {state, inc} of the reference's global pcg32{1337} (ops/code_ops/global_vars.py:13-16); it is advanced
+ * by 2^32 on return exactly like `rng.advance()` at ray_sampler.py:61.  cascades = NERF_CASCADES (5), const_dt per cfg.const_dt. */
+/* replaces RaySampler.execute (samplers/density_grid_sampler/ray_sampler.py:34-62, op_header/ray_sampler.h:4-114). Deterministic: slots are
+ * reserved in ray order (what the reference's atomicAdd gives under a serial launch). counters: u32[2] = {rays with a slot, steps reserved}.
+ * scratch: u32[n_rays + 1024]. coords [max_samples,7] is zero-filled first when zero_coords!=0 (ray_sampler.py:50). */
+int ngp_march_rays(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
+                   float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
+                   float *coords, uint32_t *numsteps /*[n,2]*/, uint32_t *counters, int32_t *ray_indices, uint32_t *scratch, int zero_coords);
+/* replaces CompactedCoord.execute (compacted_coord.py:39-64, op_header/compacted_coord.h:4-76); counter u32[1]; scratch u32[n_rays+1024] */
+int ngp_compact_coords(void *stream, uint32_t n_rays, uint32_t cap, const float *coords_in, const uint32_t *numsteps_in, float *coords_out,
+                       uint32_t *numsteps_out, uint32_t *counter, uint32_t *scratch);
+/* MI355X training path: march + compaction in one pass (the reference's dead forward pass is dropped, SURVEY.md App.B-1).
+ * Result == ngp_compact_coords(ngp_march_rays(...)) for the same inputs; rows >= min(total,cap) of coords_out are NOT touched
+ * (consumers take counters[2] as n_valid). counters: u32[4] = {rays, steps reserved, compacted steps (unclamped), min(steps,cap)}. */
+int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
+                             float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
+                             uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch);
+
+/* replaces CalcRgb.execute / .grad / .inference (calc_rgb.py:45-68, 78-104, 120-144; op_header/calc_rgb.h) */
+int ngp_composite_fwd(void *stream, uint32_t n_rays, const void *net_out, int dtype, const float *coords, const uint32_t *numsteps,
+                      const uint32_t *numsteps_compacted, const float *bg /*[n,3]*/, int cascades, float *rgb_out);
+int ngp_composite_bwd(void *stream, uint32_t n_rays, uint32_t n_elems, const void *net_out, int dtype, const float *coords,
+                      const uint32_t *numsteps_compacted, const float *loss_grad, const float *rgb_ray, const float *density_grid_mean,
+                      int cascades, void *dLdout, int zero_first);
+int ngp_composite_inference(void *stream, uint32_t n_rays, const void *net_out, int dtype, const float *coords, const uint32_t *numsteps,
+                            int cascades, float *rgb_out, float *alpha_out);
+/* HuberLoss (models/losses/huber_loss.py:6-14) value [n] and its elementwise derivative (= autograd of the summed loss) */
+int ngp_huber(void *stream, uint32_t n, const float *x, const float *target, float delta, float *loss, float *grad);
+
+/* ---- density grid (every update_den_freq steps; density_grid_sampler.py:204-264) --------------------------------------------- */
+int ngp_grid_mark_untrained(void *stream, uint32_t n_elements, float *grid, uint32_t n_images, const float *focal /*[n,2]*/,
+                            const float *xforms /*[n,4,3]*/, int W, int H);
+int ngp_grid_generate_samples(void *stream, uint32_t n, uint64_t *rng_state_host, const uint32_t *ema_step /*device*/, float aabb0, float aabb1,
+                              const float *grid, float *positions /*[n,3]*/, uint32_t *indices, uint32_t n_cascades, float thresh);
+int ngp_grid_splat_max(void *stream, uint32_t n, const uint32_t *indices, const void *density /*[n] T*/, int dtype, float *grid_tmp);
+int ngp_grid_ema(void *stream, uint32_t n_elements, float decay, float *grid, const float *grid_tmp);
+/* mean over cascade 0 -> mean[0]; grid_to_bitfield; 4x bitfield_max_pool (update_bitfield.py:15-37) */
+int ngp_grid_update_bitfield(void *stream, const float *grid, int cascades, float *mean /*[1]*/, uint8_t *bitfield);
+
+/* ---- optimiser: Adam (optims/adam.py + Jittor nn.Adam) -> ExpDecay lr (host) -> EMA.ema_step (optims/ema.py:26-37), one sweep.
+ * p/m/v/ema are fp32 masters; p_half (may be NULL) receives the fp16 copy the kernels gather from; g is fp32 or fp16 (g_dtype) and is
+ * zeroed for the next step when zero_grad!=0.  step is 1-based.  ema may be NULL (no EMA). */
+int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
+                      float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad);
+
+/* ---- ray generation (dataset/dataset.py:172-188) + target compositing (runner/runner.py:66-68) ------------------------------- */
+int ngp_generate_rays(void *stream, uint32_t n, const int64_t *pixel_index, int W, int H, const float *focal, const float *metadata /*[n_img,11]*/,
+                      const float *xforms, const float *images /*[n_img*H*W,4] or NULL*/, const float *bg /*[n,3] or NULL*/,
+                      int32_t *img_id, float *rays_o, float *rays_d, float *target /*[n,3] or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+"""ctypes binding of jnerf_amd/csrc/libngp_hip.so (C ABI: include/ngp_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.  The product path never
+touches oracle/ (CPU) code."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libngp_hip.so")
+_lib = None
+
+F32, F16 = 0, 1
+LAYOUT_AOS, LAYOUT_SOA = 0, 1
+
+_vp, _u32, _u64, _i32, _f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
+SIGNATURES = {
+    "ngp_abi_version": (C.c_int, []),
+    "ngp_last_error": (C.c_char_p, []),
+    "ngp_device_info": (C.c_int, [_i32, _vp]),
+    "ngp_selftest_mfma": (C.c_int, [_vp, _vp]),
+    "ngp_hash_encode_fwd": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "ngp_hash_encode_bwd": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp]),
+    "ngp_sh_encode": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _i32]),
+    "ngp_field_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
+    "ngp_density_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _i32]),
+    "ngp_field_bwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _u32, _vp, _vp, _vp, _i32, _vp, _vp, _u32, _vp]),
+    "ngp_field_bwd_slabs": (C.c_int, [_u32]),
+    "ngp_reduce_slabs": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
+    "ngp_march_rays": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _i32]),
+    "ngp_compact_coords": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngp_march_rays_compacted": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "ngp_composite_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ngp_composite_bwd": (C.c_int, [_vp, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),
+    "ngp_composite_inference": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "ngp_huber": (C.c_int, [_vp, _u32, _vp, _vp, _f32, _vp, _vp]),
+    "ngp_grid_mark_untrained": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _i32, _i32]),
+    "ngp_grid_generate_samples": (C.c_int, [_vp, _u32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _u32, _f32]),
+    "ngp_grid_splat_max": (C.c_int, [_vp, _u32, _vp, _vp, _i32, _vp]),
+    "ngp_grid_ema": (C.c_int, [_vp, _u32, _f32, _vp, _vp]),
+    "ngp_grid_update_bitfield": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "ngp_adam_ema_step": (C.c_int, [_vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _f32, _i32]),
+    "ngp_generate_rays": (C.c_int, [_vp, _u32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+def build():
+    """Compile every HIP source for gfx950 into csrc/libngp_hip.so (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["bash", os.path.join(_HERE, "csrc", "build.sh")])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)       # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if _lib.ngp_abi_version() != 1:
+            raise RuntimeError("libngp_hip.so ABI version mismatch")
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"libngp_hip {what} failed (rc={rc}): {lib().ngp_last_error().decode()}")

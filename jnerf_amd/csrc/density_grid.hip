@@ -1,0 +1,150 @@
+// Occupancy-grid maintenance (every update_den_freq = 16 training steps).
+// Reference: samplers/density_grid_sampler/op_header/{mark_untrained_density_grid.h:3-47, generate_grid_samples_nerf_nonuniform.h:3-35,
+// splat_grid_samples_nerf_max_nearest_neighbor.h:5-23, ema_grid_samples_nerf.h:3-25, update_bitfield.h:3-69}, orchestrated by
+// density_grid_sampler.py:204-264.  The reference's mean uses a 32-lane-warp block_reduce (density_grid_sampler_header.h:310-406);
+// here it is a wave64 reduction + one atomic per workgroup, and the four max-pool launches stay separate because each level
+// depends on the previous one across workgroups.
+#include "ngp_common.h"
+#pragma clang fp contract(off)
+
+#define G3 (NGP_GRIDSIZE * NGP_GRIDSIZE * NGP_GRIDSIZE)
+
+__global__ void k_grid_mark(uint32_t n_elements, float *__restrict__ grid, uint32_t n_images, const float *__restrict__ focal, const float *__restrict__ xforms, float half_resx, float half_resy) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	const uint32_t level = i / G3, pos_idx = i % G3;
+	const uint32_t x = morton3D_invert(pos_idx >> 0), y = morton3D_invert(pos_idx >> 1), z = morton3D_invert(pos_idx >> 2);
+	const float sc = scalbnf(1.0f, (int)level);
+	const float pos[3] = {(((float)x + 0.5f) / NGP_GRIDSIZE - 0.5f) * sc + 0.5f, (((float)y + 0.5f) / NGP_GRIDSIZE - 0.5f) * sc + 0.5f, (((float)z + 0.5f) / NGP_GRIDSIZE - 0.5f) * sc + 0.5f};
+	const float voxel_radius = 0.5f * NGP_SQRT3 * sc / NGP_GRIDSIZE;
+	int count = 0;
+	for (uint32_t j = 0; j < n_images; ++j) {
+		const float *m = xforms + (size_t)j * 12;                // column-major 3x4: col c at m[3c..3c+2]
+		const float pl[3] = {pos[0] - m[9], pos[1] - m[10], pos[2] - m[11]};
+		const float xx = pl[0] * m[0] + pl[1] * m[1] + pl[2] * m[2];
+		const float yy = pl[0] * m[3] + pl[1] * m[4] + pl[2] * m[5];
+		const float zz = pl[0] * m[6] + pl[1] * m[7] + pl[2] * m[8];
+		if (zz > 0.f && fabsf(xx) - voxel_radius < zz / focal[2 * j] * half_resx && fabsf(yy) - voxel_radius < zz / focal[2 * j + 1] * half_resy) { count = 1; break; }
+	}
+	grid[i] = count > 0 ? 0.f : -1.f;                            // the reference starts from zeros (mark_untrained_density_grid.py:21), so this is the net effect of :43-46
+}
+
+__global__ void k_grid_generate(uint32_t n, Pcg32 rng0, const uint32_t *__restrict__ step_p, float a0, float a1, const float *__restrict__ grid_in,
+                                float *__restrict__ out, uint32_t *__restrict__ indices, uint32_t n_cascades, float thresh) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	Pcg32 rng = rng0;
+	rng.advance((uint64_t)(uint32_t)(i * 4u));
+	const uint32_t level = (uint32_t)(rng.next_float() * n_cascades) % n_cascades;
+	const uint32_t step = *step_p;
+	uint32_t idx = 0;
+	for (uint32_t j = 0; j < 10; ++j) {
+		idx = ((i + step * n) * 56924617u + j * 19349663u + 96925573u) % G3;
+		idx += level * G3;
+		if (grid_in[idx] > thresh) break;
+	}
+	const uint32_t pos_idx = idx % G3;
+	const uint32_t x = morton3D_invert(pos_idx >> 0), y = morton3D_invert(pos_idx >> 1), z = morton3D_invert(pos_idx >> 2);
+	const float r0 = rng.next_float(), r1 = rng.next_float(), r2 = rng.next_float();
+	const float sc = scalbnf(1.0f, (int)level);
+	const float pos[3] = {(((float)x + r0) / NGP_GRIDSIZE - 0.5f) * sc + 0.5f, (((float)y + r1) / NGP_GRIDSIZE - 0.5f) * sc + 0.5f, (((float)z + r2) / NGP_GRIDSIZE - 0.5f) * sc + 0.5f};
+#pragma unroll
+	for (int k = 0; k < 3; ++k) out[3 * (size_t)i + k] = (pos[k] - a0) / (a1 - a0);
+	indices[i] = idx;
+}
+
+template <typename T>
+__global__ void k_grid_splat(uint32_t n, const uint32_t *__restrict__ indices, const T *__restrict__ density, float *__restrict__ grid_tmp) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float mlp = __expf((float)density[i]);
+	const float thick = mlp * min_cone_stepsize();
+	atomicMax(reinterpret_cast<uint32_t *>(grid_tmp) + indices[i], __float_as_uint(thick));
+}
+
+__global__ void k_grid_ema(uint32_t n, float decay, float *__restrict__ grid, const float *__restrict__ tmp) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float prev = grid[i];
+	grid[i] = (prev < 0.f) ? prev : fmaxf(prev * decay, tmp[i]);
+}
+
+__global__ __launch_bounds__(256) void k_grid_mean(const float *__restrict__ grid, float *__restrict__ mean) {
+	__shared__ float sh[4];
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;        // G3/4 float4 elements, grid = G3/4/256 blocks
+	const float4 v = reinterpret_cast<const float4 *>(grid)[i];
+	float s = fmaxf(v.x, 0.f) / (G3) + fmaxf(v.y, 0.f) / (G3) + fmaxf(v.z, 0.f) / (G3) + fmaxf(v.w, 0.f) / (G3);
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd(mean, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+__global__ void k_grid_to_bitfield(uint32_t n, const float *__restrict__ grid, uint8_t *__restrict__ bitfield, const float *__restrict__ mean) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float m = *mean;
+	const float thresh = 0.01f < m ? 0.01f : m;
+	const float4 a = reinterpret_cast<const float4 *>(grid)[2 * (size_t)i], b = reinterpret_cast<const float4 *>(grid)[2 * (size_t)i + 1];
+	uint8_t bits = 0;
+	bits |= a.x > thresh ? 1 : 0; bits |= a.y > thresh ? 2 : 0; bits |= a.z > thresh ? 4 : 0; bits |= a.w > thresh ? 8 : 0;
+	bits |= b.x > thresh ? 16 : 0; bits |= b.y > thresh ? 32 : 0; bits |= b.z > thresh ? 64 : 0; bits |= b.w > thresh ? 128 : 0;
+	bitfield[i] = bits;
+}
+__global__ void k_bitfield_max_pool(uint32_t n, const uint8_t *__restrict__ prev, uint8_t *__restrict__ next) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint2 p = reinterpret_cast<const uint2 *>(prev)[i];
+	uint8_t bits = 0;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) { bits |= ((p.x >> (8 * j)) & 0xffu) ? (1u << j) : 0u; bits |= ((p.y >> (8 * j)) & 0xffu) ? (1u << (4 + j)) : 0u; }
+	const uint32_t x = morton3D_invert(i >> 0) + NGP_GRIDSIZE / 8, y = morton3D_invert(i >> 1) + NGP_GRIDSIZE / 8, z = morton3D_invert(i >> 2) + NGP_GRIDSIZE / 8;
+	next[morton3D(x, y, z)] |= bits;
+}
+
+NGP_API int ngp_grid_mark_untrained(void *stream, uint32_t n_elements, float *grid, uint32_t n_images, const float *focal, const float *xforms, int W, int H) {
+	NGP_REQUIRE(grid && focal && xforms, NGP_E_ARG, "ngp_grid_mark_untrained: null pointer");
+	if (n_elements == 0) return 0;
+	hipLaunchKernelGGL(k_grid_mark, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, grid, n_images, focal, xforms, W * 0.5f, H * 0.5f);
+	NGP_LAUNCH_CHECK("ngp_grid_mark_untrained");
+	return 0;
+}
+NGP_API int ngp_grid_generate_samples(void *stream, uint32_t n, uint64_t *rng_state_host, const uint32_t *ema_step, float aabb0, float aabb1, const float *grid,
+                                      float *positions, uint32_t *indices, uint32_t n_cascades, float thresh) {
+	NGP_REQUIRE(rng_state_host && ema_step && grid && positions && indices && n_cascades >= 1, NGP_E_ARG, "ngp_grid_generate_samples: bad arguments");
+	Pcg32 rng{rng_state_host[0], rng_state_host[1]};
+	Pcg32 adv = rng; adv.advance(1ull << 32); rng_state_host[0] = adv.state;          // generate_grid_samples_nerf_nonuniform.py:44
+	if (n == 0) return 0;
+	hipLaunchKernelGGL(k_grid_generate, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, rng, ema_step, aabb0, aabb1, grid, positions, indices, n_cascades, thresh);
+	NGP_LAUNCH_CHECK("ngp_grid_generate_samples");
+	return 0;
+}
+NGP_API int ngp_grid_splat_max(void *stream, uint32_t n, const uint32_t *indices, const void *density, int dtype, float *grid_tmp) {
+	NGP_REQUIRE(indices && density && grid_tmp, NGP_E_ARG, "ngp_grid_splat_max: null pointer");
+	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_grid_splat_max: bad dtype %d", dtype);
+	if (n == 0) return 0;
+	if (dtype == NGP_F32) hipLaunchKernelGGL(k_grid_splat<float>, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, indices, (const float *)density, grid_tmp);
+	else hipLaunchKernelGGL(k_grid_splat<__half>, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, indices, (const __half *)density, grid_tmp);
+	NGP_LAUNCH_CHECK("ngp_grid_splat_max");
+	return 0;
+}
+NGP_API int ngp_grid_ema(void *stream, uint32_t n_elements, float decay, float *grid, const float *grid_tmp) {
+	NGP_REQUIRE(grid && grid_tmp, NGP_E_ARG, "ngp_grid_ema: null pointer");
+	if (n_elements == 0) return 0;
+	hipLaunchKernelGGL(k_grid_ema, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, decay, grid, grid_tmp);
+	NGP_LAUNCH_CHECK("ngp_grid_ema");
+	return 0;
+}
+NGP_API int ngp_grid_update_bitfield(void *stream, const float *grid, int cascades, float *mean, uint8_t *bitfield) {
+	NGP_REQUIRE(grid && mean && bitfield && cascades >= 1 && cascades <= 8, NGP_E_ARG, "ngp_grid_update_bitfield: bad arguments");
+	NGP_REQUIRE(((uintptr_t)grid & 15) == 0, NGP_E_ALIGN, "ngp_grid_update_bitfield: grid must be 16-byte aligned (update_bitfield.h:14-17)");
+	hipStream_t s = (hipStream_t)stream;
+	hipError_t e = hipMemsetAsync(mean, 0, 4, s);
+	if (e != hipSuccess) { ngp_set_error("ngp_grid_update_bitfield: %s", hipGetErrorString(e)); return (int)e; }
+	hipLaunchKernelGGL(k_grid_mean, dim3(G3 / 4 / 256), dim3(256), 0, s, grid, mean);
+	hipLaunchKernelGGL(k_grid_to_bitfield, dim3(div_up(G3 / 8 * cascades, 256)), dim3(256), 0, s, G3 / 8 * (uint32_t)cascades, grid, bitfield, (const float *)mean);
+	for (int level = 1; level < cascades; ++level)
+		hipLaunchKernelGGL(k_bitfield_max_pool, dim3(div_up(G3 / 64, 256)), dim3(256), 0, s, G3 / 64, (const uint8_t *)(bitfield + (size_t)G3 * (level - 1) / 8), bitfield + (size_t)G3 * level / 8);
+	NGP_LAUNCH_CHECK("ngp_grid_update_bitfield");
+	return 0;
+}

@@ -1,0 +1,418 @@
+// Fused field network for gfx950: SH direction encoding + density MLP (32->64->16) + colour MLP (32->64->64->3),
+// forward and backward, on fp16 MFMA (v_mfma_f32_16x16x32_f16, fp32 accumulate) with all weights resident in LDS.
+//
+// What it computes: NGPNetworks.execute_ / .density (models/networks/ngp_network.py:77-89) with the FMLP weight pack
+// (ngp_network.py:21-29, ops/code_ops/fully_fused_mlp.py:26-41) and SHEncoder (position_encoders/sh_encoder/op_header/
+// SphericalEncode.h:45-95); backward = what FullyFusedMlp_weight.grad (fully_fused_mlp.py:88-145) returns: dL/dinput and the
+// five weight gradients.  The reference's implementation is a binary-only tiny-cuda-nn object; nothing here derives from it.
+//
+// CDNA4 design
+//  * "Transposed" formulation: every layer is  Y^T[neurons x samples] = W[neurons x k] * X^T[k x samples], i.e. the weights are
+//    the MFMA A operand and the 16 samples of a wave tile are the B columns.  The C fragment of one layer (lane = sample
+//    lane&15, registers = neurons 4*(lane>>4)+r) is then *already* a B fragment of the next layer up to a permutation of the k
+//    index — and k order is free as long as A is loaded with the same permutation.  The weight fragments are therefore staged
+//    into LDS pre-permuted, one conflict-free ds_read_b128 per lane per fragment, and activations never leave registers
+//    between layers: no LDS round trip, no [n,64] intermediates in HBM (the reference writes 3 x 128 B/sample of them).
+//  * Backward recomputes the forward (20 MFMAs per 16 samples — cheaper than re-reading saved activations), runs the dgrad chain
+//    the same register-resident way with transposed weight fragments, and only the weight gradients (a contraction over
+//    SAMPLES) go through LDS: activations/gradients are written once as [neuron][sample] and each wave accumulates 10 of
+//    the 40 16x16 weight-gradient tiles over the whole persistent loop; one fp32 slab per workgroup is written at the end and
+//    summed by ngp_reduce_slabs (no atomics, deterministic).
+//  * Features arrive level-major ([16][n] pairs) from the XCD-aware hash kernel: every wave load is four 64-B segments.
+#include "ngp_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+// packed weights (row-major (out,in), f16):  wd: W0 @0 [64][32], W1 @2048 [16][64];  wc: V0 @0 [64][32], V1 @2048 [64][64], V2 @6144 [16][64]
+#define N_FWD_FRAGS 20
+#define N_BWD_FRAGS 22
+// logical k of MFMA slot (g = lane>>4, j) for the three kinds of B operand
+__device__ __forceinline__ int k32(int g, int j) { return 8 * g + j; }                                            // natural order (features)
+__device__ __forceinline__ int k64(int kb, int g, int j) { return 32 * kb + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)); }   // two C tiles 2kb, 2kb+1
+
+// value of weight fragment `f`, lane (o = lane&15, g = lane>>4), slot j.  f < 20: forward (A = W), f >= 20: backward (A = W^T).
+__device__ __forceinline__ _Float16 frag_value(const _Float16 *__restrict__ wd, const _Float16 *__restrict__ wc, int f, int o, int g, int j) {
+	if (f < 4) return wd[(16 * f + o) * 32 + k32(g, j)];                                         // L0  tile t=f
+	if (f < 6) return wd[2048 + o * 64 + k64(f - 4, g, j)];                                      // L1  kb
+	if (f < 10) return wc[(16 * (f - 6) + o) * 32 + k64(0, g, j)];                               // L2  tile t, input = [D(16), SH(16)]
+	if (f < 18) { int t = (f - 10) >> 1, kb = (f - 10) & 1; return wc[2048 + (16 * t + o) * 64 + k64(kb, g, j)]; }   // L3
+	if (f < 20) return wc[6144 + o * 64 + k64(f - 18, g, j)];                                    // L4
+	f -= 20;
+	if (f < 4) return j < 4 ? wc[6144 + (4 * g + j) * 64 + 16 * f + o] : (_Float16)0;            // dG1 = V2^T dO   (K = 16, upper half zero)
+	if (f < 12) { int t = (f - 4) >> 1, kb = (f - 4) & 1; return wc[2048 + k64(kb, g, j) * 64 + 16 * t + o]; }       // dG0 = V1^T dG1
+	if (f < 14) return wc[k64(f - 12, g, j) * 32 + o];                                           // dD  = (V0^T dG0)[0:16]
+	if (f < 18) return j < 4 ? wd[2048 + (4 * g + j) * 64 + 16 * (f - 14) + o] : (_Float16)0;    // dH  = W1^T dD   (K = 16)
+	{ int t = (f - 18) >> 1, kb = (f - 18) & 1; return wd[k64(kb, g, j) * 32 + 16 * t + o]; }    // dF  = W0^T dH
+}
+__device__ __forceinline__ void stage_weights(_Float16 *lds, const _Float16 *__restrict__ wd, const _Float16 *__restrict__ wc, int n_frags, int first) {
+	for (int idx = threadIdx.x; idx < n_frags * 512; idx += blockDim.x) {
+		const int f = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7;
+		lds[idx] = frag_value(wd, wc, first + f, lane & 15, lane >> 4, j);
+	}
+}
+__device__ __forceinline__ half8 ld_frag(const _Float16 *lds, int f, int lane) { return *reinterpret_cast<const half8 *>(lds + f * 512 + lane * 8); }
+
+__device__ __forceinline__ half8 pack_relu(floatx4 a, floatx4 b) {
+	half8 r;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { r[k] = (_Float16)fmaxf(a[k], 0.f); r[4 + k] = (_Float16)fmaxf(b[k], 0.f); }
+	return r;
+}
+__device__ __forceinline__ half8 pack_masked(floatx4 a, floatx4 b, half8 act) {   // relu'(act) * grad
+	half8 r;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { r[k] = act[k] > (_Float16)0 ? (_Float16)a[k] : (_Float16)0; r[4 + k] = act[4 + k] > (_Float16)0 ? (_Float16)b[k] : (_Float16)0; }
+	return r;
+}
+
+// degree-4 SH of (2d-1), components 4g..4g+3 (SphericalEncode.h:77-95)
+__device__ __forceinline__ void sh4(const float d[3], int g, float o[4]) {
+	const float x = d[0] * 2.f - 1.f, y = d[1] * 2.f - 1.f, z = d[2] * 2.f - 1.f;
+	const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+	if (g == 0) { o[0] = 0.28209479177387814f; o[1] = -0.48860251190291987f * y; o[2] = 0.48860251190291987f * z; o[3] = -0.48860251190291987f * x; }
+	else if (g == 1) { o[0] = 1.0925484305920792f * xy; o[1] = -1.0925484305920792f * yz; o[2] = 0.94617469575755997f * z2 - 0.31539156525251999f; o[3] = -1.0925484305920792f * xz; }
+	else if (g == 2) { o[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2; o[1] = 0.59004358992664352f * y * (-3.0f * x2 + y2); o[2] = 2.8906114426405538f * xy * z; o[3] = 0.45704579946446572f * y * (1.0f - 5.0f * z2); }
+	else { o[0] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f); o[1] = 0.45704579946446572f * x * (1.0f - 5.0f * z2); o[2] = 1.4453057213202769f * z * (x2 - y2); o[3] = 0.59004358992664352f * x * (-x2 + 3.0f * y2); }
+}
+
+// B fragment of the first layer: features of sample `i` for levels 4g..4g+3
+template <int LAYOUT>
+__device__ __forceinline__ half8 load_feat(const _Float16 *__restrict__ feat, uint32_t n, uint32_t i, int g) {
+	half8 r;
+	if (LAYOUT == NGP_LAYOUT_SOA) {
+		const uint32_t *f32 = reinterpret_cast<const uint32_t *>(feat);
+		uint32_t v[4];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) v[q] = f32[(size_t)(4 * g + q) * n + i];
+		r = *reinterpret_cast<half8 *>(v);
+	} else {
+		r = *reinterpret_cast<const half8 *>(feat + (size_t)i * 32 + 8 * g);
+	}
+	return r;
+}
+
+struct FwdState { half8 feat, hfrag[2], in2, g0[2], g1[2]; floatx4 den, rgb; };
+
+template <bool DENSITY_ONLY>
+__device__ __forceinline__ void forward_tile(const _Float16 *wl, int lane, half8 feat, const float sh[4], FwdState &st) {
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	floatx4 c0[4];
+#pragma unroll
+	for (int t = 0; t < 4; ++t) c0[t] = MFMA(ld_frag(wl, t, lane), feat, z);
+	st.feat = feat;
+	st.hfrag[0] = pack_relu(c0[0], c0[1]); st.hfrag[1] = pack_relu(c0[2], c0[3]);
+	floatx4 d = MFMA(ld_frag(wl, 4, lane), st.hfrag[0], z);
+	d = MFMA(ld_frag(wl, 5, lane), st.hfrag[1], d);
+	st.den = d;
+	if (DENSITY_ONLY) return;
+	half8 in2;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { in2[k] = (_Float16)d[k]; in2[4 + k] = (_Float16)sh[k]; }
+	st.in2 = in2;
+	floatx4 c2[4];
+#pragma unroll
+	for (int t = 0; t < 4; ++t) c2[t] = MFMA(ld_frag(wl, 6 + t, lane), in2, z);
+	st.g0[0] = pack_relu(c2[0], c2[1]); st.g0[1] = pack_relu(c2[2], c2[3]);
+	floatx4 c3[4];
+#pragma unroll
+	for (int t = 0; t < 4; ++t) { c3[t] = MFMA(ld_frag(wl, 10 + 2 * t, lane), st.g0[0], z); c3[t] = MFMA(ld_frag(wl, 11 + 2 * t, lane), st.g0[1], c3[t]); }
+	st.g1[0] = pack_relu(c3[0], c3[1]); st.g1[1] = pack_relu(c3[2], c3[3]);
+	floatx4 o = MFMA(ld_frag(wl, 18, lane), st.g1[0], z);
+	st.rgb = MFMA(ld_frag(wl, 19, lane), st.g1[1], o);
+}
+
+template <typename T> __device__ __forceinline__ void store_out4(T *p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store_out4<float>(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
+template <> __device__ __forceinline__ void store_out4<__half>(__half *p, float a, float b, float c, float d) {
+	half4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+	*reinterpret_cast<half4 *>(p) = v;
+}
+template <typename T> __device__ __forceinline__ void store_out1(T *p, float a);
+template <> __device__ __forceinline__ void store_out1<float>(float *p, float a) { *p = a; }
+template <> __device__ __forceinline__ void store_out1<__half>(__half *p, float a) { *p = __float2half(a); }
+
+template <typename T, int LAYOUT, bool DENSITY_ONLY>
+__global__ __launch_bounds__(256) void k_field_fwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+                                                   const _Float16 *__restrict__ wd, const _Float16 *__restrict__ wc, T *__restrict__ out,
+                                                   const uint32_t *__restrict__ n_valid) {
+	__shared__ __attribute__((aligned(16))) _Float16 wl[N_FWD_FRAGS * 512];
+	stage_weights(wl, wd, wc, DENSITY_ONLY ? 6 : N_FWD_FRAGS, 0);
+	__syncthreads();
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+	const uint32_t n_tiles = (lim + 15u) / 16u;
+	const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+		const uint32_t i = tile * 16u + s;
+		const uint32_t ic = i < lim ? i : lim - 1;
+		const half8 f = load_feat<LAYOUT>(feat, n, ic, g);
+		float sh[4] = {0.f, 0.f, 0.f, 0.f};
+		if (!DENSITY_ONLY) { const float d[3] = {dir[(size_t)ic * dir_stride], dir[(size_t)ic * dir_stride + 1], dir[(size_t)ic * dir_stride + 2]}; sh4(d, g, sh); }
+		FwdState st;
+		forward_tile<DENSITY_ONLY>(wl, lane, f, sh, st);
+		if (g == 0 && i < lim) {
+			if (DENSITY_ONLY) store_out1<T>(out + i, st.den[0]);
+			else store_out4<T>(out + (size_t)i * 4, st.rgb[0], st.rgb[1], st.rgb[2], st.den[0]);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward
+#define BT 64                 // samples per workgroup tile
+#define RS (BT + 8)           // LDS row stride in halves (144 B: 16-B aligned rows, breaks the 128-B bank period)
+// LDS rows: inputs  F 0..31 | H 32..95 | IN2 96..127 | G0 128..191 | G1 192..255 ; grads dH 256..319 | dD 320..335 | dG0 336..399 | dG1 400..463 | dO 464..479
+#define R_F 0
+#define R_H 32
+#define R_IN2 96
+#define R_G0 128
+#define R_G1 192
+#define R_DH 256
+#define R_DD 320
+#define R_DG0 336
+#define R_DG1 400
+#define R_DO 464
+#define N_ROWS 480
+
+__device__ __forceinline__ void st_rows64(_Float16 *stage, int row0, int col, int g, half8 lo, half8 hi) {   // two k64 fragments = 64 neurons
+#pragma unroll
+	for (int j = 0; j < 8; ++j) { stage[(row0 + k64(0, g, j)) * RS + col] = lo[j]; stage[(row0 + k64(1, g, j)) * RS + col] = hi[j]; }
+}
+__device__ __forceinline__ half8 ld_rows(const _Float16 *stage, int row, int col) { return *reinterpret_cast<const half8 *>(stage + row * RS + col); }
+
+template <typename T> __device__ __forceinline__ void load_dout(const T *p, float o[4]);
+template <> __device__ __forceinline__ void load_dout<float>(const float *p, float o[4]) { float4 v = *reinterpret_cast<const float4 *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void load_dout<__half>(const __half *p, float o[4]) { half4 v = *reinterpret_cast<const half4 *>(p); o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
+
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+                                                      const _Float16 *__restrict__ wd, const _Float16 *__restrict__ wc, const T *__restrict__ dout,
+                                                      _Float16 *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid) {
+	extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+	_Float16 *wl = smem;                                         // 42 fragments
+	_Float16 *stage = smem + (N_FWD_FRAGS + N_BWD_FRAGS) * 512;  // [N_ROWS][RS]
+	stage_weights(wl, wd, wc, N_FWD_FRAGS + N_BWD_FRAGS, 0);
+	const _Float16 *wb = wl + N_FWD_FRAGS * 512;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+	const uint32_t n_bt = (lim + BT - 1) / BT;
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	// this wave's 10 weight-gradient tiles: V1 (to=w, ti=0..3) | W0 (to=w, ti=0,1) | V0 (to=w, ti=0,1) | W1 (ti=w) | V2 (ti=w)
+	floatx4 aV1[4] = {z, z, z, z}, aW0[2] = {z, z}, aV0[2] = {z, z}, aW1 = z, aV2 = z;
+	__syncthreads();
+	for (uint32_t bt = blockIdx.x; bt < n_bt; bt += gridDim.x) {
+		const uint32_t i = bt * BT + 16u * w + s;
+		const bool valid = i < lim;
+		const uint32_t ic = valid ? i : lim - 1;
+		const half8 f = load_feat<LAYOUT>(feat, n, ic, g);
+		const float d3[3] = {dir[(size_t)ic * dir_stride], dir[(size_t)ic * dir_stride + 1], dir[(size_t)ic * dir_stride + 2]};
+		float sh[4]; sh4(d3, g, sh);
+		float go[4] = {0.f, 0.f, 0.f, 0.f};
+		if (valid) load_dout<T>(dout + (size_t)i * 4, go);
+		FwdState st;
+		forward_tile<false>(wl, lane, f, sh, st);
+		// ---- dgrad chain (register resident, transposed weights)
+		half8 dO;                                                 // slots j<4 <-> dO neuron 4g+j; only neurons 0..2 (g==0) are non-zero
+#pragma unroll
+		for (int j = 0; j < 8; ++j) dO[j] = (_Float16)0;
+		if (g == 0) { dO[0] = (_Float16)go[0]; dO[1] = (_Float16)go[1]; dO[2] = (_Float16)go[2]; }
+		floatx4 c[4];
+#pragma unroll
+		for (int t = 0; t < 4; ++t) c[t] = MFMA(ld_frag(wb, t, lane), dO, z);
+		const half8 dG1lo = pack_masked(c[0], c[1], st.g1[0]), dG1hi = pack_masked(c[2], c[3], st.g1[1]);
+#pragma unroll
+		for (int t = 0; t < 4; ++t) { c[t] = MFMA(ld_frag(wb, 4 + 2 * t, lane), dG1lo, z); c[t] = MFMA(ld_frag(wb, 5 + 2 * t, lane), dG1hi, c[t]); }
+		const half8 dG0lo = pack_masked(c[0], c[1], st.g0[0]), dG0hi = pack_masked(c[2], c[3], st.g0[1]);
+		floatx4 dD = MFMA(ld_frag(wb, 12, lane), dG0lo, z);
+		dD = MFMA(ld_frag(wb, 13, lane), dG0hi, dD);
+		if (g == 0) dD[0] += go[3];                               // out[:,3] = den[:,0]  (ngp_network.py:83)
+		half8 dDf;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { dDf[j] = (_Float16)dD[j]; dDf[4 + j] = (_Float16)0; }
+#pragma unroll
+		for (int t = 0; t < 4; ++t) c[t] = MFMA(ld_frag(wb, 14 + t, lane), dDf, z);
+		const half8 dHlo = pack_masked(c[0], c[1], st.hfrag[0]), dHhi = pack_masked(c[2], c[3], st.hfrag[1]);
+		floatx4 dF[2];
+#pragma unroll
+		for (int t = 0; t < 2; ++t) { dF[t] = MFMA(ld_frag(wb, 18 + 2 * t, lane), dHlo, z); dF[t] = MFMA(ld_frag(wb, 19 + 2 * t, lane), dHhi, dF[t]); }
+		if (valid) {                                              // feature 16t+4g+r  ->  level 8t+2g+(r>>1), component r&1
+#pragma unroll
+			for (int t = 0; t < 2; ++t)
+#pragma unroll
+				for (int pr = 0; pr < 2; ++pr) {
+					half2v v = {(_Float16)dF[t][2 * pr], (_Float16)dF[t][2 * pr + 1]};
+					const uint32_t level = 8 * t + 2 * g + pr;
+					if (LAYOUT == NGP_LAYOUT_SOA) *reinterpret_cast<half2v *>(dfeat + ((size_t)level * n + i) * 2) = v;
+					else *reinterpret_cast<half2v *>(dfeat + (size_t)i * 32 + 2 * level) = v;
+				}
+		}
+		// ---- stage activations and gradients as [neuron][sample] for the weight-gradient contraction over samples
+		const int col = 16 * w + s;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			stage[(R_F + k32(g, j)) * RS + col] = st.feat[j];
+			stage[(R_IN2 + k64(0, g, j)) * RS + col] = st.in2[j];
+			if (j < 4) { stage[(R_DD + 4 * g + j) * RS + col] = dDf[j]; stage[(R_DO + 4 * g + j) * RS + col] = dO[j]; }
+		}
+		st_rows64(stage, R_H, col, g, st.hfrag[0], st.hfrag[1]);
+		st_rows64(stage, R_G0, col, g, st.g0[0], st.g0[1]);
+		st_rows64(stage, R_G1, col, g, st.g1[0], st.g1[1]);
+		st_rows64(stage, R_DH, col, g, dHlo, dHhi);
+		st_rows64(stage, R_DG0, col, g, dG0lo, dG0hi);
+		st_rows64(stage, R_DG1, col, g, dG1lo, dG1hi);
+		__syncthreads();
+		// ---- weight gradients: dW[o][i] += sum_s dY[s][o] X[s][i]   (A = dY^T rows o, B = X columns i, k = sample)
+#pragma unroll
+		for (int kb = 0; kb < BT / 32; ++kb) {
+			const int cs = 32 * kb + 8 * g, o = lane & 15;
+			const half8 a_dg1 = ld_rows(stage, R_DG1 + 16 * w + o, cs), a_dh = ld_rows(stage, R_DH + 16 * w + o, cs), a_dg0 = ld_rows(stage, R_DG0 + 16 * w + o, cs);
+			const half8 a_dd = ld_rows(stage, R_DD + o, cs), a_do = ld_rows(stage, R_DO + o, cs);
+#pragma unroll
+			for (int ti = 0; ti < 4; ++ti) aV1[ti] = MFMA(a_dg1, ld_rows(stage, R_G0 + 16 * ti + o, cs), aV1[ti]);
+#pragma unroll
+			for (int ti = 0; ti < 2; ++ti) { aW0[ti] = MFMA(a_dh, ld_rows(stage, R_F + 16 * ti + o, cs), aW0[ti]); aV0[ti] = MFMA(a_dg0, ld_rows(stage, R_IN2 + 16 * ti + o, cs), aV0[ti]); }
+			aW1 = MFMA(a_dd, ld_rows(stage, R_H + 16 * w + o, cs), aW1);
+			aV2 = MFMA(a_do, ld_rows(stage, R_G1 + 16 * w + o, cs), aV2);
+		}
+		__syncthreads();
+	}
+	// ---- one fp32 slab per workgroup, packed like the weights (wd part 0..3071, wc part 3072..10239); C rows = 4g+r, cols = lane&15
+	float *slab = slabs + (size_t)blockIdx.x * 10240;
+	const int ci = lane & 15;
+#pragma unroll
+	for (int r = 0; r < 4; ++r) {
+		const int ro = 4 * g + r;
+#pragma unroll
+		for (int ti = 0; ti < 4; ++ti) slab[3072 + 2048 + (16 * w + ro) * 64 + 16 * ti + ci] = aV1[ti][r];
+#pragma unroll
+		for (int ti = 0; ti < 2; ++ti) { slab[(16 * w + ro) * 32 + 16 * ti + ci] = aW0[ti][r]; slab[3072 + (16 * w + ro) * 32 + 16 * ti + ci] = aV0[ti][r]; }
+		slab[2048 + ro * 64 + 16 * w + ci] = aW1[r];
+		slab[3072 + 6144 + ro * 64 + 16 * w + ci] = aV2[r];
+	}
+}
+
+__global__ void k_reduce_slabs(const float *__restrict__ slabs, uint32_t n_slabs, uint32_t width, float *__restrict__ out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= width) return;
+	float s = 0.f;
+	for (uint32_t k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * width + i];
+	out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- standalone SH
+template <typename T>
+__global__ void k_sh(uint32_t n, const float *__restrict__ dir, uint32_t stride, T *__restrict__ out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float d[3] = {dir[(size_t)i * stride], dir[(size_t)i * stride + 1], dir[(size_t)i * stride + 2]};
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		float o[4]; sh4(d, g, o);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) store_out1<T>(out + (size_t)i * 16 + 4 * g + k, o[k]);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------- MFMA layout self-test
+__global__ void k_selftest_mfma(uint32_t *result) {
+	// C = A * B with A[i][k] = (i*3 + k) % 7 - 3, B[k][j] = (k*5 + j*2) % 9 - 4 (asymmetric), both loaded with the layout assumed above.
+	const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+	half8 a, b;
+	for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; a[j] = (_Float16)((i * 3 + k) % 7 - 3); b[j] = (_Float16)((k * 5 + i * 2) % 9 - 4); }
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	const floatx4 c = MFMA(a, b, z);
+	uint32_t bad = 0;
+	for (int r = 0; r < 4; ++r) {
+		const int row = 4 * g + r, col = i;
+		float ref = 0.f;
+		for (int k = 0; k < 32; ++k) ref += (float)((row * 3 + k) % 7 - 3) * (float)((k * 5 + col * 2) % 9 - 4);
+		if (c[r] != ref) bad++;
+	}
+	if (bad) atomicAdd(&result[0], bad);
+	if (lane == 0) result[1] = 0xC0FFEEu;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- C ABI
+static int check_field(const char *fn, const void *feat, const void *wd, const void *wc, int layout, int out_dtype) {
+	NGP_REQUIRE(feat && wd && wc, NGP_E_ARG, "%s: null pointer", fn);
+	NGP_REQUIRE(layout == NGP_LAYOUT_AOS || layout == NGP_LAYOUT_SOA, NGP_E_ARG, "%s: bad layout %d", fn, layout);
+	NGP_REQUIRE(out_dtype == NGP_F32 || out_dtype == NGP_F16, NGP_E_DTYPE, "%s: bad dtype %d", fn, out_dtype);
+	NGP_REQUIRE(((uintptr_t)feat & 15) == 0, NGP_E_ALIGN, "%s: feature pointer must be 16-byte aligned", fn);
+	return 0;
+}
+static uint32_t fwd_grid(uint32_t n) { uint32_t b = div_up(div_up(n, 16), 4); return b < 2048 ? (b ? b : 1) : 2048; }
+
+NGP_API int ngp_field_fwd(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,
+                          void *out, int out_dtype, const uint32_t *n_valid) {
+	int rc = check_field("ngp_field_fwd", feat, wd, wc, layout, out_dtype); if (rc) return rc;
+	NGP_REQUIRE(dir && out && dir_stride >= 3, NGP_E_ARG, "ngp_field_fwd: bad dir/out");
+	if (n == 0) return 0;
+	const dim3 grid(fwd_grid(n)), block(256);
+	hipStream_t s = (hipStream_t)stream;
+#define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, false>), grid, block, 0, s, n, (const _Float16 *)feat, dir, dir_stride, (const _Float16 *)wd, (const _Float16 *)wc, (T *)out, n_valid)
+	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
+	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
+#undef GO
+	NGP_LAUNCH_CHECK("ngp_field_fwd");
+	return 0;
+}
+NGP_API int ngp_density_fwd(void *stream, uint32_t n, const void *feat, int layout, const void *wd, void *out, int out_dtype) {
+	int rc = check_field("ngp_density_fwd", feat, wd, wd, layout, out_dtype); if (rc) return rc;
+	NGP_REQUIRE(out, NGP_E_ARG, "ngp_density_fwd: null out");
+	if (n == 0) return 0;
+	const dim3 grid(fwd_grid(n)), block(256);
+	hipStream_t s = (hipStream_t)stream;
+#define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, true>), grid, block, 0, s, n, (const _Float16 *)feat, (const float *)nullptr, 3u, (const _Float16 *)wd, (const _Float16 *)wd, (T *)out, (const uint32_t *)nullptr)
+	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
+	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
+#undef GO
+	NGP_LAUNCH_CHECK("ngp_density_fwd");
+	return 0;
+}
+NGP_API int ngp_field_bwd_slabs(uint32_t n) { uint32_t b = div_up(n, BT); return (int)(b < 256 ? (b ? b : 1) : 256); }
+NGP_API int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,
+                          const void *dLdout, int out_dtype, void *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid) {
+	int rc = check_field("ngp_field_bwd", feat, wd, wc, layout, out_dtype); if (rc) return rc;
+	NGP_REQUIRE(dir && dLdout && dLdfeat && wgrad_slabs && dir_stride >= 3, NGP_E_ARG, "ngp_field_bwd: null pointer");
+	NGP_REQUIRE((int)n_slabs == ngp_field_bwd_slabs(n), NGP_E_ARG, "ngp_field_bwd: n_slabs %u != ngp_field_bwd_slabs(%u)", n_slabs, n);
+	if (n == 0) return 0;
+	const size_t shmem = ((N_FWD_FRAGS + N_BWD_FRAGS) * 512 + N_ROWS * RS) * sizeof(_Float16);
+	const dim3 grid(n_slabs), block(256);
+	hipStream_t s = (hipStream_t)stream;
+#define GO(T, L) do { \
+	static bool attr_set = false; \
+	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field_bwd<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+		if (e != hipSuccess) { ngp_set_error("ngp_field_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
+	hipLaunchKernelGGL((k_field_bwd<T, L>), grid, block, shmem, s, n, (const _Float16 *)feat, dir, dir_stride, (const _Float16 *)wd, (const _Float16 *)wc, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid); } while (0)
+	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
+	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
+#undef GO
+	NGP_LAUNCH_CHECK("ngp_field_bwd");
+	return 0;
+}
+NGP_API int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out) {
+	NGP_REQUIRE(slabs && out, NGP_E_ARG, "ngp_reduce_slabs: null pointer");
+	hipLaunchKernelGGL(k_reduce_slabs, dim3(div_up(width, 256)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, width, out);
+	NGP_LAUNCH_CHECK("ngp_reduce_slabs");
+	return 0;
+}
+NGP_API int ngp_sh_encode(void *stream, uint32_t n, const float *dir, uint32_t stride, void *out, int dtype) {
+	NGP_REQUIRE(dir && out && stride >= 3, NGP_E_ARG, "ngp_sh_encode: bad arguments");
+	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_sh_encode: bad dtype %d", dtype);
+	if (n == 0) return 0;
+	if (dtype == NGP_F32) hipLaunchKernelGGL(k_sh<float>, dim3(div_up(n, 128)), dim3(128), 0, (hipStream_t)stream, n, dir, stride, (float *)out);
+	else hipLaunchKernelGGL(k_sh<__half>, dim3(div_up(n, 128)), dim3(128), 0, (hipStream_t)stream, n, dir, stride, (__half *)out);
+	NGP_LAUNCH_CHECK("ngp_sh_encode");
+	return 0;
+}
+NGP_API int ngp_selftest_mfma(void *stream, uint32_t *result) {
+	NGP_REQUIRE(result, NGP_E_ARG, "ngp_selftest_mfma: null pointer");
+	hipError_t e = hipMemsetAsync(result, 0, 16, (hipStream_t)stream);
+	if (e != hipSuccess) { ngp_set_error("ngp_selftest_mfma: %s", hipGetErrorString(e)); return (int)e; }
+	hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, result);
+	NGP_LAUNCH_CHECK("ngp_selftest_mfma");
+	return 0;
+}

@@ -1,0 +1,281 @@
+"""Typed torch-tensor front-end of the C ABI (include/ngp_hip.h).  PyTorch is used for device memory and streams only;
+every function below is one asynchronous launch sequence on the current stream of the tensors' device."""
+import ctypes as C
+import numpy as np
+import torch
+from . import _lib as L
+from ._lib import F32, F16, LAYOUT_AOS, LAYOUT_SOA, check
+
+CAP_RAYS = 1 << 18
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "libngp_hip needs device tensors (there is no CPU path)"
+    return C.c_void_p(t.data_ptr())
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _rows(t, width):
+    """(pointer-able tensor, row stride in floats) for a [n,width] fp32 view whose rows may be strided (e.g. coords[:, 4:])."""
+    assert t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == width and t.stride(1) == 1, (t.dtype, t.shape, t.stride())
+    return t, int(t.stride(0))
+
+
+# ------------------------------------------------------------------ level table (host, fp32 semantics of HashEncode.h:149-151)
+def level_table(aabb_scale, n_levels=16, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048.0):
+    """Restates grid_encode.py:17-40 (offsets, fp64) and the per-level fp32 scale/resolution of HashEncode.h:149-151.
+    -> (table np.uint32[16,4] = offset,size,res,scale_bits ; offsets np.uint32[17] ; n_params)"""
+    from math import exp, log, log2, ceil
+    assert n_levels == 16 and base_resolution == 16
+    s = exp(log(desired_resolution * aabb_scale / base_resolution) / (n_levels - 1))
+    log2s = np.float32(log2(s))
+    table = np.zeros((16, 4), np.uint32)
+    offsets = np.zeros(17, np.uint32)
+    off = 0
+    for l in range(16):
+        scale_h = pow(2, l * log2(s)) * base_resolution - 1.0
+        res_h = ceil(scale_h) + 1
+        p = (int(res_h) ** 3 + 7) // 8 * 8
+        p = min(p, 1 << log2_hashmap_size)
+        arg = np.float32(l) * log2s
+        scale_d = np.float32(np.float32(2.0 ** float(arg)) * np.float32(16.0)) - np.float32(1.0)
+        res_d = int(np.ceil(scale_d)) + 1
+        offsets[l] = off
+        table[l] = (off, p, res_d, np.float32(scale_d).view(np.uint32))
+        off += p
+    offsets[16] = off
+    return table, offsets, off * 2
+
+
+def _tbl(table_np):
+    assert table_np.dtype == np.uint32 and table_np.size == 64
+    return np.ascontiguousarray(table_np).ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------ hash grid
+def hash_encode_fwd(pos, table, level_tbl, out=None, layout=LAYOUT_AOS, n_valid=None):
+    pos, stride = _rows(pos, 3)
+    n = pos.shape[0]
+    if out is None:
+        out = torch.empty((n, 32) if layout == LAYOUT_AOS else (16, n, 2), dtype=table.dtype, device=pos.device)
+    check(L.lib().ngp_hash_encode_fwd(_stream(), n, _p(pos), stride, _p(table), _tbl(level_tbl), _p(out), _dt(table), layout, _p(n_valid)), "ngp_hash_encode_fwd")
+    return out
+
+
+def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, layout=LAYOUT_AOS, zero_first=True, n_valid=None):
+    pos, stride = _rows(pos, 3)
+    n = pos.shape[0]
+    assert dLdy.is_contiguous()
+    if grad is None:
+        grad = torch.empty(n_params, dtype=grad_dtype or dLdy.dtype, device=pos.device)
+    check(L.lib().ngp_hash_encode_bwd(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
+                                      int(zero_first), _p(n_valid)), "ngp_hash_encode_bwd")
+    return grad
+
+
+def sh_encode(d, dtype=torch.float32):
+    d, stride = _rows(d, 3)
+    out = torch.empty((d.shape[0], 16), dtype=dtype, device=d.device)
+    check(L.lib().ngp_sh_encode(_stream(), d.shape[0], _p(d), stride, _p(out), _dt(out)), "ngp_sh_encode")
+    return out
+
+
+# ------------------------------------------------------------------ field network
+def field_fwd(feat, d, wd, wc, layout=LAYOUT_AOS, out_dtype=torch.float16, out=None, n_valid=None):
+    assert feat.dtype == torch.float16 and wd.dtype == torch.float16 and wc.dtype == torch.float16 and feat.is_contiguous()
+    assert wd.numel() == 3072 and wc.numel() == 7168
+    d, stride = _rows(d, 3)
+    n = d.shape[0]
+    if out is None:
+        out = torch.empty((n, 4), dtype=out_dtype, device=d.device)
+    check(L.lib().ngp_field_fwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(out), _dt(out), _p(n_valid)), "ngp_field_fwd")
+    return out
+
+
+def density_fwd(feat, wd, n, layout=LAYOUT_AOS, out_dtype=torch.float16):
+    assert feat.dtype == torch.float16 and wd.dtype == torch.float16 and feat.is_contiguous()
+    out = torch.empty((n,), dtype=out_dtype, device=feat.device)
+    check(L.lib().ngp_density_fwd(_stream(), n, _p(feat), layout, _p(wd), _p(out), _dt(out)), "ngp_density_fwd")
+    return out
+
+
+def field_bwd_slabs(n):
+    return int(L.lib().ngp_field_bwd_slabs(n))
+
+
+def field_bwd(feat, d, wd, wc, dLdout, layout=LAYOUT_AOS, dfeat=None, slabs=None, n_valid=None):
+    """-> (dLdfeat f16 in `layout`, slabs f32[n_slabs,10240]); sum the slabs with reduce_slabs."""
+    assert feat.dtype == torch.float16 and feat.is_contiguous() and dLdout.is_contiguous()
+    d, stride = _rows(d, 3)
+    n = d.shape[0]
+    ns = field_bwd_slabs(n)
+    if dfeat is None:
+        dfeat = torch.zeros_like(feat)
+    if slabs is None:
+        slabs = torch.empty((ns, 10240), dtype=torch.float32, device=d.device)
+    check(L.lib().ngp_field_bwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(dLdout), _dt(dLdout), _p(dfeat), _p(slabs), ns, _p(n_valid)), "ngp_field_bwd")
+    return dfeat, slabs
+
+
+def reduce_slabs(slabs, out=None):
+    ns, width = slabs.shape
+    if out is None:
+        out = torch.empty(width, dtype=torch.float32, device=slabs.device)
+    check(L.lib().ngp_reduce_slabs(_stream(), _p(slabs), ns, width, _p(out)), "ngp_reduce_slabs")
+    return out
+
+
+# ------------------------------------------------------------------ sampler
+def march_rays(rays_o, rays_d, bitfield, aabb, rng_state, max_samples, cone_angle=1.0 / 256, near=0.2, const_dt=True, cascades=5, coords=None, zero_coords=True):
+    """rng_state: np.uint64[2] (advanced by 2^32 in place).  -> coords[max_samples,7], numsteps[n,2] (i32 view of u32), counters[2], ray_indices[n]"""
+    assert rays_o.is_contiguous() and rays_d.is_contiguous() and rays_o.dtype == torch.float32 and bitfield.dtype == torch.uint8
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    if coords is None:
+        coords = torch.empty((max_samples, 7), dtype=torch.float32, device=dev)
+    numsteps = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    counters = torch.empty(2, dtype=torch.int32, device=dev)
+    ray_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+    scratch = torch.empty(n + 1024, dtype=torch.int32, device=dev)
+    check(L.lib().ngp_march_rays(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
+                                 rng_state.ctypes.data_as(C.c_void_p), max_samples, _p(coords), _p(numsteps), _p(counters), _p(ray_idx), _p(scratch), int(zero_coords)), "ngp_march_rays")
+    return coords, numsteps, counters, ray_idx
+
+
+def compact_coords(coords_in, numsteps_in, cap, coords_out=None):
+    n = numsteps_in.shape[0]
+    dev = coords_in.device
+    if coords_out is None:
+        coords_out = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+    numsteps_out = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    counter = torch.empty(1, dtype=torch.int32, device=dev)
+    check(L.lib().ngp_compact_coords(_stream(), n, cap, _p(coords_in), _p(numsteps_in), _p(coords_out), _p(numsteps_out), _p(counter), None), "ngp_compact_coords")
+    return coords_out, numsteps_out, counter
+
+
+def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng_state, max_samples, cap, cone_angle=1.0 / 256, near=0.2, const_dt=True, cascades=5,
+                         coords_out=None, numsteps=None, numsteps_c=None, counters=None, scratch=None):
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    if coords_out is None:
+        coords_out = torch.zeros((cap, 7), dtype=torch.float32, device=dev)
+    if numsteps is None:
+        numsteps = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    if numsteps_c is None:
+        numsteps_c = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    if counters is None:
+        counters = torch.empty(4, dtype=torch.int32, device=dev)
+    if scratch is None:
+        scratch = torch.empty(n + 1024, dtype=torch.int32, device=dev)
+    check(L.lib().ngp_march_rays_compacted(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
+                                           rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch)),
+          "ngp_march_rays_compacted")
+    return coords_out, numsteps, numsteps_c, counters
+
+
+def composite_fwd(net, coords, numsteps, numsteps_c, bg, cascades=5, out=None):
+    n = numsteps.shape[0]
+    assert net.is_contiguous() and coords.is_contiguous() and bg.is_contiguous()
+    if out is None:
+        out = torch.empty((n, 3), dtype=torch.float32, device=net.device)
+    check(L.lib().ngp_composite_fwd(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out)), "ngp_composite_fwd")
+    return out
+
+
+def composite_bwd(net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades=5, dout=None, zero_first=True):
+    n = numsteps_c.shape[0]
+    assert net.is_contiguous() and loss_grad.is_contiguous() and rgb_ray.is_contiguous()
+    if dout is None:
+        dout = torch.empty_like(net)
+    check(L.lib().ngp_composite_bwd(_stream(), n, net.shape[0], _p(net), _dt(net), _p(coords), _p(numsteps_c), _p(loss_grad), _p(rgb_ray), _p(density_grid_mean), cascades, _p(dout), int(zero_first)),
+          "ngp_composite_bwd")
+    return dout
+
+
+def composite_inference(net, coords, numsteps, cascades=5):
+    n = numsteps.shape[0]
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=net.device)
+    alpha = torch.empty((n, 1), dtype=torch.float32, device=net.device)
+    check(L.lib().ngp_composite_inference(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), cascades, _p(rgb), _p(alpha)), "ngp_composite_inference")
+    return rgb, alpha
+
+
+def huber(x, target, delta=0.1, want_loss=True, want_grad=True):
+    x, target = x.contiguous(), target.contiguous()
+    loss = torch.empty_like(x) if want_loss else None
+    grad = torch.empty_like(x) if want_grad else None
+    check(L.lib().ngp_huber(_stream(), x.numel(), _p(x), _p(target), delta, _p(loss), _p(grad)), "ngp_huber")
+    return loss, grad
+
+
+# ------------------------------------------------------------------ density grid
+def grid_mark_untrained(n_elements, focal, xforms, W, H, grid=None):
+    if grid is None:
+        grid = torch.empty(n_elements, dtype=torch.float32, device=focal.device)
+    check(L.lib().ngp_grid_mark_untrained(_stream(), n_elements, _p(grid), focal.shape[0], _p(focal.contiguous()), _p(xforms.contiguous()), int(W), int(H)), "ngp_grid_mark_untrained")
+    return grid
+
+
+def grid_generate_samples(n, rng_state, ema_step, aabb, grid, n_cascades, thresh, pos=None, idx=None):
+    if pos is None:
+        pos = torch.empty((n, 3), dtype=torch.float32, device=grid.device)
+    if idx is None:
+        idx = torch.empty(n, dtype=torch.int32, device=grid.device)
+    check(L.lib().ngp_grid_generate_samples(_stream(), n, rng_state.ctypes.data_as(C.c_void_p), _p(ema_step), aabb[0], aabb[1], _p(grid), _p(pos), _p(idx), n_cascades, thresh),
+          "ngp_grid_generate_samples")
+    return pos, idx
+
+
+def grid_splat_max(indices, density, grid_tmp):
+    check(L.lib().ngp_grid_splat_max(_stream(), indices.shape[0], _p(indices), _p(density), _dt(density), _p(grid_tmp)), "ngp_grid_splat_max")
+    return grid_tmp
+
+
+def grid_ema(grid, grid_tmp, decay=0.95):
+    check(L.lib().ngp_grid_ema(_stream(), grid.shape[0], decay, _p(grid), _p(grid_tmp)), "ngp_grid_ema")
+    return grid
+
+
+def grid_update_bitfield(grid, cascades=5, mean=None, bitfield=None):
+    if mean is None:
+        mean = torch.empty(1, dtype=torch.float32, device=grid.device)
+    if bitfield is None:
+        bitfield = torch.zeros(128 ** 3 * cascades // 8, dtype=torch.uint8, device=grid.device)
+    check(L.lib().ngp_grid_update_bitfield(_stream(), _p(grid), cascades, _p(mean), _p(bitfield)), "ngp_grid_update_bitfield")
+    return bitfield, mean
+
+
+# ------------------------------------------------------------------ optimiser / rays
+def adam_ema_step(p, g, m, v, ema, p_half, lr, step, b0=0.9, b1=0.99, eps=1e-15, ema_decay=0.95, zero_grad=True):
+    check(L.lib().ngp_adam_ema_step(_stream(), p.numel(), _p(p), _p(g), _dt(g), _p(m), _p(v), _p(ema), _p(p_half), lr, b0, b1, eps, step, ema_decay, int(zero_grad)), "ngp_adam_ema_step")
+
+
+def generate_rays(pixel_index, W, H, focal, metadata, xforms, images=None, bg=None):
+    n = pixel_index.shape[0]
+    dev = pixel_index.device
+    img = torch.empty(n, dtype=torch.int32, device=dev)
+    o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    target = torch.empty((n, 3), dtype=torch.float32, device=dev) if images is not None else None
+    check(L.lib().ngp_generate_rays(_stream(), n, _p(pixel_index), int(W), int(H), _p(focal), _p(metadata), _p(xforms), _p(images), _p(bg), _p(img), _p(o), _p(d), _p(target)), "ngp_generate_rays")
+    return img, o, d, target
+
+
+def selftest_mfma(device="cuda"):
+    res = torch.zeros(4, dtype=torch.int32, device=device)
+    check(L.lib().ngp_selftest_mfma(_stream(), _p(res)), "ngp_selftest_mfma")
+    r = res.cpu().numpy()
+    return int(r[0]), int(r[1]) & 0xFFFFFFFF

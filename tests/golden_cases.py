@@ -1,0 +1,124 @@
+"""Checks of an implementation (oracle.oracle on CPU, tests/hip_impl on the GPU) against tests/golden/golden_v1.npz.
+`exact=True` demands the bit-exactness the plain-C oracle achieves; the HIP path is held to bit-exactness for all integer /
+index / sample-record work and to stated float tolerances where device math (exp, fp16 accumulation order, atomics order) differs."""
+import hashlib
+import os
+import numpy as np
+import synth
+
+_G = None
+CASES = ["case_pcg32", "case_hash", "case_sh", "case_march_lego", "case_march_fox", "case_grid"]
+
+
+def load():
+    global _G
+    if _G is None:
+        _G = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz")))
+    return _G
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def close(a, b, atol, rtol=0.0, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b) - rtol * np.abs(b)
+    assert a.shape == b.shape and np.isfinite(a).all() and err.max() <= atol, f"{what}: max err {np.abs(a - b).max():.3e} (atol {atol}, rtol {rtol})"
+
+
+def case_pcg32(I, g, exact):
+    from oracle import oracle as O   # PCG32 host helper (the HIP path uses it only through march/generate kernels)
+    r = O.PCG32(1337)
+    assert np.array_equal(np.array([r.next_uint() for _ in range(32)], np.uint32), g["pcg_uints"])
+    r.advance(8 * 4095)
+    assert np.array_equal(np.array([r.next_float() for _ in range(4)], np.float32), g["pcg_after_adv"])
+    r.advance()
+    assert np.array_equal(r.st, g["pcg_state_end"])
+
+
+def case_hash(I, g, exact):
+    x, dy = g["hash_x"], g["hash_dy"]
+    for s in (1, 4):
+        table, offsets, n_params = I.level_table(s)
+        assert np.array_equal(offsets, g[f"hash_offsets_s{s}"])
+        for dt, nm in ((np.float32, "f32"), (np.float16, "f16")):
+            grid = synth.table(n_params, dt, amp=2.0)
+            out = I.hash_encode_fwd(x, grid, table)
+            ref = g[f"hash_fwd_s{s}_{nm}"]
+            # the reference evaluates the level scale with exp2f; ours is the correctly rounded value => <=1 ulp of scale
+            close(out, ref, atol=4e-3 if dt == np.float16 else 3e-5, what=f"hash fwd s{s} {nm}")
+            grad = I.hash_encode_bwd(x[:128], dy[:128].astype(dt), table, n_params)
+            idx, val = g[f"hash_bwd_idx_s{s}_{nm}"], g[f"hash_bwd_val_s{s}_{nm}"]
+            nz = np.flatnonzero(grad)
+            assert len(np.setxor1d(nz, idx)) <= max(4, len(idx) // 2000), "scatter touched different table entries"
+            close(grad[idx], val, atol=2e-4 if dt == np.float16 else 2e-7, rtol=2e-2 if dt == np.float16 else 1e-4, what=f"hash bwd s{s} {nm}")
+
+
+def case_sh(I, g, exact):
+    for dt, nm in ((np.float32, "f32"), (np.float16, "f16")):
+        out = I.sh_encode(g["sh_d"], dt)
+        if exact:
+            assert np.array_equal(out, g[f"sh_{nm}"])
+        else:
+            close(out, g[f"sh_{nm}"], atol=1e-6 if dt == np.float32 else 2e-3, what="sh")
+
+
+def _march(I, g, nm, const_dt, aabb, exact):
+    from oracle import oracle as O
+    o, d, bits = g["march_o"], g["march_d"], g["march_bits"]
+    rng = O.PCG32(1337)
+    coords, ns, cnt, ridx = I.march_rays(o, d, bits, aabb, rng, 128 * 1024, const_dt=const_dt)
+    M = int(cnt[1])
+    assert np.array_equal(ns, g[f"march_{nm}_numsteps"]) and np.array_equal(cnt, g[f"march_{nm}_counters"])
+    assert np.array_equal(rng.st, g[f"march_{nm}_rng_end"])
+    assert np.array_equal(coords[:M], g[f"march_{nm}_coords"]), "sample records differ"       # bit-exact, HIP included
+    assert np.array_equal(ridx, g[f"march_{nm}_rayidx"])
+    assert not coords[M:].any()
+    cap = M * 2 // 3
+    cc, nc, ccnt = I.compact_coords(coords[:M], ns, cap)
+    assert np.array_equal(nc, g[f"compact_{nm}_numsteps"]) and np.array_equal(ccnt, g[f"compact_{nm}_counter"])
+    net, bg, G, netfull = g[f"rgb_{nm}_net"], g[f"rgb_{nm}_bg"], g[f"rgb_{nm}_G"], g[f"rgb_{nm}_netfull"]
+    for dt, dn in ((np.float32, "f32"), (np.float16, "f16")):
+        f = I.composite_fwd(net.astype(dt), cc, ns, nc, bg)
+        b = I.composite_bwd(net.astype(dt), cc, nc, G, g[f"rgb_{nm}_fwd_{dn}"], 0.001)
+        ri, ra = I.composite_inference(netfull.astype(dt), coords[:M], ns)
+        if exact:
+            assert np.array_equal(f, g[f"rgb_{nm}_fwd_{dn}"]) and np.array_equal(b, g[f"rgb_{nm}_bwd_{dn}"])
+            assert np.array_equal(ri, g[f"rgb_{nm}_inf_{dn}"]) and np.array_equal(ra, g[f"rgb_{nm}_alpha_{dn}"])
+        else:   # device __expf / expf differ from glibc in the last ulps
+            close(f, g[f"rgb_{nm}_fwd_{dn}"], atol=2e-5, rtol=1e-5, what="composite fwd")
+            close(b, g[f"rgb_{nm}_bwd_{dn}"], atol=2e-6 if dt == np.float32 else 2e-4, rtol=1e-4 if dt == np.float32 else 4e-3, what="composite bwd")
+            close(ri, g[f"rgb_{nm}_inf_{dn}"], atol=2e-5, rtol=1e-5, what="composite inference")
+            close(ra, g[f"rgb_{nm}_alpha_{dn}"], atol=2e-5, what="alpha")
+
+
+def case_march_lego(I, g, exact):
+    _march(I, g, "lego", True, (0.0, 1.0), exact)
+
+
+def case_march_fox(I, g, exact):
+    _march(I, g, "fox", False, (-1.5, 2.5), exact)
+
+
+def case_grid(I, g, exact):
+    from oracle import oracle as O
+    xf6, focal6, _ = synth.camera_ring(6, radius=1.1)
+    n_el = 5 * 128 ** 3
+    grid0 = I.grid_mark_untrained(n_el, focal6, xf6, 64, 48)
+    assert np.array_equal(sha(grid0), g["grid_mark_sha"]) and (grid0 < 0).sum() == g["grid_mark_nneg"][0]
+    grid = np.where(grid0 < 0, grid0, synth.table(n_el, np.float32, amp=0.1) + 0.05).astype(np.float32)
+    rng = O.PCG32(1337)
+    pos, idx = I.grid_generate_samples(4096, rng, 3, (-1.5, 2.5), grid, 3, 0.01)
+    assert np.array_equal(idx, g["grid_gen_idx"]) and np.array_equal(pos, g["grid_gen_pos"]) and np.array_equal(rng.st, g["grid_gen_rng_end"])
+    tmp = I.grid_splat_max(idx, g["grid_mlp"], np.zeros(n_el, np.float32))
+    ema = I.grid_ema(grid.copy(), tmp)
+    bf, mean = I.grid_update_bitfield(ema)
+    if exact:
+        assert np.array_equal(sha(ema), g["grid_ema_sha"]) and np.array_equal(sha(bf), g["grid_bitfield_sha"]) and mean[0] == g["grid_mean"][0]
+    else:   # __expf in the splat and the parallel reduction order of the mean
+        ema_ref = O.grid_ema(grid.copy(), O.grid_splat_max(idx, g["grid_mlp"], np.zeros(n_el, np.float32)))
+        close(ema, ema_ref, atol=1e-7, rtol=1e-5, what="grid ema")
+        close(mean, g["grid_mean"], atol=0, rtol=1e-5, what="grid mean")
+        bf_ref, _ = O.grid_update_bitfield(ema)
+        assert np.array_equal(bf, bf_ref)

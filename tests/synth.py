@@ -92,3 +92,13 @@ def mlp_weights(seed=4):
     v2 = np.zeros((16, 64), np.float32); v2[:3] = u(3, 64)
     wc = np.concatenate([u(64, 32).ravel(), u(64, 64).ravel(), v2.ravel()])
     return wd, wc
+
+
+def table(n_params, dtype=np.float32, amp=1.0):
+    """Closed-form pseudo-random hash table in (-amp/2, amp/2): integer-only generator, so it is reproducible bit-for-bit anywhere."""
+    i = np.arange(n_params, dtype=np.uint64)
+    h = (i * np.uint64(2654435761) + np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x2C1B3C6D)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(12)
+    return (((h >> np.uint64(8)).astype(np.float64) / float(1 << 24) - 0.5) * amp).astype(dtype)

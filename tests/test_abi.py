@@ -1,0 +1,55 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds/loads here (hipcc cross-compiles for gfx950) and exports
+every symbol include/ngp_hip.h declares.  No compute calls — there is no GPU in this container."""
+import os
+import re
+import subprocess
+import numpy as np
+from jnerf_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ngp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.lib()
+    assert lib.ngp_abi_version() == 1
+    syms = declared_symbols()
+    assert len(syms) >= 26
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    for s in syms:
+        assert re.search(rf"\bT {s}\b", exported), f"{s} declared in include/ngp_hip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in jnerf_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_no_torch_types_or_cuda_compat_in_the_abi():
+    src = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
+    assert "torch" not in src.lower().replace("pytorch-rocm allocator", "") and "at::" not in src and "cuda" not in src.lower()
+
+
+def test_product_path_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "jnerf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libngp_oracle" not in txt, f
+
+
+def test_level_table_matches_reference_tables():
+    # BASELINE.md §3 / grid_encode.py:17-40
+    from jnerf_amd import ops
+    t, off, n = ops.level_table(1)
+    assert list(t[:, 2]) == [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 1073, 1483, 2048]
+    assert list(t[:5, 1]) == [4096, 12168, 29792, 79512, 205384] and all(t[5:, 1] == 524288) and n == 12196240
+    t, off, n = ops.level_table(4)
+    assert list(t[:, 2]) == [16, 25, 37, 56, 85, 128, 195, 295, 446, 676, 1024, 1553, 2353, 3566, 5405, 8192]
+    assert list(t[:4, 1]) == [4096, 15632, 50656, 175616] and all(t[4:, 1] == 524288) and n == 13074912
+    from oracle import oracle as O
+    for s in (1, 2, 4, 8, 16):
+        a, b = ops.level_table(s), O.level_table(s)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2] == b[2]

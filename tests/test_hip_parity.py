@@ -1,0 +1,208 @@
+"""-m gpu: the HIP path (through the C ABI, jnerf_amd.ops) against the CPU oracle and the committed golden fixture on the same
+seeded inputs; plus size-independent properties at BASELINE.json's full sizes (2^18 samples)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+import golden_cases as GC
+import synth
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hip_impl
+    return hip_impl
+
+
+def test_extension_loaded_and_mfma_layout(H):
+    from jnerf_amd import ops, _lib
+    assert _lib.lib().ngp_abi_version() == 1
+    bad, magic = ops.selftest_mfma()
+    assert magic == 0xC0FFEE, "self-test kernel did not run"
+    assert bad == 0, f"MFMA fragment layout assumption violated for {bad} elements"
+
+
+@pytest.mark.parametrize("case", [c for c in GC.CASES if c != "case_pcg32"])
+def test_hip_matches_golden(H, case):
+    getattr(GC, case)(H, GC.load(), exact=False)
+
+
+@pytest.mark.parametrize("aabb_scale", [1, 4])
+def test_hash_fwd_fp32_bit_exact_vs_oracle(H, aabb_scale):
+    from jnerf_amd import ops
+    table, offsets, n_params = O.level_table(aabb_scale)
+    x = synth.uniform_positions(4099, seed=5)          # ragged size
+    x[:4] = [[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0.5, 0.5, 0.5]]
+    grid = synth.table(n_params, np.float32, amp=2.0)
+    ref = O.hash_encode_fwd(x, grid, table)
+    out = H.hash_encode_fwd(x, grid, table)
+    assert np.array_equal(out, ref)                     # same indices, same fp32 op order
+    soa = H.hash_encode_fwd(x, grid, table, layout=ops.LAYOUT_SOA)   # [16, n, 2]
+    assert np.array_equal(soa.transpose(1, 0, 2).reshape(-1, 32), ref)
+    g16 = grid.astype(np.float16)
+    out16 = H.hash_encode_fwd(x, g16, table)
+    GC.close(out16, O.hash_encode_fwd(x, g16, table), atol=3e-3, what="fp16 fwd")
+    assert H.hash_encode_fwd(x[:0], grid, table).shape == (0, 32)    # empty input
+
+
+@pytest.mark.parametrize("dtype,grad_dtype", [(np.float32, None), (np.float16, None), (np.float16, torch.float32)])
+def test_hash_bwd_vs_oracle(H, dtype, grad_dtype):
+    from jnerf_amd import ops
+    table, offsets, n_params = O.level_table(4)
+    rng = np.random.default_rng(3)
+    x = synth.uniform_positions(3001, seed=6)
+    dy = (rng.normal(size=(3001, 32)) * 1e-2).astype(dtype)
+    dy[7] = 0                                            # zero rows are skipped
+    ref = O.hash_encode_bwd(x, dy.astype(np.float32), table, n_params)      # fp32 accumulation = ground truth
+    out = H.hash_encode_bwd(x, dy, table, n_params, grad_dtype=grad_dtype)
+    tol = dict(atol=1e-7, rtol=1e-5) if dtype == np.float32 else (dict(atol=2e-6, rtol=1e-3) if grad_dtype is not None else dict(atol=1e-4, rtol=2e-2))
+    GC.close(out, ref, what="hash bwd", **tol)
+    dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
+    out2 = H.hash_encode_bwd(x, dys, table, n_params, grad_dtype=grad_dtype, layout=ops.LAYOUT_SOA)
+    GC.close(out2, ref, what="hash bwd soa", **tol)
+
+
+def _field_inputs(n, seed=0):
+    rng = np.random.default_rng(seed)
+    feat = (rng.normal(size=(n, 32)) * 0.5).astype(np.float16)
+    d = synth.unit_dirs01(n, seed=seed + 1)
+    wd, wc = synth.mlp_weights(seed + 2)
+    wd, wc = wd.astype(np.float16), wc.astype(np.float16)
+    return feat, d, wd, wc
+
+
+@pytest.mark.parametrize("n", [16, 1000, 4096 + 5])
+def test_field_fwd_vs_oracle(H, n):
+    from jnerf_amd import ops
+    feat, d, wd, wc = _field_inputs(n)
+    sh = O.sh_encode(d, np.float32)
+    ref = O.field_fwd(feat.astype(np.float32), sh, wd.astype(np.float32), wc.astype(np.float32))
+    T = H.T
+    for layout in (ops.LAYOUT_AOS, ops.LAYOUT_SOA):
+        f = feat if layout == ops.LAYOUT_AOS else np.ascontiguousarray(feat.reshape(n, 16, 2).transpose(1, 0, 2))
+        for odt in (torch.float32, torch.float16):
+            out = H.N(ops.field_fwd(T(f), T(d), T(wd), T(wc), layout=layout, out_dtype=odt)).astype(np.float32)
+            # fp16 activations between layers vs the fp32 chain: relative to the output scale
+            GC.close(out, ref, atol=2e-2 * max(1.0, np.abs(ref).max()) * (1 if odt == torch.float32 else 2), what=f"field fwd layout {layout}")
+    den = H.N(ops.density_fwd(T(feat), T(wd), n, out_dtype=torch.float32))
+    GC.close(den, O.density_fwd(feat.astype(np.float32), wd.astype(np.float32)), atol=1e-2 * max(1.0, np.abs(ref[:, 3]).max()), what="density")
+    # strided direction rows, as the sampler hands them over (coords[:, 4:])
+    coords = np.zeros((n, 7), np.float32); coords[:, 4:] = d
+    tc = T(coords)
+    out = H.N(ops.field_fwd(T(feat), tc[:, 4:], T(wd), T(wc), out_dtype=torch.float32))
+    GC.close(out, ref, atol=2e-2 * max(1.0, np.abs(ref).max()), what="strided dirs")
+
+
+@pytest.mark.parametrize("n", [64, 1000, 8192 + 17])
+def test_field_bwd_vs_oracle(H, n):
+    from jnerf_amd import ops
+    feat, d, wd, wc = _field_inputs(n, seed=10)
+    rng = np.random.default_rng(20)
+    dout = (rng.normal(size=(n, 4)) * 1e-2).astype(np.float16)
+    sh = O.sh_encode(d, np.float32)
+    rdf, rdwd, rdwc = O.field_bwd(feat.astype(np.float32), sh, wd.astype(np.float32), wc.astype(np.float32), dout.astype(np.float32))
+    T = H.T
+    for layout in (ops.LAYOUT_AOS, ops.LAYOUT_SOA):
+        f = feat if layout == ops.LAYOUT_AOS else np.ascontiguousarray(feat.reshape(n, 16, 2).transpose(1, 0, 2))
+        dfeat, slabs = ops.field_bwd(T(f), T(d), T(wd), T(wc), T(dout), layout=layout)
+        dw = H.N(ops.reduce_slabs(slabs))
+        dfeat = H.N(dfeat).astype(np.float32)
+        if layout == ops.LAYOUT_SOA:
+            dfeat = dfeat.transpose(1, 0, 2).reshape(n, 32)
+        GC.close(dfeat, rdf, atol=3e-2 * np.abs(rdf).max(), what="dL/dfeat")
+        GC.close(dw[:3072], rdwd, atol=3e-2 * np.abs(rdwd).max(), what="dL/dW density")
+        GC.close(dw[3072:], rdwc, atol=3e-2 * np.abs(rdwc).max(), what="dL/dW rgb")
+        assert not dw[3072 + 6144 + 3 * 64:].any()       # padded rows of the last layer stay zero (fully_fused_mlp.py:136)
+
+
+@pytest.mark.parametrize("const_dt,aabb", [(True, (0.0, 1.0)), (False, (-1.5, 2.5))])
+def test_march_compacted_equals_march_then_compact(H, const_dt, aabb):
+    xf, focal, meta = synth.camera_ring(8, radius=1.3)
+    img, o, d, _ = synth.rays_from_cameras(xf, focal, meta, 64, 48, 4096, seed=9)
+    bits = synth.shell_bitfield()
+    r1, r2, r3 = O.PCG32(1337), O.PCG32(1337), O.PCG32(1337)
+    co, no, cnto, io = O.march_rays(o, d, bits, aabb, r1, 4096 * 1024, const_dt=const_dt)
+    ch, nh, cnth, ih = H.march_rays(o, d, bits, aabb, r2, 4096 * 1024, const_dt=const_dt)
+    M = int(cnto[1])
+    assert np.array_equal(nh, no) and np.array_equal(cnth, cnto) and np.array_equal(ch[:M], co[:M]) and np.array_equal(ih, io)
+    for cap in (M + 7, M // 2):
+        cc, nc, ccnt = O.compact_coords(co[:M], no, cap)
+        c2, n2, nc2, cnt4 = H.march_rays_compacted(o, d, bits, aabb, O.PCG32(1337), 4096 * 1024, cap, const_dt=const_dt)
+        k = min(M, cap)
+        assert np.array_equal(n2, no) and np.array_equal(nc2, nc) and np.array_equal(c2[:k], cc[:k])
+        assert cnt4[1] == cnto[1] and cnt4[2] == ccnt[0] and cnt4[3] == k
+    # capacity overflow in the marcher itself (ray_sampler.h:74-80)
+    small = M // 2
+    co2, no2, cnt2, _ = O.march_rays(o, d, bits, aabb, O.PCG32(1337), small, const_dt=const_dt)
+    ch2, nh2, cnth2, _ = H.march_rays(o, d, bits, aabb, O.PCG32(1337), small, const_dt=const_dt)
+    assert np.array_equal(nh2, no2) and np.array_equal(cnth2, cnt2) and np.array_equal(ch2, co2) and (no2[:, 0] == 0).any()
+    # empty batch
+    e = H.march_rays(o[:0], d[:0], bits, aabb, O.PCG32(1337), 16, const_dt=const_dt)
+    assert e[1].shape == (0, 2) and not e[2].any()
+
+
+def test_adam_ema_and_huber_and_rays(H):
+    rng = np.random.default_rng(1)
+    n = 4096 * 3 + 4
+    p = rng.normal(size=n).astype(np.float32); g = (rng.normal(size=n) * 1e-3).astype(np.float32); g[:100] = 0
+    m = (rng.normal(size=n) * 1e-3).astype(np.float32); v = (rng.random(n) * 1e-6).astype(np.float32); ema = p.copy() + 0.01
+    for step in (1, 2, 1000):
+        rp, rm, rv, re = p.copy(), m.copy(), v.copy(), ema.copy()
+        O.adam_ema_step(rp, g, rm, rv, re, 0.1, step)
+        hp, hm, hv, he, hh, hg = H.adam_ema_step(p, g, m, v, ema, 0.1, step, half=True)
+        GC.close(hp, rp, atol=1e-7, rtol=2e-6, what="adam p"); GC.close(hm, rm, atol=0, rtol=1e-6, what="adam m"); GC.close(hv, rv, atol=0, rtol=1e-6, what="adam v")
+        GC.close(he, re, atol=1e-7, rtol=2e-6, what="ema"); assert np.array_equal(hh, hp.astype(np.float16)) and not hg.any()
+        hp16 = H.adam_ema_step(p, g.astype(np.float16), m, v, None, 0.1, step)[0]
+        rp2, rm2, rv2 = p.copy(), m.copy(), v.copy()
+        O.adam_ema_step(rp2, g.astype(np.float16).astype(np.float32), rm2, rv2, None, 0.1, step)
+        GC.close(hp16, rp2, atol=1e-7, rtol=2e-6, what="adam fp16 grads, no ema")
+    x, t = rng.random((999, 3), dtype=np.float32), rng.random((999, 3), dtype=np.float32)
+    l, gr = H.huber(x, t)
+    rl, rg = O.huber(x, t)
+    assert np.array_equal(l, rl) and np.array_equal(gr, rg)
+    xf, focal, meta = synth.camera_ring(5)
+    idx = rng.integers(0, 5 * 64 * 48, size=2000)
+    hi, ho, hd = H.generate_rays(idx, 64, 48, focal, meta, xf)
+    ri, ro, rd = O.generate_rays(idx, 64, 48, focal, meta[:, 4:6], xf)
+    assert np.array_equal(hi, ri) and np.array_equal(ho, ro)
+    GC.close(hd, rd, atol=2e-7, what="ray dirs")
+
+
+def test_full_size_properties(H):
+    """BASELINE.json full size (2^18 samples): properties that need no CPU oracle run."""
+    from jnerf_amd import ops
+    T = H.T
+    n = 1 << 18
+    table, offsets, n_params = ops.level_table(4)
+    x = torch.rand((n, 3), device="cuda")
+    g1 = T(synth.table(n_params, np.float32, amp=2.0)); g2 = torch.flip(g1, [0]).contiguous()
+    # linearity of the encoding in the table
+    a, b, c = ops.hash_encode_fwd(x, g1, table), ops.hash_encode_fwd(x, g2, table), ops.hash_encode_fwd(x, 2 * g1 - 3 * g2, table)
+    assert torch.allclose(c, 2 * a - 3 * b, atol=2e-5)
+    # partition of unity: a constant table encodes to that constant
+    ones = ops.hash_encode_fwd(x, torch.full_like(g1, 0.75), table)
+    assert torch.allclose(ones, torch.full_like(ones, 0.75), atol=1e-6)
+    # adjointness <encode(x; G), dY> == <G, scatter(x; dY)>
+    dy = torch.randn((n, 32), device="cuda") * 1e-2
+    grad = ops.hash_encode_bwd(x, dy, table, n_params)
+    lhs, rhs = (a.double() * dy.double()).sum().item(), (g1.double() * grad.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)), (lhs, rhs)
+    # mass conservation of the scatter per level: sum of a level's gradient == sum of dY over that level's two features
+    for l in (0, 5, 15):
+        lo, hi = int(offsets[l]) * 2, int(offsets[l + 1]) * 2
+        assert abs(grad[lo:hi].double().sum().item() - dy[:, 2 * l:2 * l + 2].double().sum().item()) < 1e-4
+    # compositing: alpha + transmittance == 1, colours inside [0,1] for a white field
+    xf, focal, meta = synth.camera_ring(16, radius=1.3)
+    img, o, d, _ = synth.rays_from_cameras(xf, focal, meta, 64, 48, 8192, seed=4)
+    bits = T(synth.shell_bitfield())
+    coords, ns, nsc, cnt = ops.march_rays_compacted(T(o), T(d), bits, (-1.5, 2.5), O.PCG32(1337).st, 4096 * 1024, n, const_dt=False)
+    k = int(cnt[3].item())
+    assert 0 < k <= n
+    net = torch.zeros((n, 4), device="cuda"); net[:, :3] = 20.0; net[:, 3] = 3.0
+    rgb, alpha = ops.composite_inference(net, coords, nsc)
+    assert torch.allclose(rgb, alpha.expand(-1, 3), atol=1e-5) and (alpha >= 0).all() and (alpha <= 1 + 1e-6).all()
+    ns64 = ns.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert (np.diff(ns64[:, 1]) >= 0).all() and ns64[:, 0].max() <= 1024      # ray-ordered bases, MAX_STEP respected
