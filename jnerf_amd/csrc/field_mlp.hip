@@ -62,11 +62,18 @@ __device__ __forceinline__ half8 pack_relu(floatx4 a, floatx4 b) {
 	for (int k = 0; k < 4; ++k) { r[k] = (_Float16)fmaxf(a[k], 0.f); r[4 + k] = (_Float16)fmaxf(b[k], 0.f); }
 	return r;
 }
-__device__ __forceinline__ half8 pack_masked(floatx4 a, floatx4 b, half8 act) {   // relu'(act) * grad
+// relu'(pre-activation) * grad; the mask is taken from the fp32 accumulator (bit k of `mask` <-> slot k), not from the rounded fp16 activation
+__device__ __forceinline__ half8 pack_masked(floatx4 a, floatx4 b, uint32_t mask) {
 	half8 r;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) { r[k] = act[k] > (_Float16)0 ? (_Float16)a[k] : (_Float16)0; r[4 + k] = act[4 + k] > (_Float16)0 ? (_Float16)b[k] : (_Float16)0; }
+	for (int k = 0; k < 4; ++k) { r[k] = (mask >> k) & 1u ? (_Float16)a[k] : (_Float16)0; r[4 + k] = (mask >> (4 + k)) & 1u ? (_Float16)b[k] : (_Float16)0; }
 	return r;
+}
+__device__ __forceinline__ uint32_t relu_mask(floatx4 a, floatx4 b) {
+	uint32_t m = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { m |= a[k] > 0.f ? (1u << k) : 0u; m |= b[k] > 0.f ? (1u << (4 + k)) : 0u; }
+	return m;
 }
 
 // degree-4 SH of (2d-1), components 4g..4g+3 (SphericalEncode.h:77-95)
@@ -95,7 +102,7 @@ __device__ __forceinline__ half8 load_feat(const _Float16 *__restrict__ feat, ui
 	return r;
 }
 
-struct FwdState { half8 feat, hfrag[2], in2, g0[2], g1[2]; floatx4 den, rgb; };
+struct FwdState { half8 feat, hfrag[2], in2, g0[2], g1[2]; floatx4 den, rgb; uint32_t mh[2], mg0[2], mg1[2]; };
 
 template <bool DENSITY_ONLY>
 __device__ __forceinline__ void forward_tile(const _Float16 *wl, int lane, half8 feat, const float sh[4], FwdState &st) {
@@ -105,6 +112,7 @@ __device__ __forceinline__ void forward_tile(const _Float16 *wl, int lane, half8
 	for (int t = 0; t < 4; ++t) c0[t] = MFMA(ld_frag(wl, t, lane), feat, z);
 	st.feat = feat;
 	st.hfrag[0] = pack_relu(c0[0], c0[1]); st.hfrag[1] = pack_relu(c0[2], c0[3]);
+	st.mh[0] = relu_mask(c0[0], c0[1]); st.mh[1] = relu_mask(c0[2], c0[3]);
 	floatx4 d = MFMA(ld_frag(wl, 4, lane), st.hfrag[0], z);
 	d = MFMA(ld_frag(wl, 5, lane), st.hfrag[1], d);
 	st.den = d;
@@ -117,10 +125,12 @@ __device__ __forceinline__ void forward_tile(const _Float16 *wl, int lane, half8
 #pragma unroll
 	for (int t = 0; t < 4; ++t) c2[t] = MFMA(ld_frag(wl, 6 + t, lane), in2, z);
 	st.g0[0] = pack_relu(c2[0], c2[1]); st.g0[1] = pack_relu(c2[2], c2[3]);
+	st.mg0[0] = relu_mask(c2[0], c2[1]); st.mg0[1] = relu_mask(c2[2], c2[3]);
 	floatx4 c3[4];
 #pragma unroll
 	for (int t = 0; t < 4; ++t) { c3[t] = MFMA(ld_frag(wl, 10 + 2 * t, lane), st.g0[0], z); c3[t] = MFMA(ld_frag(wl, 11 + 2 * t, lane), st.g0[1], c3[t]); }
 	st.g1[0] = pack_relu(c3[0], c3[1]); st.g1[1] = pack_relu(c3[2], c3[3]);
+	st.mg1[0] = relu_mask(c3[0], c3[1]); st.mg1[1] = relu_mask(c3[2], c3[3]);
 	floatx4 o = MFMA(ld_frag(wl, 18, lane), st.g1[0], z);
 	st.rgb = MFMA(ld_frag(wl, 19, lane), st.g1[1], o);
 }
@@ -222,10 +232,10 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16
 		floatx4 c[4];
 #pragma unroll
 		for (int t = 0; t < 4; ++t) c[t] = MFMA(ld_frag(wb, t, lane), dO, z);
-		const half8 dG1lo = pack_masked(c[0], c[1], st.g1[0]), dG1hi = pack_masked(c[2], c[3], st.g1[1]);
+		const half8 dG1lo = pack_masked(c[0], c[1], st.mg1[0]), dG1hi = pack_masked(c[2], c[3], st.mg1[1]);
 #pragma unroll
 		for (int t = 0; t < 4; ++t) { c[t] = MFMA(ld_frag(wb, 4 + 2 * t, lane), dG1lo, z); c[t] = MFMA(ld_frag(wb, 5 + 2 * t, lane), dG1hi, c[t]); }
-		const half8 dG0lo = pack_masked(c[0], c[1], st.g0[0]), dG0hi = pack_masked(c[2], c[3], st.g0[1]);
+		const half8 dG0lo = pack_masked(c[0], c[1], st.mg0[0]), dG0hi = pack_masked(c[2], c[3], st.mg0[1]);
 		floatx4 dD = MFMA(ld_frag(wb, 12, lane), dG0lo, z);
 		dD = MFMA(ld_frag(wb, 13, lane), dG0hi, dD);
 		if (g == 0) dD[0] += go[3];                               // out[:,3] = den[:,0]  (ngp_network.py:83)
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16
 		for (int j = 0; j < 4; ++j) { dDf[j] = (_Float16)dD[j]; dDf[4 + j] = (_Float16)0; }
 #pragma unroll
 		for (int t = 0; t < 4; ++t) c[t] = MFMA(ld_frag(wb, 14 + t, lane), dDf, z);
-		const half8 dHlo = pack_masked(c[0], c[1], st.hfrag[0]), dHhi = pack_masked(c[2], c[3], st.hfrag[1]);
+		const half8 dHlo = pack_masked(c[0], c[1], st.mh[0]), dHhi = pack_masked(c[2], c[3], st.mh[1]);
 		floatx4 dF[2];
 #pragma unroll
 		for (int t = 0; t < 2; ++t) { dF[t] = MFMA(ld_frag(wb, 18 + 2 * t, lane), dHlo, z); dF[t] = MFMA(ld_frag(wb, 19 + 2 * t, lane), dHhi, dF[t]); }

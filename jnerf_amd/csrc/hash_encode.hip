@@ -137,10 +137,10 @@ static LevelTable load_table(const uint32_t *host) { LevelTable lt; for (int i =
 
 NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *table, const uint32_t *level_table_host,
                                 void *out, int dtype, int out_layout, const uint32_t *n_valid) {
-	NGP_REQUIRE(pos && table && level_table_host && out, NGP_E_ARG, "ngp_hash_encode_fwd: null pointer");
+	NGP_REQUIRE(n == 0 || (pos && table && level_table_host && out), NGP_E_ARG, "ngp_hash_encode_fwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_fwd: bad dtype %d", dtype);
-	NGP_REQUIRE(pos_stride >= 3, NGP_E_ARG, "ngp_hash_encode_fwd: pos stride %u < 3", pos_stride);
 	if (n == 0) return 0;
+	NGP_REQUIRE(pos_stride >= 3, NGP_E_ARG, "ngp_hash_encode_fwd: pos stride %u < 3", pos_stride);
 	const uint32_t nblk = div_up(n, 256);
 	const dim3 grid(16 * nblk), block(256);
 	const LevelTable lt = load_table(level_table_host);
@@ -155,7 +155,7 @@ NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint
 
 NGP_API int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
                                 void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid) {
-	NGP_REQUIRE(pos && dLdy && level_table_host && grad, NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
+	NGP_REQUIRE(grad && (n == 0 || (pos && dLdy && level_table_host)), NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_bwd: bad dtype %d", dtype);
 	NGP_REQUIRE(grad_dtype == NGP_F32 || (grad_dtype == NGP_F16 && dtype == NGP_F16), NGP_E_DTYPE, "ngp_hash_encode_bwd: bad grad dtype %d for dtype %d", grad_dtype, dtype);
 	hipStream_t s = (hipStream_t)stream;

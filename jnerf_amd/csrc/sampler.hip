@@ -199,7 +199,7 @@ __global__ __launch_bounds__(128) void k_march_write(uint32_t n_rays, MarchParam
 }
 
 static int check_march_args(const char *fn, uint32_t n_rays, const void *a, const void *b, const void *c, const void *d, int cascades) {
-	NGP_REQUIRE(a && b && c && d, NGP_E_ARG, "%s: null pointer", fn);
+	NGP_REQUIRE(n_rays == 0 || (a && b && c && d), NGP_E_ARG, "%s: null pointer", fn);
 	NGP_REQUIRE(cascades >= 1 && cascades <= 8, NGP_E_ARG, "%s: cascades %d out of range", fn, cascades);
 	NGP_REQUIRE(n_rays <= (1u << 18), NGP_E_CAPACITY, "%s: n_rays %u exceeds 2^18", fn, n_rays);
 	return 0;
@@ -216,10 +216,10 @@ NGP_API int ngp_march_rays(void *stream, uint32_t n_rays, const float *rays_o, c
                            float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                            float *coords, uint32_t *numsteps, uint32_t *counters, int32_t *ray_indices, uint32_t *scratch, int zero_coords) {
 	int rc = check_march_args("ngp_march_rays", n_rays, rays_o, rays_d, bitfield, coords, cascades); if (rc) return rc;
-	NGP_REQUIRE(numsteps && counters && scratch && rng_state_host, NGP_E_ARG, "ngp_march_rays: null pointer");
+	NGP_REQUIRE(counters && rng_state_host && (n_rays == 0 || (numsteps && scratch)), NGP_E_ARG, "ngp_march_rays: null pointer");
 	hipStream_t s = (hipStream_t)stream;
 	const MarchParams p = make_params(aabb0, aabb1, near_distance, cone_angle, const_dt, cascades, rng_state_host);
-	if (zero_coords) { hipError_t e = hipMemsetAsync(coords, 0, (size_t)max_samples * 28, s); if (e != hipSuccess) { ngp_set_error("ngp_march_rays memset: %s", hipGetErrorString(e)); return (int)e; } }
+	if (zero_coords && coords) { hipError_t e = hipMemsetAsync(coords, 0, (size_t)max_samples * 28, s); if (e != hipSuccess) { ngp_set_error("ngp_march_rays memset: %s", hipGetErrorString(e)); return (int)e; } }
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 8, s); return 0; }
 	hipLaunchKernelGGL(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, (float *)nullptr);
 	hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, n_rays, max_samples, 0u, (const uint32_t *)scratch, numsteps, (uint32_t *)nullptr, ray_indices, counters, 2);
@@ -232,7 +232,7 @@ NGP_API int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float 
                                      float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                                      uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch) {
 	int rc = check_march_args("ngp_march_rays_compacted", n_rays, rays_o, rays_d, bitfield, coords_out, cascades); if (rc) return rc;
-	NGP_REQUIRE(numsteps && numsteps_compacted && counters && scratch && rng_state_host, NGP_E_ARG, "ngp_march_rays_compacted: null pointer");
+	NGP_REQUIRE(counters && rng_state_host && (n_rays == 0 || (numsteps && numsteps_compacted && scratch)), NGP_E_ARG, "ngp_march_rays_compacted: null pointer");
 	hipStream_t s = (hipStream_t)stream;
 	const MarchParams p = make_params(aabb0, aabb1, near_distance, cone_angle, const_dt, cascades, rng_state_host);
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 16, s); return 0; }

@@ -14,7 +14,7 @@ def _stream():
 
 
 def _p(t):
-    if t is None:
+    if t is None or t.numel() == 0:
         return None
     assert t.is_cuda, "libngp_hip needs device tensors (there is no CPU path)"
     return C.c_void_p(t.data_ptr())
@@ -30,7 +30,10 @@ def _dt(t):
 
 def _rows(t, width):
     """(pointer-able tensor, row stride in floats) for a [n,width] fp32 view whose rows may be strided (e.g. coords[:, 4:])."""
-    assert t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == width and t.stride(1) == 1, (t.dtype, t.shape, t.stride())
+    assert t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == width, (t.dtype, t.shape)
+    if t.shape[0] == 0:
+        return t, width
+    assert t.stride(1) == 1, t.stride()
     return t, int(t.stride(0))
 
 

@@ -119,6 +119,9 @@ def case_grid(I, g, exact):
     else:   # __expf in the splat and the parallel reduction order of the mean
         ema_ref = O.grid_ema(grid.copy(), O.grid_splat_max(idx, g["grid_mlp"], np.zeros(n_el, np.float32)))
         close(ema, ema_ref, atol=1e-7, rtol=1e-5, what="grid ema")
-        close(mean, g["grid_mean"], atol=0, rtol=1e-5, what="grid mean")
+        # the reference (and the serial oracle) add 2M terms in sequence in fp32; the wave-parallel sum is the more accurate one
+        close(mean, g["grid_mean"], atol=0, rtol=1e-3, what="grid mean")
+        exact_mean = np.maximum(ema[:128 ** 3].astype(np.float64), 0).sum() / 128 ** 3
+        close(mean, [exact_mean], atol=0, rtol=1e-5, what="grid mean vs fp64")
         bf_ref, _ = O.grid_update_bitfield(ema)
         assert np.array_equal(bf, bf_ref)
