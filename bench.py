@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""bench.py — Instant-NGP training throughput on MI355X (BASELINE.json metric "training iters/s", config[1]: fox-config
+Instant-NGP, L=16 hash levels, T=2^19, fp16 fused MLP, 2^18-sample batches; synthetic procedural scene, random-init weights).
+
+One "step" = one full training iteration of Runner.train (ray generation + random background, occupancy-grid marching/compaction,
+hash encode, fused MLP, compositing, Huber, backward, fused Adam+EMA; occupancy-grid update every 16th step) over one 2^18-sample batch.
+`value` = (n_gpus * steps) / seconds: iterations per second where every rank trains its own 2^18-sample ray batch and the hash-table /
+MLP gradients are all-reduced over RCCL each step (weak scaling; at n_gpus=1 this is exactly the reference's it/s).
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(n_samples=1 << 15, n_rays=512):
+    """the oracle (plain-C port of the reference's kernels, 1 thread) on a bounded slice of one training iteration: every hot-path stage on
+    n_samples of the 2^18 samples and the parameter update on the same fraction of the 13 M parameters; scaled to iterations/s"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    import synth
+    frac = n_samples / float(1 << 18)
+    table, offsets, n_params = O.level_table(4)
+    grid = synth.table(n_params, np.float16, amp=2e-4)
+    x = synth.uniform_positions(n_samples)
+    d = synth.unit_dirs01(n_samples)
+    wd, wc = synth.mlp_weights()
+    coords = np.zeros((n_samples, 7), np.float32); coords[:, :3] = x; coords[:, 4:] = d
+    per = n_samples // n_rays
+    ns = np.stack([np.full(n_rays, per, np.uint32), (np.arange(n_rays) * per).astype(np.uint32)], 1)
+    bg = np.random.default_rng(0).random((n_rays, 3), dtype=np.float32)
+    t0 = time.perf_counter()
+    feat = O.hash_encode_fwd(x, grid, table)
+    sh = O.sh_encode(d, np.float32)
+    out = O.field_fwd(feat.astype(np.float32), sh, wd, wc)
+    rgb = O.composite_fwd(out, coords, ns, ns, bg)
+    _, G = O.huber(rgb, bg)
+    dout = O.composite_bwd(out, coords, ns, G, rgb, 0.001)
+    dfeat, dwd, dwc = O.field_bwd(feat.astype(np.float32), sh, wd, wc, dout)
+    g = O.hash_encode_bwd(x, dfeat.astype(np.float16), table, n_params)
+    npar = int(n_params * frac) // 4 * 4
+    p = np.zeros(npar, np.float32); m = np.zeros_like(p); v = np.zeros_like(p); e = np.zeros_like(p)
+    O.adam_ema_step(p, g[:npar].astype(np.float32), m, v, e, 0.1, 1)
+    t = time.perf_counter() - t0
+    return {"value": round(frac / t, 4), "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"1/{int(1 / frac)} of one iteration ({n_samples} of 2^18 samples through hash fwd/bwd, SH, both MLPs fwd/bwd, compositing fwd/bwd, Huber; "
+                      f"Adam+EMA on {npar} of {n_params} parameters), {t:.1f} s on 1 core, scaled"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--images", type=int, default=50)
+    ap.add_argument("--res", type=int, default=400)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from jnerf_amd import ops
+    from jnerf_amd.presets import ngp_cfg
+    from jnerf_amd.runner import Runner
+    torch.manual_seed(1234 + rank)
+    ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=args.images, W=args.res, H=args.res, device=f"cuda:{local_rank}", rank=rank, world_size=world)
+    runner = Runner()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        runner.train_step(step); step += 1
+    valid_sum = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.PROFILE = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.train_step(step); step += 1
+        valid_sum += runner.sampler._counters[3]
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    mean_valid = float(valid_sum.item()) / max(args.steps, 1)
+
+    # ---- per-kernel HIP-event times over the timed region -> roofline of the dominant kernel
+    P = runner.model.pos_encoder.n_params
+    alg_bytes = {   # algorithmic bytes per launch: per-sample figures x samples actually processed, per-parameter x parameters
+        "hash_fwd": mean_valid * (12 + 16 * 8 * 4 + 64),
+        "hash_bwd": mean_valid * (12 + 64 + 16 * 8 * 8),
+        "field_fwd": mean_valid * (64 + 12 + 8),
+        "field_bwd": mean_valid * (64 + 12 + 8 + 64),
+        "adam_ema": None,
+    }
+    times = {}
+    for name, evs in prof.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        times[name] = (sum(ms) / len(ms), len(ms), sum(ms))
+    adam_calls = [a.elapsed_time(b) for a, b in prof.get("adam_ema", [])]
+    roof = None
+    if times:
+        per_step = {k: v[2] / max(args.steps, 1) for k, v in times.items()}
+        dom = max((k for k in per_step if k in alg_bytes), key=lambda k: per_step[k])
+        if dom == "adam_ema":      # three launches per step (table + two weight packs); the table launch is the one that matters
+            avg_ms = max(adam_calls[i] for i in range(len(adam_calls))) if adam_calls else 0.0
+            avg_ms = sum(sorted(adam_calls)[-args.steps:]) / max(args.steps, 1)
+            nbytes = P * (5 * 4 + 5 * 4 + 2)
+        else:
+            avg_ms = times[dom][0]
+            nbytes = alg_bytes[dom]
+        achieved = nbytes / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                "traffic": None, "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(nbytes),
+                "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
+
+    extra = {"mean_samples_per_batch": round(mean_valid, 1), "rays_per_batch": runner.sampler.n_rays_per_batch}
+    if not args.no_psnr and rank == 0:
+        import numpy as np
+        from jnerf_amd.utils.registry import build_from_cfg, DATASETS
+        runner.dataset["test"] = build_from_cfg(runner.cfg.dataset.test, DATASETS)
+        torch.cuda.synchronize(); tr0 = time.perf_counter()
+        img, _, tar = runner.render_img("test", 0)
+        torch.cuda.synchronize(); tr = time.perf_counter() - tr0
+        extra["psnr_test_view_after_%d_steps" % step] = round(float(-10 * np.log10(np.mean((img - tar) ** 2))), 2)
+        extra["render_Msamples_per_s"] = round(runner.n_samples_rendered / tr / 1e6, 2)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        line = {"metric": "training iters/s", "value": round(world * args.steps / dt, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                "config": {"workload": "Instant-NGP fox config (ngp_fox.py hyper-parameters: aabb_scale 4, L=16, T=2^19, F=2, fp16 fused MLP, const_dt=False, 2^18-sample batches), "
+                                       f"procedural scene {args.images}x{args.res}x{args.res} RGBA, random-init weights",
+                           "samples_per_iter_per_gpu": 1 << 18, "parallelism": f"ray-batch dp{world}" if world > 1 else "single"},
+                "roofline": roof, "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(), "extra": extra}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

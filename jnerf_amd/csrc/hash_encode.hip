@@ -15,6 +15,7 @@
 //    fully coalesced 256-B wave accesses (no 4-byte-per-64-byte-line partial writes from sixteen different XCDs).
 //  * backward uses hardware float atomics (global_atomic_add_f32 / global_atomic_pk_add_f16), gradient zeroing is a fused memset.
 #include "ngp_common.h"
+#include <stdlib.h>
 #pragma clang fp contract(off)
 
 template <typename T> struct Pair;
@@ -133,6 +134,192 @@ __global__ __launch_bounds__(256) void k_hash_bwd(uint32_t n, const float *__res
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- owner-computes scatter
+// Measured on MI355X (tools/microbench_hash.py, profiles/): float atomics to global memory retire at ~20 G instructions/s chip-wide no
+// matter how local they are, i.e. >= 3.3 ms for the 2 x 33.5 M updates of one 2^18-sample batch (7.8 ms on real, spatially concentrated
+// samples).  This kernel removes them: every workgroup OWNS a contiguous slice of one level's table (16384 entries = 128 KiB of fp32
+// pairs in its LDS — a CU has 160 KiB), scans the samples, recomputes the eight corner indices and accumulates only the corners that
+// fall inside its slice with LDS atomics (ds_add_f32, orders of magnitude faster than memory-side atomics).  A slice owned by a
+// single workgroup is written back with plain coalesced stores: no global atomics, no memset of the 50 MB gradient, and the table
+// gradient becomes deterministic up to the fp32 add order inside one workgroup.  The small dense levels (whose whole table fits one
+// slice and whose updates collide heavily) are instead split over up to 32 sample chunks with a private LDS copy each and a short
+// atomic flush (a few thousand adds per workgroup).  The redundant index arithmetic (each sample is visited by every slice owner of a
+// level) is ~1e10 lane-ops per batch — about 0.15 ms of VALU time on 256 CUs — and the sample stream is re-read from L2, not HBM.
+#define OWN_SLICE 16384u
+struct OwnerPlan { uint32_t first_unit[17]; uint32_t chunks[16]; uint32_t order[16]; };
+
+template <typename T, typename G, int LAYOUT, bool HASHED, bool COMBINE>
+__device__ __forceinline__ void owner_unit(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, const LevelTable &lt, uint32_t level,
+                                           uint32_t slice, uint32_t chunk, uint32_t n_chunks, G *__restrict__ grad, int accumulate, uint32_t lim, float *acc) {
+	using P = typename Pair<T>::type;
+	using GP = typename Pair<G>::type;
+	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
+	const float scale = __uint_as_float(lt.v[4 * level + 3]);
+	const uint32_t lo = slice * OWN_SLICE;
+	const uint32_t cnt = min(OWN_SLICE, size - lo);
+	for (uint32_t e = threadIdx.x; e < cnt * 2; e += 1024) acc[e] = 0.f;
+	__syncthreads();
+	const uint32_t per = ((lim + n_chunks - 1) / n_chunks + 7u) & ~7u;
+	const uint32_t begin = min(chunk * per, lim), end = min(begin + per, lim);
+	const P *dy = reinterpret_cast<const P *>(dLdy);
+	const uint32_t res2 = res * res;
+	// Each thread takes OWN_K consecutive samples per trip: (a) all of their loads are issued before the first use (the loop is otherwise
+	// latency-bound: two dependent L2 round trips per sample), (b) neighbouring lanes are OWN_K samples apart, so the consecutive samples
+	// of one ray — which share cells on the coarse levels — never meet in the same ds_add and LDS same-address serialisation disappears.
+	constexpr uint32_t OWN_K = 8;
+	for (uint32_t base = begin + threadIdx.x * OWN_K; base < end; base += 1024 * OWN_K) {
+		float px[OWN_K][3]; float2 gk[OWN_K];
+		if (base + OWN_K <= end && stride == 3) {
+			const float4 *p4 = reinterpret_cast<const float4 *>(pos + (size_t)base * 3);    // 24 floats, 16-byte aligned (base % 8 == 0)
+			float4 v[6];
+#pragma unroll
+			for (int r = 0; r < 6; ++r) v[r] = p4[r];
+			const float *f = reinterpret_cast<const float *>(v);
+#pragma unroll
+			for (uint32_t kk = 0; kk < OWN_K; ++kk) { px[kk][0] = f[3 * kk]; px[kk][1] = f[3 * kk + 1]; px[kk][2] = f[3 * kk + 2]; }
+#pragma unroll
+			for (uint32_t kk = 0; kk < OWN_K; ++kk) gk[kk] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + base + kk] : dy[(size_t)(base + kk) * 16 + level]);
+		} else {
+#pragma unroll
+			for (uint32_t kk = 0; kk < OWN_K; ++kk) {
+				const uint32_t i = base + kk;
+				if (i < end) {
+					px[kk][0] = pos[(size_t)i * stride]; px[kk][1] = pos[(size_t)i * stride + 1]; px[kk][2] = pos[(size_t)i * stride + 2];
+					gk[kk] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level]);
+				} else { px[kk][0] = px[kk][1] = px[kk][2] = 0.f; gk[kk] = make_float2(0.f, 0.f); }
+			}
+		}
+		if (COMBINE) {
+			// Coarse levels: the consecutive samples a thread holds (one or two rays) mostly sit in ONE cell.  Their eight corner
+			// contributions are summed in registers and sent to LDS once per run — ds_add_f32 retires ~1 lane per 3 cycles on gfx950
+			// (tools/microbench_lds.py), so the hot slices of the small dense levels would otherwise serialise for milliseconds.
+			uint32_t key[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, local[8], hits = 0;
+			float ax[8], ay[8];
+#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q) { ax[q] = 0.f; ay[q] = 0.f; local[q] = 0; }
+#pragma unroll
+			for (uint32_t kk = 0; kk <= OWN_K; ++kk) {
+				Corner c;
+				bool same = false;
+				float2 g2 = make_float2(0.f, 0.f);
+				if (kk < OWN_K) {
+					g2 = gk[kk];
+#pragma unroll
+					for (int d = 0; d < 3; ++d) { const float p = px[kk][d] * scale + 0.5f; const float fl = floorf(p); c.g[d] = (uint32_t)(int)fl; c.w[d] = p - fl; }
+					same = c.g[0] == key[0] && c.g[1] == key[1] && c.g[2] == key[2];
+				}
+				if (!same) {                                  // run ends (or final flush at kk == OWN_K)
+#pragma unroll
+					for (uint32_t q = 0; q < 8; ++q) {
+						if ((hits >> q) & 1u) {
+							if (ax[q] != 0.f || ay[q] != 0.f) {
+								__hip_atomic_fetch_add(&acc[2 * local[q]], ax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+								__hip_atomic_fetch_add(&acc[2 * local[q] + 1], ay[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							}
+						}
+						ax[q] = 0.f; ay[q] = 0.f;
+					}
+					if (kk < OWN_K) {
+						key[0] = c.g[0]; key[1] = c.g[1]; key[2] = c.g[2];
+						uint32_t tx[2], ty[2], tz[2];
+						tx[0] = c.g[0]; tx[1] = c.g[0] + 1;
+						if (HASHED) { ty[0] = c.g[1] * 19349663u; ty[1] = ty[0] + 19349663u; tz[0] = c.g[2] * 83492791u; tz[1] = tz[0] + 83492791u; }
+						else { ty[0] = c.g[1] * res; ty[1] = ty[0] + res; tz[0] = c.g[2] * res2; tz[1] = tz[0] + res2; }
+						hits = 0;
+#pragma unroll
+						for (uint32_t q = 0; q < 8; ++q) {
+							uint32_t idx;
+							if (HASHED) idx = (tx[q & 1] ^ ty[(q >> 1) & 1] ^ tz[q >> 2]) & (size - 1);
+							else { idx = tx[q & 1] + ty[(q >> 1) & 1] + tz[q >> 2]; if (idx >= size) idx %= size; }
+							local[q] = idx - lo;
+							hits |= (local[q] < cnt) ? (1u << q) : 0u;
+						}
+					}
+				}
+				if (kk < OWN_K && hits) {
+					const float x1 = c.w[0], x0 = 1 - c.w[0], y1 = c.w[1], y0 = 1 - c.w[1], z1 = c.w[2], z0 = 1 - c.w[2];
+					const float xy[4] = {x0 * y0, x1 * y0, x0 * y1, x1 * y1};
+#pragma unroll
+					for (uint32_t q = 0; q < 8; ++q) { const float wq = xy[q & 3] * ((q >> 2) ? z1 : z0); ax[q] += wq * g2.x; ay[q] += wq * g2.y; }
+				}
+			}
+			continue;
+		}
+#pragma unroll
+		for (uint32_t kk = 0; kk < OWN_K; ++kk) {
+			const float2 g2 = gk[kk];
+			Corner c;
+#pragma unroll
+			for (int d = 0; d < 3; ++d) { const float p = px[kk][d] * scale + 0.5f; const float fl = floorf(p); c.g[d] = (uint32_t)(int)fl; c.w[d] = p - fl; }
+			// the three per-axis terms of the index are shared by the eight corners
+			uint32_t tx[2], ty[2], tz[2];
+			tx[0] = c.g[0]; tx[1] = c.g[0] + 1;
+			if (HASHED) { ty[0] = c.g[1] * 19349663u; ty[1] = ty[0] + 19349663u; tz[0] = c.g[2] * 83492791u; tz[1] = tz[0] + 83492791u; }
+			else { ty[0] = c.g[1] * res; ty[1] = ty[0] + res; tz[0] = c.g[2] * res2; tz[1] = tz[0] + res2; }
+			uint32_t local[8], hits = 0;
+#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q) {
+				uint32_t idx;
+				if (HASHED) idx = (tx[q & 1] ^ ty[(q >> 1) & 1] ^ tz[q >> 2]) & (size - 1);        // hashed levels have 2^19 entries
+				else { idx = tx[q & 1] + ty[(q >> 1) & 1] + tz[q >> 2]; if (idx >= size) idx %= size; }   // wraps only at the +1 boundary corner
+				local[q] = idx - lo;
+				hits |= (local[q] < cnt) ? (1u << q) : 0u;
+			}
+			if (g2.x == 0.f && g2.y == 0.f) hits = 0;       // zero-padded rows add exact zeros in the reference; skipping them is value-identical
+			while (hits) {                      // ~8/32 corners per sample land in this slice: one short divergent loop instead of eight regions
+				const uint32_t q = __builtin_ctz(hits);
+				hits &= hits - 1;
+				uint32_t l = local[0];
+#pragma unroll
+				for (uint32_t r = 1; r < 8; ++r) l = (q == r) ? local[r] : l;
+				const float wx = (q & 1u) ? c.w[0] : 1 - c.w[0], wy = (q & 2u) ? c.w[1] : 1 - c.w[1], wz = (q & 4u) ? c.w[2] : 1 - c.w[2];
+				const float weight = wx * wy * wz;
+				if (accumulate & 2) { if (weight == 123.f) acc[2 * l] = g2.x; continue; }   // probe: everything but the LDS atomics
+				__hip_atomic_fetch_add(&acc[2 * l], g2.x * weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_add(&acc[2 * l + 1], g2.y * weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
+	}
+	__syncthreads();
+	accumulate &= 1;
+	G *gl = grad + ((size_t)off + lo) * 2;
+	if (n_chunks == 1) {            // exclusive owner: plain stores (or a private read-modify-write when accumulating)
+		for (uint32_t e = threadIdx.x; e < cnt; e += 1024) {
+			float2 v = make_float2(acc[2 * e], acc[2 * e + 1]);
+			GP *dst = reinterpret_cast<GP *>(gl) + e;
+			if (accumulate) { const float2 old = to_f2(*dst); v.x += old.x; v.y += old.y; }
+			GP o; from_f2(o, v);
+			*dst = o;
+		}
+	} else {                        // shared slice (small dense level): flush touched entries with global atomics; the host side zeroed the level unless accumulating
+		for (uint32_t e = threadIdx.x; e < cnt; e += 1024) {
+			const float2 v = make_float2(acc[2 * e], acc[2 * e + 1]);
+			if (v.x != 0.f || v.y != 0.f) atomic_add_pair(gl + (size_t)e * 2, v);
+		}
+	}
+}
+
+template <typename T, typename G, int LAYOUT>
+__global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt,
+                                                         OwnerPlan plan, G *__restrict__ grad, int accumulate, const uint32_t *__restrict__ n_valid) {
+	extern __shared__ __attribute__((aligned(16))) float acc[];          // [slice entries][2]
+	// block -> (level, slice, chunk); single-chunk (heavy) levels come first in plan.order so they are dispatched first
+	uint32_t k = 0;
+	while (k < 15 && blockIdx.x >= plan.first_unit[k + 1]) ++k;
+	const uint32_t level = plan.order[k];
+	const uint32_t u = blockIdx.x - plan.first_unit[k];
+	const uint32_t n_chunks = plan.chunks[level];
+	const uint32_t slice = u / n_chunks, chunk = u - slice * n_chunks;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
+	const bool coarse = res <= 600;     // cells much longer than a marching step: consecutive samples of a ray share them
+	if (level_is_dense(size, res)) owner_unit<T, G, LAYOUT, false, true>(n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc);
+	else if (coarse) owner_unit<T, G, LAYOUT, true, true>(n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc);
+	else owner_unit<T, G, LAYOUT, true, false>(n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc);
+	// (hashed levels with a non-power-of-two table never reach this kernel: the host routes them to the atomic kernel)
+}
+
 static LevelTable load_table(const uint32_t *host) { LevelTable lt; for (int i = 0; i < 64; ++i) lt.v[i] = host[i]; return lt; }
 
 NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *table, const uint32_t *level_table_host,
@@ -153,25 +340,112 @@ NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint
 	return 0;
 }
 
+// method: 0 = owner-computes LDS scatter (default), 1 = one global atomic per corner (the reference's scheme).  NGP_HASH_BWD_ATOMICS=1 selects 1.
+static int hash_bwd_method() {
+	static int m = -1;
+	if (m < 0) { const char *e = getenv("NGP_HASH_BWD_ATOMICS"); m = (e && e[0] == '1') ? 1 : 0; }
+	return m;
+}
+
 NGP_API int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
                                 void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid) {
-	NGP_REQUIRE(grad && (n == 0 || (pos && dLdy && level_table_host)), NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
+	NGP_REQUIRE(grad && level_table_host && (n == 0 || (pos && dLdy)), NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_bwd: bad dtype %d", dtype);
 	NGP_REQUIRE(grad_dtype == NGP_F32 || (grad_dtype == NGP_F16 && dtype == NGP_F16), NGP_E_DTYPE, "ngp_hash_encode_bwd: bad grad dtype %d for dtype %d", grad_dtype, dtype);
 	hipStream_t s = (hipStream_t)stream;
-	if (zero_first) {
-		hipError_t e = hipMemsetAsync(grad, 0, n_params * (grad_dtype == NGP_F16 ? 2 : 4), s);
-		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; }
-	}
-	if (n == 0) return 0;
-	const uint32_t nblk = div_up(n, 256);
-	const dim3 grid(16 * nblk), block(256);
+	const size_t gsz = grad_dtype == NGP_F16 ? 2 : 4;
 	const LevelTable lt = load_table(level_table_host);
+	bool owner_ok = true;
+	for (int l = 0; l < 16; ++l) {
+		const uint32_t size = lt.v[4 * l + 1], res = lt.v[4 * l + 2];
+		uint32_t stride_ = 1; for (int d = 0; d < 3; ++d) if (stride_ <= size) stride_ *= res;
+		if (size < stride_ && (size & (size - 1)) != 0) owner_ok = false;
+	}
+	if (hash_bwd_method() == 1 || !owner_ok) {
+		if (zero_first) {
+			hipError_t e = hipMemsetAsync(grad, 0, n_params * gsz, s);
+			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; }
+		}
+		if (n == 0) return 0;
+		const uint32_t nblk = div_up(n, 256);
+		const dim3 grid(16 * nblk), block(256);
 #define GO(T, G, L) hipLaunchKernelGGL((k_hash_bwd<T, G, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)dLdy, lt, (G *)grad, nblk, n_valid)
+		if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, float, NGP_LAYOUT_SOA); else GO(float, float, NGP_LAYOUT_AOS); }
+		else if (grad_dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(__half, float, NGP_LAYOUT_SOA); else GO(__half, float, NGP_LAYOUT_AOS); }
+		else { if (in_layout == NGP_LAYOUT_SOA) GO(__half, __half, NGP_LAYOUT_SOA); else GO(__half, __half, NGP_LAYOUT_AOS); }
+#undef GO
+		NGP_LAUNCH_CHECK("ngp_hash_encode_bwd");
+		return 0;
+	}
+	// ---- owner-computes plan: slices of OWN_SLICE entries; levels with < 32 slices split the samples into chunks instead
+	OwnerPlan plan;
+	uint32_t slices[16], units = 0, k = 0;
+	for (int l = 0; l < 16; ++l) { slices[l] = div_up(lt.v[4 * l + 1], OWN_SLICE); plan.chunks[l] = slices[l] >= 32 ? 1u : (32u / slices[l] ? 32u / slices[l] : 1u); }
+	for (int pass = 0; pass < 2; ++pass)                                  // exclusive-owner (heavy) levels first
+		for (int l = 15; l >= 0; --l)
+			if ((plan.chunks[l] == 1) == (pass == 0)) { plan.order[k] = (uint32_t)l; plan.first_unit[k] = units; units += slices[l] * plan.chunks[l]; ++k; }
+	plan.first_unit[16] = units;
+	for (int l = 0; l < 16; ++l) {                                       // chunked levels are flushed with atomics -> need a zeroed destination
+		if (plan.chunks[l] > 1 && zero_first) {
+			hipError_t e = hipMemsetAsync((char *)grad + (size_t)lt.v[4 * l] * 2 * gsz, 0, (size_t)lt.v[4 * l + 1] * 2 * gsz, s);
+			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; }
+		}
+	}
+	const int accumulate = (zero_first ? 0 : 1) | ((getenv("NGP_PROBE_NO_LDS_ATOMICS") != nullptr) ? 2 : 0);
+	const size_t shmem = (size_t)OWN_SLICE * 2 * sizeof(float);
+	const dim3 grid(units), block(1024);
+#define GO(T, G, L) do { \
+	static bool attr_set = false; \
+	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_hash_bwd_owner<T, G, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
+	hipLaunchKernelGGL((k_hash_bwd_owner<T, G, L>), grid, block, shmem, s, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid); } while (0)
 	if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, float, NGP_LAYOUT_SOA); else GO(float, float, NGP_LAYOUT_AOS); }
 	else if (grad_dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(__half, float, NGP_LAYOUT_SOA); else GO(__half, float, NGP_LAYOUT_AOS); }
 	else { if (in_layout == NGP_LAYOUT_SOA) GO(__half, __half, NGP_LAYOUT_SOA); else GO(__half, __half, NGP_LAYOUT_AOS); }
 #undef GO
 	NGP_LAUNCH_CHECK("ngp_hash_encode_bwd");
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- probes (tools/microbench_hash.py only)
+// Not part of the public ABI: lets the micro-benchmark time one level at a time and compare atomic scopes.  scope 0 = agent, 1 = workgroup
+// (an L2-local atomic: only valid when every accessor of an address sits on one XCD — used here for TIMING the idea, not for results).
+template <int SCOPE, bool PK16>
+__global__ __launch_bounds__(256) void k_probe_bwd(uint32_t n, const float *__restrict__ pos, const __half2 *__restrict__ dy, LevelTable lt, void *__restrict__ grad, uint32_t level_fixed) {
+	const uint32_t level = level_fixed;
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
+	const float scale = __uint_as_float(lt.v[4 * level + 3]);
+	const bool dense = level_is_dense(size, res);
+	const float2 g2 = __half22float2(dy[(size_t)level * n + i]);
+	const Corner c = locate(pos, 3, i, scale);
+#pragma unroll
+	for (uint32_t k = 0; k < 8; ++k) {
+		float weight = 1; uint32_t g[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) { if ((k & (1u << d)) == 0) { weight *= 1 - c.w[d]; g[d] = c.g[d]; } else { weight *= c.w[d]; g[d] = c.g[d] + 1; } }
+		const uint32_t idx = grid_index(size, res, dense, g[0], g[1], g[2]);
+		if (PK16) {
+			typedef _Float16 __attribute__((ext_vector_type(2))) h2;
+			h2 x; x[0] = (_Float16)(g2.x * weight); x[1] = (_Float16)(g2.y * weight);
+			h2 *p = reinterpret_cast<h2 *>(grad) + off + idx;
+			if (SCOPE == 0) (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2 *)p, x);
+			else asm volatile("global_atomic_pk_add_f16 %0, %1, off" :: "v"(p), "v"(x) : "memory");   // no sc bits: performed in the issuing XCD's L2
+		} else {
+			float *p = reinterpret_cast<float *>(grad) + ((size_t)off + idx) * 2;
+			if (SCOPE == 0) { __hip_atomic_fetch_add(p, g2.x * weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(p + 1, g2.y * weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			else { __hip_atomic_fetch_add(p, g2.x * weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(p + 1, g2.y * weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+		}
+	}
+}
+NGP_API int ngp_x_probe_hash_bwd(void *stream, uint32_t n, const float *pos, const void *dy, const uint32_t *level_table_host, void *grad, uint32_t level, int scope, int pk16) {
+	const LevelTable lt = load_table(level_table_host);
+	const dim3 grid(div_up(n, 256)), block(256);
+	hipStream_t s = (hipStream_t)stream;
+#define GO(S, P) hipLaunchKernelGGL((k_probe_bwd<S, P>), grid, block, 0, s, n, pos, (const __half2 *)dy, lt, grad, level)
+	if (scope == 0) { if (pk16) GO(0, true); else GO(0, false); } else { if (pk16) GO(1, true); else GO(1, false); }
+#undef GO
+	NGP_LAUNCH_CHECK("ngp_x_probe_hash_bwd");
 	return 0;
 }

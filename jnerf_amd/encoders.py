@@ -1,0 +1,101 @@
+"""Position / direction encoders behind the reference's ENCODERS registry names.
+
+HashEncoder  <- python/jnerf/models/position_encoders/hash_encoder/hash_encoder.py:8-30 + grid_encode.py:11-190
+SHEncoder    <- python/jnerf/models/position_encoders/sh_encoder/sh_encoder.py:10-56
+FrequencyEncoder <- python/jnerf/models/position_encoders/freq_encoder/freq_encoder.py:11-52 (plain torch ops, "plumbing" configs only)
+
+Parameters are fp32 masters; with cfg.fp16 the kernels gather from an fp16 shadow that the fused Adam+EMA sweep refreshes."""
+import torch
+from torch import nn
+from . import ops
+from .utils.config import get_cfg
+from .utils.registry import ENCODERS
+
+
+class _HashEncode(torch.autograd.Function):
+    """GridEncode.execute / .grad (grid_encode.py:71-125, 137-190): no gradient w.r.t. the positions, table gradient by atomic scatter."""
+
+    @staticmethod
+    def forward(ctx, x, grid, enc):
+        table = enc.table_for_kernels()
+        ctx.enc = enc
+        ctx.save_for_backward(x)
+        return ops.hash_encode_fwd(x, table, enc.level_table)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        enc = ctx.enc
+        enc.accumulate_grad(x, dy.contiguous(), ops.LAYOUT_AOS)
+        return None, None, None
+
+
+@ENCODERS.register_module()
+class HashEncoder(nn.Module):
+    def __init__(self, n_pos_dims=3, n_features_per_level=2, n_levels=16, base_resolution=16, log2_hashmap_size=19):
+        super().__init__()
+        self.cfg = get_cfg()
+        self.using_fp16 = bool(self.cfg.fp16)
+        aabb_scale = self.cfg.dataset_obj.aabb_scale
+        # like the reference (hash_encoder.py:17-18) the geometry is fixed: L=16, F=2, T=2^19, base 16, whatever the ctor args say
+        self.level_table, self.offsets, self.n_params = ops.level_table(aabb_scale)
+        self.grad_type = "float16" if self.using_fp16 else "float32"
+        dev = self.cfg.device or "cuda"
+        self.m_grid = nn.Parameter(torch.empty(self.n_params, dtype=torch.float32, device=dev).uniform_(-1e-4, 1e-4))   # hash_encoder.py:22-23
+        self.register_buffer("m_grid_half", self.m_grid.detach().half() if self.using_fp16 else None, persistent=False)
+        self.shadow_dirty = False
+        self.out_dim = 32
+        self.out_dtype = torch.float16 if self.using_fp16 else torch.float32
+
+    def table_for_kernels(self):
+        if not self.using_fp16:
+            return self.m_grid.detach()
+        if self.shadow_dirty:
+            self.m_grid_half.copy_(self.m_grid.detach())
+            self.shadow_dirty = False
+        return self.m_grid_half
+
+    def grad_buffer(self):
+        if self.m_grid.grad is None:
+            self.m_grid.grad = torch.zeros_like(self.m_grid)
+        return self.m_grid.grad
+
+    def accumulate_grad(self, x, dy, layout, n_valid=None):
+        """scatter-add dL/dy into m_grid.grad (fp32 accumulation; the buffer is zeroed by the optimiser sweep, not per call)"""
+        ops.hash_encode_bwd(x, dy, self.level_table, self.n_params, grad=self.grad_buffer(), layout=layout, zero_first=False, n_valid=n_valid)
+
+    def forward(self, x):
+        return _HashEncode.apply(x, self.m_grid, self)
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self.shadow_dirty = True
+
+
+@ENCODERS.register_module()
+class SHEncoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.cfg = get_cfg()
+        self.using_fp16 = bool(self.cfg.fp16)
+        self.m_sh_degree = 4
+        self.out_dim = 16
+
+    def forward(self, x):
+        return ops.sh_encode(x.detach(), torch.float16 if self.using_fp16 else torch.float32)   # no gradient (sh_encoder.py:55-56)
+
+
+@ENCODERS.register_module()
+class FrequencyEncoder(nn.Module):
+    def __init__(self, multires, include_input=True, input_dims=3, log_sampling=True):
+        super().__init__()
+        self.include_input = include_input
+        max_freq = multires - 1
+        self.freq_bands = (2.0 ** torch.linspace(0.0, max_freq, steps=multires)) if log_sampling else torch.linspace(1.0, 2.0 ** max_freq, steps=multires)
+        self.out_dim = (input_dims if include_input else 0) + input_dims * 2 * multires
+
+    def forward(self, x):
+        outs = [x] if self.include_input else []
+        for f in self.freq_bands.tolist():
+            outs += [torch.sin(x * f), torch.cos(x * f)]
+        return torch.cat(outs, -1)

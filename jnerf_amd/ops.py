@@ -8,6 +8,29 @@ from ._lib import F32, F16, LAYOUT_AOS, LAYOUT_SOA, check
 
 CAP_RAYS = 1 << 18
 
+# ------------------------------------------------------------------ optional per-kernel timing (bench.py): HIP events on the launch stream
+PROFILE = None      # None (off) or dict: name -> list of (start_event, end_event)
+
+
+class timed:
+    """`with ops.timed("hash_bwd"): launch(...)` records a HIP event pair on the current stream when ops.PROFILE is a dict"""
+    __slots__ = ("name", "ev")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.ev[1].record()
+            PROFILE.setdefault(self.name, []).append(self.ev)
+        return False
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -74,7 +97,8 @@ def hash_encode_fwd(pos, table, level_tbl, out=None, layout=LAYOUT_AOS, n_valid=
     n = pos.shape[0]
     if out is None:
         out = torch.empty((n, 32) if layout == LAYOUT_AOS else (16, n, 2), dtype=table.dtype, device=pos.device)
-    check(L.lib().ngp_hash_encode_fwd(_stream(), n, _p(pos), stride, _p(table), _tbl(level_tbl), _p(out), _dt(table), layout, _p(n_valid)), "ngp_hash_encode_fwd")
+    with timed("hash_fwd"):
+        check(L.lib().ngp_hash_encode_fwd(_stream(), n, _p(pos), stride, _p(table), _tbl(level_tbl), _p(out), _dt(table), layout, _p(n_valid)), "ngp_hash_encode_fwd")
     return out
 
 
@@ -84,8 +108,9 @@ def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, 
     assert dLdy.is_contiguous()
     if grad is None:
         grad = torch.empty(n_params, dtype=grad_dtype or dLdy.dtype, device=pos.device)
-    check(L.lib().ngp_hash_encode_bwd(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
-                                      int(zero_first), _p(n_valid)), "ngp_hash_encode_bwd")
+    with timed("hash_bwd"):
+        check(L.lib().ngp_hash_encode_bwd(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
+                                          int(zero_first), _p(n_valid)), "ngp_hash_encode_bwd")
     return grad
 
 
@@ -104,7 +129,8 @@ def field_fwd(feat, d, wd, wc, layout=LAYOUT_AOS, out_dtype=torch.float16, out=N
     n = d.shape[0]
     if out is None:
         out = torch.empty((n, 4), dtype=out_dtype, device=d.device)
-    check(L.lib().ngp_field_fwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(out), _dt(out), _p(n_valid)), "ngp_field_fwd")
+    with timed("field_fwd"):
+        check(L.lib().ngp_field_fwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(out), _dt(out), _p(n_valid)), "ngp_field_fwd")
     return out
 
 
@@ -129,7 +155,8 @@ def field_bwd(feat, d, wd, wc, dLdout, layout=LAYOUT_AOS, dfeat=None, slabs=None
         dfeat = torch.zeros_like(feat)
     if slabs is None:
         slabs = torch.empty((ns, 10240), dtype=torch.float32, device=d.device)
-    check(L.lib().ngp_field_bwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(dLdout), _dt(dLdout), _p(dfeat), _p(slabs), ns, _p(n_valid)), "ngp_field_bwd")
+    with timed("field_bwd"):
+        check(L.lib().ngp_field_bwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(dLdout), _dt(dLdout), _p(dfeat), _p(slabs), ns, _p(n_valid)), "ngp_field_bwd")
     return dfeat, slabs
 
 
@@ -183,9 +210,10 @@ def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng_state, max_samples,
         counters = torch.empty(4, dtype=torch.int32, device=dev)
     if scratch is None:
         scratch = torch.empty(n + 1024, dtype=torch.int32, device=dev)
-    check(L.lib().ngp_march_rays_compacted(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
-                                           rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch)),
-          "ngp_march_rays_compacted")
+    with timed("march"):
+        check(L.lib().ngp_march_rays_compacted(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
+                                               rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch)),
+              "ngp_march_rays_compacted")
     return coords_out, numsteps, numsteps_c, counters
 
 
@@ -194,7 +222,8 @@ def composite_fwd(net, coords, numsteps, numsteps_c, bg, cascades=5, out=None):
     assert net.is_contiguous() and coords.is_contiguous() and bg.is_contiguous()
     if out is None:
         out = torch.empty((n, 3), dtype=torch.float32, device=net.device)
-    check(L.lib().ngp_composite_fwd(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out)), "ngp_composite_fwd")
+    with timed("composite_fwd"):
+        check(L.lib().ngp_composite_fwd(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out)), "ngp_composite_fwd")
     return out
 
 
@@ -203,8 +232,9 @@ def composite_bwd(net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean
     assert net.is_contiguous() and loss_grad.is_contiguous() and rgb_ray.is_contiguous()
     if dout is None:
         dout = torch.empty_like(net)
-    check(L.lib().ngp_composite_bwd(_stream(), n, net.shape[0], _p(net), _dt(net), _p(coords), _p(numsteps_c), _p(loss_grad), _p(rgb_ray), _p(density_grid_mean), cascades, _p(dout), int(zero_first)),
-          "ngp_composite_bwd")
+    with timed("composite_bwd"):
+        check(L.lib().ngp_composite_bwd(_stream(), n, net.shape[0], _p(net), _dt(net), _p(coords), _p(numsteps_c), _p(loss_grad), _p(rgb_ray), _p(density_grid_mean), cascades, _p(dout), int(zero_first)),
+              "ngp_composite_bwd")
     return dout
 
 
@@ -263,7 +293,8 @@ def grid_update_bitfield(grid, cascades=5, mean=None, bitfield=None):
 
 # ------------------------------------------------------------------ optimiser / rays
 def adam_ema_step(p, g, m, v, ema, p_half, lr, step, b0=0.9, b1=0.99, eps=1e-15, ema_decay=0.95, zero_grad=True):
-    check(L.lib().ngp_adam_ema_step(_stream(), p.numel(), _p(p), _p(g), _dt(g), _p(m), _p(v), _p(ema), _p(p_half), lr, b0, b1, eps, step, ema_decay, int(zero_grad)), "ngp_adam_ema_step")
+    with timed("adam_ema"):
+        check(L.lib().ngp_adam_ema_step(_stream(), p.numel(), _p(p), _p(g), _dt(g), _p(m), _p(v), _p(ema), _p(p_half), lr, b0, b1, eps, step, ema_decay, int(zero_grad)), "ngp_adam_ema_step")
 
 
 def generate_rays(pixel_index, W, H, focal, metadata, xforms, images=None, bg=None):

@@ -1,0 +1,180 @@
+"""Adam / ExpDecay / EMA behind the reference's OPTIMS registry (python/jnerf/optims/{adam,expdecay,ema}.py).
+
+API kept: optimizer.step(loss) (back-propagates the SUM of an unreduced loss like Jittor), optimizer._nested_optimizer,
+ema_optimizer.ema_step(), .param_groups[*]['params'|'values'|'m'], .state_dict().
+MI355X execution: Adam + EMA + gradient zeroing + fp16-shadow refresh are ONE streaming kernel per parameter tensor
+(csrc/optim.hip): Adam.step() defers the sweep until EMA.ema_step() when an EMA is attached (Runner builds both, runner.py:35-37),
+so parameters are read and written once per step instead of ~12 times."""
+import torch
+import torch.distributed as dist
+from . import ops
+from .utils.registry import OPTIMS
+
+
+def _owner_shadow(p):
+    return getattr(p, "_ngp_half_shadow", None)
+
+
+@OPTIMS.register_module()
+class Adam:
+    def __init__(self, params, lr=1e-1, eps=1e-15, betas=(0.9, 0.99), **kwargs):
+        self.lr, self.eps, self.betas = lr, eps, tuple(betas)
+        params = [p for p in params]
+        self.param_groups = [{"params": params, "values": [torch.zeros_like(p) for p in params], "m": [torch.zeros_like(p) for p in params]}]
+        self.n_step = 0
+        self._ema = None
+        self._pending = False
+        self._world = 1
+        self._half = {}
+
+    @property
+    def defaults(self):
+        return {"lr": self.lr, "eps": self.eps, "betas": self.betas, "n_step": self.n_step}
+
+    def attach_half_shadows(self, model):
+        """fp16 copies the gather/MFMA kernels read; refreshed by the sweep"""
+        for m in model.modules():
+            if getattr(m, "m_grid_half", None) is not None:
+                self._half[id(m.m_grid)] = m.m_grid_half
+            if getattr(m, "con_weights_half", None) is not None:
+                self._half[id(m.con_weights)] = m.con_weights_half
+
+    def zero_grad(self):
+        for p in self.param_groups[0]["params"]:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def backward(self, loss):
+        loss.sum().backward()
+
+    def allreduce_grads(self):
+        """ray-batch data parallelism: sum the hash-table and MLP gradients over ranks (RCCL over xGMI; gloo on CPU tests)"""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        for p in self.param_groups[0]["params"]:
+            if p.grad is not None:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+
+    def step(self, loss=None):
+        if loss is not None:
+            self.backward(loss)
+        self.allreduce_grads()
+        self.n_step += 1
+        if self._ema is not None:
+            self._pending = True                    # the fused sweep runs in EMA.ema_step()
+        else:
+            self._sweep(None)
+
+    @torch.no_grad()
+    def _sweep(self, ema):
+        pg = self.param_groups[0]
+        for i, p in enumerate(pg["params"]):
+            if p.grad is None:
+                continue
+            e = ema.param_groups[0]["values"][i] if ema is not None else None
+            if p.is_cuda:
+                ops.adam_ema_step(p.data, p.grad, pg["m"][i], pg["values"][i], e, self._half.get(id(p)), self.lr, self.n_step, self.betas[0], self.betas[1], self.eps,
+                                  ema.decay if ema is not None else 0.0, zero_grad=True)
+            else:                                   # CPU tensors (gloo unit tests of the data-parallel logic): same math in torch
+                b0, b1 = self.betas
+                g = p.grad
+                m, v = pg["m"][i], pg["values"][i]
+                m.mul_(b0).add_(g, alpha=1 - b0)
+                v.mul_(b1).addcmul_(g, g, value=1 - b1)
+                step_size = self.lr * (1 - b1 ** self.n_step) ** 0.5 / (1 - b0 ** self.n_step)
+                p.data.sub_(m * step_size / (v.sqrt() + self.eps))
+                if ema is not None:
+                    d, k = ema.decay, self.n_step
+                    p.data.copy_(((1 - d) * p.data + d * e * (1 - d ** (k - 1))) / (1 - d ** k))
+                    e.copy_(p.data)
+                g.zero_()
+        self._pending = False
+
+    def state_dict(self):
+        return {"defaults": {"lr": self.lr, "eps": self.eps, "betas": self.betas, "n_step": self.n_step,
+                             "param_groups": [{"values": [t.detach().cpu() for t in self.param_groups[0]["values"]], "m": [t.detach().cpu() for t in self.param_groups[0]["m"]]}]}}
+
+    def load_state_dict(self, sd):
+        d = sd["defaults"]
+        self.lr, self.eps, self.betas, self.n_step = d["lr"], d["eps"], tuple(d["betas"]), d["n_step"]
+        for k in ("values", "m"):
+            for dst, src in zip(self.param_groups[0][k], d["param_groups"][0][k]):
+                dst.copy_(src)
+
+
+@OPTIMS.register_module()
+class ExpDecay:
+    """optims/expdecay.py:7-30"""
+
+    def __init__(self, nested_optimizer, decay_start, decay_interval, decay_base, decay_end=None):
+        self.base_lr = nested_optimizer.lr
+        self._nested_optimizer = nested_optimizer
+        self.decay_start, self.decay_interval, self.decay_base = decay_start, decay_interval, decay_base
+        self.decay_end = 10000000 if decay_end is None else decay_end
+        self.steps = 0
+        self.m_learning_rate_factor = 1
+
+    def step(self, loss=None):
+        if self.steps >= self.decay_start and (self.steps - self.decay_start) % self.decay_interval == 0 and self.steps <= self.decay_end:
+            self.m_learning_rate_factor *= self.decay_base
+        self._nested_optimizer.lr = self.base_lr * self.m_learning_rate_factor
+        self._nested_optimizer.step(loss)
+        self.steps += 1
+
+    def zero_grad(self):
+        return self._nested_optimizer.zero_grad()
+
+    def backward(self, loss, retain_graph=False):
+        return self._nested_optimizer.backward(loss)
+
+    def state_dict(self):
+        return {"steps": self.steps, "m_learning_rate_factor": self.m_learning_rate_factor}
+
+    def load_state_dict(self, sd):
+        self.steps, self.m_learning_rate_factor = sd["steps"], sd["m_learning_rate_factor"]
+
+
+@OPTIMS.register_module()
+class EMA:
+    """optims/ema.py:8-37 — the trained parameters ARE their debiased EMA (ema_step overwrites them)."""
+
+    def __init__(self, params, decay):
+        params = [p for p in params]
+        self.decay = decay
+        self.steps = 0
+        self.param_groups = [{"params": params, "values": [p.detach().clone() for p in params]}]
+        self._adam = None
+
+    def attach(self, adam):
+        """fuse with the Adam sweep (Runner wires this; without it ema_step runs standalone)"""
+        adam = getattr(adam, "_nested_optimizer", adam)
+        self._adam = adam
+        adam._ema = self
+
+    @torch.no_grad()
+    def ema_step(self, loss=None):
+        assert loss is None
+        self.steps += 1
+        if self._adam is not None and self._adam._pending:
+            assert self._adam.n_step == self.steps, "EMA and Adam must be stepped in lock-step to be fused"
+            self._adam._sweep(self)
+            return
+        old = 1 - self.decay ** (self.steps - 1)
+        new = 1 / (1 - self.decay ** self.steps)
+        for p, v in zip(self.param_groups[0]["params"], self.param_groups[0]["values"]):
+            p.data.copy_(((1 - self.decay) * p.data + self.decay * v * old) * new)
+            v.copy_(p.data)
+        if self._adam is not None:
+            for p in self.param_groups[0]["params"]:
+                h = self._adam._half.get(id(p))
+                if h is not None:
+                    h.copy_(p.data)
+
+    def state_dict(self):
+        return {"defaults": {"decay": self.decay, "steps": self.steps, "param_groups": [{"values": [t.detach().cpu() for t in self.param_groups[0]["values"]]}]}}
+
+    def load_state_dict(self, sd):
+        d = sd["defaults"]
+        self.decay, self.steps = d["decay"], d["steps"]
+        for dst, src in zip(self.param_groups[0]["values"], d["param_groups"][0]["values"]):
+            dst.copy_(src)

@@ -1,0 +1,195 @@
+"""DensityGridSampler behind the reference's SAMPLERS registry
+(python/jnerf/models/samplers/density_grid_sampler/density_grid_sampler.py:18-271).
+
+Same constructor arguments, attributes (n_rays_per_batch, density_grid, density_grid_bitfield, density_grid_mean, _coords,
+_rays_numsteps[_compacted]) and methods (sample, rays2rgb, update_density_grid, update_batch_rays).  Differences, all MI355X-motivated:
+  * training sampling is ONE pass (march + compaction, deterministic ray-ordered slots); the reference's dead first forward
+    (density_grid_sampler.py:153-159, SURVEY.md App.B-1) is dropped — its result never influenced the output;
+  * counters stay on the device: the only host read-back on the training loop is the scalar every 16th step (update_batch_rays);
+  * rows >= counters[3] of the compacted buffer are skipped by every consumer instead of being zero-filled and pushed through the net."""
+from math import ceil, log2
+import numpy as np
+import torch
+from torch import nn
+from . import ops
+from .utils.config import get_cfg
+from .utils.registry import SAMPLERS
+
+
+class _Composite(torch.autograd.Function):
+    """CalcRgb.execute / .grad (calc_rgb.py:31-108)"""
+
+    @staticmethod
+    def forward(ctx, net_out, bg, s):
+        rgb = ops.composite_fwd(net_out, s._coords, s._rays_numsteps, s._rays_numsteps_compacted, bg, s.NERF_CASCADES)
+        ctx.s = s
+        ctx.save_for_backward(net_out, rgb)
+        ctx.coords, ctx.nsc = s._coords, s._rays_numsteps_compacted
+        return rgb
+
+    @staticmethod
+    def backward(ctx, grad_rgb):
+        net_out, rgb = ctx.saved_tensors
+        s = ctx.s
+        dout = ops.composite_bwd(net_out, ctx.coords, ctx.nsc, grad_rgb.contiguous(), rgb, s.density_grid_mean, s.NERF_CASCADES, dout=s._dout_buffer(net_out), zero_first=True)
+        return dout, None, None
+
+
+@SAMPLERS.register_module()
+class DensityGridSampler(nn.Module):
+    def __init__(self, update_den_freq=16, update_block_size=5000000):
+        super().__init__()
+        self.cfg = get_cfg()
+        self.model = self.cfg.model_obj
+        self.dataset = self.cfg.dataset_obj
+        self.update_den_freq = update_den_freq
+        self.update_block_size = update_block_size
+        self.n_rays_per_batch = self.cfg.n_rays_per_batch
+        self.cone_angle_constant = self.cfg.cone_angle_constant
+        self.using_fp16 = bool(self.cfg.fp16)
+        self.near_distance = self.cfg.near_distance
+        self.n_training_steps = self.cfg.n_training_steps
+        self.target_batch_size = self.cfg.target_batch_size
+        self.const_dt = bool(self.cfg.const_dt)
+        self.NERF_CASCADES = 5
+        self.NERF_GRIDSIZE = 128
+        self.NERF_MIN_OPTICAL_THICKNESS = 0.01
+        self.MAX_STEP = 1024
+        self.background_color = self.cfg.background_color
+        self.aabb_range = tuple(float(v) for v in self.dataset.aabb_range)
+        max_aabb_scale = 1 << (self.NERF_CASCADES - 1)
+        if self.dataset.aabb_scale > max_aabb_scale:
+            self.NERF_CASCADES = ceil(log2(self.dataset.aabb_scale)) + 1
+        self.max_cascade = 0
+        while (1 << self.max_cascade) < self.dataset.aabb_scale:
+            self.max_cascade += 1
+        dev = self.cfg.device or "cuda"
+        self.device = torch.device(dev)
+        G3 = self.NERF_GRIDSIZE ** 3
+        self.density_grid_decay = 0.95
+        self.density_n_elements = self.NERF_CASCADES * G3
+        self.register_buffer("density_grid", torch.zeros(self.density_n_elements, dtype=torch.float32, device=dev))
+        self.density_grid_tmp = torch.zeros(self.density_n_elements, dtype=torch.float32, device=dev)
+        self.register_buffer("density_grid_bitfield", torch.zeros(self.density_n_elements // 8, dtype=torch.uint8, device=dev))
+        self.register_buffer("density_grid_mean", torch.zeros(1, dtype=torch.float32, device=dev))
+        self.register_buffer("density_grid_ema_step", torch.zeros(1, dtype=torch.int32, device=dev))
+        self.max_samples = 4096 * self.MAX_STEP                        # ray_sampler.py:15 — fixed even after the ray count grows
+        # the reference's global pcg32{1337} (ops/code_ops/global_vars.py:13-16); multi-GPU ranks take disjoint sub-streams
+        from .rng import pcg32_seed
+        self.rng_state = pcg32_seed(1337)
+        rank = int(self.cfg.rank or 0)
+        if rank:
+            from .rng import pcg32_advance
+            pcg32_advance(self.rng_state, rank << 40)
+        self.measured_batch_size = torch.zeros(1, dtype=torch.int32, device=dev)
+        cap_r = 1 << 18
+        self._numsteps_buf = torch.empty((cap_r, 2), dtype=torch.int32, device=dev)
+        self._numsteps_c_buf = torch.empty((cap_r, 2), dtype=torch.int32, device=dev)
+        self._counters = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._scratch = torch.empty(cap_r + 1024, dtype=torch.int32, device=dev)
+        self._coords_train = torch.zeros((self.target_batch_size, 7), dtype=torch.float32, device=dev)
+        self._dout = None
+        self._coords = None
+        self._n_valid = None
+
+    # ------------------------------------------------------------------ hot path
+    def n_valid_for(self, pos):
+        """device-side sample count when `pos` is a view of this sampler's compacted buffer (training), else None"""
+        if self._n_valid is not None and self._coords is self._coords_train and pos.data_ptr() == self._coords_train.data_ptr():
+            return self._n_valid
+        return None
+
+    def _dout_buffer(self, like):
+        if self._dout is None or self._dout.shape != like.shape or self._dout.dtype != like.dtype:
+            self._dout = torch.empty_like(like)
+        return self._dout
+
+    def sample(self, img_ids, rays_o, rays_d, rgb_target=None, is_training=False):
+        if is_training and self.cfg.m_training_step % self.update_den_freq == 0:
+            self.update_density_grid()
+        rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+        n = rays_o.shape[0]
+        if not is_training:
+            coords, numsteps, counters, _ = ops.march_rays(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples,
+                                                           self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
+                                                           coords=self._inference_coords(), zero_coords=False)
+            samples = int(counters[1].item())                          # ray_sampler.py:70 (inference only)
+            samples = min(samples, self.max_samples)
+            self._coords = coords[:samples]
+            self._rays_numsteps = numsteps
+            self._n_valid = None
+            return self._coords[:, :3], self._coords[:, 4:]
+        numsteps, numsteps_c = self._numsteps_buf[:n], self._numsteps_c_buf[:n]
+        ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.target_batch_size,
+                                 self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
+                                 coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=self._scratch)
+        self.measured_batch_size += self._counters[2:3]                # density_grid_sampler.py:155
+        if self.cfg.m_training_step % self.update_den_freq == (self.update_den_freq - 1):
+            self.update_batch_rays()
+        self._coords = self._coords_train
+        self._rays_numsteps, self._rays_numsteps_compacted = numsteps, numsteps_c
+        self._n_valid = self._counters[3:4]
+        return self._coords[:, :3], self._coords[:, 4:]
+
+    def _inference_coords(self):
+        if getattr(self, "_coords_inf", None) is None:
+            self._coords_inf = torch.empty((self.max_samples, 7), dtype=torch.float32, device=self.device)
+        return self._coords_inf
+
+    def rays2rgb(self, network_outputs, training_background_color=None, inference=False):
+        assert network_outputs.shape[0] == self._coords.shape[0]
+        if inference:
+            return ops.composite_inference(network_outputs.contiguous(), self._coords, self._rays_numsteps, self.NERF_CASCADES)
+        bg = training_background_color
+        if bg is None:
+            bg = torch.tensor(self.background_color, dtype=torch.float32, device=self.device).expand(self._rays_numsteps.shape[0], 3).contiguous()
+        return _Composite.apply(network_outputs, bg.contiguous(), self)
+
+    # ------------------------------------------------------------------ occupancy grid (density_grid_sampler.py:204-264)
+    @torch.no_grad()
+    def update_density_grid_nerf(self, decay, n_uniform, n_nonuniform):
+        if self.cfg.m_training_step == 0:
+            ops.grid_mark_untrained(self.density_n_elements, self.dataset.focal_lengths, self.dataset.transforms_gpu,
+                                    self.dataset.resolution[0], self.dataset.resolution[1], grid=self.density_grid)
+        self.density_grid_tmp.zero_()
+        n_total = n_uniform + n_nonuniform
+        pos = torch.empty((n_total, 3), dtype=torch.float32, device=self.device)
+        idx = torch.empty(n_total, dtype=torch.int32, device=self.device)
+        ops.grid_generate_samples(n_uniform, self.rng_state, self.density_grid_ema_step, self.aabb_range, self.density_grid, self.max_cascade + 1, -0.01,
+                                  pos=pos[:n_uniform], idx=idx[:n_uniform])
+        if n_nonuniform:
+            ops.grid_generate_samples(n_nonuniform, self.rng_state, self.density_grid_ema_step, self.aabb_range, self.density_grid, self.max_cascade + 1,
+                                      self.NERF_MIN_OPTICAL_THICKNESS, pos=pos[n_uniform:], idx=idx[n_uniform:])
+        else:   # the reference still advances the global rng for the empty second call (generate_grid_samples…py:44)
+            from .rng import pcg32_advance
+            pcg32_advance(self.rng_state, 1 << 32)
+        for i in range(0, n_total, self.update_block_size):
+            d = self.model.density(pos[i:i + self.update_block_size])
+            ops.grid_splat_max(idx[i:i + self.update_block_size], d.reshape(-1).contiguous(), self.density_grid_tmp)
+        ops.grid_ema(self.density_grid, self.density_grid_tmp, self.density_grid_decay)
+        self.density_grid_ema_step += 1
+        ops.grid_update_bitfield(self.density_grid, self.NERF_CASCADES, mean=self.density_grid_mean, bitfield=self.density_grid_bitfield)
+
+    def update_density_grid(self):
+        alpha = pow(self.density_grid_decay, self.n_training_steps / 16)
+        n_cascades = self.max_cascade + 1
+        G3 = self.NERF_GRIDSIZE ** 3
+        if self.cfg.m_training_step < 256:
+            self.update_density_grid_nerf(alpha, G3 * n_cascades, 0)
+        else:
+            self.update_density_grid_nerf(alpha, G3 * n_cascades // 4, G3 * n_cascades // 4)
+
+    def update_batch_rays(self):
+        measured = self.measured_batch_size
+        if self.cfg.world_size and self.cfg.world_size > 1:
+            import torch.distributed as dist
+            m = measured.float()
+            dist.all_reduce(m)                                          # every rank must pick the same ray count
+            measured_val = m.item() / self.cfg.world_size
+        else:
+            measured_val = measured.item()
+        measured_batch_size = max(measured_val / 16, 1)                 # density_grid_sampler.py:266-271
+        rays_per_batch = int(self.n_rays_per_batch * self.target_batch_size / measured_batch_size)
+        self.n_rays_per_batch = int(min((int(rays_per_batch) + 127) // 128 * 128, self.target_batch_size))
+        self.measured_batch_size.zero_()
+        self.dataset.batch_size = self.n_rays_per_batch

@@ -1,0 +1,27 @@
+"""Turns a rocprofv3 rocpd database (kernel trace) into the per-kernel summary committed under profiles/.
+usage: python tools/rocprof_summary.py gpurun_out/prof/xyz_results.db profiles/r01_xyz.md "title" """
+import sqlite3
+import sys
+
+
+def main(db, out, title):
+    c = sqlite3.connect(db)
+    q = """select s.kernel_name, count(*), sum(d.end-d.start)/1e3, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3, max(d.end-d.start)/1e3,
+                  max(s.arch_vgpr_count), max(s.sgpr_count), max(d.group_segment_size), max(d.grid_size_x), max(d.workgroup_size_x)
+           from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by s.kernel_name order by 3 desc"""
+    rows = list(c.execute(q))
+    tot = sum(r[2] for r in rows)
+    with open(out, "w") as f:
+        f.write(f"# {title}\n\nsource: `rocprofv3 --kernel-trace --stats` (rocpd database), all durations in microseconds\n\n")
+        f.write("| kernel | calls | total ms | % | avg us | min us | max us | vgpr | sgpr | lds B | grid | wg |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
+        for r in rows[:45]:
+            name = r[0].replace(".kd", "")
+            if len(name) > 110:
+                name = name[:107] + "..."
+            f.write(f"| `{name}` | {r[1]} | {r[2] / 1e3:.2f} | {100 * r[2] / tot:.1f} | {r[3]:.1f} | {r[4]:.1f} | {r[5]:.1f} | {r[6]} | {r[7]} | {r[8]} | {r[9]} | {r[10]} |\n")
+        f.write(f"\ntotal kernel time {tot / 1e3:.1f} ms over {sum(r[1] for r in rows)} dispatches\n")
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 kernel summary")
