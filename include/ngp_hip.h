@@ -80,7 +80,9 @@ int ngp_compact_coords(void *stream, uint32_t n_rays, uint32_t cap, const float 
                        uint32_t *numsteps_out, uint32_t *counter, uint32_t *scratch);
 /* MI355X training path: march + compaction in one pass (the reference's dead forward pass is dropped, SURVEY.md App.B-1).
  * Result == ngp_compact_coords(ngp_march_rays(...)) for the same inputs; rows >= min(total,cap) of coords_out are NOT touched
- * (consumers take counters[2] as n_valid). counters: u32[4] = {rays, steps reserved, compacted steps (unclamped), min(steps,cap)}. */
+ * (consumers take counters[2] as n_valid). counters: u32[4] = {rays, steps reserved, compacted steps (unclamped), min(steps,cap)}.
+ * scratch: u32[ngp_march_scratch_elems(n_rays)]. */
+uint64_t ngp_march_scratch_elems(uint32_t n_rays);   /* u32 elements of `scratch` ngp_march_rays_compacted needs (step counts + per-ray t-cache) */
 int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
                              float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                              uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch);

@@ -91,9 +91,11 @@ __device__ __forceinline__ float ray_start(const MarchParams &p, uint32_t i, con
 }
 
 // One traversal of a ray.  WRITE=false: count occupied steps (limit NERF_STEPS).  WRITE=true: emit the first `limit` records.
+#define NGP_TCACHE NGP_STEPS   // per-ray cache [n_rays][NGP_STEPS] of the sample parameters t (only touched entries cost anything): the write pass never marches again
+
 template <bool WRITE>
 __device__ __forceinline__ uint32_t march(const MarchParams &p, const uint8_t *__restrict__ bitfield, const float o[3], const float d[3], float startt,
-                                          uint32_t limit, float *__restrict__ out) {
+                                          uint32_t limit, float *__restrict__ out, float *__restrict__ tcache = nullptr, uint32_t tstride = 0) {
 	const float idir[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
 	float wdir[3];
 	if (WRITE) { wdir[0] = (d[0] + 1.0f) * 0.5f; wdir[1] = (d[1] + 1.0f) * 0.5f; wdir[2] = (d[2] + 1.0f) * 0.5f; }
@@ -113,7 +115,7 @@ __device__ __forceinline__ uint32_t march(const MarchParams &p, const uint8_t *_
 				for (int k = 0; k < 3; ++k) c[k] = (pos[k] - p.a0) / (p.a1 - p.a0);   // warp_position
 				c[3] = (dt - dtmin) / dtspan;
 				c[4] = wdir[0]; c[5] = wdir[1]; c[6] = wdir[2];
-			}
+			} else if (tcache) tcache[j] = t;
 			++j; t += dt;
 		} else {
 			t = advance_to_next_voxel(t, pos, d, idir, NGP_GRIDSIZE >> mip, p);
@@ -128,8 +130,7 @@ __global__ __launch_bounds__(128) void k_march_count(uint32_t n_rays, MarchParam
 	if (i >= n_rays) return;
 	const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]}, d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
 	const float startt = ray_start(p, i, o, d);
-	steps[i] = march<false>(p, bitfield, o, d, startt, NGP_STEPS, nullptr);
-	(void)startts;
+	steps[i] = march<false>(p, bitfield, o, d, startt, NGP_STEPS, nullptr, startts ? startts + (size_t)i * NGP_TCACHE : nullptr, 1);
 }
 
 // Single-workgroup exclusive scans in ray order (n_rays <= 2^18 in this path; 1024 threads x <=256 rays each).
@@ -151,38 +152,51 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 	__syncthreads();
 	return res;
 }
+#define SCAN_TILE 8192u     // rays per tile: coalesced load -> LDS -> each thread scans 8 consecutive rays -> workgroup scan -> coalesced store
 __global__ __launch_bounds__(1024) void k_march_scan(uint32_t n_rays, uint32_t max_samples, uint32_t cap, const uint32_t *__restrict__ steps,
                                                      uint32_t *__restrict__ numsteps, uint32_t *__restrict__ numsteps_c, int32_t *__restrict__ ray_indices,
                                                      uint32_t *__restrict__ counters, int n_counters) {
 	__shared__ uint32_t sh[17];
-	const uint32_t per = (n_rays + 1023u) / 1024u;
-	const uint32_t lo = min(threadIdx.x * per, n_rays), hi = min(lo + per, n_rays);
-	uint32_t sum = 0;
-	for (uint32_t i = lo; i < hi; ++i) sum += steps[i];
-	uint32_t total;
-	uint32_t base = block_exclusive_scan_1024(sum, sh, total);
-	uint32_t nok = 0, sumok = 0;
-	for (uint32_t i = lo; i < hi; ++i) {
-		const uint32_t s = steps[i];
-		const bool ok = base + s <= max_samples;
-		numsteps[2 * i] = ok ? s : 0u; numsteps[2 * i + 1] = base;
-		nok += ok; sumok += ok ? s : 0u;
-		base += s;
-	}
-	uint32_t total_ok, total_sumok;
-	uint32_t ridx = block_exclusive_scan_1024(nok, sh, total_ok);
-	uint32_t cbase = block_exclusive_scan_1024(sumok, sh, total_sumok);
-	for (uint32_t i = lo; i < hi; ++i) {
-		const uint32_t s = numsteps[2 * i];
-		const bool ok = numsteps[2 * i + 1] + steps[i] <= max_samples;
-		if (ray_indices) ray_indices[i] = !ok ? 0 /*left untouched by the reference*/ : (s == 0 ? -1 : (int32_t)ridx);
-		ridx += ok;
-		if (numsteps_c) { numsteps_c[2 * i] = min(cap - min(cap, cbase), s); numsteps_c[2 * i + 1] = cbase; }
-		cbase += s;
+	__shared__ uint32_t tile[SCAN_TILE + SCAN_TILE / 8];      // +1 word per 8 to dodge the 8-stride bank conflict
+	uint32_t run_base = 0, run_ok = 0, run_sumok = 0;           // running totals of the three scans (wave-uniform, identical in every thread)
+	for (uint32_t t0 = 0; t0 < n_rays; t0 += SCAN_TILE) {
+		const uint32_t cnt = min(SCAN_TILE, n_rays - t0);
+		for (uint32_t e = threadIdx.x; e < SCAN_TILE; e += 1024) tile[e + (e >> 3)] = e < cnt ? steps[t0 + e] : 0u;
+		__syncthreads();
+		uint32_t v[8], sum = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { v[k] = tile[threadIdx.x * 9 + k]; sum += v[k]; }
+		uint32_t total;
+		uint32_t base = run_base + block_exclusive_scan_1024(sum, sh, total);
+		uint32_t nok = 0, sumok = 0, okmask = 0, bases[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const bool ok = (t0 + threadIdx.x * 8 + k < n_rays) && base + v[k] <= max_samples;
+			bases[k] = base; okmask |= ok ? (1u << k) : 0u;
+			nok += ok; sumok += ok ? v[k] : 0u;
+			base += v[k];
+		}
+		uint32_t total_ok, total_sumok;
+		uint32_t ridx = run_ok + block_exclusive_scan_1024(nok, sh, total_ok);
+		uint32_t cbase = run_sumok + block_exclusive_scan_1024(sumok, sh, total_sumok);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const uint32_t i = t0 + threadIdx.x * 8 + k;
+			const bool ok = (okmask >> k) & 1u;
+			const uint32_t sk = ok ? v[k] : 0u;
+			if (i < n_rays) {
+				numsteps[2 * i] = sk; numsteps[2 * i + 1] = bases[k];
+				if (ray_indices) ray_indices[i] = !ok ? 0 /*left untouched by the reference*/ : (sk == 0 ? -1 : (int32_t)ridx);
+				if (numsteps_c) { numsteps_c[2 * i] = min(cap - min(cap, cbase), sk); numsteps_c[2 * i + 1] = cbase; }
+			}
+			ridx += ok; cbase += sk;
+		}
+		run_base += total; run_ok += total_ok; run_sumok += total_sumok;
+		__syncthreads();
 	}
 	if (threadIdx.x == 0) {
-		counters[0] = total_ok; counters[1] = total;
-		if (n_counters == 4) { counters[2] = total_sumok; counters[3] = min(total_sumok, cap); }
+		counters[0] = run_ok; counters[1] = run_base;
+		if (n_counters == 4) { counters[2] = run_sumok; counters[3] = min(run_sumok, cap); }
 	}
 }
 
@@ -196,6 +210,36 @@ __global__ __launch_bounds__(128) void k_march_write(uint32_t n_rays, MarchParam
 	const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]}, d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
 	const float startt = ray_start(p, i, o, d);
 	march<true>(p, bitfield, o, d, startt, ns, coords + (size_t)base * 7);
+}
+
+// Write pass from the t-cache ([n_rays][NGP_STEPS]), one thread per SAMPLE: the 28-byte records of consecutive samples are consecutive in
+// memory, so the stores are fully coalesced; the owning ray is found by binary search over the (monotonic) compacted bases.
+// Every record is an independent function of (o, d, t): pos = o + t*d and dt = calc_dt(t) are the very expressions the marcher evaluates,
+// so the records are bit-identical to a second traversal.
+__global__ __launch_bounds__(256) void k_march_write_cached(uint32_t n_rays, MarchParams p, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                            const uint32_t *__restrict__ numsteps, const uint32_t *__restrict__ counters, uint32_t total_idx,
+                                                            const float *__restrict__ tcache, float *__restrict__ coords) {
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= counters[total_idx]) return;
+	// last ray whose base <= s and that owns s (rays with zero steps share a base with their successor)
+	uint32_t lo = 0, hi = n_rays - 1;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi + 1) >> 1;
+		if (numsteps[2 * mid + 1] <= s) lo = mid; else hi = mid - 1;
+	}
+	uint32_t i = lo;
+	while (numsteps[2 * i] == 0 || s - numsteps[2 * i + 1] >= numsteps[2 * i]) { if (i == 0) return; --i; }   // skip empty / truncated rays sharing the base
+	const uint32_t j = s - numsteps[2 * i + 1];
+	const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]}, d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
+	const float t = tcache[(size_t)i * NGP_TCACHE + j];
+	const float dt = calc_dt(t, p);
+	const float dtmin = min_cone_stepsize();
+	const float dtspan = dtmin * (1 << (p.cascades - 1)) - dtmin;
+	float *c = coords + (size_t)s * 7;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) c[k] = ((o[k] + t * d[k]) - p.a0) / (p.a1 - p.a0);
+	c[3] = (dt - dtmin) / dtspan;
+	c[4] = (d[0] + 1.0f) * 0.5f; c[5] = (d[1] + 1.0f) * 0.5f; c[6] = (d[2] + 1.0f) * 0.5f;
 }
 
 static int check_march_args(const char *fn, uint32_t n_rays, const void *a, const void *b, const void *c, const void *d, int cascades) {
@@ -228,6 +272,8 @@ NGP_API int ngp_march_rays(void *stream, uint32_t n_rays, const float *rays_o, c
 	return 0;
 }
 
+NGP_API uint64_t ngp_march_scratch_elems(uint32_t n_rays) { return (uint64_t)((n_rays + 1023u) & ~1023u) + (uint64_t)NGP_TCACHE * n_rays + 1024u; }
+
 NGP_API int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
                                      float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                                      uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch) {
@@ -236,9 +282,12 @@ NGP_API int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float 
 	hipStream_t s = (hipStream_t)stream;
 	const MarchParams p = make_params(aabb0, aabb1, near_distance, cone_angle, const_dt, cascades, rng_state_host);
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 16, s); return 0; }
-	hipLaunchKernelGGL(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, (float *)nullptr);
+	// scratch = steps[n_rays] | pad to 1024 | t-cache[NGP_TCACHE][n_rays]  (ngp_march_scratch_elems(n_rays) u32 elements)
+	float *tcache = reinterpret_cast<float *>(scratch + ((n_rays + 1023u) & ~1023u));
+	hipLaunchKernelGGL(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
 	hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, n_rays, max_samples, cap, (const uint32_t *)scratch, numsteps, numsteps_compacted, (int32_t *)nullptr, counters, 4);
-	hipLaunchKernelGGL(k_march_write<true>, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, (const uint32_t *)numsteps_compacted, coords_out);
+	hipLaunchKernelGGL(k_march_write_cached, dim3(div_up(cap, 256)), dim3(256), 0, s, n_rays, p, rays_o, rays_d, (const uint32_t *)numsteps_compacted,
+	                   (const uint32_t *)counters, 3u, (const float *)tcache, coords_out);
 	NGP_LAUNCH_CHECK("ngp_march_rays_compacted");
 	return 0;
 }
@@ -321,6 +370,7 @@ __global__ __launch_bounds__(128) void k_composite_fwd(uint32_t n_rays, const T 
 		return;
 	}
 	float T_ = 1.f, ray[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4
 	for (uint32_t k = 0; k < ns; ++k) {
 		const size_t s = (size_t)base + k;
 		float o[4]; load4<T>(net + s * 4, o);
@@ -352,6 +402,7 @@ __global__ __launch_bounds__(128) void k_composite_bwd(uint32_t n_rays, const T 
 	const float l1 = *density_grid_mean < 0.01f ? 1e-4f : 0.0f;                       // :112
 	const float G[3] = {loss_grad[3 * i], loss_grad[3 * i + 1], loss_grad[3 * i + 2]}, R[3] = {rgb_ray[3 * i], rgb_ray[3 * i + 1], rgb_ray[3 * i + 2]};
 	float T_ = 1.f, ray2[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4
 	for (uint32_t k = 0; k < ns; ++k) {
 		const size_t s = (size_t)base + k;
 		float o[4]; load4<T>(net + s * 4, o);

@@ -60,6 +60,15 @@ class _RayDatasetBase:
         self.idx_now += self.batch_size
         return self.generate_random_data(index, self.batch_size)
 
+    def next_fused(self, bg):
+        """(ours) next(ds) with the target compositing of runner.py:68 (rgb*a + bg*(1-a)) done inside the ray-generation kernel:
+        -> (img_ids, rays_o, rays_d, target[R,3])"""
+        if self.shuffle_index is None or self.idx_now + self.batch_size >= self.shuffle_index.shape[0]:
+            self._reshuffle()
+        index = self.shuffle_index[self.idx_now:self.idx_now + self.batch_size]
+        self.idx_now += self.batch_size
+        return ops.generate_rays(index, self.W, self.H, self.focal_lengths, self.metadata, self.transforms_gpu, images=self.image_data, bg=bg)
+
     def generate_random_data(self, index, bs):
         img_ids, rays_o, rays_d, _ = ops.generate_rays(index, self.W, self.H, self.focal_lengths, self.metadata, self.transforms_gpu)
         rgb_tar = self.image_data.view(-1, 4)[index]

@@ -2,7 +2,24 @@
 import math
 import torch
 from torch import nn
+from . import ops
 from .utils.registry import LOSSES
+
+
+class _Huber(torch.autograd.Function):
+    """value and elementwise derivative in one kernel (csrc/sampler.hip k_huber); the ~10 tiny elementwise launches of the generic
+    formulation cost more than the maths"""
+
+    @staticmethod
+    def forward(ctx, x, target, delta):
+        loss, grad = ops.huber(x, target, delta)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g * grad, None, None
 
 
 @LOSSES.register_module()
@@ -15,6 +32,8 @@ class HuberLoss(nn.Module):
         self.delta_quad = 0.5 * delta ** 2
 
     def forward(self, x, target):
+        if x.is_cuda and x.dtype == torch.float32 and not target.requires_grad:
+            return _Huber.apply(x, target, self.delta)
         rel = torch.abs(x - target)
         sqr = 0.5 / self.delta * rel * rel
         return torch.where(rel > self.delta, rel - 0.5 * self.delta, sqr)

@@ -196,6 +196,10 @@ def compact_coords(coords_in, numsteps_in, cap, coords_out=None):
     return coords_out, numsteps_out, counter
 
 
+def march_scratch_elems(n_rays):
+    return int(L.lib().ngp_march_scratch_elems(n_rays))
+
+
 def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng_state, max_samples, cap, cone_angle=1.0 / 256, near=0.2, const_dt=True, cascades=5,
                          coords_out=None, numsteps=None, numsteps_c=None, counters=None, scratch=None):
     n = rays_o.shape[0]
@@ -208,8 +212,10 @@ def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng_state, max_samples,
         numsteps_c = torch.empty((n, 2), dtype=torch.int32, device=dev)
     if counters is None:
         counters = torch.empty(4, dtype=torch.int32, device=dev)
+    need = march_scratch_elems(n)
     if scratch is None:
-        scratch = torch.empty(n + 1024, dtype=torch.int32, device=dev)
+        scratch = torch.empty(need, dtype=torch.int32, device=dev)
+    assert scratch.numel() >= need, "march scratch too small: use ops.march_scratch_elems(n_rays)"
     with timed("march"):
         check(L.lib().ngp_march_rays_compacted(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
                                                rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch)),

@@ -86,7 +86,7 @@ class DensityGridSampler(nn.Module):
         self._numsteps_buf = torch.empty((cap_r, 2), dtype=torch.int32, device=dev)
         self._numsteps_c_buf = torch.empty((cap_r, 2), dtype=torch.int32, device=dev)
         self._counters = torch.zeros(4, dtype=torch.int32, device=dev)
-        self._scratch = torch.empty(cap_r + 1024, dtype=torch.int32, device=dev)
+        self._scratch = None
         self._coords_train = torch.zeros((self.target_batch_size, 7), dtype=torch.float32, device=dev)
         self._dout = None
         self._coords = None
@@ -120,6 +120,9 @@ class DensityGridSampler(nn.Module):
             self._n_valid = None
             return self._coords[:, :3], self._coords[:, 4:]
         numsteps, numsteps_c = self._numsteps_buf[:n], self._numsteps_c_buf[:n]
+        need = ops.march_scratch_elems(n)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(max(need, ops.march_scratch_elems(min(2 * n, 1 << 18))), dtype=torch.int32, device=self.device)
         ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.target_batch_size,
                                  self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
                                  coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=self._scratch)

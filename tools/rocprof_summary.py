@@ -4,11 +4,18 @@ import sqlite3
 import sys
 
 
-def main(db, out, title):
+def main(db, out, title, last_steps=0):
     c = sqlite3.connect(db)
-    q = """select s.kernel_name, count(*), sum(d.end-d.start)/1e3, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3, max(d.end-d.start)/1e3,
+    cutoff = 0
+    if last_steps:      # restrict to the last N training steps: cut at the start of the N-th from last Adam sweep over the hash table (largest grid)
+        marks = [r[0] for r in c.execute("""select d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
+                                            where s.kernel_name like '%k_march_count%' order by d.start""")]
+        if len(marks) > last_steps:
+            cutoff = marks[-last_steps]
+            title += f" — last {last_steps} training steps only"
+    q = f"""select s.kernel_name, count(*), sum(d.end-d.start)/1e3, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3, max(d.end-d.start)/1e3,
                   max(s.arch_vgpr_count), max(s.sgpr_count), max(d.group_segment_size), max(d.grid_size_x), max(d.workgroup_size_x)
-           from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by s.kernel_name order by 3 desc"""
+           from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id where d.start >= {cutoff} group by s.kernel_name order by 3 desc"""
     rows = list(c.execute(q))
     tot = sum(r[2] for r in rows)
     with open(out, "w") as f:
@@ -24,4 +31,4 @@ def main(db, out, title):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 kernel summary")
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 kernel summary", int(sys.argv[4]) if len(sys.argv) > 4 else 0)
