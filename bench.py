@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--images", type=int, default=50)
     ap.add_argument("--res", type=int, default=400)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     args = ap.parse_args()
 
     import torch
@@ -69,10 +70,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})"
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     from jnerf_amd import ops
     from jnerf_amd.presets import ngp_cfg
     from jnerf_amd.runner import Runner
@@ -92,10 +97,12 @@ def main():
     ops.PROFILE = {}
     barrier()
     t0 = time.perf_counter()
+    loss = None
     for _ in range(args.steps):
-        runner.train_step(step); step += 1
+        loss = runner.train_step(step); step += 1
         valid_sum += runner.sampler._counters[3]
     barrier()
+    last_loss = loss.mean().item() if loss is not None else float("nan")
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -148,7 +155,7 @@ def main():
         dist.barrier()
     if rank == 0:
         line = {"metric": "training iters/s", "value": round(world * args.steps / dt, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic", "loss": round(float(last_loss), 6),
                 "config": {"workload": "Instant-NGP fox config (ngp_fox.py hyper-parameters: aabb_scale 4, L=16, T=2^19, F=2, fp16 fused MLP, const_dt=False, 2^18-sample batches), "
                                        f"procedural scene {args.images}x{args.res}x{args.res} RGBA, random-init weights",
                            "samples_per_iter_per_gpu": 1 << 18, "parallelism": f"ray-batch dp{world}" if world > 1 else "single"},

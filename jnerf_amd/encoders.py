@@ -48,6 +48,8 @@ class HashEncoder(nn.Module):
         self.out_dtype = torch.float16 if self.using_fp16 else torch.float32
 
     def table_for_kernels(self):
+        from .optim import flush_all
+        flush_all()
         if not self.using_fp16:
             return self.m_grid.detach()
         if self.shadow_dirty:

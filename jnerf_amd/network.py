@@ -38,6 +38,8 @@ class FMLP(nn.Module):
         self.shadow_dirty = False
 
     def half_weights(self):
+        from .optim import flush_all
+        flush_all()
         if self.shadow_dirty:
             self.con_weights_half.copy_(self.con_weights.detach())
             self.shadow_dirty = False
@@ -63,6 +65,8 @@ class FMLP(nn.Module):
         return out
 
     def forward(self, x):
+        from .optim import flush_all
+        flush_all()
         h = x.float()
         ls = self.layers()
         for i, w in enumerate(ls):

@@ -5,14 +5,19 @@ ema_optimizer.ema_step(), .param_groups[*]['params'|'values'|'m'], .state_dict()
 MI355X execution: Adam + EMA + gradient zeroing + fp16-shadow refresh are ONE streaming kernel per parameter tensor
 (csrc/optim.hip): Adam.step() defers the sweep until EMA.ema_step() when an EMA is attached (Runner builds both, runner.py:35-37),
 so parameters are read and written once per step instead of ~12 times."""
+import weakref
 import torch
 import torch.distributed as dist
 from . import ops
 from .utils.registry import OPTIMS
 
+_LIVE = weakref.WeakSet()
 
-def _owner_shadow(p):
-    return getattr(p, "_ngp_half_shadow", None)
+
+def flush_all():
+    """complete every deferred gradient all-reduce + parameter sweep (called by the modules right before parameters are read)"""
+    for o in list(_LIVE):
+        o.flush()
 
 
 @OPTIMS.register_module()
@@ -24,8 +29,11 @@ class Adam:
         self.n_step = 0
         self._ema = None
         self._pending = False
-        self._world = 1
         self._half = {}
+        self._comm_stream = None
+        self._comm_pending = False
+        self._deferred_ema = None
+        _LIVE.add(self)
 
     @property
     def defaults(self):
@@ -47,13 +55,37 @@ class Adam:
     def backward(self, loss):
         loss.sum().backward()
 
+    @staticmethod
+    def _world():
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
     def allreduce_grads(self):
-        """ray-batch data parallelism: sum the hash-table and MLP gradients over ranks (RCCL over xGMI; gloo on CPU tests)"""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        """Ray-batch data parallelism: SUM the hash-table gradient (49.9 MB fp32) and the two MLP gradients over ranks — RCCL over xGMI on
+        the GPUs, gloo in the CPU unit tests.  On the GPU the collectives are issued on a side stream right after backward and are only
+        waited for when the parameters are next READ (flush()): the next iteration's ray generation and occupancy-grid marching — which
+        do not depend on the parameters — run underneath the all-reduce."""
+        if self._world() == 1:
             return
-        for p in self.param_groups[0]["params"]:
-            if p.grad is not None:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+        grads = [p.grad for p in self.param_groups[0]["params"] if p.grad is not None]
+        if grads and grads[0].is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                for g in grads:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            self._comm_pending = True
+        else:
+            for g in grads:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+
+    def flush(self):
+        if self._comm_pending:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            self._comm_pending = False
+        if self._deferred_ema is not None:
+            ema, self._deferred_ema = self._deferred_ema, None
+            self._sweep(ema if ema is not False else None)
 
     def step(self, loss=None):
         if loss is not None:
@@ -62,6 +94,8 @@ class Adam:
         self.n_step += 1
         if self._ema is not None:
             self._pending = True                    # the fused sweep runs in EMA.ema_step()
+        elif self._comm_pending:
+            self._deferred_ema = False              # sweep (without EMA) once the all-reduce has landed
         else:
             self._sweep(None)
 
@@ -91,6 +125,7 @@ class Adam:
         self._pending = False
 
     def state_dict(self):
+        self.flush()
         return {"defaults": {"lr": self.lr, "eps": self.eps, "betas": self.betas, "n_step": self.n_step,
                              "param_groups": [{"values": [t.detach().cpu() for t in self.param_groups[0]["values"]], "m": [t.detach().cpu() for t in self.param_groups[0]["m"]]}]}}
 
@@ -157,7 +192,11 @@ class EMA:
         self.steps += 1
         if self._adam is not None and self._adam._pending:
             assert self._adam.n_step == self.steps, "EMA and Adam must be stepped in lock-step to be fused"
-            self._adam._sweep(self)
+            if self._adam._comm_pending:
+                self._adam._pending = False
+                self._adam._deferred_ema = self     # sweep at the next parameter read, after the all-reduce
+            else:
+                self._adam._sweep(self)
             return
         old = 1 - self.decay ** (self.steps - 1)
         new = 1 / (1 - self.decay ** self.steps)

@@ -91,6 +91,8 @@ class Runner:
             return tot / len(mse_list)
 
     def save_ckpt(self, path):
+        from .optim import flush_all
+        flush_all()
         os.makedirs(os.path.dirname(path), exist_ok=True)
         torch.save({"global_step": self.cfg.m_training_step, "model": self.model.state_dict(), "sampler": self.sampler.state_dict(),
                     "optimizer": self.optimizer.state_dict(), "nested_optimizer": self.optimizer._nested_optimizer.state_dict(),
