@@ -38,6 +38,8 @@ int ngp_selftest_mfma(void *stream, uint32_t *result);
 /* ---- hash grid ------------------------------------------------------------------------------------------------
  * level_table_host: u32[16][4] = {offset (entries), size (entries), resolution, scale (f32 bits)} per level, built by the host
  * exactly as position_encoders/hash_encoder/grid_encode.py:17-40 + op_header/HashEncode.h:149-151 prescribe. */
+/* host helper: fills level_table_host for an aabb_scale, returns m_n_params (grid_encode.py:36) */
+uint32_t ngp_level_table(double aabb_scale, uint32_t *level_table_host);
 /* replaces GridEncode.execute (grid_encode.py:71-125: extract_position + kernel_grid + transpose_encoded_position) */
 int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *table,
                         const uint32_t *level_table_host, void *out, int dtype, int out_layout, const uint32_t *n_valid /*device u32 or NULL*/);

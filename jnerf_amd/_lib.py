@@ -19,6 +19,7 @@ SIGNATURES = {
     "ngp_last_error": (C.c_char_p, []),
     "ngp_device_info": (C.c_int, [_i32, _vp]),
     "ngp_selftest_mfma": (C.c_int, [_vp, _vp]),
+    "ngp_level_table": (C.c_uint32, [C.c_double, _vp]),
     "ngp_hash_encode_fwd": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ngp_hash_encode_bwd": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp]),
     "ngp_sh_encode": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _i32]),

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.lib()
     assert lib.ngp_abi_version() == 1
     syms = declared_symbols()
-    assert len(syms) >= 26
+    assert len(syms) >= 28
     exported = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     for s in syms:
         assert re.search(rf"\bT {s}\b", exported), f"{s} declared in include/ngp_hip.h but not exported"
@@ -50,6 +50,9 @@ def test_level_table_matches_reference_tables():
     assert list(t[:, 2]) == [16, 25, 37, 56, 85, 128, 195, 295, 446, 676, 1024, 1553, 2353, 3566, 5405, 8192]
     assert list(t[:4, 1]) == [4096, 15632, 50656, 175616] and all(t[4:, 1] == 524288) and n == 13074912
     from oracle import oracle as O
+    import ctypes as C
     for s in (1, 2, 4, 8, 16):
         a, b = ops.level_table(s), O.level_table(s)
         assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2] == b[2]
+        c = np.zeros((16, 4), np.uint32)
+        assert _lib.lib().ngp_level_table(float(s), c.ctypes.data_as(C.c_void_p)) == a[2] and (c == a[0]).all()

@@ -1,0 +1,87 @@
+"""Host-side logic that needs no GPU: Config semantics (python/jnerf/utils/config.py), registries, pose convention, camera path, presets."""
+import os
+import numpy as np
+import pytest
+from jnerf_amd.utils.config import Config, init_cfg, get_cfg, reset_cfg
+from jnerf_amd.utils.registry import Registry, build_from_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_missing_key_is_none_and_base_cover(tmp_path):
+    (tmp_path / "base.py").write_text("a = 1\nd = dict(x=1, y=dict(p=1, q=2))\nlst = [1, 2]\n")
+    (tmp_path / "child.py").write_text("_base_ = 'base.py'\nb = 2\nd = dict(y=dict(q=3), z=5)\n")
+    (tmp_path / "cover.py").write_text("_base_ = 'base.py'\nd = dict(_cover_=True, only=1)\n")
+    c = Config(str(tmp_path / "child.py"))
+    assert c.a == 1 and c.b == 2 and c.nothing is None                       # config.py:24-27
+    assert c.d.x == 1 and c.d.y.p == 1 and c.d.y.q == 3 and c.d.z == 5       # recursive merge (config.py:75-92)
+    assert c.name == "child" and c.work_dir == "work_dirs/child"             # config.py:107-110
+    k = Config(str(tmp_path / "cover.py"))
+    assert dict(k.d) == {"only": 1}                                          # _cover_ replaces (config.py:85-88)
+    c.live_object = object()
+    assert c["live_object"] is c.live_object                                 # live objects are stuffed into the same dict (runner.py:25)
+
+
+def test_shipped_configs_load():
+    init_cfg(os.path.join(ROOT, "projects/ngp/configs/ngp_fox.py"))
+    c = get_cfg()
+    assert c.fp16 is True and c.const_dt is False and c.dataset.val is None and c.dataset.train.root_dir == "data/fox"
+    assert c.optim.lr == 0.1 and c.expdecay.decay_start == 20000 and c.target_batch_size == 1 << 18 and c.hash_func.startswith("p0 ^ p1")
+    init_cfg(os.path.join(ROOT, "projects/ngp/configs/ngp_base.py"))
+    assert get_cfg().fp16 is None and get_cfg().const_dt is True and get_cfg().dataset.val.mode == "val"
+    reset_cfg(x=1)
+    assert get_cfg().x == 1 and get_cfg().fp16 is None
+
+
+def test_registry_and_build_from_cfg():
+    R = Registry()
+
+    @R.register_module()
+    class Foo:
+        def __init__(self, a, b=2):
+            self.a, self.b = a, b
+    f = build_from_cfg(dict(type="Foo", a=1), R, b=5)
+    assert (f.a, f.b) == (1, 5) and build_from_cfg(None, R) is None
+    with pytest.raises(AssertionError):
+        R.register_module()(Foo)
+    with pytest.raises(TypeError):
+        build_from_cfg(dict(type="Foo"), R)
+    import jnerf_amd.runner  # noqa: F401  registers everything
+    from jnerf_amd.utils import registry as G
+    for reg, names in ((G.ENCODERS, ["HashEncoder", "SHEncoder", "FrequencyEncoder"]), (G.NETWORKS, ["NGPNetworks"]), (G.SAMPLERS, ["DensityGridSampler"]),
+                       (G.LOSSES, ["HuberLoss", "MSELoss"]), (G.OPTIMS, ["Adam", "ExpDecay", "EMA"]), (G.DATASETS, ["NerfDataset", "SyntheticNerfDataset"])):
+        for n in names:
+            reg.get(n)
+
+
+def test_nerf2ngp_pose_convention():
+    from jnerf_amd.dataset import _RayDatasetBase
+    d = _RayDatasetBase.__new__(_RayDatasetBase)
+    d.correct_pose = [1, -1, -1]
+    m = np.arange(12, dtype=np.float32).reshape(3, 4)
+    out = d.matrix_nerf2ngp(m.copy(), 0.33, [0.5, 0.5, 0.5])
+    ref = m.copy(); ref[:, 1] *= -1; ref[:, 2] *= -1; ref[:, 3] = ref[:, 3] * 0.33 + 0.5; ref = ref[[1, 2, 0]]   # dataset.py:255-262
+    assert np.array_equal(out, ref)
+
+
+def test_expdecay_schedule():
+    from jnerf_amd.optim import ExpDecay
+
+    class Fake:
+        lr = 0.1
+        def step(self, loss=None):
+            pass
+    e = ExpDecay(Fake(), decay_start=3, decay_interval=2, decay_base=0.33)
+    lrs = []
+    for _ in range(8):
+        e.step()
+        lrs.append(round(e._nested_optimizer.lr, 6))
+    assert lrs == [0.1, 0.1, 0.1, 0.033, 0.033, round(0.1 * 0.33 ** 2, 6), round(0.1 * 0.33 ** 2, 6), round(0.1 * 0.33 ** 3, 6)]   # expdecay.py:20-25
+
+
+def test_camera_path():
+    from jnerf_amd.camera_path import path_spherical
+    p = path_spherical(8)
+    assert len(p) == 8 and p[0].shape == (3, 4)
+    for m in p:
+        assert np.allclose(m[:, :3] @ m[:, :3].T, np.eye(3), atol=1e-5) and abs(np.linalg.norm(m[:, 3]) - 4.0) < 1e-4

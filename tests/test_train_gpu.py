@@ -82,3 +82,39 @@ def test_two_ranks_data_parallel_on_one_gpu():
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and np.isfinite(d["loss"]) and d["config"]["parallelism"] == "ray-batch dp2"
+
+
+def test_nerf_dataset_on_disk(tmp_path):
+    """NerfDataset (dataset.py:68-170 semantics): transforms JSON + PNGs, train includes val, missing files skipped, fl_x / camera_angle_x, aabb_scale"""
+    import json
+    from PIL import Image
+    from jnerf_amd.utils.config import reset_cfg
+    from jnerf_amd.dataset import NerfDataset, fov_to_focal_length
+    reset_cfg(device="cuda")
+    rng = np.random.default_rng(0)
+    W, H = 20, 12
+
+    def frames(prefix, n):
+        out = []
+        for i in range(n):
+            Image.fromarray(rng.integers(0, 255, (H, W, 4), dtype=np.uint8)).save(tmp_path / f"{prefix}_{i}.png")
+            m = np.eye(4); m[:3, 3] = rng.normal(size=3)
+            out.append({"file_path": f"./{prefix}_{i}", "transform_matrix": m.tolist()})
+        return out
+    tr = frames("train", 3)
+    tr.append({"file_path": "./missing", "transform_matrix": np.eye(4).tolist()})
+    json.dump({"camera_angle_x": 0.7, "aabb_scale": 2, "frames": tr}, open(tmp_path / "transforms_train.json", "w"))
+    json.dump({"camera_angle_x": 0.7, "aabb_scale": 2, "frames": frames("val", 2)}, open(tmp_path / "transforms_val.json", "w"))
+    ds = NerfDataset(str(tmp_path), batch_size=64, mode="train")
+    assert ds.n_images == 5 and ds.resolution == [W, H] and ds.aabb_scale == 2 and ds.aabb_range == (-0.5, 1.5)
+    assert ds.image_data.shape == (5, H * W, 4) and ds.transforms_gpu.shape == (5, 4, 3) and ds.metadata.shape == (5, 11)
+    f = fov_to_focal_length(W, 0.7 * 180 / np.pi)
+    assert np.allclose(ds.focal_lengths.cpu().numpy(), f)
+    img_ids, o, d, rgba = next(ds)
+    assert img_ids.shape == (64,) and o.shape == (64, 3) and rgba.shape == (64, 4)
+    assert torch.allclose(d.norm(dim=-1), torch.ones(64, device="cuda"), atol=1e-5)
+    ro, rd, pix = ds.generate_rays_total_test(torch.zeros(H * W, dtype=torch.int32, device="cuda"), W, H)
+    assert ro.shape == (H * W, 3) and torch.equal(pix, torch.arange(H * W, device="cuda"))
+    # origin = translation * 0.33 + 0.5 with rows cycled [1,2,0] (dataset.py:255-262)
+    t = np.array(tr[0]["transform_matrix"])[:3, 3] * 0.33 + 0.5
+    assert np.allclose(ro[0].cpu().numpy(), t[[1, 2, 0]], atol=1e-6)
