@@ -48,6 +48,13 @@ int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint32_t pos
 int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, const uint32_t *level_table_host,
                         void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid);
 
+/* Same contract, exclusive table slices accumulated in 32-bit FIXED POINT (one 64-bit LDS integer atomic per corner instead of two LDS float
+ * atomics, which gfx950 retires ~12x slower).  level_scratch: device f32[16], receives the per-level L1 norm of dLdy that bounds every entry's
+ * sum (=> overflow-free scale); resolution = L1(level) / 2^30, results independent of the order of accumulation. */
+int ngp_hash_encode_bwd_fx(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, const uint32_t *level_table_host,
+                           void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid,
+                           float *level_scratch);
+
 /* ---- direction encoding: replaces SHEncoder.execute (position_encoders/sh_encoder/sh_encoder.py:29-51, SphericalEncode.h:45-95) */
 int ngp_sh_encode(void *stream, uint32_t n, const float *dir, uint32_t dir_stride_floats, void *out /*[n,16]*/, int dtype);
 

@@ -22,6 +22,7 @@ SIGNATURES = {
     "ngp_level_table": (C.c_uint32, [C.c_double, _vp]),
     "ngp_hash_encode_fwd": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ngp_hash_encode_bwd": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp]),
+    "ngp_hash_encode_bwd_fx": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ngp_sh_encode": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _i32]),
     "ngp_field_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
     "ngp_density_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _i32]),

@@ -147,10 +147,38 @@ __global__ __launch_bounds__(256) void k_hash_bwd(uint32_t n, const float *__res
 // atomic flush (a few thousand adds per workgroup).  The redundant index arithmetic (each sample is visited by every slice owner of a
 // level) is ~1e10 lane-ops per batch — about 0.15 ms of VALU time on 256 CUs — and the sample stream is re-read from L2, not HBM.
 #define OWN_SLICE 16384u
-struct OwnerPlan { uint32_t first_unit[17]; uint32_t chunks[16]; uint32_t order[16]; };
 
-template <typename T, typename G, int LAYOUT, bool HASHED, bool COMBINE>
-__device__ __forceinline__ void owner_unit(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, const LevelTable &lt, uint32_t level,
+// One accumulation into the owned LDS slice.  FX = false: two ds_add_f32 (the LDS float-atomic path retires ~1 lane / 3 cycles / CU on gfx950).
+// FX = true: both features as 32-bit fixed-point fields of ONE ds_add_u64 (16.6 cycles per wave instruction, tools/microbench_lds.py):
+// sum = (sum_y << 32) + sum_x in two's complement, decoded exactly at the flush.  The scale is the power of two with scale * L1(level) <= 2^30,
+// where L1(level) = sum over all samples of |dL/dy| bounds any entry's |sum| — overflow is impossible by construction, integer adds commute,
+// so the exclusive slices become bit-reproducible.
+template <bool FX>
+__device__ __forceinline__ void acc_add(float *acc, uint32_t l, float vx, float vy, float fx_scale) {
+	if (FX) {
+		const int ix = __float2int_rn(vx * fx_scale), iy = __float2int_rn(vy * fx_scale);
+		const unsigned long long add = (unsigned long long)(long long)ix + ((unsigned long long)(uint32_t)iy << 32);
+		__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(acc) + l, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	} else {
+		__hip_atomic_fetch_add(&acc[2 * l], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add(&acc[2 * l + 1], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+}
+template <bool FX>
+__device__ __forceinline__ float2 acc_read(const float *acc, uint32_t e, float fx_inv) {
+	if (FX) {
+		const unsigned long long t = reinterpret_cast<const unsigned long long *>(acc)[e];
+		const int lo = (int)(uint32_t)(t & 0xffffffffull);
+		const int hi = (int)(uint32_t)((t - (unsigned long long)(long long)lo) >> 32);
+		return make_float2((float)lo * fx_inv, (float)hi * fx_inv);
+	}
+	return make_float2(acc[2 * e], acc[2 * e + 1]);
+}
+
+struct OwnerPlan { uint32_t first_unit[17]; uint32_t chunks[16]; uint32_t order[16]; uint32_t level_mask; uint32_t coarse_res; };
+
+template <typename T, typename G, int LAYOUT, bool HASHED, bool COMBINE, bool FX>
+__device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, const LevelTable &lt, uint32_t level,
                                            uint32_t slice, uint32_t chunk, uint32_t n_chunks, G *__restrict__ grad, int accumulate, uint32_t lim, float *acc) {
 	using P = typename Pair<T>::type;
 	using GP = typename Pair<G>::type;
@@ -214,8 +242,7 @@ __device__ __forceinline__ void owner_unit(uint32_t n, const float *__restrict__
 					for (uint32_t q = 0; q < 8; ++q) {
 						if ((hits >> q) & 1u) {
 							if (ax[q] != 0.f || ay[q] != 0.f) {
-								__hip_atomic_fetch_add(&acc[2 * local[q]], ax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-								__hip_atomic_fetch_add(&acc[2 * local[q] + 1], ay[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+								acc_add<FX>(acc, local[q], ax[q], ay[q], fx_scale);
 							}
 						}
 						ax[q] = 0.f; ay[q] = 0.f;
@@ -257,36 +284,50 @@ __device__ __forceinline__ void owner_unit(uint32_t n, const float *__restrict__
 			tx[0] = c.g[0]; tx[1] = c.g[0] + 1;
 			if (HASHED) { ty[0] = c.g[1] * 19349663u; ty[1] = ty[0] + 19349663u; tz[0] = c.g[2] * 83492791u; tz[1] = tz[0] + 83492791u; }
 			else { ty[0] = c.g[1] * res; ty[1] = ty[0] + res; tz[0] = c.g[2] * res2; tz[1] = tz[0] + res2; }
-			uint32_t local[8], hits = 0;
+			uint32_t hits = 0;
+			if (HASHED) {
+				// Slice test for all eight corners at once: the slice id of a corner is bits 14..18 of tx^ty^tz and XOR commutes with bit
+				// extraction, so it is sx_i ^ sy_j ^ sz_k of three 5-bit fields.  Four (i,j) combinations are packed one per byte, the two
+				// k values are XORed in with a byte-replicating multiply, and "byte == slice" becomes a zero-byte test (no cross-byte borrow
+				// because every byte is < 32).  ~30 VALU ops instead of ~100 for eight separate index computations.
+				const uint32_t sx0 = (tx[0] >> 14) & 31u, sx1 = (tx[1] >> 14) & 31u, sy0 = (ty[0] >> 14) & 31u, sy1 = (ty[1] >> 14) & 31u;
+				const uint32_t sz0 = (tz[0] >> 14) & 31u, sz1 = (tz[1] >> 14) & 31u;
+				const uint32_t A = (sx0 ^ sy0) | ((sx1 ^ sy0) << 8) | ((sx0 ^ sy1) << 16) | ((sx1 ^ sy1) << 24);
+				const uint32_t S = slice * 0x01010101u;
+				const uint32_t X0 = A ^ (sz0 * 0x01010101u) ^ S, X1 = A ^ (sz1 * 0x01010101u) ^ S;
+				const uint32_t m0 = ~((X0 | 0x80808080u) - 0x01010101u) & 0x80808080u, m1 = ~((X1 | 0x80808080u) - 0x01010101u) & 0x80808080u;
+				hits = ((m0 * 0x00204081u) >> 28) | (((m1 * 0x00204081u) >> 28) << 4);     // msb of each byte -> one bit per corner
+			} else {
 #pragma unroll
-			for (uint32_t q = 0; q < 8; ++q) {
-				uint32_t idx;
-				if (HASHED) idx = (tx[q & 1] ^ ty[(q >> 1) & 1] ^ tz[q >> 2]) & (size - 1);        // hashed levels have 2^19 entries
-				else { idx = tx[q & 1] + ty[(q >> 1) & 1] + tz[q >> 2]; if (idx >= size) idx %= size; }   // wraps only at the +1 boundary corner
-				local[q] = idx - lo;
-				hits |= (local[q] < cnt) ? (1u << q) : 0u;
+				for (uint32_t q = 0; q < 8; ++q) {
+					uint32_t idx = tx[q & 1] + ty[(q >> 1) & 1] + tz[q >> 2];
+					if (idx >= size) idx %= size;                                            // wraps only at the +1 boundary corner
+					hits |= (idx - lo < cnt) ? (1u << q) : 0u;
+				}
 			}
 			if (g2.x == 0.f && g2.y == 0.f) hits = 0;       // zero-padded rows add exact zeros in the reference; skipping them is value-identical
 			while (hits) {                      // ~8/32 corners per sample land in this slice: one short divergent loop instead of eight regions
 				const uint32_t q = __builtin_ctz(hits);
 				hits &= hits - 1;
-				uint32_t l = local[0];
-#pragma unroll
-				for (uint32_t r = 1; r < 8; ++r) l = (q == r) ? local[r] : l;
+				const uint32_t ex = (q & 1u) ? tx[1] : tx[0], ey = (q & 2u) ? ty[1] : ty[0], ez = (q & 4u) ? tz[1] : tz[0];
+				uint32_t idx;
+				if (HASHED) idx = (ex ^ ey ^ ez) & (size - 1);
+				else { idx = ex + ey + ez; if (idx >= size) idx %= size; }
+				const uint32_t l = idx - lo;
 				const float wx = (q & 1u) ? c.w[0] : 1 - c.w[0], wy = (q & 2u) ? c.w[1] : 1 - c.w[1], wz = (q & 4u) ? c.w[2] : 1 - c.w[2];
 				const float weight = wx * wy * wz;
 				if (accumulate & 2) { if (weight == 123.f) acc[2 * l] = g2.x; continue; }   // probe: everything but the LDS atomics
-				__hip_atomic_fetch_add(&acc[2 * l], g2.x * weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_fetch_add(&acc[2 * l + 1], g2.y * weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				acc_add<FX>(acc, l, g2.x * weight, g2.y * weight, fx_scale);
 			}
 		}
 	}
 	__syncthreads();
 	accumulate &= 1;
+	const float fx_inv = FX ? 1.0f / fx_scale : 1.0f;
 	G *gl = grad + ((size_t)off + lo) * 2;
 	if (n_chunks == 1) {            // exclusive owner: plain stores (or a private read-modify-write when accumulating)
 		for (uint32_t e = threadIdx.x; e < cnt; e += 1024) {
-			float2 v = make_float2(acc[2 * e], acc[2 * e + 1]);
+			float2 v = acc_read<FX>(acc, e, fx_inv);
 			GP *dst = reinterpret_cast<GP *>(gl) + e;
 			if (accumulate) { const float2 old = to_f2(*dst); v.x += old.x; v.y += old.y; }
 			GP o; from_f2(o, v);
@@ -294,7 +335,7 @@ __device__ __forceinline__ void owner_unit(uint32_t n, const float *__restrict__
 		}
 	} else {                        // shared slice (small dense level): flush touched entries with global atomics; the host side zeroed the level unless accumulating
 		for (uint32_t e = threadIdx.x; e < cnt; e += 1024) {
-			const float2 v = make_float2(acc[2 * e], acc[2 * e + 1]);
+			const float2 v = acc_read<FX>(acc, e, fx_inv);
 			if (v.x != 0.f || v.y != 0.f) atomic_add_pair(gl + (size_t)e * 2, v);
 		}
 	}
@@ -302,9 +343,10 @@ __device__ __forceinline__ void owner_unit(uint32_t n, const float *__restrict__
 
 template <typename T, typename G, int LAYOUT>
 __global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt,
-                                                         OwnerPlan plan, G *__restrict__ grad, int accumulate, const uint32_t *__restrict__ n_valid) {
+                                                         OwnerPlan plan, G *__restrict__ grad, int accumulate, const uint32_t *__restrict__ n_valid,
+                                                         const float *__restrict__ level_l1) {
 	extern __shared__ __attribute__((aligned(16))) float acc[];          // [slice entries][2]
-	// block -> (level, slice, chunk); single-chunk (heavy) levels come first in plan.order so they are dispatched first
+	// block -> (level, slice, chunk); plan.order lists the chunked dense levels first, then the exclusive-owner (hashed) levels
 	uint32_t k = 0;
 	while (k < 15 && blockIdx.x >= plan.first_unit[k + 1]) ++k;
 	const uint32_t level = plan.order[k];
@@ -312,12 +354,47 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float
 	const uint32_t n_chunks = plan.chunks[level];
 	const uint32_t slice = u / n_chunks, chunk = u - slice * n_chunks;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	if (!((plan.level_mask >> level) & 1u)) return;      // probe hook (tools/microbench_hash.py); all ones in production
 	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
-	const bool coarse = res <= 600;     // cells much longer than a marching step: consecutive samples of a ray share them
-	if (level_is_dense(size, res)) owner_unit<T, G, LAYOUT, false, true>(n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc);
-	else if (coarse) owner_unit<T, G, LAYOUT, true, true>(n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc);
-	else owner_unit<T, G, LAYOUT, true, false>(n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc);
+	const bool coarse = res <= plan.coarse_res;     // cells much longer than a marching step: consecutive samples of a ray share them
+	const bool dense = level_is_dense(size, res);
+#define OWNER_GO(H, C, F, SC) owner_unit<T, G, LAYOUT, H, C, F>(SC, n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc)
+	if (level_l1) {
+		const float l1 = level_l1[level];
+		if (!(l1 > 0.f)) {                                       // nothing to add on this level: write zeros / leave the accumulating buffer alone
+			if (n_chunks == 1 && !(accumulate & 1)) {
+				const uint32_t off = lt.v[4 * level], lo = slice * OWN_SLICE, cnt = min(OWN_SLICE, size - lo);
+				typename Pair<G>::type z; from_f2(z, make_float2(0.f, 0.f));
+				for (uint32_t e = threadIdx.x; e < cnt; e += 1024) reinterpret_cast<typename Pair<G>::type *>(grad + ((size_t)off + lo) * 2)[e] = z;
+			}
+			return;
+		}
+		int ex; frexpf(l1, &ex);                                 // l1 < 2^ex  =>  scale = 2^(30-ex) keeps |sum| * scale < 2^30
+		const float sc = ldexpf(1.0f, 30 - ex);
+		if (dense) OWNER_GO(false, true, true, sc); else if (coarse) OWNER_GO(true, true, true, sc); else OWNER_GO(true, false, true, sc);
+	} else {
+		if (dense) OWNER_GO(false, true, false, 1.0f); else if (coarse) OWNER_GO(true, true, false, 1.0f); else OWNER_GO(true, false, false, 1.0f);
+	}
+#undef OWNER_GO
 	// (hashed levels with a non-power-of-two table never reach this kernel: the host routes them to the atomic kernel)
+}
+
+
+// per-level L1 norm of dL/dy (the overflow bound of the fixed-point accumulation): l1[level] += sum |dy|
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void k_level_l1(uint32_t n, const T *__restrict__ dLdy, float *__restrict__ l1, const uint32_t *__restrict__ n_valid) {
+	using P = typename Pair<T>::type;
+	const uint32_t level = blockIdx.y;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const P *dy = reinterpret_cast<const P *>(dLdy);
+	float s = 0.f;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < lim; i += gridDim.x * 256u) {
+		const float2 g = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level]);
+		s += fabsf(g.x) + fabsf(g.y);
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+	if ((threadIdx.x & 63u) == 0 && s != 0.f) __hip_atomic_fetch_add(&l1[level], s * 1.0001f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 1e-4 slack for the fp32 summation error
 }
 
 static LevelTable load_table(const uint32_t *host) { LevelTable lt; for (int i = 0; i < 64; ++i) lt.v[i] = host[i]; return lt; }
@@ -347,8 +424,8 @@ static int hash_bwd_method() {
 	return m;
 }
 
-NGP_API int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
-                                void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid) {
+static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
+                         void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, float *level_scratch) {
 	NGP_REQUIRE(grad && level_table_host && (n == 0 || (pos && dLdy)), NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_bwd: bad dtype %d", dtype);
 	NGP_REQUIRE(grad_dtype == NGP_F32 || (grad_dtype == NGP_F16 && dtype == NGP_F16), NGP_E_DTYPE, "ngp_hash_encode_bwd: bad grad dtype %d for dtype %d", grad_dtype, dtype);
@@ -381,16 +458,19 @@ NGP_API int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint
 	OwnerPlan plan;
 	uint32_t slices[16], units = 0, k = 0;
 	for (int l = 0; l < 16; ++l) { slices[l] = div_up(lt.v[4 * l + 1], OWN_SLICE); plan.chunks[l] = slices[l] >= 32 ? 1u : (32u / slices[l] ? 32u / slices[l] : 1u); }
-	for (int pass = 0; pass < 2; ++pass)                                  // exclusive-owner (heavy) levels first
+	for (int pass = 0; pass < 2; ++pass)                                  // chunked dense levels first (their hot slices are the long poles), largest level first
 		for (int l = 15; l >= 0; --l)
-			if ((plan.chunks[l] == 1) == (pass == 0)) { plan.order[k] = (uint32_t)l; plan.first_unit[k] = units; units += slices[l] * plan.chunks[l]; ++k; }
+			if ((plan.chunks[l] > 1) == (pass == 0)) { plan.order[k] = (uint32_t)l; plan.first_unit[k] = units; units += slices[l] * plan.chunks[l]; ++k; }
 	plan.first_unit[16] = units;
+	{ const char *e = getenv("NGP_PROBE_LEVEL_MASK"); plan.level_mask = e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffu; }
+	{ const char *e = getenv("NGP_PROBE_COARSE_RES"); plan.coarse_res = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }
 	for (int l = 0; l < 16; ++l) {                                       // chunked levels are flushed with atomics -> need a zeroed destination
 		if (plan.chunks[l] > 1 && zero_first) {
 			hipError_t e = hipMemsetAsync((char *)grad + (size_t)lt.v[4 * l] * 2 * gsz, 0, (size_t)lt.v[4 * l + 1] * 2 * gsz, s);
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; }
 		}
 	}
+	if (level_scratch) { hipError_t e = hipMemsetAsync(level_scratch, 0, 16 * sizeof(float), s); if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; } }
 	const int accumulate = (zero_first ? 0 : 1) | ((getenv("NGP_PROBE_NO_LDS_ATOMICS") != nullptr) ? 2 : 0);
 	const size_t shmem = (size_t)OWN_SLICE * 2 * sizeof(float);
 	const dim3 grid(units), block(1024);
@@ -398,13 +478,24 @@ NGP_API int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_hash_bwd_owner<T, G, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	hipLaunchKernelGGL((k_hash_bwd_owner<T, G, L>), grid, block, shmem, s, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid); } while (0)
+	if (level_scratch) hipLaunchKernelGGL((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
+	hipLaunchKernelGGL((k_hash_bwd_owner<T, G, L>), grid, block, shmem, s, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch); } while (0)
 	if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, float, NGP_LAYOUT_SOA); else GO(float, float, NGP_LAYOUT_AOS); }
 	else if (grad_dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(__half, float, NGP_LAYOUT_SOA); else GO(__half, float, NGP_LAYOUT_AOS); }
 	else { if (in_layout == NGP_LAYOUT_SOA) GO(__half, __half, NGP_LAYOUT_SOA); else GO(__half, __half, NGP_LAYOUT_AOS); }
 #undef GO
 	NGP_LAUNCH_CHECK("ngp_hash_encode_bwd");
 	return 0;
+}
+
+NGP_API int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
+                                void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid) {
+	return hash_bwd_impl(stream, n, pos, pos_stride, dLdy, level_table_host, grad, n_params, dtype, grad_dtype, in_layout, zero_first, n_valid, nullptr);
+}
+NGP_API int ngp_hash_encode_bwd_fx(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
+                                   void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, float *level_scratch) {
+	NGP_REQUIRE(level_scratch, NGP_E_ARG, "ngp_hash_encode_bwd_fx: level_scratch (device f32[16]) is required");
+	return hash_bwd_impl(stream, n, pos, pos_stride, dLdy, level_table_host, grad, n_params, dtype, grad_dtype, in_layout, zero_first, n_valid, level_scratch);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- probes (tools/microbench_hash.py only)

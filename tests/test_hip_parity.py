@@ -65,6 +65,37 @@ def test_hash_bwd_vs_oracle(H, dtype, grad_dtype):
     GC.close(out2, ref, what="hash bwd soa", **tol)
 
 
+def test_hash_bwd_fixed_point_vs_oracle_and_deterministic(H):
+    """ngp_hash_encode_bwd_fx: 32-bit fixed-point LDS accumulation with the provable scale 2^30 / L1(level)"""
+    from jnerf_amd import ops
+    table, offsets, n_params = O.level_table(4)
+    rng = np.random.default_rng(4)
+    n = 5003
+    x = synth.uniform_positions(n, seed=8)
+    x[:2000] = 0.5 + (x[:2000] - 0.5) * 0.02                 # a dense cluster: many hits per entry on the coarse levels
+    dy = (rng.normal(size=(n, 32)) * 1e-3 * np.exp(rng.normal(size=(n, 1)) * 2)).astype(np.float16)     # gradients spanning ~3 decades
+    ref = O.hash_encode_bwd(x, dy.astype(np.float32), table, n_params)
+    T = H.T
+    scratch = torch.zeros(16, device="cuda")
+    dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
+    outs = []
+    for _ in range(2):
+        g = ops.hash_encode_bwd(T(x), T(dys), table, n_params, grad_dtype=torch.float32, layout=ops.LAYOUT_SOA, fixed_point_scratch=scratch)
+        outs.append(H.N(g))
+    l1 = H.N(scratch)
+    exact_l1 = np.abs(dy.astype(np.float64)).reshape(n, 16, 2).sum((0, 2))
+    assert np.allclose(l1, exact_l1, rtol=1e-3) and (l1 >= exact_l1).all()          # the bound really bounds
+    for l in range(16):
+        lo, hi = int(offsets[l]) * 2, int(offsets[l + 1]) * 2
+        res = 2.0 ** (np.ceil(np.log2(l1[l])) - 30 + 1)                               # one fixed-point ulp (scale is a power of two <= 2^30/L1)
+        hits = 8 * n                                                                  # worst case: every contribution rounded separately into one entry
+        err = np.abs(outs[0][lo:hi].astype(np.float64) - ref[lo:hi]).max()
+        assert err <= 0.5 * res * 64 + 1e-6 * np.abs(ref[lo:hi]).max(), (l, err, res)
+        if table[l, 1] == 1 << 19:      # exclusive (hashed) slices: integer accumulation => bit-reproducible
+            assert np.array_equal(outs[0][lo:hi], outs[1][lo:hi])
+    GC.close(outs[0], ref, atol=4e-9 * float(l1.max()) * 64, rtol=1e-4, what="fx scatter")
+
+
 def _field_inputs(n, seed=0):
     rng = np.random.default_rng(seed)
     feat = (rng.normal(size=(n, 32)) * 0.5).astype(np.float16)

@@ -66,5 +66,37 @@ def main():
         print(f"bwd fp16->f32 SoA {name} (product kernel, XCD map): {us:.1f} us")
 
 
+def per_level():
+    """time the owner-computes scatter one level at a time (NGP_PROBE_LEVEL_MASK is read at every call)"""
+    n = 1 << 18
+    table, offsets, n_params = ops.level_table(4)
+    torch.manual_seed(0)
+    nr = n // 7 + 1
+    dirs = torch.nn.functional.normalize(torch.randn((nr, 1, 3), device="cuda"), dim=-1)
+    tt = torch.arange(7, device="cuda").view(1, 7, 1) * 4e-4
+    conc = (0.5 + dirs * 0.08 + torch.nn.functional.normalize(torch.randn((nr, 1, 3), device="cuda"), dim=-1) * tt).reshape(-1, 3)[:n].contiguous()
+    uni = torch.rand((n, 3), device="cuda")
+    dy = (torch.randn((16, n, 2), device="cuda") * 1e-3).half()
+    gb = torch.zeros(n_params, device="cuda")
+    fxs = torch.zeros(16, device="cuda")
+    for name, pos, fx in (("uniform", uni, None), ("concentrated", conc, None), ("uniform, fixed-point", uni, fxs), ("concentrated, fixed-point", conc, fxs)):
+        row = []
+        for l in list(range(16)) + [None]:
+            os.environ["NGP_PROBE_LEVEL_MASK"] = hex(1 << l) if l is not None else "0xffff"
+            fn = lambda: ops.hash_encode_bwd(pos, dy, table, n_params, grad=gb, layout=ops.LAYOUT_SOA, zero_first=False, fixed_point_scratch=fx)
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            row.append(a.elapsed_time(b) / 5 * 1e3)
+        print(f"owner scatter per level [{name}] us: " + " ".join(f"{v:.0f}" for v in row[:-1]) + f" | all levels {row[-1]:.0f}")
+    os.environ.pop("NGP_PROBE_LEVEL_MASK", None)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "levels":
+        per_level()
+        sys.exit(0)
     main()

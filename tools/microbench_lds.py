@@ -9,7 +9,7 @@ f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_in
 out = torch.zeros(1024, device="cuda")
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 blocks, iters = 256, 4096
-for use_int in (0, 1):
+for use_int in (0, 1, 2, 3):
     for distinct in (64, 32, 16, 8, 4, 2, 1):
         f(s, blocks, iters, distinct, C.c_void_p(out.data_ptr()), use_int); torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -17,4 +17,4 @@ for use_int in (0, 1):
         ms = a.elapsed_time(b)
         lane_ops = blocks * 1024 * iters
         cyc_per_wave_instr = ms * 1e-3 * 2.4e9 / (iters * 16)   # per CU: 16 waves x iters instructions
-        print(f"{'u32' if use_int else 'f32'} distinct={distinct:2d} ({64 // distinct:2d}-way): {ms:8.3f} ms  {lane_ops / ms / 1e6:9.1f} G lane-ops/s chip  ~{cyc_per_wave_instr:7.1f} cycles per wave-instruction per CU")
+        print(f"{['f32', 'u32', 'u64', 'pk_f16'][use_int]} distinct={distinct:2d} ({64 // distinct:2d}-way): {ms:8.3f} ms  {lane_ops / ms / 1e6:9.1f} G lane-ops/s chip  ~{cyc_per_wave_instr:7.1f} cycles per wave-instruction per CU")
