@@ -146,11 +146,16 @@ def main():
         import numpy as np
         from jnerf_amd.utils.registry import build_from_cfg, DATASETS
         runner.dataset["test"] = build_from_cfg(runner.cfg.dataset.test, DATASETS)
-        torch.cuda.synchronize(); tr0 = time.perf_counter()
-        img, _, tar = runner.render_img("test", 0)
-        torch.cuda.synchronize(); tr = time.perf_counter() - tr0
+        img, _, tar = runner.render_img("test", 0)                      # first call allocates the inference buffers
         extra["psnr_test_view_after_%d_steps" % step] = round(float(-10 * np.log10(np.mean((img - tar) ** 2))), 2)
-        extra["render_Msamples_per_s"] = round(runner.n_samples_rendered / tr / 1e6, 2)
+        torch.cuda.synchronize(); tr0 = time.perf_counter()
+        n_s = 0
+        for v in range(4):                                              # 4 full views incl. ray generation and the device->host copy of each image
+            runner.render_img("test", v % runner.dataset["test"].n_images)
+            n_s += runner.n_samples_rendered
+        torch.cuda.synchronize(); tr = time.perf_counter() - tr0
+        extra["render_Msamples_per_s"] = round(n_s / tr / 1e6, 2)
+        extra["render_ms_per_%dx%d_view" % (args.res, args.res)] = round(tr / 4 * 1e3, 2)
     if world > 1:
         dist.barrier()
     if rank == 0:

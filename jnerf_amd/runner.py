@@ -45,6 +45,7 @@ class Runner:
         self.alpha_image = cfg.alpha_image
         cfg.m_training_step = 0
         self.val_freq = 4096
+        self.render_chunk = int(cfg.render_chunk or 32768)       # rays per inference pass (the reference: n_rays_per_batch = 4096)
         self.W, self.H = self.dataset["train"].resolution
 
     # ---- one training iteration == the body of Runner.train (runner.py:64-76)
@@ -138,35 +139,40 @@ class Runner:
         Image.fromarray((img * 255 + 0.5).clip(0, 255).astype("uint8")).save(path)
 
     @torch.no_grad()
+    def _render_rays(self, img_ids, rays_o_total, rays_d_total, chunk):
+        """sampler.sample -> model -> rays2rgb(inference) over ray chunks (runner.py:211-226), results assembled on the device.
+        `chunk` rays per pass; the reference uses n_rays_per_batch = 4096 and two .numpy() read-backs per chunk."""
+        n = rays_o_total.shape[0]
+        dev = rays_o_total.device
+        imgs = torch.empty((n, 3), device=dev)
+        alphas = torch.empty((n, 1), device=dev)
+        counts = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.sampler.sync_free_inference = True
+        try:
+            for pixel in range(0, n, chunk):
+                rays_o, rays_d = rays_o_total[pixel:pixel + chunk], rays_d_total[pixel:pixel + chunk]
+                pos, dirs = self.sampler.sample(img_ids, rays_o, rays_d)
+                counts += self.sampler._inference_counter[3]
+                network_outputs = self.model(pos, dirs)
+                rgb, alpha = self.sampler.rays2rgb(network_outputs, inference=True)
+                imgs[pixel:pixel + chunk] = rgb
+                alphas[pixel:pixel + chunk] = alpha
+        finally:
+            self.sampler.sync_free_inference = False
+        self.n_samples_rendered = int(counts.item())
+        return imgs, alphas
+
+    @torch.no_grad()
     def render_img(self, dataset_mode="train", img_id=None):
-        """runner.py:197-236, with the per-chunk results assembled on the device (one D2H copy per image instead of 2 x n_chunks)"""
+        """runner.py:197-236"""
         ds = self.dataset[dataset_mode]
         W, H = int(self.W), int(self.H)
         if img_id is None:
             img_id = int(np.random.randint(0, ds.n_images))
         img_ids = torch.full((H * W,), img_id, dtype=torch.int32, device=ds.device)
         rays_o_total, rays_d_total, _ = ds.generate_rays_total_test(img_ids, W, H)
-        imgs = torch.empty((H * W + self.n_rays_per_batch, 3), device=ds.device)
-        alphas = torch.empty((H * W + self.n_rays_per_batch, 1), device=ds.device)
-        self.n_samples_rendered = 0
-        for pixel in range(0, W * H, self.n_rays_per_batch):
-            end = pixel + self.n_rays_per_batch
-            rays_o, rays_d = rays_o_total[pixel:end], rays_d_total[pixel:end]
-            if end > H * W:
-                pad = end - H * W
-                rays_o = torch.cat([rays_o, torch.ones((pad, 3), device=ds.device)], 0)
-                rays_d = torch.cat([rays_d, torch.ones((pad, 3), device=ds.device)], 0)
-            pos, dirs = self.sampler.sample(img_ids, rays_o, rays_d)
-            self.n_samples_rendered += pos.shape[0]
-            if pos.shape[0] == 0:
-                imgs[pixel:end] = 0
-                alphas[pixel:end] = 0
-                continue
-            network_outputs = self.model(pos, dirs)
-            rgb, alpha = self.sampler.rays2rgb(network_outputs, inference=True)
-            imgs[pixel:end] = rgb
-            alphas[pixel:end] = alpha
-        imgs, alphas = imgs[:H * W].view(H, W, 3), alphas[:H * W].view(H, W, 1)
+        imgs, alphas = self._render_rays(img_ids, rays_o_total, rays_d_total, self.render_chunk)
+        imgs, alphas = imgs.view(H, W, 3), alphas.view(H, W, 1)
         tar = ds.image_data[img_id].view(H, W, 4)
         bgc = torch.tensor(self.background_color, dtype=torch.float32, device=ds.device)
         tar = tar[..., :3] * tar[..., 3:] + bgc * (1 - tar[..., 3:])
@@ -177,27 +183,13 @@ class Runner:
 
     @torch.no_grad()
     def render_img_with_pose(self, pose):
+        """runner.py:238-264"""
         ds = self.dataset["train"]
         W, H = int(self.W), int(self.H)
         fake_ids = torch.zeros((H * W,), dtype=torch.int32, device=ds.device)
         rays_o_total, rays_d_total = ds.generate_rays_with_pose(pose, W, H)
-        img = torch.empty((H * W + self.n_rays_per_batch, 3), device=ds.device)
-        alpha = torch.empty((H * W + self.n_rays_per_batch, 1), device=ds.device)
-        for pixel in range(0, W * H, self.n_rays_per_batch):
-            end = pixel + self.n_rays_per_batch
-            rays_o, rays_d = rays_o_total[pixel:end], rays_d_total[pixel:end]
-            if end > H * W:
-                pad = end - H * W
-                rays_o = torch.cat([rays_o, torch.ones((pad, 3), device=ds.device)], 0)
-                rays_d = torch.cat([rays_d, torch.ones((pad, 3), device=ds.device)], 0)
-            pos, dirs = self.sampler.sample(fake_ids, rays_o, rays_d)
-            if pos.shape[0] == 0:
-                img[pixel:end] = 0
-                alpha[pixel:end] = 0
-                continue
-            rgb, a = self.sampler.rays2rgb(self.model(pos, dirs), inference=True)
-            img[pixel:end], alpha[pixel:end] = rgb, a
-        img, alpha = img[:H * W].view(H, W, 3), alpha[:H * W].view(H, W, 1)
+        img, alpha = self._render_rays(fake_ids, rays_o_total, rays_d_total, self.render_chunk)
+        img, alpha = img.view(H, W, 3), alpha.view(H, W, 1)
         if not self.alpha_image:
             img = img + torch.tensor(self.background_color, dtype=torch.float32, device=ds.device) * (1 - alpha)
         return img.cpu().numpy()

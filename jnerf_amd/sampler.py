@@ -91,11 +91,12 @@ class DensityGridSampler(nn.Module):
         self._dout = None
         self._coords = None
         self._n_valid = None
+        self.sync_free_inference = False        # Runner.render_img switches it on (large ray chunks, no .item() per chunk)
 
     # ------------------------------------------------------------------ hot path
     def n_valid_for(self, pos):
-        """device-side sample count when `pos` is a view of this sampler's compacted buffer (training), else None"""
-        if self._n_valid is not None and self._coords is self._coords_train and pos.data_ptr() == self._coords_train.data_ptr():
+        """device-side sample count when `pos` is a view of one of this sampler's fixed-capacity buffers, else None"""
+        if self._n_valid is not None and self._coords is not None and pos.data_ptr() == self._coords.data_ptr():
             return self._n_valid
         return None
 
@@ -110,6 +111,21 @@ class DensityGridSampler(nn.Module):
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
         n = rays_o.shape[0]
         if not is_training:
+            if self.sync_free_inference:
+                # (ours) no host read-back: fixed-capacity buffers + device-side sample count, same one-pass marcher as training with cap = capacity
+                need = ops.march_scratch_elems(n)
+                if self._scratch is None or self._scratch.numel() < need:
+                    self._scratch = torch.empty(need, dtype=torch.int32, device=self.device)
+                coords = self._inference_coords()
+                numsteps, numsteps_c = self._numsteps_buf[:n], self._numsteps_c_buf[:n]
+                ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.max_samples,
+                                         self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
+                                         coords_out=coords, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=self._scratch)
+                self._coords = coords
+                self._rays_numsteps = numsteps_c
+                self._n_valid = self._counters[3:4]
+                self._inference_counter = self._counters
+                return coords[:, :3], coords[:, 4:]
             coords, numsteps, counters, _ = ops.march_rays(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples,
                                                            self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
                                                            coords=self._inference_coords(), zero_coords=False)
