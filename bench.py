@@ -137,8 +137,15 @@ def main():
             avg_ms = times[dom][0]
             nbytes = alg_bytes[dom]
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
+        traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hash_bwd.json")))
+            if dom == "hash_bwd":
+                traffic = pm["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                "traffic": None, "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(nbytes),
+                "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(nbytes),
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
 
     extra = {"mean_samples_per_batch": round(mean_valid, 1), "rays_per_batch": runner.sampler.n_rays_per_batch}
