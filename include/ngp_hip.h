@@ -55,6 +55,17 @@ int ngp_hash_encode_bwd_fx(void *stream, uint32_t n, const float *pos, uint32_t 
                            void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid,
                            float *level_scratch);
 
+/* Same contract with a caller-provided workspace (>= ngp_hash_bwd_workspace_bytes(level table, n)) — the fastest path:
+ *  - hashed levels: corner indices are computed ONCE per sample and binned (64 bins of 8192 entries per level, 8-byte records), then every bin is
+ *    accumulated by one workgroup in exact 64-bit integer arithmetic in LDS (contributions rounded to scaled fp16 once; order-independent,
+ *    bit-reproducible).  Used when dtype == NGP_F16, grad_dtype == NGP_F32 and level_scratch == NULL (otherwise the owner-computes scan);
+ *  - small dense levels: 32 sample chunks per slice, partial slabs in the workspace, reduced by a second kernel (no global atomics, no memset).
+ * level_scratch may be NULL or device f32[16] (selects the fixed-point owner-computes scan for the hashed levels instead of binning). */
+uint64_t ngp_hash_bwd_workspace_bytes(const uint32_t *level_table_host, uint32_t n);
+int ngp_hash_encode_bwd_ws(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, const uint32_t *level_table_host,
+                           void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid,
+                           float *level_scratch, void *workspace, uint64_t workspace_bytes);
+
 /* ---- direction encoding: replaces SHEncoder.execute (position_encoders/sh_encoder/sh_encoder.py:29-51, SphericalEncode.h:45-95) */
 int ngp_sh_encode(void *stream, uint32_t n, const float *dir, uint32_t dir_stride_floats, void *out /*[n,16]*/, int dtype);
 

@@ -48,6 +48,7 @@ class HashEncoder(nn.Module):
         # measured ~20 % slower than the float path: the kernel is VALU-bound, not LDS-atomic-bound — profiles/r01_microbench_scatter.md)
         self.fixed_point_grad = self.cfg.hash_grad_fixed_point is True
         self._fx_scratch = None
+        self._bwd_ws = None
         self.out_dim = 32
         self.out_dtype = torch.float16 if self.using_fp16 else torch.float32
 
@@ -73,7 +74,11 @@ class HashEncoder(nn.Module):
             if self._fx_scratch is None:
                 self._fx_scratch = torch.zeros(16, dtype=torch.float32, device=self.m_grid.device)
             fx = self._fx_scratch
-        ops.hash_encode_bwd(x, dy, self.level_table, self.n_params, grad=self.grad_buffer(), layout=layout, zero_first=False, n_valid=n_valid, fixed_point_scratch=fx)
+        need = ops.hash_bwd_workspace_bytes(self.level_table, x.shape[0])
+        if self._bwd_ws is None or self._bwd_ws.numel() < need:
+            self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=self.m_grid.device)
+        ops.hash_encode_bwd(x, dy, self.level_table, self.n_params, grad=self.grad_buffer(), layout=layout, zero_first=False, n_valid=n_valid, fixed_point_scratch=fx,
+                            workspace=self._bwd_ws)
 
     def forward(self, x):
         return _HashEncode.apply(x, self.m_grid, self)

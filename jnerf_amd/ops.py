@@ -102,21 +102,29 @@ def hash_encode_fwd(pos, table, level_tbl, out=None, layout=LAYOUT_AOS, n_valid=
     return out
 
 
-def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, layout=LAYOUT_AOS, zero_first=True, n_valid=None, fixed_point_scratch=None):
-    """fixed_point_scratch: device f32[16] -> fixed-point LDS accumulation (ngp_hash_encode_bwd_fx); None -> float accumulation"""
+def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, layout=LAYOUT_AOS, zero_first=True, n_valid=None, fixed_point_scratch=None, workspace=None):
+    """fixed_point_scratch: device f32[16] -> fixed-point LDS accumulation; workspace: uint8 tensor of >= hash_bwd_workspace_bytes(level_tbl) ->
+    atomic-free dense levels (ngp_hash_encode_bwd_ws)"""
     pos, stride = _rows(pos, 3)
     n = pos.shape[0]
     assert dLdy.is_contiguous()
     if grad is None:
         grad = torch.empty(n_params, dtype=grad_dtype or dLdy.dtype, device=pos.device)
     with timed("hash_bwd"):
-        if fixed_point_scratch is not None:
+        if workspace is not None:
+            check(L.lib().ngp_hash_encode_bwd_ws(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
+                                                 int(zero_first), _p(n_valid), _p(fixed_point_scratch), _p(workspace), workspace.numel() * workspace.element_size()), "ngp_hash_encode_bwd_ws")
+        elif fixed_point_scratch is not None:
             check(L.lib().ngp_hash_encode_bwd_fx(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
                                                  int(zero_first), _p(n_valid), _p(fixed_point_scratch)), "ngp_hash_encode_bwd_fx")
         else:
             check(L.lib().ngp_hash_encode_bwd(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
                                               int(zero_first), _p(n_valid)), "ngp_hash_encode_bwd")
     return grad
+
+
+def hash_bwd_workspace_bytes(level_tbl, n):
+    return int(L.lib().ngp_hash_bwd_workspace_bytes(_tbl(level_tbl), n))
 
 
 def sh_encode(d, dtype=torch.float32):

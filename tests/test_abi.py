@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.lib()
     assert lib.ngp_abi_version() == 1
     syms = declared_symbols()
-    assert len(syms) >= 29
+    assert len(syms) >= 31
     exported = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     for s in syms:
         assert re.search(rf"\bT {s}\b", exported), f"{s} declared in include/ngp_hip.h but not exported"

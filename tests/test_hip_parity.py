@@ -63,6 +63,23 @@ def test_hash_bwd_vs_oracle(H, dtype, grad_dtype):
     dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
     out2 = H.hash_encode_bwd(x, dys, table, n_params, grad_dtype=grad_dtype, layout=ops.LAYOUT_SOA)
     GC.close(out2, ref, what="hash bwd soa", **tol)
+    # workspace variant (atomic-free dense levels), overwrite and accumulate semantics
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, x.shape[0]), dtype=torch.uint8, device="cuda")
+    gdt = grad_dtype or (torch.float16 if dtype == np.float16 else torch.float32)
+    g = torch.full((n_params,), 7.0, dtype=gdt, device="cuda")
+    ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
+    binned = dtype == np.float16 and gdt == torch.float32
+    # binned hashed levels: every contribution (|v| up to ~4e-2 here) is rounded to scaled fp16 once => 2^-11 of the contribution, not of the (cancelling) sum
+    wtol = dict(atol=2e-5, rtol=1.5e-3) if binned else tol
+    GC.close(H.N(g), ref, what="hash bwd workspace", **wtol)
+    if binned:                                                 # exact integer accumulation => bit-reproducible on the hashed levels
+        g2 = torch.zeros_like(g)
+        ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g2, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
+        lo = int(offsets[4]) * 2
+        assert torch.equal(g[lo:], g2[lo:])
+    tol = wtol
+    ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=False, workspace=ws)
+    GC.close(H.N(g).astype(np.float64) / 2, ref, what="hash bwd workspace accumulate", atol=tol["atol"] * 2, rtol=tol["rtol"] * 2)
 
 
 def test_hash_bwd_fixed_point_vs_oracle_and_deterministic(H):

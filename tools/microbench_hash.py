@@ -79,11 +79,12 @@ def per_level():
     dy = (torch.randn((16, n, 2), device="cuda") * 1e-3).half()
     gb = torch.zeros(n_params, device="cuda")
     fxs = torch.zeros(16, device="cuda")
-    for name, pos, fx in (("uniform", uni, None), ("concentrated", conc, None), ("uniform, fixed-point", uni, fxs), ("concentrated, fixed-point", conc, fxs)):
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n), dtype=torch.uint8, device="cuda")
+    for name, pos, fx, w in (("uniform", uni, None, None), ("concentrated", conc, None, None), ("uniform, workspace", uni, None, ws), ("concentrated, workspace", conc, None, ws)):
         row = []
         for l in list(range(16)) + [None]:
             os.environ["NGP_PROBE_LEVEL_MASK"] = hex(1 << l) if l is not None else "0xffff"
-            fn = lambda: ops.hash_encode_bwd(pos, dy, table, n_params, grad=gb, layout=ops.LAYOUT_SOA, zero_first=False, fixed_point_scratch=fx)
+            fn = lambda: ops.hash_encode_bwd(pos, dy, table, n_params, grad=gb, layout=ops.LAYOUT_SOA, zero_first=False, fixed_point_scratch=fx, workspace=w)
             fn(); torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
