@@ -480,7 +480,16 @@ __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__res
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
 	const P *dy = reinterpret_cast<const P *>(dLdy);
 	float m = 0.f;
-	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < lim; i += gridDim.x * 256u) {
+	const uint32_t step = gridDim.x * 256u;
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	for (; i + 3 * step < lim; i += 4 * step) {                        // four independent loads in flight
+		float2 g[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) g[u] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i + u * step] : dy[(size_t)(i + u * step) * 16 + level]);
+#pragma unroll
+		for (int u = 0; u < 4; ++u) m = fmaxf(m, fmaxf(fabsf(g[u].x), fabsf(g[u].y)));
+	}
+	for (; i < lim; i += step) {
 		const float2 g = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level]);
 		m = fmaxf(m, fmaxf(fabsf(g.x), fabsf(g.y)));
 	}
@@ -592,12 +601,23 @@ static uint64_t hash_bwd_workspace_bytes_binned(const LevelTable &lt, uint32_t n
 }
 NGP_API uint64_t ngp_hash_bwd_workspace_bytes(const uint32_t *level_table_host, uint32_t n) { return hash_bwd_workspace_bytes_binned(load_table(level_table_host), n); }
 
+// helper stream for the dense-level kernels of the binned path (created once per process; the hash table gradient regions of the two paths are disjoint)
+struct SideStream {
+	hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false;
+	SideStream() {
+		if (getenv("NGP_HASH_BWD_NO_SIDE_STREAM")) return;
+		ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+		     hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+	}
+};
+
 static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
                          void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, float *level_scratch, void *workspace, uint64_t workspace_bytes) {
 	NGP_REQUIRE(grad && level_table_host && (n == 0 || (pos && dLdy)), NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_bwd: bad dtype %d", dtype);
 	NGP_REQUIRE(grad_dtype == NGP_F32 || (grad_dtype == NGP_F16 && dtype == NGP_F16), NGP_E_DTYPE, "ngp_hash_encode_bwd: bad grad dtype %d for dtype %d", grad_dtype, dtype);
 	hipStream_t s = (hipStream_t)stream;
+	static SideStream side;
 	const size_t gsz = grad_dtype == NGP_F16 ? 2 : 4;
 	const LevelTable lt = load_table(level_table_host);
 	bool owner_ok = true;
@@ -675,16 +695,20 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_hash_bwd_owner<T, G, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
 	if (level_scratch) hipLaunchKernelGGL((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
+	if (use_bins && bp.n_levels && units && side.ok) hipEventRecord(side.fork, s);   /* fork point: before the binning kernels */ \
 	if (use_bins && bp.n_levels) { \
 		static bool attr2 = false; \
 		if (!attr2) { hipError_t e = hipFuncSetAttribute((const void *)k_bin_accumulate<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_ENTRIES * 16)); \
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr2 = true; } \
-		hipLaunchKernelGGL((k_level_absmax<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
+		hipLaunchKernelGGL((k_level_absmax<T, L>), dim3(128, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
 		hipLaunchKernelGGL((k_bin_records<T, L>), dim3(div_up(n, 1024), bp.n_levels), dim3(1024), 0, s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, records, (float *)grad, n_valid); \
 		hipLaunchKernelGGL((k_bin_accumulate<G>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const uint2 *)records, (G *)grad); \
 	} \
-	if (units) hipLaunchKernelGGL((k_hash_bwd_owner<T, G, L>), grid, block, shmem, s, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr); \
-	if (use_slabs) hipLaunchKernelGGL((k_reduce_dense<G>), dim3(1024, 16), dim3(256), 0, s, lt, plan, (const float2 *)workspace, (G *)grad, accumulate & 1); } while (0)
+	hipStream_t sd = s; \
+	if (use_bins && bp.n_levels && units && side.ok) { sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* dense levels run beside the binning kernels */ \
+	if (units) hipLaunchKernelGGL((k_hash_bwd_owner<T, G, L>), grid, block, shmem, sd, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr); \
+	if (use_slabs) hipLaunchKernelGGL((k_reduce_dense<G>), dim3(1024, 16), dim3(256), 0, sd, lt, plan, (const float2 *)workspace, (G *)grad, accumulate & 1); \
+	if (sd != s) { hipEventRecord(side.join, sd); hipStreamWaitEvent(s, side.join, 0); } } while (0)
 	if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, float, NGP_LAYOUT_SOA); else GO(float, float, NGP_LAYOUT_AOS); }
 	else if (grad_dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(__half, float, NGP_LAYOUT_SOA); else GO(__half, float, NGP_LAYOUT_AOS); }
 	else { if (in_layout == NGP_LAYOUT_SOA) GO(__half, __half, NGP_LAYOUT_SOA); else GO(__half, __half, NGP_LAYOUT_AOS); }

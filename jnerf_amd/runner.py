@@ -45,12 +45,28 @@ class Runner:
         self.alpha_image = cfg.alpha_image
         cfg.m_training_step = 0
         self.val_freq = 4096
+        self.pipeline = cfg.pipeline_sampling is not False      # `pipeline_sampling = False` in the config restores the strictly sequential loop
+        self._next, self._side, self._prev_done = None, None, None
         self.render_chunk = int(cfg.render_chunk or 32768)       # rays per inference pass (the reference: n_rays_per_batch = 4096)
         self.W, self.H = self.dataset["train"].resolution
 
+    def drain(self):
+        """wait for a batch that was marched ahead on the side stream (call before dropping the Runner or touching its buffers from elsewhere)"""
+        if self._side is not None:
+            self._side.synchronize()
+        self._next = None
+
+    def __del__(self):
+        try:
+            self.drain()
+        except Exception:
+            pass
+
     # ---- one training iteration == the body of Runner.train (runner.py:64-76)
-    def train_step(self, i):
-        self.cfg.m_training_step = i
+    def _make_batch(self, step):
+        """ray generation, random background, target compositing (runner.py:65-68) and occupancy-grid sampling (runner.py:70) of ONE batch, on the
+        current stream"""
+        self.cfg.m_training_step = step
         ds = self.dataset["train"]
         if hasattr(ds, "next_fused"):       # same values as the three lines of runner.py:65-68, one kernel
             bg = torch.rand((ds.batch_size, 3), device=ds.device)
@@ -60,11 +76,48 @@ class Runner:
             bg = torch.rand((rgb_target.shape[0], 3), device=rgb_target.device)
             rgb_target = rgb_target[..., :3] * rgb_target[..., 3:] + bg * (1 - rgb_target[..., 3:])
         pos, dirs = self.sampler.sample(img_ids, rays_o, rays_d, is_training=True)
-        network_outputs = self.model(pos, dirs)
-        rgb = self.sampler.rays2rgb(network_outputs, bg)
-        loss = self.loss_func(rgb, rgb_target)
+        return {"step": step, "bg": bg, "target": rgb_target, "pos": pos, "dirs": dirs, "state": self.sampler.export_batch_state(),
+                "keep": (img_ids, rays_o, rays_d)}
+
+    def train_step(self, i):
+        """Software-pipelined: batch i+1's ray generation + marching only read the dataset and the occupancy bitfield, so they are issued on a
+        side stream while batch i goes through the network / backward / optimiser (the marcher is a dependent-latency kernel that leaves
+        the chip almost idle).  Not possible on steps that refresh the occupancy grid (every update_den_freq-th), which need the new weights."""
+        cfg = self.cfg
+        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        b = self._next
+        self._next = None
+        if b is not None and b["step"] == i:
+            main.wait_event(b["ready"])
+            self.sampler.import_batch_state(b["state"])
+        else:
+            b = self._make_batch(i)
+        cfg.m_training_step = i
+        nxt = i + 1
+        if self.pipeline and main is not None and nxt < self.tot_train_steps and nxt % self.sampler.update_den_freq != 0:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            if self._prev_done is not None:
+                self._side.wait_event(self._prev_done)      # the buffer set batch i+1 writes was last read by step i-1
+            cur_state = self.sampler.export_batch_state()
+            with torch.cuda.stream(self._side):
+                nb = self._make_batch(nxt)
+                nb["ready"] = torch.cuda.Event()
+                nb["ready"].record(self._side)
+            for t in (nb["bg"], nb["target"]) + tuple(nb["keep"]):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+            self._next = nb
+            self.sampler.import_batch_state(cur_state)
+            cfg.m_training_step = i
+        network_outputs = self.model(b["pos"], b["dirs"])
+        rgb = self.sampler.rays2rgb(network_outputs, b["bg"])
+        loss = self.loss_func(rgb, b["target"])
         self.optimizer.step(loss)
         self.ema_optimizer.ema_step()
+        if main is not None:
+            self._prev_done = torch.cuda.Event()
+            self._prev_done.record(main)
         return loss
 
     def train(self):
@@ -75,6 +128,7 @@ class Runner:
             if i > 0 and i % self.val_freq == 0:
                 psnr = mse2psnr(self.val_img(i))
                 print("STEP={} | LOSS={} | VAL PSNR={}".format(i, loss.mean().item(), psnr))
+        self.drain()
         self.save_ckpt(os.path.join(self.save_path, "params.pkl"))
         self.test()
 

@@ -83,11 +83,15 @@ class DensityGridSampler(nn.Module):
             pcg32_advance(self.rng_state, rank << 40)
         self.measured_batch_size = torch.zeros(1, dtype=torch.int32, device=dev)
         cap_r = 1 << 18
-        self._numsteps_buf = torch.empty((cap_r, 2), dtype=torch.int32, device=dev)
-        self._numsteps_c_buf = torch.empty((cap_r, 2), dtype=torch.int32, device=dev)
-        self._counters = torch.zeros(4, dtype=torch.int32, device=dev)
+        # two buffer sets: the Runner marches batch i+1 on a side stream while batch i is still being trained on (software pipelining)
+        self._sets = [dict(numsteps=torch.empty((cap_r, 2), dtype=torch.int32, device=dev), numsteps_c=torch.empty((cap_r, 2), dtype=torch.int32, device=dev),
+                           counters=torch.zeros(4, dtype=torch.int32, device=dev), coords=torch.zeros((self.target_batch_size, 7), dtype=torch.float32, device=dev),
+                           scratch=None) for _ in range(2)]
+        self._set_idx = 0
+        self._numsteps_buf, self._numsteps_c_buf = self._sets[0]["numsteps"], self._sets[0]["numsteps_c"]
+        self._counters = self._sets[0]["counters"]
         self._scratch = None
-        self._coords_train = torch.zeros((self.target_batch_size, 7), dtype=torch.float32, device=dev)
+        self._coords_train = self._sets[0]["coords"]
         self._dout = None
         self._coords = None
         self._n_valid = None
@@ -117,7 +121,11 @@ class DensityGridSampler(nn.Module):
                 if self._scratch is None or self._scratch.numel() < need:
                     self._scratch = torch.empty(need, dtype=torch.int32, device=self.device)
                 coords = self._inference_coords()
-                numsteps, numsteps_c = self._numsteps_buf[:n], self._numsteps_c_buf[:n]
+                if getattr(self, "_inf_bufs", None) is None:
+                    self._inf_bufs = (torch.empty((1 << 18, 2), dtype=torch.int32, device=self.device), torch.empty((1 << 18, 2), dtype=torch.int32, device=self.device),
+                                      torch.zeros(4, dtype=torch.int32, device=self.device))
+                numsteps, numsteps_c = self._inf_bufs[0][:n], self._inf_bufs[1][:n]
+                self._counters = self._inf_bufs[2]
                 ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.max_samples,
                                          self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
                                          coords_out=coords, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=self._scratch)
@@ -135,13 +143,17 @@ class DensityGridSampler(nn.Module):
             self._rays_numsteps = numsteps
             self._n_valid = None
             return self._coords[:, :3], self._coords[:, 4:]
-        numsteps, numsteps_c = self._numsteps_buf[:n], self._numsteps_c_buf[:n]
+        self._set_idx ^= 1
+        bs = self._sets[self._set_idx]
+        self._coords_train, self._counters = bs["coords"], bs["counters"]
+        numsteps, numsteps_c = bs["numsteps"][:n], bs["numsteps_c"][:n]
         need = ops.march_scratch_elems(n)
-        if self._scratch is None or self._scratch.numel() < need:
-            self._scratch = torch.empty(max(need, ops.march_scratch_elems(min(2 * n, 1 << 18))), dtype=torch.int32, device=self.device)
+        if bs["scratch"] is None or bs["scratch"].numel() < need:
+            # sized once for the largest ray count update_batch_rays can choose (<= target_batch_size): no re-allocation while two streams use the sets
+            bs["scratch"] = torch.empty(max(need, ops.march_scratch_elems(min(self.target_batch_size, 1 << 18))), dtype=torch.int32, device=self.device)
         ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.target_batch_size,
                                  self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
-                                 coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=self._scratch)
+                                 coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=bs["scratch"])
         self.measured_batch_size += self._counters[2:3]                # density_grid_sampler.py:155
         if self.cfg.m_training_step % self.update_den_freq == (self.update_den_freq - 1):
             self.update_batch_rays()
@@ -149,6 +161,13 @@ class DensityGridSampler(nn.Module):
         self._rays_numsteps, self._rays_numsteps_compacted = numsteps, numsteps_c
         self._n_valid = self._counters[3:4]
         return self._coords[:, :3], self._coords[:, 4:]
+
+    # ---- batch state hand-over for the pipelined training loop (Runner): everything rays2rgb / the network need about ONE sampled batch
+    def export_batch_state(self):
+        return (self._coords, self._rays_numsteps, getattr(self, "_rays_numsteps_compacted", None), self._n_valid, self._coords_train, self._counters)
+
+    def import_batch_state(self, st):
+        self._coords, self._rays_numsteps, self._rays_numsteps_compacted, self._n_valid, self._coords_train, self._counters = st
 
     def _inference_coords(self):
         if getattr(self, "_coords_inf", None) is None:

@@ -19,3 +19,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _drain_gpu_between_tests():
+    """runners march one batch ahead on a side stream: finish all device work before the next test re-uses the memory"""
+    yield
+    import gc
+    import torch
+    if torch.cuda.is_available():
+        from jnerf_amd.utils.config import get_cfg
+        get_cfg().clear()
+        gc.collect()
+        torch.cuda.synchronize()
