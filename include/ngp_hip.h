@@ -84,7 +84,7 @@ int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int feat_layout, c
                   const void *wd, const void *wc, const void *dLdout, int out_dtype, void *dLdfeat, float *wgrad_slabs, uint32_t n_slabs,
                   const uint32_t *n_valid);
 int ngp_field_bwd_slabs(uint32_t n);                       /* number of slabs ngp_field_bwd writes for capacity n */
-int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out /*[width]*/);
+int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out /*[width]*/, int accumulate /*out += sum*/);
 
 /* ---- sampler ------------------------------------------------------------------------------------------------------
  * rng_state_host: u64[2] = {state, inc} of the reference's global pcg32{1337} (ops/code_ops/global_vars.py:13-16); it is advanced
@@ -130,7 +130,8 @@ int ngp_grid_update_bitfield(void *stream, const float *grid, int cascades, floa
 
 /* ---- optimiser: Adam (optims/adam.py + Jittor nn.Adam) -> ExpDecay lr (host) -> EMA.ema_step (optims/ema.py:26-37), one sweep.
  * p/m/v/ema are fp32 masters; p_half (may be NULL) receives the fp16 copy the kernels gather from; g is fp32 or fp16 (g_dtype) and is
- * zeroed for the next step when zero_grad!=0.  step is 1-based.  ema may be NULL (no EMA). */
+ * zeroed for the next step when zero_grad!=0.  step is 1-based.  ema may be NULL (no EMA), a separate buffer, or == p: the caller declares that the
+ * stored EMA equals the parameter (true after every ema_step, ema.py:37 `v <- p`), which saves 8 B/parameter of traffic. */
 int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
                       float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad);
 

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16
 	}
 }
 
-__global__ __launch_bounds__(1024) void k_reduce_slabs(const float *__restrict__ slabs, uint32_t n_slabs, uint32_t width, float *__restrict__ out) {
+__global__ __launch_bounds__(1024) void k_reduce_slabs(const float *__restrict__ slabs, uint32_t n_slabs, uint32_t width, float *__restrict__ out, int accumulate) {
 	// 64 columns x 16 slab groups per workgroup; LDS tree over the groups
 	__shared__ float part[16][65];
 	const uint32_t col = blockIdx.x * 64u + (threadIdx.x & 63u), grp = threadIdx.x >> 6;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs(const float *__restrict__
 		float t = 0.f;
 #pragma unroll
 		for (int g = 0; g < 16; ++g) t += part[g][threadIdx.x];
-		out[col] = t;
+		out[col] = accumulate ? out[col] + t : t;
 	}
 }
 
@@ -411,9 +411,9 @@ NGP_API int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int layout
 	NGP_LAUNCH_CHECK("ngp_field_bwd");
 	return 0;
 }
-NGP_API int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out) {
+NGP_API int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out, int accumulate) {
 	NGP_REQUIRE(slabs && out, NGP_E_ARG, "ngp_reduce_slabs: null pointer");
-	hipLaunchKernelGGL(k_reduce_slabs, dim3(div_up(width, 64)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, width, out);
+	hipLaunchKernelGGL(k_reduce_slabs, dim3(div_up(width, 64)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, width, out, accumulate);
 	NGP_LAUNCH_CHECK("ngp_reduce_slabs");
 	return 0;
 }

@@ -10,7 +10,7 @@
 
 struct AdamConsts { float step_size, b0, b1, eps, ema_decay, debias_old, debias_new; };
 
-template <typename G, bool EMA, bool HALF, bool ZERO>
+template <typename G, int EMA /*0 none, 1 separate buffer, 2 the EMA state IS the parameter (v == p at every step boundary)*/, bool HALF, bool ZERO>
 __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restrict__ p, G *__restrict__ g, float4 *__restrict__ m, float4 *__restrict__ v, float4 *__restrict__ ema,
                                                   uint2 *__restrict__ p_half, AdamConsts c) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restric
 			if (ZERO) reinterpret_cast<uint2 *>(g)[i] = make_uint2(0u, 0u);
 		}
 		float4 P = p[i], M = m[i], V = v[i], E;
-		if (EMA) E = ema[i];
+		if (EMA == 1) E = ema[i];
+		if (EMA == 2) E = P;                       // ema.py:26-37 ends with v <- p, so the stored EMA equals the parameter it is about to blend with
 		float *pp = &P.x, *mm = &M.x, *vv = &V.x, *ee = &E.x;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restric
 			pp[k] = pi;
 		}
 		p[i] = P; m[i] = M; v[i] = V;
-		if (EMA) ema[i] = E;
+		if (EMA == 1) ema[i] = E;
 		if (HALF) {
 			__half2 a = __floats2half2_rn(P.x, P.y), b = __floats2half2_rn(P.z, P.w);
 			p_half[i] = make_uint2(*reinterpret_cast<uint32_t *>(&a), *reinterpret_cast<uint32_t *>(&b));
@@ -61,7 +62,7 @@ NGP_API int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g
 #define GO(G, E, H, Z) hipLaunchKernelGGL((k_adam_ema<G, E, H, Z>), dim3(blocks), dim3(256), 0, s, n4, (float4 *)p, (G *)g, (float4 *)m, (float4 *)v, (float4 *)ema, (uint2 *)p_half, c)
 #define GO_Z(G, E, H) do { if (zero_grad) GO(G, E, H, true); else GO(G, E, H, false); } while (0)
 #define GO_H(G, E) do { if (p_half) GO_Z(G, E, true); else GO_Z(G, E, false); } while (0)
-#define GO_E(G) do { if (ema) GO_H(G, true); else GO_H(G, false); } while (0)
+#define GO_E(G) do { if (ema == p) GO_H(G, 2); else if (ema) GO_H(G, 1); else GO_H(G, 0); } while (0)
 	if (g_dtype == NGP_F32) GO_E(float); else GO_E(__half);
 #undef GO
 	NGP_LAUNCH_CHECK("ngp_adam_ema_step");

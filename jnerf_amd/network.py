@@ -100,9 +100,7 @@ class _FusedField(torch.autograd.Function):
         n = pos.shape[0]
         dfeat, slabs, wsum = net._bwd_buffers(n)
         ops.field_bwd(feat, dirs, net.density_mlp.half_weights(), net.rgb_mlp.half_weights(), dout.contiguous(), layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid)
-        ops.reduce_slabs(slabs, out=wsum)
-        net.density_mlp.grad_buffer().add_(wsum[:3072])
-        net.rgb_mlp.grad_buffer().add_(wsum[3072:])
+        ops.reduce_slabs(slabs, out=net._flat_weight_grad(), accumulate=True)     # both MLP packs' .grad are views of this one buffer
         enc.accumulate_grad(pos, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
         return None, None, None, None, None, None, None
 
@@ -141,6 +139,20 @@ class NGPNetworks(nn.Module):
         if b is None or b.shape[1] != n:
             b = self._bufs["feat"] = torch.empty((16, n, 2), dtype=torch.float16, device=self.pos_encoder.m_grid.device)
         return b
+
+    def _flat_weight_grad(self):
+        """density_mlp.con_weights.grad and rgb_mlp.con_weights.grad as two views of ONE fp32[10240] buffer (slab layout of ngp_field_bwd)"""
+        g = self._bufs.get("wgrad")
+        dg, cg = self.density_mlp.con_weights.grad, self.rgb_mlp.con_weights.grad
+        if g is None or dg is None or cg is None or dg.data_ptr() != g.data_ptr() or cg.data_ptr() != g[3072:].data_ptr():
+            g = torch.zeros(10240, dtype=torch.float32, device=self.pos_encoder.m_grid.device)
+            if dg is not None:
+                g[:3072] += dg
+            if cg is not None:
+                g[3072:] += cg
+            self.density_mlp.con_weights.grad, self.rgb_mlp.con_weights.grad = g[:3072], g[3072:]
+            self._bufs["wgrad"] = g
+        return g
 
     def _bwd_buffers(self, n):
         key = ("bwd", n)

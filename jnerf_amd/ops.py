@@ -173,11 +173,12 @@ def field_bwd(feat, d, wd, wc, dLdout, layout=LAYOUT_AOS, dfeat=None, slabs=None
     return dfeat, slabs
 
 
-def reduce_slabs(slabs, out=None):
+def reduce_slabs(slabs, out=None, accumulate=False):
     ns, width = slabs.shape
     if out is None:
         out = torch.empty(width, dtype=torch.float32, device=slabs.device)
-    check(L.lib().ngp_reduce_slabs(_stream(), _p(slabs), ns, width, _p(out)), "ngp_reduce_slabs")
+        accumulate = False
+    check(L.lib().ngp_reduce_slabs(_stream(), _p(slabs), ns, width, _p(out), int(accumulate)), "ngp_reduce_slabs")
     return out
 
 

@@ -31,7 +31,7 @@ class _Composite(torch.autograd.Function):
     def backward(ctx, grad_rgb):
         net_out, rgb = ctx.saved_tensors
         s = ctx.s
-        dout = ops.composite_bwd(net_out, ctx.coords, ctx.nsc, grad_rgb.contiguous(), rgb, s.density_grid_mean, s.NERF_CASCADES, dout=s._dout_buffer(net_out), zero_first=True)
+        dout = ops.composite_bwd(net_out, ctx.coords, ctx.nsc, grad_rgb.contiguous(), rgb, s.density_grid_mean, s.NERF_CASCADES, dout=s._dout_buffer(net_out), zero_first=s._n_valid is None)   # rows < n_valid are all written by their rays; rows beyond are never read
         return dout, None, None
 
 

@@ -207,6 +207,13 @@ def test_adam_ema_and_huber_and_rays(H):
         hp, hm, hv, he, hh, hg = H.adam_ema_step(p, g, m, v, ema, 0.1, step, half=True)
         GC.close(hp, rp, atol=1e-7, rtol=2e-6, what="adam p"); GC.close(hm, rm, atol=0, rtol=1e-6, what="adam m"); GC.close(hv, rv, atol=0, rtol=1e-6, what="adam v")
         GC.close(he, re, atol=1e-7, rtol=2e-6, what="ema"); assert np.array_equal(hh, hp.astype(np.float16)) and not hg.any()
+        # alias mode: the stored EMA equals the parameter (true after every ema_step) -> ema pointer == p, no separate buffer traffic
+        from jnerf_amd import ops
+        tp, tg, tm, tv = H.T(p), H.T(g), H.T(m), H.T(v)
+        rp3, rm3, rv3, re3 = p.copy(), m.copy(), v.copy(), p.copy()
+        O.adam_ema_step(rp3, g, rm3, rv3, re3, 0.1, step)
+        ops.adam_ema_step(tp, tg, tm, tv, tp, None, 0.1, step)
+        GC.close(H.N(tp), rp3, atol=1e-7, rtol=2e-6, what="adam+ema alias mode")
         hp16 = H.adam_ema_step(p, g.astype(np.float16), m, v, None, 0.1, step)[0]
         rp2, rm2, rv2 = p.copy(), m.copy(), v.copy()
         O.adam_ema_step(rp2, g.astype(np.float16).astype(np.float32), rm2, rv2, None, 0.1, step)
