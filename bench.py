@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--images", type=int, default=50)
     ap.add_argument("--res", type=int, default=400)
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event brackets (then no roofline object)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     args = ap.parse_args()
 
@@ -91,10 +92,22 @@ def main():
         torch.cuda.synchronize()
 
     step = 0
-    for _ in range(args.warmup):
+    probe = min(32, args.warmup // 2)
+    for _ in range(args.warmup - probe):
         runner.train_step(step); step += 1
+    # last `probe` warm-up steps: HIP-event brackets around every hot-path launch to find the dominant kernel and the per-step breakdown ...
+    ops.PROFILE = None if args.no_kernel_events else {}
+    for _ in range(probe):
+        runner.train_step(step); step += 1
+    torch.cuda.synchronize()
+    probe_prof, ops.PROFILE = (ops.PROFILE or {}), None
+    single = ("hash_fwd", "field_fwd", "field_bwd", "composite_fwd", "composite_bwd", "adam_ema")          # brackets that contain exactly one kernel
+    breakdown = {k: sum(a.elapsed_time(b) for a, b in v) / max(probe, 1) for k, v in probe_prof.items()}
+    dom = max((k for k in breakdown if k in single), key=lambda k: breakdown[k]) if breakdown else None
+    # ... in the timed region only that kernel keeps its bracket (an event pair per launch costs ~2-3 us; eight of them per step were ~5 %)
+    ops.PROFILE_ONLY = dom
     valid_sum = torch.zeros(1, dtype=torch.int64, device="cuda")
-    ops.PROFILE = {}
+    ops.PROFILE = None if (args.no_kernel_events or dom is None) else {}
     barrier()
     t0 = time.perf_counter()
     loss = None
@@ -104,49 +117,39 @@ def main():
     barrier()
     last_loss = loss.mean().item() if loss is not None else float("nan")
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof, ops.PROFILE = (ops.PROFILE or {}), None
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     mean_valid = float(valid_sum.item()) / max(args.steps, 1)
 
-    # ---- per-kernel HIP-event times over the timed region -> roofline of the dominant kernel
+    # ---- roofline of the dominant single kernel: HIP-event durations over the timed region, algorithmic bytes per launch
     P = runner.model.pos_encoder.n_params
-    alg_bytes = {   # algorithmic bytes per launch: per-sample figures x samples actually processed, per-parameter x parameters
-        "hash_fwd": mean_valid * (12 + 16 * 8 * 4 + 64),
-        "hash_bwd": mean_valid * (12 + 64 + 16 * 8 * 8),
-        "field_fwd": mean_valid * (64 + 12 + 8),
-        "field_bwd": mean_valid * (64 + 12 + 8 + 64),
-        "adam_ema": None,
-    }
-    times = {}
-    for name, evs in prof.items():
-        ms = [a.elapsed_time(b) for a, b in evs]
-        times[name] = (sum(ms) / len(ms), len(ms), sum(ms))
-    adam_calls = [a.elapsed_time(b) for a, b in prof.get("adam_ema", [])]
+    alg_bytes = {"hash_fwd": mean_valid * (12 + 16 * 8 * 4 + 64), "field_fwd": mean_valid * (64 + 12 + 8), "field_bwd": mean_valid * (64 + 12 + 8 + 64),
+                 "composite_fwd": mean_valid * 36, "composite_bwd": mean_valid * 44, "adam_ema": P * 34}
     roof = None
-    if times:
-        per_step = {k: v[2] / max(args.steps, 1) for k, v in times.items()}
-        dom = max((k for k in per_step if k in alg_bytes), key=lambda k: per_step[k])
-        if dom == "adam_ema":      # three launches per step (table + two weight packs); the table launch is the one that matters
-            avg_ms = max(adam_calls[i] for i in range(len(adam_calls))) if adam_calls else 0.0
-            avg_ms = sum(sorted(adam_calls)[-args.steps:]) / max(args.steps, 1)
-            nbytes = P * (5 * 4 + 5 * 4 + 2)
-        else:
-            avg_ms = times[dom][0]
-            nbytes = alg_bytes[dom]
+    if dom is not None and prof.get(dom):
+        ms = [a.elapsed_time(b) for a, b in prof[dom]]
+        if dom == "adam_ema":
+            ms = sorted(ms)[-args.steps:]                                  # three launches per step; the hash-table one is the kernel meant here
+        avg_ms = sum(ms) / len(ms)
+        nbytes = alg_bytes[dom]
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
+        flops = {"field_fwd": 20480.0, "field_bwd": 61440.0}.get(dom)      # per sample: 20 MFMA 16x16x32 per 16 samples forward; recompute + dgrad + wgrad backward
         traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hash_bwd.json")))
-            if dom == "hash_bwd":
-                traffic = pm["hbm_bytes_per_launch"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            traffic = pm.get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(nbytes),
-                "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
+        mfma = None if flops is None else {"achieved_TFLOPs": round(flops * mean_valid / (avg_ms * 1e-3) / 1e12, 1), "peak_TFLOPs": 2500.0,
+                                           "frac": round(flops * mean_valid / (avg_ms * 1e-3) / 1e12 / 2500.0, 4)}
+        roof = {"bound": "hbm", "mfma": mfma, "kernel": {"hash_fwd": "k_hash_fwd", "field_fwd": "k_field_fwd", "field_bwd": "k_field_bwd", "composite_fwd": "k_composite_fwd",
+                                            "composite_bwd": "k_composite_bwd", "adam_ema": "k_adam_ema"}[dom],
+                "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms), "alg_bytes_per_launch": int(nbytes),
+                "ms_per_step_by_launch_group": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])}}
 
     extra = {"mean_samples_per_batch": round(mean_valid, 1), "rays_per_batch": runner.sampler.n_rays_per_batch}
     if not args.no_psnr and rank == 0:

@@ -46,7 +46,7 @@ class Runner:
         cfg.m_training_step = 0
         self.val_freq = 4096
         self.pipeline = cfg.pipeline_sampling is not False      # `pipeline_sampling = False` in the config restores the strictly sequential loop
-        self._next, self._side, self._prev_done = None, None, None
+        self._next, self._side, self._prev_done, self._fast = None, None, None, None
         self.render_chunk = int(cfg.render_chunk or 32768)       # rays per inference pass (the reference: n_rays_per_batch = 4096)
         self.W, self.H = self.dataset["train"].resolution
 
@@ -110,11 +110,17 @@ class Runner:
             self._next = nb
             self.sampler.import_batch_state(cur_state)
             cfg.m_training_step = i
-        network_outputs = self.model(b["pos"], b["dirs"])
-        rgb = self.sampler.rays2rgb(network_outputs, b["bg"])
-        loss = self.loss_func(rgb, b["target"])
-        self.optimizer.step(loss)
-        self.ema_optimizer.ema_step()
+        if self._fast is None:
+            from .fastpath import FusedTrainStep
+            self._fast = FusedTrainStep(self) if FusedTrainStep.applicable(self) else False
+        if self._fast:
+            loss = self._fast(b)                         # same kernels, same order, no autograd / nn.Module overhead (fastpath.py)
+        else:
+            network_outputs = self.model(b["pos"], b["dirs"])
+            rgb = self.sampler.rays2rgb(network_outputs, b["bg"])
+            loss = self.loss_func(rgb, b["target"])
+            self.optimizer.step(loss)
+            self.ema_optimizer.ema_step()
         if main is not None:
             self._prev_done = torch.cuda.Event()
             self._prev_done.record(main)

@@ -118,3 +118,19 @@ def test_nerf_dataset_on_disk(tmp_path):
     # origin = translation * 0.33 + 0.5 with rows cycled [1,2,0] (dataset.py:255-262)
     t = np.array(tr[0]["transform_matrix"])[:3, 3] * 0.33 + 0.5
     assert np.allclose(ro[0].cpu().numpy(), t[[1, 2, 0]], atol=1e-6)
+
+
+def test_fast_path_equals_module_path():
+    """fastpath.FusedTrainStep launches the same kernels as the autograd/module path: parameters after a few steps agree (the only difference
+    is the fp32 atomic order inside the dense-level scatter)"""
+    res = []
+    for fast in (True, False):
+        r = _runner(fp16=True, aabb_scale=1, const_dt=True, fast_path=fast, pipeline_sampling=False)
+        for i in range(3):
+            l = r.train_step(i)
+        assert bool(r._fast) == fast
+        res.append((r.model.pos_encoder.m_grid.detach().clone(), r.model.rgb_mlp.con_weights.detach().clone(), float(l.sum().item())))
+        r.drain()
+    (g0, w0, l0), (g1, w1, l1) = res
+    assert torch.allclose(w0, w1, rtol=2e-3, atol=2e-4), (w0 - w1).abs().max()
+    assert (g0 - g1).abs().max() < 2e-3 and abs(l0 - l1) < 2e-2 * max(abs(l1), 1e-3)
