@@ -356,77 +356,107 @@ __device__ __forceinline__ float unwarp_dt(float dt, int cascades) {            
 	return dt * (max_stepsize - min_cone_stepsize()) + min_cone_stepsize();
 }
 
+// One wavefront per ray.  The reference walks a ray's samples serially in one thread (calc_rgb.h:20-60) - 4096 threads, each a chain of dependent, uncoalesced loads.
+// Here the 64 lanes load 64 consecutive samples of the ray coalesced and evaluate the transcendental part (exp, logistic) in parallel; the transmittance / colour
+// recurrences are then replayed in the reference's exact serial order (so results stay bit-identical) with the per-sample terms broadcast by v_readlane.  The replay is
+// wave-uniform VALU work of ~13 instructions per sample with no memory access in it.
+__device__ __forceinline__ float bcast(float v, uint32_t k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)k)); }
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+constexpr uint32_t COMPOSITE_RAYS_PER_BLOCK = 4;
+
 template <typename T, bool INFERENCE>
-__global__ __launch_bounds__(128) void k_composite_fwd(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps,
+__global__ __launch_bounds__(256) void k_composite_fwd(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps,
                                                        const uint32_t *__restrict__ numsteps_c, const float *__restrict__ bg, int cascades,
                                                        float *__restrict__ rgb_out, float *__restrict__ alpha_out) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u, i = uniform(blockIdx.x * COMPOSITE_RAYS_PER_BLOCK + (threadIdx.x >> 6));
 	if (i >= n_rays) return;
 	const uint32_t *nsrc = INFERENCE ? numsteps : numsteps_c;
-	const uint32_t ns = nsrc[2 * i], base = nsrc[2 * i + 1];
+	const uint32_t ns = uniform(nsrc[2 * i]), base = uniform(nsrc[2 * i + 1]);
 	if (ns == 0) {
-		if (INFERENCE) { rgb_out[3 * i] = rgb_out[3 * i + 1] = rgb_out[3 * i + 2] = 0.f; alpha_out[i] = 0.f; }
-		else { rgb_out[3 * i] = bg[3 * i]; rgb_out[3 * i + 1] = bg[3 * i + 1]; rgb_out[3 * i + 2] = bg[3 * i + 2]; }
+		if (lane < 3) rgb_out[3 * i + lane] = INFERENCE ? 0.f : bg[3 * i + lane];
+		if (INFERENCE && lane == 0) alpha_out[i] = 0.f;
 		return;
 	}
 	float T_ = 1.f, ray[3] = {0.f, 0.f, 0.f};
-#pragma unroll 4
-	for (uint32_t k = 0; k < ns; ++k) {
-		const size_t s = (size_t)base + k;
-		float o[4]; load4<T>(net + s * 4, o);
-		const float dt = unwarp_dt(coords[s * 7 + 3], cascades);
-		const float density = __expf(o[3]);
-		const float alpha = 1.f - __expf(-density * dt);
-		const float weight = alpha * T_;
+	for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
+		const uint32_t m = min(64u, ns - c0);
+		float rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f;
+		if (lane < m) {
+			const size_t s = (size_t)base + c0 + lane;
+			float o[4]; load4<T>(net + s * 4, o);
+			const float dt = unwarp_dt(coords[s * 7 + 3], cascades);
+			const float density = __expf(o[3]);
+			alpha = 1.f - __expf(-density * dt);
 #pragma unroll
-		for (int c = 0; c < 3; ++c) ray[c] += weight * logistic(o[c]);
-		T_ *= (1.f - alpha);
+			for (int c = 0; c < 3; ++c) rgb[c] = logistic(o[c]);
+		}
+#pragma unroll 4
+		for (uint32_t k = 0; k < m; ++k) {
+			const float a = bcast(alpha, k);
+			const float weight = a * T_;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) ray[c] += weight * bcast(rgb[c], k);
+			T_ *= (1.f - a);
+		}
 	}
 	if (!INFERENCE && ns == numsteps[2 * i]) {
 #pragma unroll
 		for (int c = 0; c < 3; ++c) ray[c] += T_ * bg[3 * i + c];
 	}
+	if (lane == 0) {
 #pragma unroll
-	for (int c = 0; c < 3; ++c) rgb_out[3 * i + c] = ray[c];
-	if (INFERENCE) alpha_out[i] = 1 - T_;
+		for (int c = 0; c < 3; ++c) rgb_out[3 * i + c] = ray[c];
+		if (INFERENCE) alpha_out[i] = 1 - T_;
+	}
 }
 
 template <typename T>
-__global__ __launch_bounds__(128) void k_composite_bwd(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps_c,
+__global__ __launch_bounds__(256) void k_composite_bwd(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps_c,
                                                        const float *__restrict__ loss_grad, const float *__restrict__ rgb_ray, const float *__restrict__ density_grid_mean,
                                                        int cascades, T *__restrict__ dout) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u, i = uniform(blockIdx.x * COMPOSITE_RAYS_PER_BLOCK + (threadIdx.x >> 6));
 	if (i >= n_rays) return;
 	float loss_scale = 128; loss_scale /= n_rays;                                    // calc_rgb.h:100-101
-	const uint32_t ns = numsteps_c[2 * i], base = numsteps_c[2 * i + 1];
+	const uint32_t ns = uniform(numsteps_c[2 * i]), base = uniform(numsteps_c[2 * i + 1]);
+	if (ns == 0) return;
 	const float l1 = *density_grid_mean < 0.01f ? 1e-4f : 0.0f;                       // :112
 	const float G[3] = {loss_grad[3 * i], loss_grad[3 * i + 1], loss_grad[3 * i + 2]}, R[3] = {rgb_ray[3 * i], rgb_ray[3 * i + 1], rgb_ray[3 * i + 2]};
 	float T_ = 1.f, ray2[3] = {0.f, 0.f, 0.f};
-#pragma unroll 4
-	for (uint32_t k = 0; k < ns; ++k) {
-		const size_t s = (size_t)base + k;
-		float o[4]; load4<T>(net + s * 4, o);
-		float rgb[3];
+	for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
+		const uint32_t m = min(64u, ns - c0);
+		const size_t s = (size_t)base + c0 + lane;
+		float o[4] = {0.f, 0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f, dt = 0.f;
+		if (lane < m) {
+			load4<T>(net + s * 4, o);
 #pragma unroll
-		for (int c = 0; c < 3; ++c) rgb[c] = logistic(o[c]);
-		const float dt = unwarp_dt(coords[s * 7 + 3], cascades);
-		const float density = __expf(o[3]);
-		const float alpha = 1.f - __expf(-density * dt);
-		const float weight = alpha * T_;
-#pragma unroll
-		for (int c = 0; c < 3; ++c) ray2[c] += weight * rgb[c];
-		T_ *= (1.f - alpha);
-		float dl[4], dv[3];
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			const float suffix = R[c] - ray2[c];
-			dl[c] = loss_scale * ((weight * G[c]) * (rgb[c] * (1 - rgb[c])) + fmaxf(0.0f, 0.0f * o[c]));
-			dv[c] = G[c] * (T_ * rgb[c] - suffix);
+			for (int c = 0; c < 3; ++c) rgb[c] = logistic(o[c]);
+			dt = unwarp_dt(coords[s * 7 + 3], cascades);
+			const float density = __expf(o[3]);
+			alpha = 1.f - __expf(-density * dt);
 		}
-		const float dotv = dv[0] + (dv[1] + dv[2]);                                  // Eigen's 3-vector dot() order
-		const float dd = __expf(clampf(o[3], -15.0f, 15.0f));
-		dl[3] = loss_scale * (dd * (dt * dotv)) + (o[3] < 0 ? -l1 : 0.0f);
-		store4<T>(dout + s * 4, dl);
+		float my_w = 0.f, my_T = 0.f, my_r2[3] = {0.f, 0.f, 0.f};                      // the recurrence's state right after this lane's sample
+#pragma unroll 4
+		for (uint32_t k = 0; k < m; ++k) {
+			const float a = bcast(alpha, k);
+			const float weight = a * T_;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) ray2[c] += weight * bcast(rgb[c], k);
+			T_ *= (1.f - a);
+			if (lane == k) { my_w = weight; my_T = T_; my_r2[0] = ray2[0]; my_r2[1] = ray2[1]; my_r2[2] = ray2[2]; }
+		}
+		if (lane < m) {
+			float dl[4], dv[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const float suffix = R[c] - my_r2[c];
+				dl[c] = loss_scale * ((my_w * G[c]) * (rgb[c] * (1 - rgb[c])) + fmaxf(0.0f, 0.0f * o[c]));
+				dv[c] = G[c] * (my_T * rgb[c] - suffix);
+			}
+			const float dotv = dv[0] + (dv[1] + dv[2]);                                  // Eigen's 3-vector dot() order
+			const float dd = __expf(clampf(o[3], -15.0f, 15.0f));
+			dl[3] = loss_scale * (dd * (dt * dotv)) + (o[3] < 0 ? -l1 : 0.0f);
+			store4<T>(dout + s * 4, dl);
+		}
 	}
 }
 
@@ -435,7 +465,7 @@ NGP_API int ngp_composite_fwd(void *stream, uint32_t n_rays, const void *net, in
 	NGP_REQUIRE(net && coords && numsteps && numsteps_c && bg && rgb_out, NGP_E_ARG, "ngp_composite_fwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_composite_fwd: bad dtype %d", dtype);
 	if (n_rays == 0) return 0;
-	const dim3 grid(div_up(n_rays, 128)), block(128);
+	const dim3 grid(div_up(n_rays, COMPOSITE_RAYS_PER_BLOCK)), block(64 * COMPOSITE_RAYS_PER_BLOCK);
 	hipStream_t s = (hipStream_t)stream;
 	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, false>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr);
 	else hipLaunchKernelGGL((k_composite_fwd<__half, false>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr);
@@ -447,7 +477,7 @@ NGP_API int ngp_composite_inference(void *stream, uint32_t n_rays, const void *n
 	NGP_REQUIRE(net && coords && numsteps && rgb_out && alpha_out, NGP_E_ARG, "ngp_composite_inference: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_composite_inference: bad dtype %d", dtype);
 	if (n_rays == 0) return 0;
-	const dim3 grid(div_up(n_rays, 128)), block(128);
+	const dim3 grid(div_up(n_rays, COMPOSITE_RAYS_PER_BLOCK)), block(64 * COMPOSITE_RAYS_PER_BLOCK);
 	hipStream_t s = (hipStream_t)stream;
 	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, true>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out);
 	else hipLaunchKernelGGL((k_composite_fwd<__half, true>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out);
@@ -461,7 +491,7 @@ NGP_API int ngp_composite_bwd(void *stream, uint32_t n_rays, uint32_t n_elems, c
 	hipStream_t s = (hipStream_t)stream;
 	if (zero_first) { hipError_t e = hipMemsetAsync(dout, 0, (size_t)n_elems * 4 * (dtype == NGP_F16 ? 2 : 4), s); if (e != hipSuccess) { ngp_set_error("ngp_composite_bwd memset: %s", hipGetErrorString(e)); return (int)e; } }
 	if (n_rays == 0) return 0;
-	const dim3 grid(div_up(n_rays, 128)), block(128);
+	const dim3 grid(div_up(n_rays, COMPOSITE_RAYS_PER_BLOCK)), block(64 * COMPOSITE_RAYS_PER_BLOCK);
 	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_bwd<float>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (float *)dout);
 	else hipLaunchKernelGGL((k_composite_bwd<__half>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (__half *)dout);
 	NGP_LAUNCH_CHECK("ngp_composite_bwd");
