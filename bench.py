@@ -131,8 +131,6 @@ def main():
     roof = None
     if dom is not None and prof.get(dom):
         ms = [a.elapsed_time(b) for a, b in prof[dom]]
-        if dom == "adam_ema":
-            ms = sorted(ms)[-args.steps:]                                  # three launches per step; the hash-table one is the kernel meant here
         avg_ms = sum(ms) / len(ms)
         nbytes = alg_bytes[dom]
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
@@ -155,6 +153,9 @@ def main():
                      "ms_per_step_by_launch_group": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])}})
 
     extra = {"mean_samples_per_batch": round(mean_valid, 1), "rays_per_batch": runner.sampler.n_rays_per_batch}
+    if breakdown:       # every single-kernel bracket against the HBM roofline, from the probe steps (algorithmic bytes / HIP-event duration)
+        extra["probe_kernels"] = {k: {"avg_launch_ms": round(breakdown[k], 4), "alg_GBps": round(alg_bytes[k] / (breakdown[k] * 1e-3) / 1e9, 1),
+                                      "frac_hbm": round(alg_bytes[k] / (breakdown[k] * 1e-3) / 8e12, 4)} for k in single if breakdown.get(k)}
     if not args.no_psnr and rank == 0:
         import numpy as np
         from jnerf_amd.utils.registry import build_from_cfg, DATASETS

@@ -20,6 +20,9 @@
 //    summed by ngp_reduce_slabs (no atomics, deterministic).
 //  * Features arrive level-major ([16][n] pairs) from the XCD-aware hash kernel: every wave load is four 64-B segments.
 #include "ngp_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -48,11 +51,18 @@ __device__ __forceinline__ _Float16 frag_value(const _Float16 *__restrict__ wd, 
 	if (f < 18) return j < 4 ? wd[2048 + (4 * g + j) * 64 + 16 * (f - 14) + o] : (_Float16)0;    // dH  = W1^T dD   (K = 16)
 	{ int t = (f - 18) >> 1, kb = (f - 18) & 1; return wd[k64(kb, g, j) * 32 + 16 * t + o]; }    // dF  = W0^T dH
 }
-__device__ __forceinline__ void stage_weights(_Float16 *lds, const _Float16 *__restrict__ wd, const _Float16 *__restrict__ wc, int n_frags, int first) {
-	for (int idx = threadIdx.x; idx < n_frags * 512; idx += blockDim.x) {
-		const int f = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7;
-		lds[idx] = frag_value(wd, wc, first + f, lane & 15, lane >> 4, j);
-	}
+// The permuted fragments are built once per call by a small kernel (k_pack_frags, 42 x 512 halves) into a per-stream scratch; every workgroup then stages them
+// into LDS with plain 16-byte copies.  (Building them per workgroup cost 40-84 dependent 2-byte gathers per thread - more than the MFMA work of the whole launch.)
+__global__ __launch_bounds__(256) void k_pack_frags(const _Float16 *__restrict__ wd, const _Float16 *__restrict__ wc, _Float16 *__restrict__ out, int n_frags) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= n_frags * 512) return;
+	const int f = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7;
+	out[idx] = frag_value(wd, wc, f, lane & 15, lane >> 4, j);
+}
+__device__ __forceinline__ void stage_weights(_Float16 *lds, const _Float16 *__restrict__ packed, int n_frags) {
+	const uint4 *src = reinterpret_cast<const uint4 *>(packed);
+	uint4 *dst = reinterpret_cast<uint4 *>(lds);
+	for (int idx = threadIdx.x; idx < n_frags * 64; idx += blockDim.x) dst[idx] = src[idx];
 }
 __device__ __forceinline__ half8 ld_frag(const _Float16 *lds, int f, int lane) { return *reinterpret_cast<const half8 *>(lds + f * 512 + lane * 8); }
 
@@ -147,10 +157,10 @@ template <> __device__ __forceinline__ void store_out1<__half>(__half *p, float 
 
 template <typename T, int LAYOUT, bool DENSITY_ONLY>
 __global__ __launch_bounds__(256) void k_field_fwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
-                                                   const _Float16 *__restrict__ wd, const _Float16 *__restrict__ wc, T *__restrict__ out,
+                                                   const _Float16 *__restrict__ packed, T *__restrict__ out,
                                                    const uint32_t *__restrict__ n_valid) {
 	__shared__ __attribute__((aligned(16))) _Float16 wl[N_FWD_FRAGS * 512];
-	stage_weights(wl, wd, wc, DENSITY_ONLY ? 6 : N_FWD_FRAGS, 0);
+	stage_weights(wl, packed, DENSITY_ONLY ? 6 : N_FWD_FRAGS);
 	__syncthreads();
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
 	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
@@ -199,12 +209,12 @@ template <> __device__ __forceinline__ void load_dout<__half>(const __half *p, f
 
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
-                                                      const _Float16 *__restrict__ wd, const _Float16 *__restrict__ wc, const T *__restrict__ dout,
+                                                      const _Float16 *__restrict__ packed, const T *__restrict__ dout,
                                                       _Float16 *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid) {
 	extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
 	_Float16 *wl = smem;                                         // 42 fragments
 	_Float16 *stage = smem + (N_FWD_FRAGS + N_BWD_FRAGS) * 512;  // [N_ROWS][RS]
-	stage_weights(wl, wd, wc, N_FWD_FRAGS + N_BWD_FRAGS, 0);
+	stage_weights(wl, packed, N_FWD_FRAGS + N_BWD_FRAGS);
 	const _Float16 *wb = wl + N_FWD_FRAGS * 512;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
 	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
@@ -361,6 +371,22 @@ static int check_field(const char *fn, const void *feat, const void *wd, const v
 	NGP_REQUIRE(((uintptr_t)feat & 15) == 0, NGP_E_ALIGN, "%s: feature pointer must be 16-byte aligned", fn);
 	return 0;
 }
+// per-(device, stream) scratch for the packed fragments; launches on one stream are ordered, so one buffer per stream is enough
+static _Float16 *pack_weights(const char *fn, hipStream_t s, const void *wd, const void *wc, int n_frags) {
+	static std::mutex mu;
+	static std::map<std::pair<int, hipStream_t>, _Float16 *> pool;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { ngp_set_error("%s: hipGetDevice failed", fn); return nullptr; }
+	_Float16 *buf;
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		_Float16 *&slot = pool[{dev, s}];
+		if (!slot) { hipError_t e = hipMalloc((void **)&slot, (size_t)(N_FWD_FRAGS + N_BWD_FRAGS) * 512 * sizeof(_Float16)); if (e != hipSuccess) { slot = nullptr; ngp_set_error("%s: hipMalloc(fragment scratch): %s", fn, hipGetErrorString(e)); return nullptr; } }
+		buf = slot;
+	}
+	hipLaunchKernelGGL(k_pack_frags, dim3(div_up((uint32_t)n_frags * 512u, 256u)), dim3(256), 0, s, (const _Float16 *)wd, (const _Float16 *)wc, buf, n_frags);
+	return buf;
+}
 static uint32_t fwd_grid(uint32_t n) { uint32_t b = div_up(div_up(n, 16), 4); return b < 2048 ? (b ? b : 1) : 2048; }
 
 NGP_API int ngp_field_fwd(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,
@@ -370,7 +396,8 @@ NGP_API int ngp_field_fwd(void *stream, uint32_t n, const void *feat, int layout
 	if (n == 0) return 0;
 	const dim3 grid(fwd_grid(n)), block(256);
 	hipStream_t s = (hipStream_t)stream;
-#define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, false>), grid, block, 0, s, n, (const _Float16 *)feat, dir, dir_stride, (const _Float16 *)wd, (const _Float16 *)wc, (T *)out, n_valid)
+	const _Float16 *packed = pack_weights("ngp_field_fwd", s, wd, wc, N_FWD_FRAGS); if (!packed) return NGP_E_ARG;
+#define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, false>), grid, block, 0, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (T *)out, n_valid)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO
@@ -383,7 +410,8 @@ NGP_API int ngp_density_fwd(void *stream, uint32_t n, const void *feat, int layo
 	if (n == 0) return 0;
 	const dim3 grid(fwd_grid(n)), block(256);
 	hipStream_t s = (hipStream_t)stream;
-#define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, true>), grid, block, 0, s, n, (const _Float16 *)feat, (const float *)nullptr, 3u, (const _Float16 *)wd, (const _Float16 *)wd, (T *)out, (const uint32_t *)nullptr)
+	const _Float16 *packed = pack_weights("ngp_density_fwd", s, wd, wd, 6); if (!packed) return NGP_E_ARG;
+#define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, true>), grid, block, 0, s, n, (const _Float16 *)feat, (const float *)nullptr, 3u, packed, (T *)out, (const uint32_t *)nullptr)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO
@@ -400,11 +428,12 @@ NGP_API int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int layout
 	const size_t shmem = ((N_FWD_FRAGS + N_BWD_FRAGS) * 512 + N_ROWS * RS) * sizeof(_Float16);
 	const dim3 grid(n_slabs), block(256);
 	hipStream_t s = (hipStream_t)stream;
+	const _Float16 *packed = pack_weights("ngp_field_bwd", s, wd, wc, N_FWD_FRAGS + N_BWD_FRAGS); if (!packed) return NGP_E_ARG;
 #define GO(T, L) do { \
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field_bwd<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	hipLaunchKernelGGL((k_field_bwd<T, L>), grid, block, shmem, s, n, (const _Float16 *)feat, dir, dir_stride, (const _Float16 *)wd, (const _Float16 *)wc, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid); } while (0)
+	hipLaunchKernelGGL((k_field_bwd<T, L>), grid, block, shmem, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid); } while (0)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO

@@ -150,14 +150,28 @@ __global__ __launch_bounds__(256) void k_hash_bwd(uint32_t n, const float *__res
 // level) is ~1e10 lane-ops per batch — about 0.15 ms of VALU time on 256 CUs — and the sample stream is re-read from L2, not HBM.
 #define OWN_SLICE 16384u
 
+__device__ __forceinline__ float bin_scale(uint32_t absmax_bits) {     // power of two s with 2^13 <= max*s < 2^14 (0 if the level has no gradient)
+	const float m = __uint_as_float(absmax_bits);
+	if (!(m > 0.f) || !(m < 3.0e38f)) return 0.f;
+	int ex; frexpf(m, &ex);                                           // m = f * 2^ex, f in [0.5, 1)
+	return ldexpf(1.0f, 14 - ex);
+}
+
+
 // One accumulation into the owned LDS slice.  FX = false: two ds_add_f32 (the LDS float-atomic path retires ~1 lane / 3 cycles / CU on gfx950).
 // FX = true: both features as 32-bit fixed-point fields of ONE ds_add_u64 (16.6 cycles per wave instruction, tools/microbench_lds.py):
 // sum = (sum_y << 32) + sum_x in two's complement, decoded exactly at the flush.  The scale is the power of two with scale * L1(level) <= 2^30,
 // where L1(level) = sum over all samples of |dL/dy| bounds any entry's |sum| — overflow is impossible by construction, integer adds commute,
 // so the exclusive slices become bit-reproducible.
-template <bool FX>
+// FX = 2: each feature as its own 64-bit fixed-point sum (two ds_add_u64).  The scale is 2^24 * the power of two that puts the level's largest |dL/dy| in
+// [2^13, 2^14) (k_level_absmax, shared with the binned path): 24 fractional bits below that, and |sum| < 2^14 * 2^24 * 2^24 contributions cannot overflow.
+template <int FX>
 __device__ __forceinline__ void acc_add(float *acc, uint32_t l, float vx, float vy, float fx_scale) {
-	if (FX) {
+	if (FX == 2) {
+		unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + 2 * l;
+		__hip_atomic_fetch_add(a, (unsigned long long)__float2ll_rn(vx * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add(a + 1, (unsigned long long)__float2ll_rn(vy * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	} else if (FX == 1) {
 		const int ix = __float2int_rn(vx * fx_scale), iy = __float2int_rn(vy * fx_scale);
 		const unsigned long long add = (unsigned long long)(long long)ix + ((unsigned long long)(uint32_t)iy << 32);
 		__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(acc) + l, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -166,9 +180,13 @@ __device__ __forceinline__ void acc_add(float *acc, uint32_t l, float vx, float 
 		__hip_atomic_fetch_add(&acc[2 * l + 1], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 }
-template <bool FX>
+template <int FX>
 __device__ __forceinline__ float2 acc_read(const float *acc, uint32_t e, float fx_inv) {
-	if (FX) {
+	if (FX == 2) {
+		const long long *a = reinterpret_cast<const long long *>(acc) + 2 * e;
+		return make_float2((float)a[0] * fx_inv, (float)a[1] * fx_inv);
+	}
+	if (FX == 1) {
 		const unsigned long long t = reinterpret_cast<const unsigned long long *>(acc)[e];
 		const int lo = (int)(uint32_t)(t & 0xffffffffull);
 		const int hi = (int)(uint32_t)((t - (unsigned long long)(long long)lo) >> 32);
@@ -179,16 +197,17 @@ __device__ __forceinline__ float2 acc_read(const float *acc, uint32_t e, float f
 
 struct OwnerPlan { uint32_t first_unit[17]; uint32_t chunks[16]; uint32_t order[16]; uint32_t slab_off[16]; uint32_t level_mask; uint32_t coarse_res; };   // slab_off: float2 offset of the level's [chunks][size] partial slabs, ~0u = none
 
-template <typename T, typename G, int LAYOUT, bool HASHED, bool COMBINE, bool FX>
+template <typename T, typename G, int LAYOUT, bool HASHED, bool COMBINE, int FX>
 __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, const LevelTable &lt, uint32_t level,
                                            uint32_t slice, uint32_t chunk, uint32_t n_chunks, G *__restrict__ grad, int accumulate, uint32_t lim, float *acc, float2 *__restrict__ slab) {
 	using P = typename Pair<T>::type;
 	using GP = typename Pair<G>::type;
 	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
-	const uint32_t lo = slice * OWN_SLICE;
-	const uint32_t cnt = min(OWN_SLICE, size - lo);
-	for (uint32_t e = threadIdx.x; e < cnt * 2; e += 1024) acc[e] = 0.f;
+	constexpr uint32_t SLICE = FX == 2 ? OWN_SLICE / 2 : OWN_SLICE;      // 16 bytes per entry instead of 8
+	const uint32_t lo = slice * SLICE;
+	const uint32_t cnt = min(SLICE, size - lo);
+	for (uint32_t e = threadIdx.x; e < cnt * (FX == 2 ? 4 : 2); e += 1024) acc[e] = 0.f;
 	__syncthreads();
 	const uint32_t per = ((lim + n_chunks - 1) / n_chunks + 7u) & ~7u;
 	const uint32_t begin = min(chunk * per, lim), end = min(begin + per, lim);
@@ -243,9 +262,7 @@ __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const flo
 #pragma unroll
 					for (uint32_t q = 0; q < 8; ++q) {
 						if ((hits >> q) & 1u) {
-							if (ax[q] != 0.f || ay[q] != 0.f) {
-								acc_add<FX>(acc, local[q], ax[q], ay[q], fx_scale);
-							}
+							if ((ax[q] != 0.f || ay[q] != 0.f) && !(accumulate & 2)) acc_add<FX>(acc, local[q], ax[q], ay[q], fx_scale);   // (& 2: probe, everything but the LDS atomics)
 						}
 						ax[q] = 0.f; ay[q] = 0.f;
 					}
@@ -325,7 +342,7 @@ __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const flo
 	}
 	__syncthreads();
 	accumulate &= 1;
-	const float fx_inv = FX ? 1.0f / fx_scale : 1.0f;
+	const float fx_inv = FX != 0 ? 1.0f / fx_scale : 1.0f;
 	G *gl = grad + ((size_t)off + lo) * 2;
 	if (n_chunks == 1) {            // exclusive owner: plain stores (or a private read-modify-write when accumulating)
 		for (uint32_t e = threadIdx.x; e < cnt; e += 1024) {
@@ -349,7 +366,7 @@ __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const flo
 template <typename T, typename G, int LAYOUT>
 __global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt,
                                                          OwnerPlan plan, G *__restrict__ grad, int accumulate, const uint32_t *__restrict__ n_valid,
-                                                         const float *__restrict__ level_l1, float2 *__restrict__ slabs) {
+                                                         const float *__restrict__ level_l1, float2 *__restrict__ slabs, const uint32_t *__restrict__ absmax_bits) {
 	extern __shared__ __attribute__((aligned(16))) float acc[];          // [slice entries][2]
 	// block -> (level, slice, chunk); plan.order lists the chunked dense levels first, then the exclusive-owner (hashed) levels
 	uint32_t k = 0;
@@ -365,7 +382,15 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float
 	const bool coarse = res <= plan.coarse_res;     // cells much longer than a marching step: consecutive samples of a ray share them
 	const bool dense = level_is_dense(size, res);
 #define OWNER_GO(H, C, F, SC) owner_unit<T, G, LAYOUT, H, C, F>(SC, n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc, slab)
-	if (level_l1) {
+	if (absmax_bits && slab && dense) {                          // dense level with partial slabs: 64-bit integer sums over 8192-entry slices
+		const float sc = bin_scale(absmax_bits[level]) * 16777216.0f;
+		if (sc == 0.f) {                                         // no gradient on this level: the slab part is zeros
+			const uint32_t lo = slice * (OWN_SLICE / 2), cnt = min(OWN_SLICE / 2, size - lo);
+			for (uint32_t e = threadIdx.x; e < cnt; e += 1024) slab[(size_t)chunk * size + lo + e] = make_float2(0.f, 0.f);
+			return;
+		}
+		OWNER_GO(false, true, 2, sc);
+	} else if (level_l1) {
 		const float l1 = level_l1[level];
 		if (!(l1 > 0.f)) {                                       // nothing to add on this level: write zeros / leave the accumulating buffer alone
 			if (n_chunks == 1 && !(accumulate & 1)) {
@@ -377,9 +402,9 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float
 		}
 		int ex; frexpf(l1, &ex);                                 // l1 < 2^ex  =>  scale = 2^(30-ex) keeps |sum| * scale < 2^30
 		const float sc = ldexpf(1.0f, 30 - ex);
-		if (dense) OWNER_GO(false, true, true, sc); else if (coarse) OWNER_GO(true, true, true, sc); else OWNER_GO(true, false, true, sc);
+		if (dense) OWNER_GO(false, true, 1, sc); else if (coarse) OWNER_GO(true, true, 1, sc); else OWNER_GO(true, false, 1, sc);
 	} else {
-		if (dense) OWNER_GO(false, true, false, 1.0f); else if (coarse) OWNER_GO(true, true, false, 1.0f); else OWNER_GO(true, false, false, 1.0f);
+		if (dense) OWNER_GO(false, true, 0, 1.0f); else if (coarse) OWNER_GO(true, true, 0, 1.0f); else OWNER_GO(true, false, 0, 1.0f);
 	}
 #undef OWNER_GO
 	// (hashed levels with a non-power-of-two table never reach this kernel: the host routes them to the atomic kernel)
@@ -495,14 +520,14 @@ __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__res
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-	if ((threadIdx.x & 63u) == 0 && m > 0.f) atomicMax(&absmax_bits[level], __float_as_uint(m));   // positive floats order like their bit patterns
-}
-
-__device__ __forceinline__ float bin_scale(uint32_t absmax_bits) {     // power of two s with 2^13 <= max*s < 2^14 (0 if the level has no gradient)
-	const float m = __uint_as_float(absmax_bits);
-	if (!(m > 0.f) || !(m < 3.0e38f)) return 0.f;
-	int ex; frexpf(m, &ex);                                           // m = f * 2^ex, f in [0.5, 1)
-	return ldexpf(1.0f, 14 - ex);
+	// one atomic per workgroup: same-address global atomics retire one at a time at the L2 (8192 of them on 16 addresses took ~90 us)
+	__shared__ float wave_max[4];
+	if ((threadIdx.x & 63u) == 0) wave_max[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+		if (m > 0.f) atomicMax(&absmax_bits[level], __float_as_uint(m));                      // positive floats order like their bit patterns
+	}
 }
 
 template <typename T, int LAYOUT>
@@ -650,10 +675,14 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	// an fp32 table keeps the float scan), fp32 gradient (the overflow fallback adds floats) and no fixed-point request
 	const bool use_bins = use_slabs && !level_scratch && dtype == NGP_F16 && grad_dtype == NGP_F32 && workspace_bytes >= hash_bwd_workspace_bytes_binned(lt, n) && getenv("NGP_HASH_BWD_NO_BINS") == nullptr;
 	uint64_t slab_cursor = 0;
+	bool any_binned = false;
+	for (int l = 0; l < 16; ++l) any_binned |= div_up(lt.v[4 * l + 1], OWN_SLICE) >= 32;
+	const bool fx64 = use_bins && any_binned;                             // the abs-max pass runs -> dense levels can use the 64-bit integer sums
 	for (int l = 0; l < 16; ++l) {
 		slices[l] = div_up(lt.v[4 * l + 1], OWN_SLICE);
 		plan.slab_off[l] = ~0u;
 		if (slices[l] >= 32) { plan.chunks[l] = 1u; continue; }
+		if (fx64) slices[l] = div_up(lt.v[4 * l + 1], OWN_SLICE / 2);      // 64-bit integer sums: half as many entries per LDS slice
 		if (use_slabs) { plan.chunks[l] = 32u; plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)32u * lt.v[4 * l + 1]; }   // 32 sample chunks per slice, partial slabs
 		else plan.chunks[l] = 32u / slices[l] ? 32u / slices[l] : 1u;
 	}
@@ -690,23 +719,25 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	const int accumulate = (zero_first ? 0 : 1) | ((getenv("NGP_PROBE_NO_LDS_ATOMICS") != nullptr) ? 2 : 0);
 	const size_t shmem = (size_t)OWN_SLICE * 2 * sizeof(float);
 	const dim3 grid(units), block(1024);
+	const bool probe_skip_bins = getenv("NGP_PROBE_SKIP_BINS") != nullptr;      // tools/probe_scatter.py: time the dense-level kernel alone
 #define GO(T, G, L) do { \
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_hash_bwd_owner<T, G, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
 	if (level_scratch) hipLaunchKernelGGL((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
-	if (use_bins && bp.n_levels && units && side.ok) hipEventRecord(side.fork, s);   /* fork point: before the binning kernels */ \
 	if (use_bins && bp.n_levels) { \
 		static bool attr2 = false; \
 		if (!attr2) { hipError_t e = hipFuncSetAttribute((const void *)k_bin_accumulate<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_ENTRIES * 16)); \
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr2 = true; } \
-		hipLaunchKernelGGL((k_level_absmax<T, L>), dim3(128, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
+		hipLaunchKernelGGL((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
+		if (units && side.ok) hipEventRecord(side.fork, s);   /* fork point: the dense-level kernel needs the abs-max too */ \
+		if (!probe_skip_bins) { \
 		hipLaunchKernelGGL((k_bin_records<T, L>), dim3(div_up(n, 1024), bp.n_levels), dim3(1024), 0, s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, records, (float *)grad, n_valid); \
-		hipLaunchKernelGGL((k_bin_accumulate<G>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const uint2 *)records, (G *)grad); \
+		hipLaunchKernelGGL((k_bin_accumulate<G>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const uint2 *)records, (G *)grad); } \
 	} \
 	hipStream_t sd = s; \
 	if (use_bins && bp.n_levels && units && side.ok) { sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* dense levels run beside the binning kernels */ \
-	if (units) hipLaunchKernelGGL((k_hash_bwd_owner<T, G, L>), grid, block, shmem, sd, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr); \
+	if (units) hipLaunchKernelGGL((k_hash_bwd_owner<T, G, L>), grid, block, shmem, sd, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr, fx64 ? (const uint32_t *)absmax : (const uint32_t *)nullptr); \
 	if (use_slabs) hipLaunchKernelGGL((k_reduce_dense<G>), dim3(1024, 16), dim3(256), 0, sd, lt, plan, (const float2 *)workspace, (G *)grad, accumulate & 1); \
 	if (sd != s) { hipEventRecord(side.join, sd); hipStreamWaitEvent(s, side.join, 0); } } while (0)
 	if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, float, NGP_LAYOUT_SOA); else GO(float, float, NGP_LAYOUT_AOS); }

@@ -97,12 +97,13 @@ class Runner:
         if self.pipeline and main is not None and nxt < self.tot_train_steps and nxt % self.sampler.update_den_freq != 0:
             if self._side is None:
                 self._side = torch.cuda.Stream()
+                self._events = (torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
             if self._prev_done is not None:
                 self._side.wait_event(self._prev_done)      # the buffer set batch i+1 writes was last read by step i-1
             cur_state = self.sampler.export_batch_state()
             with torch.cuda.stream(self._side):
                 nb = self._make_batch(nxt)
-                nb["ready"] = torch.cuda.Event()
+                nb["ready"] = self._events[nxt & 1]         # persistent events, re-recorded (no create/destroy per step)
                 nb["ready"].record(self._side)
             for t in (nb["bg"], nb["target"]) + tuple(nb["keep"]):
                 if torch.is_tensor(t):
@@ -121,8 +122,8 @@ class Runner:
             loss = self.loss_func(rgb, b["target"])
             self.optimizer.step(loss)
             self.ema_optimizer.ema_step()
-        if main is not None:
-            self._prev_done = torch.cuda.Event()
+        if main is not None and self._side is not None:
+            self._prev_done = self._events[2]
             self._prev_done.record(main)
         return loss
 

@@ -20,7 +20,7 @@ def test_smoke_entry():
     g.smoke()
 
 
-@pytest.mark.parametrize("fp16,aabb_scale,const_dt,min_psnr", [(True, 1, True, 30.0), (False, 1, True, 26.0), (True, 4, False, 17.0)])
+@pytest.mark.parametrize("fp16,aabb_scale,const_dt,min_psnr", [(True, 1, True, 30.0), (False, 1, True, 20.0), (True, 4, False, 17.0)])
 def test_training_converges(fp16, aabb_scale, const_dt, min_psnr, tmp_path):
     # (fused fp16-MFMA path | fp32 path the reference's ngp_base.py takes | fox-style aabb 4 + cone stepping, which carves 8 tiny views slowly in any precision)
     r = _runner(fp16=fp16, aabb_scale=aabb_scale, const_dt=const_dt, log_dir=str(tmp_path))
