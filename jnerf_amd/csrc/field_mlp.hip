@@ -166,18 +166,28 @@ __global__ __launch_bounds__(256) void k_field_fwd(uint32_t n, const _Float16 *_
 	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
 	const uint32_t n_tiles = (lim + 15u) / 16u;
 	const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
-	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+	// two tiles in flight per wave: the next tile's features / direction are requested before the current tile's MFMA chain starts
+	auto fetch = [&](uint32_t tile, half8 &f, float d[3]) {
 		const uint32_t i = tile * 16u + s;
 		const uint32_t ic = i < lim ? i : lim - 1;
-		const half8 f = load_feat<LAYOUT>(feat, n, ic, g);
+		f = load_feat<LAYOUT>(feat, n, ic, g);
+		if (!DENSITY_ONLY) { d[0] = dir[(size_t)ic * dir_stride]; d[1] = dir[(size_t)ic * dir_stride + 1]; d[2] = dir[(size_t)ic * dir_stride + 2]; }
+	};
+	half8 f, fn; float d[3] = {0.f, 0.f, 0.f}, dn[3] = {0.f, 0.f, 0.f};
+	if (wave < n_tiles) fetch(wave, f, d);
+	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+		const uint32_t i = tile * 16u + s;
+		const bool more = tile + n_waves < n_tiles;
+		if (more) fetch(tile + n_waves, fn, dn);
 		float sh[4] = {0.f, 0.f, 0.f, 0.f};
-		if (!DENSITY_ONLY) { const float d[3] = {dir[(size_t)ic * dir_stride], dir[(size_t)ic * dir_stride + 1], dir[(size_t)ic * dir_stride + 2]}; sh4(d, g, sh); }
+		if (!DENSITY_ONLY) sh4(d, g, sh);
 		FwdState st;
 		forward_tile<DENSITY_ONLY>(wl, lane, f, sh, st);
 		if (g == 0 && i < lim) {
 			if (DENSITY_ONLY) store_out1<T>(out + i, st.den[0]);
 			else store_out4<T>(out + (size_t)i * 4, st.rgb[0], st.rgb[1], st.rgb[2], st.den[0]);
 		}
+		if (more) { f = fn; d[0] = dn[0]; d[1] = dn[1]; d[2] = dn[2]; }
 	}
 }
 
@@ -223,15 +233,27 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16
 	// this wave's 10 weight-gradient tiles: V1 (to=w, ti=0..3) | W0 (to=w, ti=0,1) | V0 (to=w, ti=0,1) | W1 (ti=w) | V2 (ti=w)
 	floatx4 aV1[4] = {z, z, z, z}, aW0[2] = {z, z}, aV0[2] = {z, z}, aW1 = z, aV2 = z;
 	__syncthreads();
-	for (uint32_t bt = blockIdx.x; bt < n_bt; bt += gridDim.x) {
+	// the next tile's inputs are requested while the current tile is in its MFMA / LDS phases (one workgroup per CU: nothing else hides the HBM round trip)
+	struct Inputs { half8 f; float d3[3]; float go[4]; };
+	auto fetch = [&](uint32_t bt, Inputs &in) {
 		const uint32_t i = bt * BT + 16u * w + s;
 		const bool valid = i < lim;
 		const uint32_t ic = valid ? i : lim - 1;
-		const half8 f = load_feat<LAYOUT>(feat, n, ic, g);
-		const float d3[3] = {dir[(size_t)ic * dir_stride], dir[(size_t)ic * dir_stride + 1], dir[(size_t)ic * dir_stride + 2]};
-		float sh[4]; sh4(d3, g, sh);
-		float go[4] = {0.f, 0.f, 0.f, 0.f};
-		if (valid) load_dout<T>(dout + (size_t)i * 4, go);
+		in.f = load_feat<LAYOUT>(feat, n, ic, g);
+		in.d3[0] = dir[(size_t)ic * dir_stride]; in.d3[1] = dir[(size_t)ic * dir_stride + 1]; in.d3[2] = dir[(size_t)ic * dir_stride + 2];
+		in.go[0] = in.go[1] = in.go[2] = in.go[3] = 0.f;
+		if (valid) load_dout<T>(dout + (size_t)i * 4, in.go);
+	};
+	Inputs cur, nxt;
+	if (blockIdx.x < n_bt) fetch(blockIdx.x, cur);
+	for (uint32_t bt = blockIdx.x; bt < n_bt; bt += gridDim.x) {
+		const uint32_t i = bt * BT + 16u * w + s;
+		const bool valid = i < lim;
+		const bool more = bt + gridDim.x < n_bt;
+		if (more) fetch(bt + gridDim.x, nxt);
+		const half8 f = cur.f;
+		float sh[4]; sh4(cur.d3, g, sh);
+		float go[4] = {cur.go[0], cur.go[1], cur.go[2], cur.go[3]};
 		FwdState st;
 		forward_tile<false>(wl, lane, f, sh, st);
 		// ---- dgrad chain (register resident, transposed weights)
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16
 			aV2 = MFMA(a_do, ld_rows(stage, R_G1 + 16 * w + o, cs), aV2);
 		}
 		__syncthreads();
+		if (more) cur = nxt;
 	}
 	// ---- one fp32 slab per workgroup, packed like the weights (wd part 0..3071, wc part 3072..10239); C rows = 4g+r, cols = lane&15
 	float *slab = slabs + (size_t)blockIdx.x * 10240;

@@ -31,7 +31,8 @@ __device__ __forceinline__ void from_f2(__half2 &o, float2 v) { o = __floats2hal
 __device__ __forceinline__ uint32_t grid_index(uint32_t size, uint32_t res, bool dense, uint32_t gx, uint32_t gy, uint32_t gz) {
 	uint32_t index = dense ? gx + gy * res + gz * res * res : (gx ^ gy * 19349663u ^ gz * 83492791u);
 	if ((size & (size - 1)) == 0) return index & (size - 1);   // hashed levels are 2^19 entries
-	return index < size ? index : index % size;                // dense levels wrap only at the +1 boundary corner
+	if (index >= size) { index -= size; if (index >= size) index %= size; }   // dense levels wrap only at the +1 boundary corner, and then by < size (res(1+res+res^2) < 2 res^3): the division is never executed for in-range positions
+	return index;
 }
 // the reference decides "dense" by letting the stride loop run while stride <= size (HashEncode.h:82-91)
 __device__ __forceinline__ bool level_is_dense(uint32_t size, uint32_t res) {
@@ -163,14 +164,15 @@ __device__ __forceinline__ float bin_scale(uint32_t absmax_bits) {     // power 
 // sum = (sum_y << 32) + sum_x in two's complement, decoded exactly at the flush.  The scale is the power of two with scale * L1(level) <= 2^30,
 // where L1(level) = sum over all samples of |dL/dy| bounds any entry's |sum| — overflow is impossible by construction, integer adds commute,
 // so the exclusive slices become bit-reproducible.
-// FX = 2: each feature as its own 64-bit fixed-point sum (two ds_add_u64).  The scale is 2^24 * the power of two that puts the level's largest |dL/dy| in
-// [2^13, 2^14) (k_level_absmax, shared with the binned path): 24 fractional bits below that, and |sum| < 2^14 * 2^24 * 2^24 contributions cannot overflow.
+// FX = 2: each feature as its own 64-bit fixed-point sum (two ds_add_u64).  The scale is 2^8 * the power of two that puts the level's largest |dL/dy| in
+// [2^13, 2^14) (k_level_absmax, shared with the binned path): a register-combined run of <= 8 samples converts with ONE v_cvt_i32_f32 (|x| < 2^25), the quantum is
+// max|dL/dy| * 2^-21 per run (the hashed levels round every contribution to fp16, 2^-11 relative), and a 64-bit sum of 2^24 such terms cannot overflow.
 template <int FX>
 __device__ __forceinline__ void acc_add(float *acc, uint32_t l, float vx, float vy, float fx_scale) {
 	if (FX == 2) {
 		unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + 2 * l;
-		__hip_atomic_fetch_add(a, (unsigned long long)__float2ll_rn(vx * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		__hip_atomic_fetch_add(a + 1, (unsigned long long)__float2ll_rn(vy * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add(a, (unsigned long long)(long long)__float2int_rn(vx * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // |v * scale| < 2^22 * run length: one v_cvt_i32_f32
+		__hip_atomic_fetch_add(a + 1, (unsigned long long)(long long)__float2int_rn(vy * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	} else if (FX == 1) {
 		const int ix = __float2int_rn(vx * fx_scale), iy = __float2int_rn(vy * fx_scale);
 		const unsigned long long add = (unsigned long long)(long long)ix + ((unsigned long long)(uint32_t)iy << 32);
@@ -277,7 +279,7 @@ __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const flo
 						for (uint32_t q = 0; q < 8; ++q) {
 							uint32_t idx;
 							if (HASHED) idx = (tx[q & 1] ^ ty[(q >> 1) & 1] ^ tz[q >> 2]) & (size - 1);
-							else { idx = tx[q & 1] + ty[(q >> 1) & 1] + tz[q >> 2]; if (idx >= size) idx %= size; }
+							else { idx = tx[q & 1] + ty[(q >> 1) & 1] + tz[q >> 2]; if (idx >= size) { idx -= size; if (idx >= size) idx %= size; } }
 							local[q] = idx - lo;
 							hits |= (local[q] < cnt) ? (1u << q) : 0u;
 						}
@@ -320,7 +322,7 @@ __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const flo
 #pragma unroll
 				for (uint32_t q = 0; q < 8; ++q) {
 					uint32_t idx = tx[q & 1] + ty[(q >> 1) & 1] + tz[q >> 2];
-					if (idx >= size) idx %= size;                                            // wraps only at the +1 boundary corner
+					if (idx >= size) { idx -= size; if (idx >= size) idx %= size; }                                            // wraps only at the +1 boundary corner
 					hits |= (idx - lo < cnt) ? (1u << q) : 0u;
 				}
 			}
@@ -331,7 +333,7 @@ __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const flo
 				const uint32_t ex = (q & 1u) ? tx[1] : tx[0], ey = (q & 2u) ? ty[1] : ty[0], ez = (q & 4u) ? tz[1] : tz[0];
 				uint32_t idx;
 				if (HASHED) idx = (ex ^ ey ^ ez) & (size - 1);
-				else { idx = ex + ey + ez; if (idx >= size) idx %= size; }
+				else { idx = ex + ey + ez; if (idx >= size) { idx -= size; if (idx >= size) idx %= size; } }
 				const uint32_t l = idx - lo;
 				const float wx = (q & 1u) ? c.w[0] : 1 - c.w[0], wy = (q & 2u) ? c.w[1] : 1 - c.w[1], wz = (q & 4u) ? c.w[2] : 1 - c.w[2];
 				const float weight = wx * wy * wz;
@@ -382,14 +384,18 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float
 	const bool coarse = res <= plan.coarse_res;     // cells much longer than a marching step: consecutive samples of a ray share them
 	const bool dense = level_is_dense(size, res);
 #define OWNER_GO(H, C, F, SC) owner_unit<T, G, LAYOUT, H, C, F>(SC, n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc, slab)
-	if (absmax_bits && slab && dense) {                          // dense level with partial slabs: 64-bit integer sums over 8192-entry slices
-		const float sc = bin_scale(absmax_bits[level]) * 16777216.0f;
+	if (absmax_bits && slab && dense) {                          // dense level with partial slabs: integer sums, both features in ONE ds_add_u64 (two 32-bit fields)
+		// scale: largest |dL/dy| of the level -> [2^13, 2^14) (k_level_absmax, shared with the binned path), times 2^k with k the largest value that keeps
+		// (samples of this chunk) * 2^14 * 2^k <= 2^31: an entry receives at most one corner (weight <= 1) per sample, so a field cannot overflow.
+		const uint32_t per = (lim + n_chunks - 1) / n_chunks + 8u;
+		int k = 17 - (32 - __builtin_clz(per));
+		const float sc = k < -13 ? 0.f : ldexpf(bin_scale(absmax_bits[level]), k);
 		if (sc == 0.f) {                                         // no gradient on this level: the slab part is zeros
-			const uint32_t lo = slice * (OWN_SLICE / 2), cnt = min(OWN_SLICE / 2, size - lo);
+			const uint32_t lo = slice * OWN_SLICE, cnt = min(OWN_SLICE, size - lo);
 			for (uint32_t e = threadIdx.x; e < cnt; e += 1024) slab[(size_t)chunk * size + lo + e] = make_float2(0.f, 0.f);
 			return;
 		}
-		OWNER_GO(false, true, 2, sc);
+		OWNER_GO(false, true, 1, sc);
 	} else if (level_l1) {
 		const float l1 = level_l1[level];
 		if (!(l1 > 0.f)) {                                       // nothing to add on this level: write zeros / leave the accumulating buffer alone
@@ -496,6 +502,7 @@ static int hash_bwd_method() {
 #define BIN_BITS 13u
 #define BIN_ENTRIES (1u << BIN_BITS)
 #define BINS_PER_LEVEL 64u
+#define BIN_SPT 2u                 // samples per thread in k_bin_records
 struct BinPlan { uint32_t level[16]; uint32_t n_levels; uint32_t cap; };   // hashed levels, records per bin
 
 template <typename T, int LAYOUT>
@@ -541,43 +548,58 @@ __global__ __launch_bounds__(1024) void k_bin_records(uint32_t n, const float *_
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const float vs = bin_scale(absmax_bits[level]);
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	if (vs == 0.f || blockIdx.x * 1024u >= lim) return;                // uniform exit
+	if (vs == 0.f || blockIdx.x * (1024u * BIN_SPT) >= lim) return;    // uniform exit
 	if (threadIdx.x < BINS_PER_LEVEL) cnt[threadIdx.x] = 0;
 	__syncthreads();
-	const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
 	const P *dy = reinterpret_cast<const P *>(dLdy);
-	uint32_t idx[8], rank[8]; __half2 val[8];
-	bool live = false;
-	if (i < lim) {
-		const float2 g2 = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level]);
-		live = (g2.x != 0.f || g2.y != 0.f);
-		if (live) {
-			const Corner c = locate(pos, stride, i, scale);
+	// BIN_SPT samples per thread, all of their loads issued before the first use: the kernel is a chain of latencies (loads -> LDS histogram -> barrier -> one global
+	// atomic per bin -> barrier -> stores), so more work per trip is what shortens it; it also halves the same-address traffic on the 64 cursors of the level.
+	uint32_t idx[BIN_SPT][8], rank[BIN_SPT][8]; __half2 val[BIN_SPT][8];
+	float2 g2[BIN_SPT]; float px[BIN_SPT][3];
+	bool live[BIN_SPT];
+#pragma unroll
+	for (uint32_t u = 0; u < BIN_SPT; ++u) {
+		const uint32_t i = blockIdx.x * (1024u * BIN_SPT) + u * 1024u + threadIdx.x;
+		live[u] = i < lim;
+		const uint32_t ic = live[u] ? i : 0u;
+		g2[u] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + ic] : dy[(size_t)ic * 16 + level]);
+		px[u][0] = pos[(size_t)ic * stride]; px[u][1] = pos[(size_t)ic * stride + 1]; px[u][2] = pos[(size_t)ic * stride + 2];
+	}
+#pragma unroll
+	for (uint32_t u = 0; u < BIN_SPT; ++u) {
+		live[u] = live[u] && (g2[u].x != 0.f || g2[u].y != 0.f);
+		if (live[u]) {
+			Corner c;
+#pragma unroll
+			for (int d = 0; d < 3; ++d) { const float p = px[u][d] * scale + 0.5f; const float fl = floorf(p); c.g[d] = (uint32_t)(int)fl; c.w[d] = p - fl; }
 			const uint32_t ty0 = c.g[1] * 19349663u, tz0 = c.g[2] * 83492791u;
-			const float gx = g2.x * vs, gy = g2.y * vs;
+			const float gx = g2[u].x * vs, gy = g2[u].y * vs;
 #pragma unroll
 			for (uint32_t q = 0; q < 8; ++q) {
 				const uint32_t ex = c.g[0] + (q & 1u), ey = ty0 + ((q & 2u) ? 19349663u : 0u), ez = tz0 + ((q & 4u) ? 83492791u : 0u);
-				idx[q] = (ex ^ ey ^ ez) & (size - 1);
+				idx[u][q] = (ex ^ ey ^ ez) & (size - 1);
 				const float w = ((q & 1u) ? c.w[0] : 1 - c.w[0]) * ((q & 2u) ? c.w[1] : 1 - c.w[1]) * ((q & 4u) ? c.w[2] : 1 - c.w[2]);
-				val[q] = __floats2half2_rn(gx * w, gy * w);
-				rank[q] = atomicAdd(&cnt[idx[q] >> BIN_BITS], 1u);
+				val[u][q] = __floats2half2_rn(gx * w, gy * w);
+				rank[u][q] = atomicAdd(&cnt[idx[u][q] >> BIN_BITS], 1u);
 			}
 		}
 	}
 	__syncthreads();
 	if (threadIdx.x < BINS_PER_LEVEL) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursors[hl * BINS_PER_LEVEL + threadIdx.x], cnt[threadIdx.x]) : 0u;
 	__syncthreads();
-	if (!live) return;
 #pragma unroll
-	for (uint32_t q = 0; q < 8; ++q) {
-		const uint32_t bin = idx[q] >> BIN_BITS, slot = base[bin] + rank[q];
-		if (slot < bp.cap) {
-			uint2 r; r.x = idx[q] & (BIN_ENTRIES - 1u); r.y = *reinterpret_cast<uint32_t *>(&val[q]);
-			records[((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap + slot] = r;
-		} else {                                                        // bin full (pathological clustering): add this contribution directly
-			const float2 v = __half22float2(val[q]);
-			atomic_add_pair(grad_f32 + ((size_t)off + idx[q]) * 2, make_float2(v.x / vs, v.y / vs));
+	for (uint32_t u = 0; u < BIN_SPT; ++u) {
+		if (!live[u]) continue;
+#pragma unroll
+		for (uint32_t q = 0; q < 8; ++q) {
+			const uint32_t bin = idx[u][q] >> BIN_BITS, slot = base[bin] + rank[u][q];
+			if (slot < bp.cap) {
+				uint2 r; r.x = idx[u][q] & (BIN_ENTRIES - 1u); r.y = *reinterpret_cast<uint32_t *>(&val[u][q]);
+				records[((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap + slot] = r;
+			} else {                                                    // bin full (pathological clustering): add this contribution directly
+				const float2 v = __half22float2(val[u][q]);
+				atomic_add_pair(grad_f32 + ((size_t)off + idx[u][q]) * 2, make_float2(v.x / vs, v.y / vs));
+			}
 		}
 	}
 }
@@ -594,20 +616,38 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	for (uint32_t e = threadIdx.x; e < BIN_ENTRIES * 2; e += 1024) iacc[e] = 0ull;
 	__syncthreads();
 	const uint2 *rec = records + ((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap;
-	for (uint32_t r = threadIdx.x; r < count; r += 1024) {
-		const uint2 x = rec[r];
-		const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&x.y));
+	auto add = [&](uint32_t local, uint32_t packed) {
+		const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&packed));
 		const long long ix = (long long)(v.x * 16777216.0f), iy = (long long)(v.y * 16777216.0f);    // exact: fp16 values are multiples of 2^-24
-		__hip_atomic_fetch_add(&iacc[2 * x.x], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		__hip_atomic_fetch_add(&iacc[2 * x.x + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add(&iacc[2 * local + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+	// one workgroup per CU (128 KiB of LDS) and ~32 records per thread: with one load per trip the loop is a chain of HBM round trips.
+	// Eight records (four 16-byte loads) are requested before the first is used.
+	const uint4 *rec2 = reinterpret_cast<const uint4 *>(rec);              // two records per load (bin regions are 16-byte aligned: cap is even)
+	const uint32_t pairs = count >> 1;
+	uint32_t r = threadIdx.x;
+	for (; r + 3 * 1024 < pairs; r += 4 * 1024) {
+		uint4 x[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) x[u] = rec2[r + u * 1024];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { add(x[u].x, x[u].y); add(x[u].z, x[u].w); }
 	}
+	for (; r < pairs; r += 1024) { const uint4 x = rec2[r]; add(x.x, x.y); add(x.z, x.w); }
+	if ((count & 1u) && threadIdx.x == 0) { const uint2 x = rec[count - 1]; add(x.x, x.y); }
 	__syncthreads();
 	const float inv = 1.0f / (vs * 16777216.0f);
 	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level] + (size_t)bin * BIN_ENTRIES;
-	for (uint32_t e = threadIdx.x; e < BIN_ENTRIES; e += 1024) {
+	GP oldv[BIN_ENTRIES / 1024];
+#pragma unroll
+	for (uint32_t k = 0; k < BIN_ENTRIES / 1024; ++k) oldv[k] = dst[threadIdx.x + k * 1024];      // all eight read-modify-write loads in flight
+#pragma unroll
+	for (uint32_t k = 0; k < BIN_ENTRIES / 1024; ++k) {
+		const uint32_t e = threadIdx.x + k * 1024;
 		const long long sx = (long long)iacc[2 * e], sy = (long long)iacc[2 * e + 1];
 		if (sx == 0 && sy == 0) continue;
-		const float2 old = to_f2(dst[e]);
+		const float2 old = to_f2(oldv[k]);
 		GP o; from_f2(o, make_float2(old.x + (float)sx * inv, old.y + (float)sy * inv));
 		dst[e] = o;
 	}
@@ -618,7 +658,7 @@ static uint64_t hash_bwd_workspace_bytes(const LevelTable &lt) {           // de
 	for (int l = 0; l < 16; ++l) if (div_up(lt.v[4 * l + 1], OWN_SLICE) < 32) entries += (uint64_t)32u * lt.v[4 * l + 1];
 	return (entries * sizeof(float2) + 255) & ~(uint64_t)255;
 }
-static uint32_t bin_capacity(uint32_t n) { uint32_t c = n / 2; return c < 4096u ? 4096u : c; }   // 4x the expected n*8/64 records per bin
+static uint32_t bin_capacity(uint32_t n) { uint32_t c = (n / 2 + 1u) & ~1u; return c < 4096u ? 4096u : c; }   // 4x the expected n*8/64 records per bin
 static uint64_t hash_bwd_workspace_bytes_binned(const LevelTable &lt, uint32_t n) {
 	uint32_t n_hashed = 0;
 	for (int l = 0; l < 16; ++l) if (div_up(lt.v[4 * l + 1], OWN_SLICE) >= 32) ++n_hashed;
@@ -682,7 +722,6 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		slices[l] = div_up(lt.v[4 * l + 1], OWN_SLICE);
 		plan.slab_off[l] = ~0u;
 		if (slices[l] >= 32) { plan.chunks[l] = 1u; continue; }
-		if (fx64) slices[l] = div_up(lt.v[4 * l + 1], OWN_SLICE / 2);      // 64-bit integer sums: half as many entries per LDS slice
 		if (use_slabs) { plan.chunks[l] = 32u; plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)32u * lt.v[4 * l + 1]; }   // 32 sample chunks per slice, partial slabs
 		else plan.chunks[l] = 32u / slices[l] ? 32u / slices[l] : 1u;
 	}
@@ -732,7 +771,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		hipLaunchKernelGGL((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
 		if (units && side.ok) hipEventRecord(side.fork, s);   /* fork point: the dense-level kernel needs the abs-max too */ \
 		if (!probe_skip_bins) { \
-		hipLaunchKernelGGL((k_bin_records<T, L>), dim3(div_up(n, 1024), bp.n_levels), dim3(1024), 0, s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, records, (float *)grad, n_valid); \
+		hipLaunchKernelGGL((k_bin_records<T, L>), dim3(div_up(n, 1024 * BIN_SPT), bp.n_levels), dim3(1024), 0, s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, records, (float *)grad, n_valid); \
 		hipLaunchKernelGGL((k_bin_accumulate<G>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const uint2 *)records, (G *)grad); } \
 	} \
 	hipStream_t sd = s; \
