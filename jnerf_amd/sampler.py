@@ -231,3 +231,4 @@ class DensityGridSampler(nn.Module):
         self.n_rays_per_batch = int(min((int(rays_per_batch) + 127) // 128 * 128, self.target_batch_size))
         self.measured_batch_size.zero_()
         self.dataset.batch_size = self.n_rays_per_batch
+        self.n_ray_count_updates = getattr(self, "n_ray_count_updates", 0) + 1
