@@ -101,8 +101,15 @@ def main():
         runner.train_step(step); step += 1
     torch.cuda.synchronize()
     probe_prof, ops.PROFILE = (ops.PROFILE or {}), None
+    # what an empty event pair measures on this stream (the two timestamp packets themselves): subtracted from every bracket below
+    pairs = []
+    for _ in range(64):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b.record(); pairs.append((a, b))
+    torch.cuda.synchronize()
+    ev_overhead = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
     single = ("hash_fwd", "field_fwd", "field_bwd", "composite_fwd", "composite_bwd", "adam_ema")          # brackets that contain exactly one kernel
-    breakdown = {k: sum(a.elapsed_time(b) for a, b in v) / max(probe, 1) for k, v in probe_prof.items()}
+    breakdown = {k: sum(max(a.elapsed_time(b) - ev_overhead, 0.0) for a, b in v) / max(probe, 1) for k, v in probe_prof.items()}
     dom = max((k for k in breakdown if k in single), key=lambda k: breakdown[k]) if breakdown else None
     # ... in the timed region only that kernel keeps its bracket (an event pair per launch costs ~2-3 us; eight of them per step were ~5 %)
     ops.PROFILE_ONLY = dom
@@ -131,7 +138,8 @@ def main():
     roof = None
     if dom is not None and prof.get(dom):
         ms = [a.elapsed_time(b) for a, b in prof[dom]]
-        avg_ms = sum(ms) / len(ms)
+        avg_raw = sum(ms) / len(ms)
+        avg_ms = max(avg_raw - ev_overhead, 1e-6)
         nbytes = alg_bytes[dom]
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         flops = {"field_fwd": 20480.0, "field_bwd": 61440.0}.get(dom)      # per sample: 20 MFMA 16x16x32 per 16 samples forward; recompute + dgrad + wgrad backward
@@ -149,7 +157,7 @@ def main():
         else:       # the fused MLP kernels are MFMA work (fp16 16x16x32, dense peak 2.5 PFLOP/s); their HBM side is reported next to it
             tf = flops * mean_valid / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "hbm": hbm}
-        roof.update({"kernel": kname, "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms), "alg_bytes_per_launch": int(nbytes),
+        roof.update({"kernel": kname, "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_raw": round(avg_raw, 4), "event_pair_overhead_ms": round(ev_overhead, 4), "launches_timed": len(ms), "alg_bytes_per_launch": int(nbytes),
                      "ms_per_step_by_launch_group": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])}})
 
     extra = {"mean_samples_per_batch": round(mean_valid, 1), "rays_per_batch": runner.sampler.n_rays_per_batch}

@@ -26,7 +26,8 @@ extern "C" {
 enum { NGP_F32 = 0, NGP_F16 = 1 };
 enum { NGP_E_ARG = -1, NGP_E_DTYPE = -2, NGP_E_ALIGN = -3, NGP_E_CAPACITY = -4 };
 /* feature-tensor layouts between the encoder and the MLP */
-enum { NGP_LAYOUT_AOS = 0 /* [n,32] as HashEncoder returns it */, NGP_LAYOUT_SOA = 1 /* [16][n] pairs, level-major */ };
+enum { NGP_LAYOUT_AOS = 0 /* [n,32] as HashEncoder returns it */, NGP_LAYOUT_SOA = 1 /* [16][n] pairs, level-major */,
+       NGP_WEIGHTS_PACKED = 0x100 /* OR into feat_layout of the field-network calls: `wd` is the fragment buffer ngp_field_pack_weights wrote, `wc` is ignored */ };
 
 int ngp_abi_version(void);
 const char *ngp_last_error(void);
@@ -73,7 +74,12 @@ int ngp_sh_encode(void *stream, uint32_t n, const float *dir, uint32_t dir_strid
  * Both MLPs of NGPNetworks.execute_ (models/networks/ngp_network.py:77-84) in one fp16-MFMA kernel, weights resident in LDS:
  * replaces mlp_fused_forward_func x2 (ops/code_ops/fully_fused_mlp.py:52-86) + SHEncoder + the three concats.
  * wd: f16[3072] = W0[64x32] W1[16x64];  wc: f16[7168] = V0[64x32] V1[64x64] V2[16x64]  — the FMLP pack (ngp_network.py:21-29).
- * feat: f16 features in `feat_layout`; dir: f32 warped directions; out: [n,4] T = (r,g,b logits, log-density). */
+ * feat: f16 features in `feat_layout`; dir: f32 warped directions; out: [n,4] T = (r,g,b logits, log-density).
+ * The kernels read the weights as MFMA-ordered fragments.  By default every call builds them from wd/wc (a 5 us kernel, into a per-stream scratch);
+ * a caller that runs forward and backward on the same weights builds them once with ngp_field_pack_weights (f16[NGP_PACKED_WEIGHT_HALVES], 16-byte
+ * aligned) and passes feat_layout | NGP_WEIGHTS_PACKED. */
+#define NGP_PACKED_WEIGHT_HALVES 21504
+int ngp_field_pack_weights(void *stream, const void *wd, const void *wc, void *packed_out);
 int ngp_field_fwd(void *stream, uint32_t n, const void *feat, int feat_layout, const float *dir, uint32_t dir_stride_floats,
                   const void *wd, const void *wc, void *out, int out_dtype, const uint32_t *n_valid);
 /* NGPNetworks.density (ngp_network.py:86-89): density MLP only, out [n] T (column 0) */

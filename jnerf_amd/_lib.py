@@ -30,6 +30,7 @@ SIGNATURES = {
     "ngp_density_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _i32]),
     "ngp_field_bwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _u32, _vp, _vp, _vp, _i32, _vp, _vp, _u32, _vp]),
     "ngp_field_bwd_slabs": (C.c_int, [_u32]),
+    "ngp_field_pack_weights": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ngp_reduce_slabs": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _i32]),
     "ngp_march_rays": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _i32]),
     "ngp_compact_coords": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),

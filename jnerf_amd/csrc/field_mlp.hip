@@ -388,14 +388,18 @@ __global__ void k_selftest_mfma(uint32_t *result) {
 
 // ---------------------------------------------------------------------------------------------------------------- C ABI
 static int check_field(const char *fn, const void *feat, const void *wd, const void *wc, int layout, int out_dtype) {
-	NGP_REQUIRE(feat && wd && wc, NGP_E_ARG, "%s: null pointer", fn);
+	const bool prepacked = (layout & NGP_WEIGHTS_PACKED) != 0;
+	layout &= ~NGP_WEIGHTS_PACKED;
+	NGP_REQUIRE(feat && wd && (wc || prepacked), NGP_E_ARG, "%s: null pointer", fn);
+	NGP_REQUIRE(!prepacked || ((uintptr_t)wd & 15) == 0, NGP_E_ALIGN, "%s: packed weight buffer must be 16-byte aligned", fn);
 	NGP_REQUIRE(layout == NGP_LAYOUT_AOS || layout == NGP_LAYOUT_SOA, NGP_E_ARG, "%s: bad layout %d", fn, layout);
 	NGP_REQUIRE(out_dtype == NGP_F32 || out_dtype == NGP_F16, NGP_E_DTYPE, "%s: bad dtype %d", fn, out_dtype);
 	NGP_REQUIRE(((uintptr_t)feat & 15) == 0, NGP_E_ALIGN, "%s: feature pointer must be 16-byte aligned", fn);
 	return 0;
 }
 // per-(device, stream) scratch for the packed fragments; launches on one stream are ordered, so one buffer per stream is enough
-static _Float16 *pack_weights(const char *fn, hipStream_t s, const void *wd, const void *wc, int n_frags) {
+static const _Float16 *pack_weights(const char *fn, hipStream_t s, const void *wd, const void *wc, int n_frags, int layout_flags) {
+	if (layout_flags & NGP_WEIGHTS_PACKED) return (const _Float16 *)wd;
 	static std::mutex mu;
 	static std::map<std::pair<int, hipStream_t>, _Float16 *> pool;
 	int dev = 0;
@@ -415,11 +419,12 @@ static uint32_t fwd_grid(uint32_t n) { uint32_t b = div_up(div_up(n, 16), 4); re
 NGP_API int ngp_field_fwd(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,
                           void *out, int out_dtype, const uint32_t *n_valid) {
 	int rc = check_field("ngp_field_fwd", feat, wd, wc, layout, out_dtype); if (rc) return rc;
+	const int layout_flags = layout; layout &= ~NGP_WEIGHTS_PACKED;
 	NGP_REQUIRE(dir && out && dir_stride >= 3, NGP_E_ARG, "ngp_field_fwd: bad dir/out");
 	if (n == 0) return 0;
 	const dim3 grid(fwd_grid(n)), block(256);
 	hipStream_t s = (hipStream_t)stream;
-	const _Float16 *packed = pack_weights("ngp_field_fwd", s, wd, wc, N_FWD_FRAGS); if (!packed) return NGP_E_ARG;
+	const _Float16 *packed = pack_weights("ngp_field_fwd", s, wd, wc, N_FWD_FRAGS, layout_flags); if (!packed) return NGP_E_ARG;
 #define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, false>), grid, block, 0, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (T *)out, n_valid)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
@@ -429,11 +434,12 @@ NGP_API int ngp_field_fwd(void *stream, uint32_t n, const void *feat, int layout
 }
 NGP_API int ngp_density_fwd(void *stream, uint32_t n, const void *feat, int layout, const void *wd, void *out, int out_dtype) {
 	int rc = check_field("ngp_density_fwd", feat, wd, wd, layout, out_dtype); if (rc) return rc;
+	const int layout_flags = layout; layout &= ~NGP_WEIGHTS_PACKED;
 	NGP_REQUIRE(out, NGP_E_ARG, "ngp_density_fwd: null out");
 	if (n == 0) return 0;
 	const dim3 grid(fwd_grid(n)), block(256);
 	hipStream_t s = (hipStream_t)stream;
-	const _Float16 *packed = pack_weights("ngp_density_fwd", s, wd, wd, 6); if (!packed) return NGP_E_ARG;
+	const _Float16 *packed = pack_weights("ngp_density_fwd", s, wd, wd, 6, layout_flags); if (!packed) return NGP_E_ARG;
 #define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, true>), grid, block, 0, s, n, (const _Float16 *)feat, (const float *)nullptr, 3u, packed, (T *)out, (const uint32_t *)nullptr)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
@@ -441,17 +447,26 @@ NGP_API int ngp_density_fwd(void *stream, uint32_t n, const void *feat, int layo
 	NGP_LAUNCH_CHECK("ngp_density_fwd");
 	return 0;
 }
+NGP_API int ngp_field_pack_weights(void *stream, const void *wd, const void *wc, void *packed_out) {
+	NGP_REQUIRE(wd && wc && packed_out, NGP_E_ARG, "ngp_field_pack_weights: null pointer");
+	NGP_REQUIRE(((uintptr_t)packed_out & 15) == 0, NGP_E_ALIGN, "ngp_field_pack_weights: output must be 16-byte aligned");
+	const int n_frags = N_FWD_FRAGS + N_BWD_FRAGS;
+	hipLaunchKernelGGL(k_pack_frags, dim3(div_up((uint32_t)n_frags * 512u, 256u)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)wd, (const _Float16 *)wc, (_Float16 *)packed_out, n_frags);
+	NGP_LAUNCH_CHECK("ngp_field_pack_weights");
+	return 0;
+}
 NGP_API int ngp_field_bwd_slabs(uint32_t n) { uint32_t b = div_up(n, BT); return (int)(b < 256 ? (b ? b : 1) : 256); }
 NGP_API int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,
                           const void *dLdout, int out_dtype, void *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid) {
 	int rc = check_field("ngp_field_bwd", feat, wd, wc, layout, out_dtype); if (rc) return rc;
+	const int layout_flags = layout; layout &= ~NGP_WEIGHTS_PACKED;
 	NGP_REQUIRE(dir && dLdout && dLdfeat && wgrad_slabs && dir_stride >= 3, NGP_E_ARG, "ngp_field_bwd: null pointer");
 	NGP_REQUIRE((int)n_slabs == ngp_field_bwd_slabs(n), NGP_E_ARG, "ngp_field_bwd: n_slabs %u != ngp_field_bwd_slabs(%u)", n_slabs, n);
 	if (n == 0) return 0;
 	const size_t shmem = ((N_FWD_FRAGS + N_BWD_FRAGS) * 512 + N_ROWS * RS) * sizeof(_Float16);
 	const dim3 grid(n_slabs), block(256);
 	hipStream_t s = (hipStream_t)stream;
-	const _Float16 *packed = pack_weights("ngp_field_bwd", s, wd, wc, N_FWD_FRAGS + N_BWD_FRAGS); if (!packed) return NGP_E_ARG;
+	const _Float16 *packed = pack_weights("ngp_field_bwd", s, wd, wc, N_FWD_FRAGS + N_BWD_FRAGS, layout_flags); if (!packed) return NGP_E_ARG;
 #define GO(T, L) do { \
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field_bwd<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \

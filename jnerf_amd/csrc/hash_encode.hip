@@ -502,7 +502,6 @@ static int hash_bwd_method() {
 #define BIN_BITS 13u
 #define BIN_ENTRIES (1u << BIN_BITS)
 #define BINS_PER_LEVEL 64u
-#define BIN_SPT 2u                 // samples per thread in k_bin_records
 struct BinPlan { uint32_t level[16]; uint32_t n_levels; uint32_t cap; };   // hashed levels, records per bin
 
 template <typename T, int LAYOUT>
@@ -537,69 +536,75 @@ __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__res
 	}
 }
 
+// Records are staged in LDS grouped by bin and written out run by run: a wave then stores 64 consecutive records (four full 128-byte lines) instead of 64
+// scattered 8-byte words.  The scattered version was bound by the L2 request rate (2.4e7 partial-line writes ~ one per clock per channel), not by bytes.
+#define BIN_STAGE_BYTES (1024u * 8u * 8u + 3u * BINS_PER_LEVEL * 4u)
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(1024) void k_bin_records(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp,
                                                       const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ cursors, uint2 *__restrict__ records,
                                                       float *__restrict__ grad_f32, const uint32_t *__restrict__ n_valid) {
-	__shared__ uint32_t cnt[BINS_PER_LEVEL], base[BINS_PER_LEVEL];
+	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
+	uint2 *stage = reinterpret_cast<uint2 *>(bin_smem);                       // [8192] records, grouped by bin
+	uint32_t *cnt = bin_smem + 1024u * 8u * 2u, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL;
 	using P = typename Pair<T>::type;
 	const uint32_t hl = blockIdx.y, level = bp.level[hl];
 	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const float vs = bin_scale(absmax_bits[level]);
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	if (vs == 0.f || blockIdx.x * (1024u * BIN_SPT) >= lim) return;    // uniform exit
+	if (vs == 0.f || blockIdx.x * 1024u >= lim) return;                // uniform exit
 	if (threadIdx.x < BINS_PER_LEVEL) cnt[threadIdx.x] = 0;
 	__syncthreads();
+	const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
 	const P *dy = reinterpret_cast<const P *>(dLdy);
-	// BIN_SPT samples per thread, all of their loads issued before the first use: the kernel is a chain of latencies (loads -> LDS histogram -> barrier -> one global
-	// atomic per bin -> barrier -> stores), so more work per trip is what shortens it; it also halves the same-address traffic on the 64 cursors of the level.
-	uint32_t idx[BIN_SPT][8], rank[BIN_SPT][8]; __half2 val[BIN_SPT][8];
-	float2 g2[BIN_SPT]; float px[BIN_SPT][3];
-	bool live[BIN_SPT];
-#pragma unroll
-	for (uint32_t u = 0; u < BIN_SPT; ++u) {
-		const uint32_t i = blockIdx.x * (1024u * BIN_SPT) + u * 1024u + threadIdx.x;
-		live[u] = i < lim;
-		const uint32_t ic = live[u] ? i : 0u;
-		g2[u] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + ic] : dy[(size_t)ic * 16 + level]);
-		px[u][0] = pos[(size_t)ic * stride]; px[u][1] = pos[(size_t)ic * stride + 1]; px[u][2] = pos[(size_t)ic * stride + 2];
-	}
-#pragma unroll
-	for (uint32_t u = 0; u < BIN_SPT; ++u) {
-		live[u] = live[u] && (g2[u].x != 0.f || g2[u].y != 0.f);
-		if (live[u]) {
-			Corner c;
-#pragma unroll
-			for (int d = 0; d < 3; ++d) { const float p = px[u][d] * scale + 0.5f; const float fl = floorf(p); c.g[d] = (uint32_t)(int)fl; c.w[d] = p - fl; }
+	uint32_t idx[8], rank[8]; __half2 val[8];
+	bool live = false;
+	if (i < lim) {
+		const float2 g2 = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level]);
+		live = (g2.x != 0.f || g2.y != 0.f);
+		if (live) {
+			const Corner c = locate(pos, stride, i, scale);
 			const uint32_t ty0 = c.g[1] * 19349663u, tz0 = c.g[2] * 83492791u;
-			const float gx = g2[u].x * vs, gy = g2[u].y * vs;
+			const float gx = g2.x * vs, gy = g2.y * vs;
 #pragma unroll
 			for (uint32_t q = 0; q < 8; ++q) {
 				const uint32_t ex = c.g[0] + (q & 1u), ey = ty0 + ((q & 2u) ? 19349663u : 0u), ez = tz0 + ((q & 4u) ? 83492791u : 0u);
-				idx[u][q] = (ex ^ ey ^ ez) & (size - 1);
+				idx[q] = (ex ^ ey ^ ez) & (size - 1);
 				const float w = ((q & 1u) ? c.w[0] : 1 - c.w[0]) * ((q & 2u) ? c.w[1] : 1 - c.w[1]) * ((q & 4u) ? c.w[2] : 1 - c.w[2]);
-				val[u][q] = __floats2half2_rn(gx * w, gy * w);
-				rank[u][q] = atomicAdd(&cnt[idx[u][q] >> BIN_BITS], 1u);
+				val[q] = __floats2half2_rn(gx * w, gy * w);
+				rank[q] = atomicAdd(&cnt[idx[q] >> BIN_BITS], 1u);
 			}
 		}
 	}
 	__syncthreads();
-	if (threadIdx.x < BINS_PER_LEVEL) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursors[hl * BINS_PER_LEVEL + threadIdx.x], cnt[threadIdx.x]) : 0u;
-	__syncthreads();
+	if (threadIdx.x < BINS_PER_LEVEL) {                                    // wave 0: global run reservation + exclusive prefix of the counts (LDS offsets of the runs)
+		const uint32_t c = cnt[threadIdx.x];
+		base[threadIdx.x] = c ? atomicAdd(&cursors[hl * BINS_PER_LEVEL + threadIdx.x], c) : 0u;
+		uint32_t x = c;
 #pragma unroll
-	for (uint32_t u = 0; u < BIN_SPT; ++u) {
-		if (!live[u]) continue;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)threadIdx.x >= o) x += y; }
+		loff[threadIdx.x] = x - c;
+	}
+	__syncthreads();
+	if (live) {
 #pragma unroll
 		for (uint32_t q = 0; q < 8; ++q) {
-			const uint32_t bin = idx[u][q] >> BIN_BITS, slot = base[bin] + rank[u][q];
-			if (slot < bp.cap) {
-				uint2 r; r.x = idx[u][q] & (BIN_ENTRIES - 1u); r.y = *reinterpret_cast<uint32_t *>(&val[u][q]);
-				records[((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap + slot] = r;
-			} else {                                                    // bin full (pathological clustering): add this contribution directly
-				const float2 v = __half22float2(val[u][q]);
-				atomic_add_pair(grad_f32 + ((size_t)off + idx[u][q]) * 2, make_float2(v.x / vs, v.y / vs));
-			}
+			const uint32_t bin = idx[q] >> BIN_BITS;
+			uint2 r; r.x = idx[q]; r.y = *reinterpret_cast<uint32_t *>(&val[q]);          // full level index for now: the copy-out needs the bin
+			stage[loff[bin] + rank[q]] = r;
+		}
+	}
+	__syncthreads();
+	const uint32_t total = loff[BINS_PER_LEVEL - 1] + cnt[BINS_PER_LEVEL - 1];
+	for (uint32_t p = threadIdx.x; p < total; p += 1024u) {
+		uint2 r = stage[p];
+		const uint32_t bin = r.x >> BIN_BITS, slot = base[bin] + (p - loff[bin]);
+		if (slot < bp.cap) {
+			r.x &= BIN_ENTRIES - 1u;
+			records[((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap + slot] = r;
+		} else {                                                        // bin full (pathological clustering): add this contribution directly
+			const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&r.y));
+			atomic_add_pair(grad_f32 + ((size_t)off + r.x) * 2, make_float2(v.x / vs, v.y / vs));
 		}
 	}
 }
@@ -766,12 +771,14 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	if (level_scratch) hipLaunchKernelGGL((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
 	if (use_bins && bp.n_levels) { \
 		static bool attr2 = false; \
-		if (!attr2) { hipError_t e = hipFuncSetAttribute((const void *)k_bin_accumulate<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_ENTRIES * 16)); \
+		if (!attr2) { hipError_t e = hipFuncSetAttribute((const void *)k_bin_records<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIN_STAGE_BYTES); \
+			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+			e = hipFuncSetAttribute((const void *)k_bin_accumulate<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_ENTRIES * 16)); \
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr2 = true; } \
 		hipLaunchKernelGGL((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
 		if (units && side.ok) hipEventRecord(side.fork, s);   /* fork point: the dense-level kernel needs the abs-max too */ \
 		if (!probe_skip_bins) { \
-		hipLaunchKernelGGL((k_bin_records<T, L>), dim3(div_up(n, 1024 * BIN_SPT), bp.n_levels), dim3(1024), 0, s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, records, (float *)grad, n_valid); \
+		hipLaunchKernelGGL((k_bin_records<T, L>), dim3(div_up(n, 1024), bp.n_levels), dim3(1024), BIN_STAGE_BYTES, s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, records, (float *)grad, n_valid); \
 		hipLaunchKernelGGL((k_bin_accumulate<G>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const uint2 *)records, (G *)grad); } \
 	} \
 	hipStream_t sd = s; \

@@ -46,18 +46,18 @@ class FusedTrainStep:
         n = self.n
         nr = numsteps.shape[0]
         rgb, loss, lgrad = self._ray_bufs(nr, coords.device)
-        wd, wc = self.dm.half_weights(), self.cm.half_weights()          # (also completes a deferred all-reduce + sweep)
+        packed = m.packed_weights(refresh=True)                            # (reading the weights also completes a deferred all-reduce + sweep)
         table = enc.table_for_kernels()
         dirs = coords[:, 4:]
         self.pos.copy_(coords[:, :3])
         feat = m._feat_buffer(n)
         ops.hash_encode_fwd(self.pos, table, enc.level_table, out=feat, layout=ops.LAYOUT_SOA, n_valid=n_valid)
-        ops.field_fwd(feat, dirs, wd, wc, layout=ops.LAYOUT_SOA, out=self.out, n_valid=n_valid)
+        ops.field_fwd(feat, dirs, None, None, layout=ops.LAYOUT_SOA, out=self.out, n_valid=n_valid, packed=packed)
         ops.composite_fwd(self.out, coords, numsteps, numsteps_c, b["bg"], s.NERF_CASCADES, out=rgb)
         ops.huber(rgb, b["target"], r.loss_func.delta, loss=loss, grad=lgrad)
         ops.composite_bwd(self.out, coords, numsteps_c, lgrad, rgb, s.density_grid_mean, s.NERF_CASCADES, dout=self.dout, zero_first=False)
         dfeat, slabs, _ = m._bwd_buffers(n)
-        ops.field_bwd(feat, dirs, wd, wc, self.dout, layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid)
+        ops.field_bwd(feat, dirs, None, None, self.dout, layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid, packed=packed)
         ops.reduce_slabs(slabs, out=m._flat_weight_grad(), accumulate=True)
         enc.accumulate_grad(self.pos, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
         r.optimizer.step(None)            # ExpDecay lr schedule -> Adam.step without a loss: all-reduce (data parallel) + bookkeeping

@@ -87,7 +87,7 @@ class _FusedField(torch.autograd.Function):
             pos = pos.contiguous()      # compact [n,3] copy (3 MB): the 16 level passes then stream 12 B/sample out of L2 instead of 28 B records
         feat = net._feat_buffer(n)
         ops.hash_encode_fwd(pos, enc.table_for_kernels(), enc.level_table, out=feat, layout=ops.LAYOUT_SOA, n_valid=n_valid)
-        out = ops.field_fwd(feat, dirs, net.density_mlp.half_weights(), net.rgb_mlp.half_weights(), layout=ops.LAYOUT_SOA, out_dtype=torch.float16, n_valid=n_valid)
+        out = ops.field_fwd(feat, dirs, None, None, layout=ops.LAYOUT_SOA, out_dtype=torch.float16, n_valid=n_valid, packed=net.packed_weights(refresh=True))
         ctx.net, ctx.n_valid = net, n_valid
         ctx.save_for_backward(pos, dirs, feat)
         return out
@@ -99,7 +99,8 @@ class _FusedField(torch.autograd.Function):
         enc = net.pos_encoder
         n = pos.shape[0]
         dfeat, slabs, wsum = net._bwd_buffers(n)
-        ops.field_bwd(feat, dirs, net.density_mlp.half_weights(), net.rgb_mlp.half_weights(), dout.contiguous(), layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid)
+        ops.field_bwd(feat, dirs, None, None, dout.contiguous(), layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid,
+                      packed=net.packed_weights(refresh=False))      # the fragments the forward of this step built (the weights have not changed since)
         ops.reduce_slabs(slabs, out=net._flat_weight_grad(), accumulate=True)     # both MLP packs' .grad are views of this one buffer
         enc.accumulate_grad(pos, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
         return None, None, None, None, None, None, None
@@ -163,6 +164,16 @@ class NGPNetworks(nn.Module):
                                torch.empty((ops.field_bwd_slabs(n), 10240), dtype=torch.float32, device=dev),
                                torch.empty(10240, dtype=torch.float32, device=dev))
         return self._bufs[key]
+
+    def packed_weights(self, refresh=True):
+        """MFMA-ordered fragments of both weight packs (ngp_field_pack_weights); rebuilt from the current fp16 weights when `refresh`"""
+        buf = getattr(self, "_packed", None)
+        if buf is None or refresh:
+            wd, wc = self.density_mlp.half_weights(), self.rgb_mlp.half_weights()
+            if buf is None:
+                buf = self._packed = torch.empty(ops.PACKED_WEIGHT_HALVES, dtype=torch.float16, device=wd.device)
+            ops.field_pack_weights(wd, wc, out=buf)
+        return buf
 
     def forward(self, pos_input, dir_input):
         if self.fused:

@@ -142,9 +142,26 @@ def sh_encode(d, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------ field network
-def field_fwd(feat, d, wd, wc, layout=LAYOUT_AOS, out_dtype=torch.float16, out=None, n_valid=None):
-    assert feat.dtype == torch.float16 and wd.dtype == torch.float16 and wc.dtype == torch.float16 and feat.is_contiguous()
-    assert wd.numel() == 3072 and wc.numel() == 7168
+WEIGHTS_PACKED = 0x100
+PACKED_WEIGHT_HALVES = 21504
+
+
+def field_pack_weights(wd, wc, out=None):
+    """MFMA-ordered fragments of both weight packs (f16[21504]); pass as `packed=` to field_fwd / field_bwd / density_fwd to build them once per step"""
+    assert wd.dtype == torch.float16 and wc.dtype == torch.float16 and wd.numel() == 3072 and wc.numel() == 7168
+    if out is None:
+        out = torch.empty(PACKED_WEIGHT_HALVES, dtype=torch.float16, device=wd.device)
+    with timed("field_pack"):
+        check(L.lib().ngp_field_pack_weights(_stream(), _p(wd), _p(wc), _p(out)), "ngp_field_pack_weights")
+    return out
+
+
+def field_fwd(feat, d, wd, wc, layout=LAYOUT_AOS, out_dtype=torch.float16, out=None, n_valid=None, packed=None):
+    assert feat.dtype == torch.float16 and feat.is_contiguous()
+    if packed is not None:
+        wd, wc, layout = packed, None, layout | WEIGHTS_PACKED
+    else:
+        assert wd.dtype == torch.float16 and wc.dtype == torch.float16 and wd.numel() == 3072 and wc.numel() == 7168
     d, stride = _rows(d, 3)
     n = d.shape[0]
     if out is None:
@@ -154,8 +171,11 @@ def field_fwd(feat, d, wd, wc, layout=LAYOUT_AOS, out_dtype=torch.float16, out=N
     return out
 
 
-def density_fwd(feat, wd, n, layout=LAYOUT_AOS, out_dtype=torch.float16):
-    assert feat.dtype == torch.float16 and wd.dtype == torch.float16 and feat.is_contiguous()
+def density_fwd(feat, wd, n, layout=LAYOUT_AOS, out_dtype=torch.float16, packed=None):
+    assert feat.dtype == torch.float16 and feat.is_contiguous()
+    if packed is not None:
+        wd, layout = packed, layout | WEIGHTS_PACKED
+    assert wd.dtype == torch.float16
     out = torch.empty((n,), dtype=out_dtype, device=feat.device)
     check(L.lib().ngp_density_fwd(_stream(), n, _p(feat), layout, _p(wd), _p(out), _dt(out)), "ngp_density_fwd")
     return out
@@ -165,9 +185,11 @@ def field_bwd_slabs(n):
     return int(L.lib().ngp_field_bwd_slabs(n))
 
 
-def field_bwd(feat, d, wd, wc, dLdout, layout=LAYOUT_AOS, dfeat=None, slabs=None, n_valid=None):
+def field_bwd(feat, d, wd, wc, dLdout, layout=LAYOUT_AOS, dfeat=None, slabs=None, n_valid=None, packed=None):
     """-> (dLdfeat f16 in `layout`, slabs f32[n_slabs,10240]); sum the slabs with reduce_slabs."""
     assert feat.dtype == torch.float16 and feat.is_contiguous() and dLdout.is_contiguous()
+    if packed is not None:
+        wd, wc, layout = packed, None, layout | WEIGHTS_PACKED
     d, stride = _rows(d, 3)
     n = d.shape[0]
     ns = field_bwd_slabs(n)
