@@ -46,7 +46,7 @@ class Runner:
         cfg.m_training_step = 0
         self.val_freq = 4096
         self.pipeline = cfg.pipeline_sampling is not False      # `pipeline_sampling = False` in the config restores the strictly sequential loop
-        self._next, self._side, self._prev_done, self._fast = None, None, None, None
+        self._next, self._side, self._done_valid, self._fast = None, None, False, None
         self.render_chunk = int(cfg.render_chunk or 32768)       # rays per inference pass (the reference: n_rays_per_batch = 4096)
         self.W, self.H = self.dataset["train"].resolution
 
@@ -93,24 +93,6 @@ class Runner:
         else:
             b = self._make_batch(i)
         cfg.m_training_step = i
-        nxt = i + 1
-        if self.pipeline and main is not None and nxt < self.tot_train_steps and nxt % self.sampler.update_den_freq != 0:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-                self._events = (torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
-            if self._prev_done is not None:
-                self._side.wait_event(self._prev_done)      # the buffer set batch i+1 writes was last read by step i-1
-            cur_state = self.sampler.export_batch_state()
-            with torch.cuda.stream(self._side):
-                nb = self._make_batch(nxt)
-                nb["ready"] = self._events[nxt & 1]         # persistent events, re-recorded (no create/destroy per step)
-                nb["ready"].record(self._side)
-            for t in (nb["bg"], nb["target"]) + tuple(nb["keep"]):
-                if torch.is_tensor(t):
-                    t.record_stream(main)
-            self._next = nb
-            self.sampler.import_batch_state(cur_state)
-            cfg.m_training_step = i
         if self._fast is None:
             from .fastpath import FusedTrainStep
             self._fast = FusedTrainStep(self) if FusedTrainStep.applicable(self) else False
@@ -122,9 +104,32 @@ class Runner:
             loss = self.loss_func(rgb, b["target"])
             self.optimizer.step(loss)
             self.ema_optimizer.ema_step()
-        if main is not None and self._side is not None:
-            self._prev_done = self._events[2]
-            self._prev_done.record(main)
+        # ---- batch i+1 on the side stream.  Issued AFTER step i's own launches: every 16th prefetch ends in update_batch_rays' host read-back, and
+        # the main stream should have step i queued while the host waits for it.
+        nxt = i + 1
+        if self.pipeline and main is not None and nxt < self.tot_train_steps and nxt % self.sampler.update_den_freq != 0:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+                self._events = tuple(torch.cuda.Event() for _ in range(4))      # ready[2], done[2]: persistent, re-recorded (no create/destroy per step)
+            self._events[2 + (i & 1)].record(main)           # done(i)
+            if self._done_valid:
+                self._side.wait_event(self._events[2 + ((i - 1) & 1)])          # the buffer set batch i+1 writes was last read by step i-1
+            cur_state = self.sampler.export_batch_state()
+            with torch.cuda.stream(self._side):
+                nb = self._make_batch(nxt)
+                nb["ready"] = self._events[nxt & 1]
+                nb["ready"].record(self._side)
+            for t in (nb["bg"], nb["target"]) + tuple(nb["keep"]):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+            self._next = nb
+            self.sampler.import_batch_state(cur_state)
+            cfg.m_training_step = i
+            self._done_valid = True
+        else:
+            if self._side is not None and main is not None:
+                self._events[2 + (i & 1)].record(main)
+                self._done_valid = True
         return loss
 
     def train(self):
