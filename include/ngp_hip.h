@@ -112,10 +112,17 @@ uint64_t ngp_march_scratch_elems(uint32_t n_rays);   /* u32 elements of `scratch
 int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
                              float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                              uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch);
+/* same, and also writes the warped positions as a compact f32[cap,3] array (what ngp_hash_encode_fwd/_bwd stream 16 times per step); pos_out may be NULL */
+int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
+                                 float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
+                                 uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch, float *pos_out);
 
 /* replaces CalcRgb.execute / .grad / .inference (calc_rgb.py:45-68, 78-104, 120-144; op_header/calc_rgb.h) */
 int ngp_composite_fwd(void *stream, uint32_t n_rays, const void *net_out, int dtype, const float *coords, const uint32_t *numsteps,
                       const uint32_t *numsteps_compacted, const float *bg /*[n,3]*/, int cascades, float *rgb_out);
+/* ngp_composite_fwd followed by ngp_huber on the composited colours (runner.py:72 with HuberLoss), one launch: loss (may be NULL) and loss_grad are [n_rays,3] */
+int ngp_composite_fwd_huber(void *stream, uint32_t n_rays, const void *net_out, int dtype, const float *coords, const uint32_t *numsteps,
+                            const uint32_t *numsteps_compacted, const float *bg, int cascades, float *rgb_out, const float *target, float delta, float *loss, float *loss_grad);
 int ngp_composite_bwd(void *stream, uint32_t n_rays, uint32_t n_elems, const void *net_out, int dtype, const float *coords,
                       const uint32_t *numsteps_compacted, const float *loss_grad, const float *rgb_ray, const float *density_grid_mean,
                       int cascades, void *dLdout, int zero_first);

@@ -36,7 +36,9 @@ SIGNATURES = {
     "ngp_compact_coords": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngp_march_scratch_elems": (C.c_uint64, [_u32]),
     "ngp_march_rays_compacted": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "ngp_march_rays_compacted_pos": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngp_composite_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ngp_composite_fwd_huber": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp]),
     "ngp_composite_bwd": (C.c_int, [_vp, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),
     "ngp_composite_inference": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ngp_huber": (C.c_int, [_vp, _u32, _vp, _vp, _f32, _vp, _vp]),

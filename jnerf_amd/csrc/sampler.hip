@@ -218,7 +218,7 @@ __global__ __launch_bounds__(128) void k_march_write(uint32_t n_rays, MarchParam
 // so the records are bit-identical to a second traversal.
 __global__ __launch_bounds__(256) void k_march_write_cached(uint32_t n_rays, MarchParams p, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                             const uint32_t *__restrict__ numsteps, const uint32_t *__restrict__ counters, uint32_t total_idx,
-                                                            const float *__restrict__ tcache, float *__restrict__ coords) {
+                                                            const float *__restrict__ tcache, float *__restrict__ coords, float *__restrict__ pos_out) {
 	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= counters[total_idx]) return;
 	// last ray whose base <= s and that owns s (rays with zero steps share a base with their successor)
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void k_march_write_cached(uint32_t n_rays, Mar
 	for (int k = 0; k < 3; ++k) c[k] = ((o[k] + t * d[k]) - p.a0) / (p.a1 - p.a0);
 	c[3] = (dt - dtmin) / dtspan;
 	c[4] = (d[0] + 1.0f) * 0.5f; c[5] = (d[1] + 1.0f) * 0.5f; c[6] = (d[2] + 1.0f) * 0.5f;
+	if (pos_out) { pos_out[(size_t)s * 3] = c[0]; pos_out[(size_t)s * 3 + 1] = c[1]; pos_out[(size_t)s * 3 + 2] = c[2]; }   // compact [n,3] copy for the hash-grid kernels
 }
 
 static int check_march_args(const char *fn, uint32_t n_rays, const void *a, const void *b, const void *c, const void *d, int cascades) {
@@ -272,11 +273,20 @@ NGP_API int ngp_march_rays(void *stream, uint32_t n_rays, const float *rays_o, c
 	return 0;
 }
 
+NGP_API int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
+                                         float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
+                                         uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch, float *pos_out);
 NGP_API uint64_t ngp_march_scratch_elems(uint32_t n_rays) { return (uint64_t)((n_rays + 1023u) & ~1023u) + (uint64_t)NGP_TCACHE * n_rays + 1024u; }
 
 NGP_API int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
                                      float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                                      uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch) {
+	return ngp_march_rays_compacted_pos(stream, n_rays, rays_o, rays_d, bitfield, aabb0, aabb1, near_distance, cone_angle, const_dt, cascades, rng_state_host, max_samples,
+	                                    cap, coords_out, numsteps, numsteps_compacted, counters, scratch, nullptr);
+}
+NGP_API int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
+                                         float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
+                                         uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch, float *pos_out) {
 	int rc = check_march_args("ngp_march_rays_compacted", n_rays, rays_o, rays_d, bitfield, coords_out, cascades); if (rc) return rc;
 	NGP_REQUIRE(counters && rng_state_host && (n_rays == 0 || (numsteps && numsteps_compacted && scratch)), NGP_E_ARG, "ngp_march_rays_compacted: null pointer");
 	hipStream_t s = (hipStream_t)stream;
@@ -287,7 +297,7 @@ NGP_API int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float 
 	hipLaunchKernelGGL(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
 	hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, n_rays, max_samples, cap, (const uint32_t *)scratch, numsteps, numsteps_compacted, (int32_t *)nullptr, counters, 4);
 	hipLaunchKernelGGL(k_march_write_cached, dim3(div_up(cap, 256)), dim3(256), 0, s, n_rays, p, rays_o, rays_d, (const uint32_t *)numsteps_compacted,
-	                   (const uint32_t *)counters, 3u, (const float *)tcache, coords_out);
+	                   (const uint32_t *)counters, 3u, (const float *)tcache, coords_out, pos_out);
 	NGP_LAUNCH_CHECK("ngp_march_rays_compacted");
 	return 0;
 }
@@ -364,16 +374,28 @@ __device__ __forceinline__ float bcast(float v, uint32_t k) { return __int_as_fl
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 constexpr uint32_t COMPOSITE_RAYS_PER_BLOCK = 4;
 
+// Huber loss + its gradient of one ray's three channels (models/losses/huber_loss.py:6-14), the expressions of k_huber
+__device__ __forceinline__ void huber3(const float *__restrict__ target, float delta, float *__restrict__ loss, float *__restrict__ grad, uint32_t i, uint32_t c, float x) {
+	const float d = x - target[3 * i + c], rel = fabsf(d);
+	if (loss) loss[3 * i + c] = rel > delta ? rel - 0.5f * delta : 0.5f / delta * rel * rel;
+	grad[3 * i + c] = rel > delta ? (d > 0 ? 1.0f : -1.0f) : d / delta;
+}
+struct HuberArgs { const float *target; float delta; float *loss, *grad; };     // target == nullptr: no loss stage
+
 template <typename T, bool INFERENCE>
 __global__ __launch_bounds__(256) void k_composite_fwd(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps,
                                                        const uint32_t *__restrict__ numsteps_c, const float *__restrict__ bg, int cascades,
-                                                       float *__restrict__ rgb_out, float *__restrict__ alpha_out) {
+                                                       float *__restrict__ rgb_out, float *__restrict__ alpha_out, HuberArgs hub) {
 	const uint32_t lane = threadIdx.x & 63u, i = uniform(blockIdx.x * COMPOSITE_RAYS_PER_BLOCK + (threadIdx.x >> 6));
 	if (i >= n_rays) return;
 	const uint32_t *nsrc = INFERENCE ? numsteps : numsteps_c;
 	const uint32_t ns = uniform(nsrc[2 * i]), base = uniform(nsrc[2 * i + 1]);
 	if (ns == 0) {
-		if (lane < 3) rgb_out[3 * i + lane] = INFERENCE ? 0.f : bg[3 * i + lane];
+		if (lane < 3) {
+			const float v = INFERENCE ? 0.f : bg[3 * i + lane];
+			rgb_out[3 * i + lane] = v;
+			if (!INFERENCE && hub.target) huber3(hub.target, hub.delta, hub.loss, hub.grad, i, lane, v);
+		}
 		if (INFERENCE && lane == 0) alpha_out[i] = 0.f;
 		return;
 	}
@@ -407,6 +429,10 @@ __global__ __launch_bounds__(256) void k_composite_fwd(uint32_t n_rays, const T 
 #pragma unroll
 		for (int c = 0; c < 3; ++c) rgb_out[3 * i + c] = ray[c];
 		if (INFERENCE) alpha_out[i] = 1 - T_;
+		if (!INFERENCE && hub.target) {
+#pragma unroll
+			for (int c = 0; c < 3; ++c) huber3(hub.target, hub.delta, hub.loss, hub.grad, i, (uint32_t)c, ray[c]);
+		}
 	}
 }
 
@@ -460,15 +486,26 @@ __global__ __launch_bounds__(256) void k_composite_bwd(uint32_t n_rays, const T 
 	}
 }
 
+static int composite_fwd_impl(void *stream, uint32_t n_rays, const void *net, int dtype, const float *coords, const uint32_t *numsteps,
+                              const uint32_t *numsteps_c, const float *bg, int cascades, float *rgb_out, HuberArgs hub);
 NGP_API int ngp_composite_fwd(void *stream, uint32_t n_rays, const void *net, int dtype, const float *coords, const uint32_t *numsteps,
                               const uint32_t *numsteps_c, const float *bg, int cascades, float *rgb_out) {
+	return composite_fwd_impl(stream, n_rays, net, dtype, coords, numsteps, numsteps_c, bg, cascades, rgb_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
+}
+NGP_API int ngp_composite_fwd_huber(void *stream, uint32_t n_rays, const void *net, int dtype, const float *coords, const uint32_t *numsteps,
+                                    const uint32_t *numsteps_c, const float *bg, int cascades, float *rgb_out, const float *target, float delta, float *loss, float *loss_grad) {
+	NGP_REQUIRE(target && loss_grad, NGP_E_ARG, "ngp_composite_fwd_huber: null pointer");
+	return composite_fwd_impl(stream, n_rays, net, dtype, coords, numsteps, numsteps_c, bg, cascades, rgb_out, HuberArgs{target, delta, loss, loss_grad});
+}
+static int composite_fwd_impl(void *stream, uint32_t n_rays, const void *net, int dtype, const float *coords, const uint32_t *numsteps,
+                              const uint32_t *numsteps_c, const float *bg, int cascades, float *rgb_out, HuberArgs hub) {
 	NGP_REQUIRE(net && coords && numsteps && numsteps_c && bg && rgb_out, NGP_E_ARG, "ngp_composite_fwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_composite_fwd: bad dtype %d", dtype);
 	if (n_rays == 0) return 0;
 	const dim3 grid(div_up(n_rays, COMPOSITE_RAYS_PER_BLOCK)), block(64 * COMPOSITE_RAYS_PER_BLOCK);
 	hipStream_t s = (hipStream_t)stream;
-	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, false>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr);
-	else hipLaunchKernelGGL((k_composite_fwd<__half, false>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr);
+	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, false>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
+	else hipLaunchKernelGGL((k_composite_fwd<__half, false>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
 	NGP_LAUNCH_CHECK("ngp_composite_fwd");
 	return 0;
 }
@@ -479,8 +516,8 @@ NGP_API int ngp_composite_inference(void *stream, uint32_t n_rays, const void *n
 	if (n_rays == 0) return 0;
 	const dim3 grid(div_up(n_rays, COMPOSITE_RAYS_PER_BLOCK)), block(64 * COMPOSITE_RAYS_PER_BLOCK);
 	hipStream_t s = (hipStream_t)stream;
-	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, true>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out);
-	else hipLaunchKernelGGL((k_composite_fwd<__half, true>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out);
+	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, true>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
+	else hipLaunchKernelGGL((k_composite_fwd<__half, true>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
 	NGP_LAUNCH_CHECK("ngp_composite_inference");
 	return 0;
 }

@@ -27,7 +27,6 @@ class FusedTrainStep:
         dev = self.enc.m_grid.device
         n = self.s.target_batch_size
         self.n = n
-        self.pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
         self.out = torch.empty((n, 4), dtype=torch.float16, device=dev)
         self.dout = torch.empty((n, 4), dtype=torch.float16, device=dev)
         self._per_rays = {}
@@ -49,17 +48,16 @@ class FusedTrainStep:
         packed = m.packed_weights(refresh=True)                            # (reading the weights also completes a deferred all-reduce + sweep)
         table = enc.table_for_kernels()
         dirs = coords[:, 4:]
-        self.pos.copy_(coords[:, :3])
+        pos = s._pos_train                                                # compact [n,3] positions (the marcher writes them next to the 28-byte records)
         feat = m._feat_buffer(n)
-        ops.hash_encode_fwd(self.pos, table, enc.level_table, out=feat, layout=ops.LAYOUT_SOA, n_valid=n_valid)
+        ops.hash_encode_fwd(pos, table, enc.level_table, out=feat, layout=ops.LAYOUT_SOA, n_valid=n_valid)
         ops.field_fwd(feat, dirs, None, None, layout=ops.LAYOUT_SOA, out=self.out, n_valid=n_valid, packed=packed)
-        ops.composite_fwd(self.out, coords, numsteps, numsteps_c, b["bg"], s.NERF_CASCADES, out=rgb)
-        ops.huber(rgb, b["target"], r.loss_func.delta, loss=loss, grad=lgrad)
+        ops.composite_fwd_huber(self.out, coords, numsteps, numsteps_c, b["bg"], b["target"], r.loss_func.delta, s.NERF_CASCADES, out=rgb, loss=loss, grad=lgrad)
         ops.composite_bwd(self.out, coords, numsteps_c, lgrad, rgb, s.density_grid_mean, s.NERF_CASCADES, dout=self.dout, zero_first=False)
         dfeat, slabs, _ = m._bwd_buffers(n)
         ops.field_bwd(feat, dirs, None, None, self.dout, layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid, packed=packed)
         ops.reduce_slabs(slabs, out=m._flat_weight_grad(), accumulate=True)
-        enc.accumulate_grad(self.pos, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
+        enc.accumulate_grad(pos, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
         r.optimizer.step(None)            # ExpDecay lr schedule -> Adam.step without a loss: all-reduce (data parallel) + bookkeeping
         r.ema_optimizer.ema_step()        # fused Adam + EMA sweep (deferred to the next parameter read under data parallelism)
         return loss

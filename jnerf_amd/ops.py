@@ -244,7 +244,7 @@ def march_scratch_elems(n_rays):
 
 
 def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng_state, max_samples, cap, cone_angle=1.0 / 256, near=0.2, const_dt=True, cascades=5,
-                         coords_out=None, numsteps=None, numsteps_c=None, counters=None, scratch=None):
+                         coords_out=None, numsteps=None, numsteps_c=None, counters=None, scratch=None, pos_out=None):
     n = rays_o.shape[0]
     dev = rays_o.device
     if coords_out is None:
@@ -260,9 +260,9 @@ def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng_state, max_samples,
         scratch = torch.empty(need, dtype=torch.int32, device=dev)
     assert scratch.numel() >= need, "march scratch too small: use ops.march_scratch_elems(n_rays)"
     with timed("march"):
-        check(L.lib().ngp_march_rays_compacted(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
-                                               rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch)),
-              "ngp_march_rays_compacted")
+        check(L.lib().ngp_march_rays_compacted_pos(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
+                                                   rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch),
+                                                   _p(pos_out)), "ngp_march_rays_compacted_pos")
     return coords_out, numsteps, numsteps_c, counters
 
 
@@ -274,6 +274,20 @@ def composite_fwd(net, coords, numsteps, numsteps_c, bg, cascades=5, out=None):
     with timed("composite_fwd"):
         check(L.lib().ngp_composite_fwd(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out)), "ngp_composite_fwd")
     return out
+
+
+def composite_fwd_huber(net, coords, numsteps, numsteps_c, bg, target, delta, cascades=5, out=None, loss=None, grad=None):
+    """composite_fwd + huber in one launch -> (rgb, loss, loss_grad), all [n_rays,3] f32"""
+    n = numsteps.shape[0]
+    assert net.is_contiguous() and coords.is_contiguous() and bg.is_contiguous() and target.is_contiguous()
+    dev = net.device
+    out = torch.empty((n, 3), dtype=torch.float32, device=dev) if out is None else out
+    loss = torch.empty((n, 3), dtype=torch.float32, device=dev) if loss is None else loss
+    grad = torch.empty((n, 3), dtype=torch.float32, device=dev) if grad is None else grad
+    with timed("composite_fwd"):
+        check(L.lib().ngp_composite_fwd_huber(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out), _p(target), delta, _p(loss), _p(grad)),
+              "ngp_composite_fwd_huber")
+    return out, loss, grad
 
 
 def composite_bwd(net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades=5, dout=None, zero_first=True):

@@ -71,6 +71,18 @@ class Adam:
         if self._world() == 1:
             return
         grads = [p.grad for p in self.param_groups[0]["params"] if p.grad is not None]
+        # gradients that are views tiling one flat buffer (the two MLP packs, network.py:_flat_weight_grad) travel as ONE collective
+        by_base = {}
+        for g in grads:
+            by_base.setdefault(id(g._base) if g._base is not None else id(g), []).append(g)
+        merged = []
+        for group in by_base.values():
+            base = group[0]._base
+            if base is not None and len(group) > 1 and base.is_contiguous() and sum(g.numel() for g in group) == base.numel():
+                merged.append(base)
+            else:
+                merged.extend(group)
+        grads = merged
         if grads and grads[0].is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()

@@ -86,7 +86,7 @@ class DensityGridSampler(nn.Module):
         # two buffer sets: the Runner marches batch i+1 on a side stream while batch i is still being trained on (software pipelining)
         self._sets = [dict(numsteps=torch.empty((cap_r, 2), dtype=torch.int32, device=dev), numsteps_c=torch.empty((cap_r, 2), dtype=torch.int32, device=dev),
                            counters=torch.zeros(4, dtype=torch.int32, device=dev), coords=torch.zeros((self.target_batch_size, 7), dtype=torch.float32, device=dev),
-                           scratch=None) for _ in range(2)]
+                           pos=torch.zeros((self.target_batch_size, 3), dtype=torch.float32, device=dev), scratch=None) for _ in range(2)]
         self._set_idx = 0
         self._numsteps_buf, self._numsteps_c_buf = self._sets[0]["numsteps"], self._sets[0]["numsteps_c"]
         self._counters = self._sets[0]["counters"]
@@ -153,7 +153,8 @@ class DensityGridSampler(nn.Module):
             bs["scratch"] = torch.empty(max(need, ops.march_scratch_elems(min(self.target_batch_size, 1 << 18))), dtype=torch.int32, device=self.device)
         ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.target_batch_size,
                                  self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
-                                 coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=bs["scratch"])
+                                 coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=bs["scratch"], pos_out=bs["pos"])
+        self._pos_train = bs["pos"]                                    # compact [n,3] copy of coords[:, :3], written by the marcher's write pass
         self.measured_batch_size += self._counters[2:3]                # density_grid_sampler.py:155
         if self.cfg.m_training_step % self.update_den_freq == (self.update_den_freq - 1):
             self.update_batch_rays()
@@ -164,10 +165,11 @@ class DensityGridSampler(nn.Module):
 
     # ---- batch state hand-over for the pipelined training loop (Runner): everything rays2rgb / the network need about ONE sampled batch
     def export_batch_state(self):
-        return (self._coords, self._rays_numsteps, getattr(self, "_rays_numsteps_compacted", None), self._n_valid, self._coords_train, self._counters)
+        return (self._coords, self._rays_numsteps, getattr(self, "_rays_numsteps_compacted", None), self._n_valid, self._coords_train, self._counters,
+                getattr(self, "_pos_train", None))
 
     def import_batch_state(self, st):
-        self._coords, self._rays_numsteps, self._rays_numsteps_compacted, self._n_valid, self._coords_train, self._counters = st
+        self._coords, self._rays_numsteps, self._rays_numsteps_compacted, self._n_valid, self._coords_train, self._counters, self._pos_train = st
 
     def _inference_coords(self):
         if getattr(self, "_coords_inf", None) is None:

@@ -52,6 +52,17 @@ def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng, max_samples, cap, 
     return N(c), u32(ns), u32(nsc), u32(cnt)
 
 
+def march_rays_compacted_pos(rays_o, rays_d, bitfield, aabb, rng, max_samples, cap, cone_angle=1.0 / 256, near=0.2, const_dt=True, cascades=5):
+    pos = torch.full((cap, 3), -7.0, dtype=torch.float32, device=DEV)
+    c, ns, nsc, cnt = ops.march_rays_compacted(T(rays_o), T(rays_d), T(bitfield), aabb, rng.st, max_samples, cap, cone_angle, near, const_dt, cascades, pos_out=pos)
+    return N(c), u32(cnt), N(pos)
+
+
+def composite_fwd_huber(net, coords, numsteps, numsteps_c, bg, target, delta, cascades=5):
+    r, l, g = ops.composite_fwd_huber(T(net), T(coords), T(numsteps.view(np.int32)), T(numsteps_c.view(np.int32)), T(bg), T(target), delta, cascades)
+    return N(r), N(l), N(g)
+
+
 def compact_coords(coords_in, numsteps_in, cap):
     c, ns, cnt = ops.compact_coords(T(coords_in), T(numsteps_in.view(np.int32)), cap)
     return N(c), u32(ns), u32(cnt)

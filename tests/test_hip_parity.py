@@ -186,6 +186,8 @@ def test_march_compacted_equals_march_then_compact(H, const_dt, aabb):
         k = min(M, cap)
         assert np.array_equal(n2, no) and np.array_equal(nc2, nc) and np.array_equal(c2[:k], cc[:k])
         assert cnt4[1] == cnto[1] and cnt4[2] == ccnt[0] and cnt4[3] == k
+        c3, cnt5, pos3 = H.march_rays_compacted_pos(o, d, bits, aabb, O.PCG32(1337), 4096 * 1024, cap, const_dt=const_dt)    # + compact positions
+        assert np.array_equal(c3[:k], cc[:k]) and np.array_equal(pos3[:k], cc[:k, :3]) and (pos3[k:] == -7.0).all() and np.array_equal(cnt5, cnt4)
     # capacity overflow in the marcher itself (ray_sampler.h:74-80)
     small = M // 2
     co2, no2, cnt2, _ = O.march_rays(o, d, bits, aabb, O.PCG32(1337), small, const_dt=const_dt)
@@ -194,6 +196,24 @@ def test_march_compacted_equals_march_then_compact(H, const_dt, aabb):
     # empty batch
     e = H.march_rays(o[:0], d[:0], bits, aabb, O.PCG32(1337), 16, const_dt=const_dt)
     assert e[1].shape == (0, 2) and not e[2].any()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_composite_fwd_huber_equals_the_two_calls(H, dtype):
+    """the fused launch of the fast training path == ngp_composite_fwd then ngp_huber, bit for bit; both == oracle"""
+    xf, focal, meta = synth.camera_ring(8, radius=1.3)
+    _, o, d, _ = synth.rays_from_cameras(xf, focal, meta, 64, 48, 2048, seed=3)
+    coords, ns, nsc, cnt = H.march_rays_compacted(o, d, synth.shell_bitfield(), (0.0, 1.0), O.PCG32(1337), 4096 * 1024, 1 << 16, const_dt=True)
+    rng = np.random.default_rng(5)
+    net = rng.standard_normal((coords.shape[0], 4)).astype(dtype)
+    bg, target = rng.random((2048, 3), dtype=np.float32), rng.random((2048, 3), dtype=np.float32)
+    rgb = H.composite_fwd(net, coords, ns, nsc, bg)
+    l0, g0 = H.huber(rgb, target, 0.1)
+    rgb2, l1, g1 = H.composite_fwd_huber(net, coords, ns, nsc, bg, target, 0.1)
+    assert np.array_equal(rgb, rgb2) and np.array_equal(l0, l1) and np.array_equal(g0, g1)
+    lo, go = O.huber(rgb, target, 0.1)
+    assert np.array_equal(l1, lo) and np.array_equal(g1, go)
+    assert (ns[:, 0] == 0).any()            # rays without samples take the background branch
 
 
 def test_adam_ema_and_huber_and_rays(H):

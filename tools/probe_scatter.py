@@ -32,7 +32,7 @@ def main():
     dfeat, _, _ = r.model._bwd_buffers(n)
     n_valid = f.s._n_valid
     print("n_valid", int(n_valid.item()) if n_valid.numel() == 1 else n_valid)
-    fn = lambda: enc.accumulate_grad(f.pos, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
+    fn = lambda: enc.accumulate_grad(f.s._pos_train, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
     rows = []
     def run(name, **env):
         for k, v in env.items():
