@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(n_samples=1 << 15, n_rays=512):
+def cpu_baseline(n_samples=1 << 18, n_rays=4096, n_march_rays=39424):
     """the oracle (plain-C port of the reference's kernels, 1 thread) on a bounded slice of one training iteration: every hot-path stage on
     n_samples of the 2^18 samples and the parameter update on the same fraction of the 13 M parameters; scaled to iterations/s"""
     import numpy as np
@@ -34,7 +34,12 @@ def cpu_baseline(n_samples=1 << 15, n_rays=512):
     per = n_samples // n_rays
     ns = np.stack([np.full(n_rays, per, np.uint32), (np.arange(n_rays) * per).astype(np.uint32)], 1)
     bg = np.random.default_rng(0).random((n_rays, 3), dtype=np.float32)
+    xf, focal, meta = synth.camera_ring(8, radius=1.3)
+    m_rays = int(n_march_rays * frac)
+    _, ro, rd, _ = synth.rays_from_cameras(xf, focal, meta, 400, 400, m_rays, seed=1)
+    bits = synth.shell_bitfield()
     t0 = time.perf_counter()
+    O.march_rays(ro, rd, bits, (-1.5, 2.5), O.PCG32(1337), 4096 * 1024, const_dt=False)       # the batch's ray count through the two-pass marcher
     feat = O.hash_encode_fwd(x, grid, table)
     sh = O.sh_encode(d, np.float32)
     out = O.field_fwd(feat.astype(np.float32), sh, wd, wc)
@@ -48,8 +53,8 @@ def cpu_baseline(n_samples=1 << 15, n_rays=512):
     O.adam_ema_step(p, g[:npar].astype(np.float32), m, v, e, 0.1, 1)
     t = time.perf_counter() - t0
     return {"value": round(frac / t, 4), "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"1/{int(1 / frac)} of one iteration ({n_samples} of 2^18 samples through hash fwd/bwd, SH, both MLPs fwd/bwd, compositing fwd/bwd, Huber; "
-                      f"Adam+EMA on {npar} of {n_params} parameters), {t:.1f} s on 1 core, scaled"}
+            "sample": f"{'one' if frac == 1 else f'1/{int(1 / frac)} of one'} training iteration: {m_rays} rays marched, {n_samples} samples through hash fwd/bwd, SH, both MLPs fwd/bwd, "
+                      f"compositing fwd/bwd, Huber; Adam+EMA on {npar} of {n_params} parameters (occupancy-grid refresh not included); {t:.1f} s on 1 core"}
 
 
 def main():
@@ -179,6 +184,15 @@ def main():
         extra["render_Msamples_per_s"] = round(n_s / tr / 1e6, 2)
         extra["render_ms_per_%dx%d_view" % (args.res, args.res)] = round(tr / 4 * 1e3, 2)
     if world > 1:
+        # data-parallel invariant: every rank must hold bit-identical parameters (identical summed gradients + a deterministic sweep)
+        from jnerf_amd import optim as _optim
+        _optim.flush_all()
+        enc = runner.model.pos_encoder
+        sig = torch.stack([enc.m_grid.detach().double().sum(), enc.m_grid.detach().double().abs().sum(),
+                           runner.model.density_mlp.con_weights.detach().double().sum(), runner.model.rgb_mlp.con_weights.detach().double().sum()])
+        sigs = [torch.empty_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        extra["replicas_identical"] = bool(all(torch.equal(sigs[0], x) for x in sigs))
         dist.barrier()
     if rank == 0:
         line = {"metric": "training iters/s", "value": round(world * args.steps / dt, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

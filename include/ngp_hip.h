@@ -145,6 +145,9 @@ int ngp_grid_update_bitfield(void *stream, const float *grid, int cascades, floa
  * p/m/v/ema are fp32 masters; p_half (may be NULL) receives the fp16 copy the kernels gather from; g is fp32 or fp16 (g_dtype) and is
  * zeroed for the next step when zero_grad!=0.  step is 1-based.  ema may be NULL (no EMA), a separate buffer, or == p: the caller declares that the
  * stored EMA equals the parameter (true after every ema_step, ema.py:37 `v <- p`), which saves 8 B/parameter of traffic. */
+/* data parallel: fp32 gradient -> fp16 buffer for the RCCL all-reduce (half the bytes over xGMI; the reference keeps fp16 gradients anyway), source optionally
+ * zeroed in the same pass.  n % 8 == 0, 16-byte aligned.  Feed the reduced fp16 buffer to ngp_adam_ema_step with g_dtype = NGP_F16. */
+int ngp_grad_to_half(void *stream, uint64_t n, float *grad_f32, void *grad_f16, int zero_src);
 int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
                       float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad);
 

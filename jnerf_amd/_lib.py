@@ -47,6 +47,7 @@ SIGNATURES = {
     "ngp_grid_splat_max": (C.c_int, [_vp, _u32, _vp, _vp, _i32, _vp]),
     "ngp_grid_ema": (C.c_int, [_vp, _u32, _f32, _vp, _vp]),
     "ngp_grid_update_bitfield": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "ngp_grad_to_half": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _i32]),
     "ngp_adam_ema_step": (C.c_int, [_vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _f32, _i32]),
     "ngp_generate_rays": (C.c_int, [_vp, _u32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -44,6 +44,28 @@ __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restric
 	}
 }
 
+// fp32 gradient -> fp16 communication buffer (data-parallel all-reduce at half the bytes; the reference's gradients are fp16 to begin with), optionally
+// zeroing the source for the next backward in the same sweep.  Streaming, 32 B in / 16 B out per thread.
+__global__ __launch_bounds__(256) void k_grad_to_half(uint64_t n8, float4 *__restrict__ src, uint4 *__restrict__ dst, int zero_src) {
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (uint64_t)gridDim.x * 256) {
+		const float4 a = src[2 * i], b = src[2 * i + 1];
+		const __half2 h0 = __floats2half2_rn(a.x, a.y), h1 = __floats2half2_rn(a.z, a.w), h2 = __floats2half2_rn(b.x, b.y), h3 = __floats2half2_rn(b.z, b.w);
+		dst[i] = make_uint4(*reinterpret_cast<const uint32_t *>(&h0), *reinterpret_cast<const uint32_t *>(&h1), *reinterpret_cast<const uint32_t *>(&h2), *reinterpret_cast<const uint32_t *>(&h3));
+		if (zero_src) { src[2 * i] = make_float4(0.f, 0.f, 0.f, 0.f); src[2 * i + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+	}
+}
+NGP_API int ngp_grad_to_half(void *stream, uint64_t n, float *grad_f32, void *grad_f16, int zero_src) {
+	NGP_REQUIRE(n == 0 || (grad_f32 && grad_f16), NGP_E_ARG, "ngp_grad_to_half: null pointer");
+	NGP_REQUIRE(n % 8 == 0, NGP_E_ALIGN, "ngp_grad_to_half: n (%llu) must be a multiple of 8", (unsigned long long)n);
+	NGP_REQUIRE((((uintptr_t)grad_f32 | (uintptr_t)grad_f16) & 15) == 0, NGP_E_ALIGN, "ngp_grad_to_half: buffers must be 16-byte aligned");
+	if (n == 0) return 0;
+	const uint64_t n8 = n / 8;
+	uint32_t blocks = (uint32_t)((n8 + 255) / 256); if (blocks > 2048 * 4) blocks = 2048 * 4;
+	hipLaunchKernelGGL(k_grad_to_half, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n8, (float4 *)grad_f32, (uint4 *)grad_f16, zero_src);
+	NGP_LAUNCH_CHECK("ngp_grad_to_half");
+	return 0;
+}
+
 NGP_API int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
                               float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad) {
 	NGP_REQUIRE(p && g && m && v && step >= 1, NGP_E_ARG, "ngp_adam_ema_step: bad arguments");

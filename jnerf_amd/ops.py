@@ -357,6 +357,12 @@ def grid_update_bitfield(grid, cascades=5, mean=None, bitfield=None):
 
 
 # ------------------------------------------------------------------ optimiser / rays
+def grad_to_half(g32, g16, zero_src=True):
+    assert g32.dtype == torch.float32 and g16.dtype == torch.float16 and g32.numel() == g16.numel()
+    check(L.lib().ngp_grad_to_half(_stream(), g32.numel(), _p(g32), _p(g16), int(zero_src)), "ngp_grad_to_half")
+    return g16
+
+
 def adam_ema_step(p, g, m, v, ema, p_half, lr, step, b0=0.9, b1=0.99, eps=1e-15, ema_decay=0.95, zero_grad=True):
     with timed("adam_ema" if p.numel() >= (1 << 20) else "adam_ema_small"):          # the hash table vs the two MLP weight packs
         check(L.lib().ngp_adam_ema_step(_stream(), p.numel(), _p(p), _p(g), _dt(g), _p(m), _p(v), _p(ema), _p(p_half), lr, b0, b1, eps, step, ema_decay, int(zero_grad)), "ngp_adam_ema_step")

@@ -32,6 +32,8 @@ class Adam:
         self._half = {}
         self._comm_stream = None
         self._comm_pending = False
+        self._comm_half = {}            # id(param) -> fp16 communication buffer (large fp32 gradients travel as fp16, see allreduce_grads)
+        self._eff_grad = {}             # id(param) -> the reduced fp16 buffer the next sweep reads instead of p.grad
         self._deferred_ema = None
         _LIVE.add(self)
 
@@ -84,11 +86,28 @@ class Adam:
                 merged.extend(group)
         grads = merged
         if grads and grads[0].is_cuda:
+            from .utils.config import get_cfg
+            half_ok = get_cfg().dp_grad_dtype != "fp32" and bool(get_cfg().fp16)      # `dp_grad_dtype = "fp32"` in the config keeps full-width collectives
+            main = torch.cuda.current_stream()
+            send = []
+            for g in grads:
+                owner = next((p for p in self.param_groups[0]["params"] if p.grad is g), None)
+                if half_ok and owner is not None and g.dtype == torch.float32 and g.numel() >= (1 << 20) and g.numel() % 8 == 0:
+                    # the hash-table gradient: 52 MB fp32 -> 26 MB fp16 over xGMI (the reference's gradients are fp16 in the first place);
+                    # one streaming pass converts and zeroes the fp32 buffer, the sweep then reads the reduced fp16 buffer
+                    hb = self._comm_half.get(id(owner))
+                    if hb is None or hb.numel() != g.numel():
+                        hb = self._comm_half[id(owner)] = torch.empty(g.numel(), dtype=torch.float16, device=g.device)
+                    ops.grad_to_half(g.view(-1), hb, zero_src=True)
+                    self._eff_grad[id(owner)] = hb
+                    send.append(hb)
+                else:
+                    send.append(g)
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
-            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            self._comm_stream.wait_stream(main)
             with torch.cuda.stream(self._comm_stream):
-                for g in grads:
+                for g in send:
                     dist.all_reduce(g, op=dist.ReduceOp.SUM)
             self._comm_pending = True
         else:
@@ -123,7 +142,8 @@ class Adam:
                 continue
             e = ema.param_groups[0]["values"][i] if ema is not None else None
             if p.is_cuda:
-                ops.adam_ema_step(p.data, p.grad, pg["m"][i], pg["values"][i], e, self._half.get(id(p)), self.lr, self.n_step, self.betas[0], self.betas[1], self.eps,
+                g_eff = self._eff_grad.pop(id(p), None)            # reduced fp16 gradient of the data-parallel path (p.grad was zeroed by the conversion pass)
+                ops.adam_ema_step(p.data, g_eff.view_as(p.grad) if g_eff is not None else p.grad, pg["m"][i], pg["values"][i], e, self._half.get(id(p)), self.lr, self.n_step, self.betas[0], self.betas[1], self.eps,
                                   ema.decay if ema is not None else 0.0, zero_grad=True)
             else:                                   # CPU tensors (gloo unit tests of the data-parallel logic): same math in torch
                 b0, b1 = self.betas

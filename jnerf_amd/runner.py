@@ -28,6 +28,7 @@ class Runner:
         self.sampler = build_from_cfg(cfg.sampler, SAMPLERS)
         cfg.sampler_obj = self.sampler
         params = list(self.model.parameters())
+        self._sync_initial_parameters(params)
         self.optimizer = build_from_cfg(cfg.optim, OPTIMS, params=params)
         self.optimizer.attach_half_shadows(self.model)
         self.optimizer = build_from_cfg(cfg.expdecay, OPTIMS, nested_optimizer=self.optimizer)
@@ -49,6 +50,19 @@ class Runner:
         self._next, self._side, self._done_valid, self._fast = None, None, False, None
         self.render_chunk = int(cfg.render_chunk or 32768)       # rays per inference pass (the reference: n_rays_per_batch = 4096)
         self.W, self.H = self.dataset["train"].resolution
+
+    def _sync_initial_parameters(self, params):
+        """data parallel: every rank starts from rank 0's random initialisation (each rank seeds its own RNG for ray batches and backgrounds);
+        identical summed gradients + the deterministic sweep then keep the replicas bit-identical"""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        with torch.no_grad():
+            for p in params:
+                dist.broadcast(p.data, src=0)
+        for m in self.model.modules():
+            if hasattr(m, "shadow_dirty"):
+                m.shadow_dirty = True                       # fp16 shadows are rebuilt from the synchronised masters at the next read
 
     def drain(self):
         """wait for a batch that was marched ahead on the side stream (call before dropping the Runner or touching its buffers from elsewhere)"""

@@ -216,6 +216,19 @@ def test_composite_fwd_huber_equals_the_two_calls(H, dtype):
     assert (ns[:, 0] == 0).any()            # rays without samples take the background branch
 
 
+def test_grad_to_half(H):
+    import torch
+    from jnerf_amd import ops
+    g = np.random.default_rng(2).standard_normal(8 * 12345).astype(np.float32) * np.float32(1e-3)
+    g[:16] = [0.0, -0.0, 65504.0, 1e-8, 6e-8, -3e-5, 1.0, -1.0] * 2
+    t32 = torch.from_numpy(g.copy()).cuda()
+    t16 = torch.empty(g.size, dtype=torch.float16, device="cuda")
+    ops.grad_to_half(t32, t16, zero_src=False)
+    assert np.array_equal(t16.cpu().numpy(), g.astype(np.float16)) and np.array_equal(t32.cpu().numpy(), g)       # round-to-nearest-even, source untouched
+    ops.grad_to_half(t32, t16, zero_src=True)
+    assert np.array_equal(t16.cpu().numpy(), g.astype(np.float16)) and not t32.any()
+
+
 def test_adam_ema_and_huber_and_rays(H):
     rng = np.random.default_rng(1)
     n = 4096 * 3 + 4

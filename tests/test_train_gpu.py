@@ -82,6 +82,7 @@ def test_two_ranks_data_parallel_on_one_gpu():
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and np.isfinite(d["loss"]) and d["config"]["parallelism"] == "ray-batch dp2"
+    assert d["extra"]["replicas_identical"] is True           # both ranks hold bit-identical parameters after 60 data-parallel steps
 
 
 def test_nerf_dataset_on_disk(tmp_path):
