@@ -366,13 +366,15 @@ __device__ __forceinline__ float unwarp_dt(float dt, int cascades) {            
 	return dt * (max_stepsize - min_cone_stepsize()) + min_cone_stepsize();
 }
 
-// One wavefront per ray.  The reference walks a ray's samples serially in one thread (calc_rgb.h:20-60) - 4096 threads, each a chain of dependent, uncoalesced loads.
-// Here the 64 lanes load 64 consecutive samples of the ray coalesced and evaluate the transcendental part (exp, logistic) in parallel; the transmittance / colour
-// recurrences are then replayed in the reference's exact serial order (so results stay bit-identical) with the per-sample terms broadcast by v_readlane.  The replay is
-// wave-uniform VALU work of ~13 instructions per sample with no memory access in it.
-__device__ __forceinline__ float bcast(float v, uint32_t k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)k)); }
-__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-constexpr uint32_t COMPOSITE_RAYS_PER_BLOCK = 4;
+// Sixteen lanes per ray (four rays per wavefront).  The reference walks a ray's samples serially in one thread (calc_rgb.h:20-60) - tens of thousands of threads,
+// each a chain of dependent, uncoalesced loads.  Here a ray's lanes load 16 consecutive samples coalesced and evaluate the transcendental part (exp, logistic)
+// in parallel; the transmittance / colour recurrences are then replayed in the reference's exact serial order (so results stay bit-identical) with the per-sample
+// terms broadcast inside the 16-lane group (ds_bpermute).  The replay is ~13 VALU instructions per sample with no memory access in it.  16 rather than 64 lanes
+// because the adaptive ray count settles at ~7 samples per ray: a 64-lane group would idle 90 % of its lanes.
+// Inference chunks hold only rays that hit something (dozens of samples each) and keep one wavefront per ray.
+template <uint32_t CG> __device__ __forceinline__ float bcast(float v, uint32_t k) { return __shfl(v, (int)k, (int)CG); }
+template <> __device__ __forceinline__ float bcast<64>(float v, uint32_t k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)k)); }
+constexpr uint32_t CG_TRAIN = 16, CG_INFER = 64;                   // lanes per ray
 
 // Huber loss + its gradient of one ray's three channels (models/losses/huber_loss.py:6-14), the expressions of k_huber
 __device__ __forceinline__ void huber3(const float *__restrict__ target, float delta, float *__restrict__ loss, float *__restrict__ grad, uint32_t i, uint32_t c, float x) {
@@ -386,10 +388,11 @@ template <typename T, bool INFERENCE>
 __global__ __launch_bounds__(256) void k_composite_fwd(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps,
                                                        const uint32_t *__restrict__ numsteps_c, const float *__restrict__ bg, int cascades,
                                                        float *__restrict__ rgb_out, float *__restrict__ alpha_out, HuberArgs hub) {
-	const uint32_t lane = threadIdx.x & 63u, i = uniform(blockIdx.x * COMPOSITE_RAYS_PER_BLOCK + (threadIdx.x >> 6));
+	constexpr uint32_t CG = INFERENCE ? CG_INFER : CG_TRAIN;
+	const uint32_t lane = threadIdx.x & (CG - 1u), i = blockIdx.x * (256u / CG) + threadIdx.x / CG;
 	if (i >= n_rays) return;
 	const uint32_t *nsrc = INFERENCE ? numsteps : numsteps_c;
-	const uint32_t ns = uniform(nsrc[2 * i]), base = uniform(nsrc[2 * i + 1]);
+	const uint32_t ns = nsrc[2 * i], base = nsrc[2 * i + 1];
 	if (ns == 0) {
 		if (lane < 3) {
 			const float v = INFERENCE ? 0.f : bg[3 * i + lane];
@@ -400,8 +403,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(uint32_t n_rays, const T 
 		return;
 	}
 	float T_ = 1.f, ray[3] = {0.f, 0.f, 0.f};
-	for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
-		const uint32_t m = min(64u, ns - c0);
+	for (uint32_t c0 = 0; c0 < ns; c0 += CG) {                        // trip counts differ between the four rays of a wavefront; a ray's lanes stay together
+		const uint32_t m = min(CG, ns - c0);
 		float rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f;
 		if (lane < m) {
 			const size_t s = (size_t)base + c0 + lane;
@@ -412,12 +415,13 @@ __global__ __launch_bounds__(256) void k_composite_fwd(uint32_t n_rays, const T 
 #pragma unroll
 			for (int c = 0; c < 3; ++c) rgb[c] = logistic(o[c]);
 		}
-#pragma unroll 4
-		for (uint32_t k = 0; k < m; ++k) {
-			const float a = bcast(alpha, k);
+#pragma unroll
+		for (uint32_t k = 0; k < CG; ++k) {
+			if (k >= m) break;
+			const float a = bcast<CG>(alpha, k);
 			const float weight = a * T_;
 #pragma unroll
-			for (int c = 0; c < 3; ++c) ray[c] += weight * bcast(rgb[c], k);
+			for (int c = 0; c < 3; ++c) ray[c] += weight * bcast<CG>(rgb[c], k);
 			T_ *= (1.f - a);
 		}
 	}
@@ -440,16 +444,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_composite_bwd(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps_c,
                                                        const float *__restrict__ loss_grad, const float *__restrict__ rgb_ray, const float *__restrict__ density_grid_mean,
                                                        int cascades, T *__restrict__ dout) {
-	const uint32_t lane = threadIdx.x & 63u, i = uniform(blockIdx.x * COMPOSITE_RAYS_PER_BLOCK + (threadIdx.x >> 6));
+	constexpr uint32_t CG = CG_TRAIN;
+	const uint32_t lane = threadIdx.x & (CG - 1u), i = blockIdx.x * (256u / CG) + threadIdx.x / CG;
 	if (i >= n_rays) return;
 	float loss_scale = 128; loss_scale /= n_rays;                                    // calc_rgb.h:100-101
-	const uint32_t ns = uniform(numsteps_c[2 * i]), base = uniform(numsteps_c[2 * i + 1]);
+	const uint32_t ns = numsteps_c[2 * i], base = numsteps_c[2 * i + 1];
 	if (ns == 0) return;
 	const float l1 = *density_grid_mean < 0.01f ? 1e-4f : 0.0f;                       // :112
 	const float G[3] = {loss_grad[3 * i], loss_grad[3 * i + 1], loss_grad[3 * i + 2]}, R[3] = {rgb_ray[3 * i], rgb_ray[3 * i + 1], rgb_ray[3 * i + 2]};
 	float T_ = 1.f, ray2[3] = {0.f, 0.f, 0.f};
-	for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
-		const uint32_t m = min(64u, ns - c0);
+	for (uint32_t c0 = 0; c0 < ns; c0 += CG) {
+		const uint32_t m = min(CG, ns - c0);
 		const size_t s = (size_t)base + c0 + lane;
 		float o[4] = {0.f, 0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f, dt = 0.f;
 		if (lane < m) {
@@ -461,12 +466,13 @@ __global__ __launch_bounds__(256) void k_composite_bwd(uint32_t n_rays, const T 
 			alpha = 1.f - __expf(-density * dt);
 		}
 		float my_w = 0.f, my_T = 0.f, my_r2[3] = {0.f, 0.f, 0.f};                      // the recurrence's state right after this lane's sample
-#pragma unroll 4
-		for (uint32_t k = 0; k < m; ++k) {
-			const float a = bcast(alpha, k);
+#pragma unroll
+		for (uint32_t k = 0; k < CG; ++k) {
+			if (k >= m) break;
+			const float a = bcast<CG>(alpha, k);
 			const float weight = a * T_;
 #pragma unroll
-			for (int c = 0; c < 3; ++c) ray2[c] += weight * bcast(rgb[c], k);
+			for (int c = 0; c < 3; ++c) ray2[c] += weight * bcast<CG>(rgb[c], k);
 			T_ *= (1.f - a);
 			if (lane == k) { my_w = weight; my_T = T_; my_r2[0] = ray2[0]; my_r2[1] = ray2[1]; my_r2[2] = ray2[2]; }
 		}
@@ -502,7 +508,7 @@ static int composite_fwd_impl(void *stream, uint32_t n_rays, const void *net, in
 	NGP_REQUIRE(net && coords && numsteps && numsteps_c && bg && rgb_out, NGP_E_ARG, "ngp_composite_fwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_composite_fwd: bad dtype %d", dtype);
 	if (n_rays == 0) return 0;
-	const dim3 grid(div_up(n_rays, COMPOSITE_RAYS_PER_BLOCK)), block(64 * COMPOSITE_RAYS_PER_BLOCK);
+	const dim3 grid(div_up(n_rays, 256u / CG_TRAIN)), block(256);
 	hipStream_t s = (hipStream_t)stream;
 	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, false>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
 	else hipLaunchKernelGGL((k_composite_fwd<__half, false>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
@@ -514,7 +520,7 @@ NGP_API int ngp_composite_inference(void *stream, uint32_t n_rays, const void *n
 	NGP_REQUIRE(net && coords && numsteps && rgb_out && alpha_out, NGP_E_ARG, "ngp_composite_inference: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_composite_inference: bad dtype %d", dtype);
 	if (n_rays == 0) return 0;
-	const dim3 grid(div_up(n_rays, COMPOSITE_RAYS_PER_BLOCK)), block(64 * COMPOSITE_RAYS_PER_BLOCK);
+	const dim3 grid(div_up(n_rays, 256u / CG_INFER)), block(256);
 	hipStream_t s = (hipStream_t)stream;
 	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, true>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
 	else hipLaunchKernelGGL((k_composite_fwd<__half, true>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
@@ -528,7 +534,7 @@ NGP_API int ngp_composite_bwd(void *stream, uint32_t n_rays, uint32_t n_elems, c
 	hipStream_t s = (hipStream_t)stream;
 	if (zero_first) { hipError_t e = hipMemsetAsync(dout, 0, (size_t)n_elems * 4 * (dtype == NGP_F16 ? 2 : 4), s); if (e != hipSuccess) { ngp_set_error("ngp_composite_bwd memset: %s", hipGetErrorString(e)); return (int)e; } }
 	if (n_rays == 0) return 0;
-	const dim3 grid(div_up(n_rays, COMPOSITE_RAYS_PER_BLOCK)), block(64 * COMPOSITE_RAYS_PER_BLOCK);
+	const dim3 grid(div_up(n_rays, 256u / CG_TRAIN)), block(256);
 	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_bwd<float>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (float *)dout);
 	else hipLaunchKernelGGL((k_composite_bwd<__half>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (__half *)dout);
 	NGP_LAUNCH_CHECK("ngp_composite_bwd");
