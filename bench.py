@@ -118,9 +118,17 @@ def main():
     single = ("hash_fwd", "field_fwd", "field_bwd", "composite_fwd", "composite_bwd", "adam_ema")          # brackets that contain exactly one kernel
     breakdown = {k: sum(max(a.elapsed_time(b) - ev_overhead, 0.0) for a, b in v) / max(probe, 1) for k, v in probe_prof.items()}
     dom = max((k for k in breakdown if k in single), key=lambda k: breakdown[k]) if breakdown else None
-    # ... in the timed region only that kernel keeps its bracket (an event pair per launch costs ~2-3 us; eight of them per step were ~5 %)
+    # ... in the timed region only that kernel keeps its bracket (an event pair per launch costs ~2-3 us; eight of them per step were ~5 %).
+    # Single-GPU runs issue the step through ngp_train_step, which records the pair itself; data-parallel runs keep the Python-side bracket.
+    fast = runner._fast if getattr(runner, "_fast", None) else None
+    native = bool(fast and fast.native)
     ops.PROFILE_ONLY = dom
-    ops.PROFILE = None if (args.no_kernel_events or dom is None) else {}
+    if native:
+        fast.timed_stage = None if (args.no_kernel_events or dom is None) else dom
+        fast.stage_timings()                                  # drop anything recorded so far
+        ops.PROFILE = None
+    else:
+        ops.PROFILE = None if (args.no_kernel_events or dom is None) else {}
     barrier()
     t0 = time.perf_counter()
     loss = None
@@ -130,6 +138,10 @@ def main():
     last_loss = loss.mean().item() if loss is not None else float("nan")
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = (ops.PROFILE or {}), None
+    dom_ms = [a.elapsed_time(b) for a, b in prof.get(dom, [])] if dom else []
+    if native and fast.timed_stage is not None:
+        dom_ms = fast.stage_timings()
+        fast.timed_stage = None
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -141,8 +153,8 @@ def main():
     alg_bytes = {"hash_fwd": mean_valid * (12 + 16 * 8 * 4 + 64), "field_fwd": mean_valid * (64 + 12 + 8), "field_bwd": mean_valid * (64 + 12 + 8 + 64),
                  "composite_fwd": mean_valid * 36, "composite_bwd": mean_valid * 44, "adam_ema": P * 34}
     roof = None
-    if dom is not None and prof.get(dom):
-        ms = [a.elapsed_time(b) for a, b in prof[dom]]
+    if dom is not None and dom_ms:
+        ms = dom_ms
         avg_raw = sum(ms) / len(ms)
         avg_ms = max(avg_raw - ev_overhead, 1e-6)
         nbytes = alg_bytes[dom]

@@ -156,6 +156,46 @@ int ngp_generate_rays(void *stream, uint32_t n, const int64_t *pixel_index, int 
                       const float *xforms, const float *images /*[n_img*H*W,4] or NULL*/, const float *bg /*[n,3] or NULL*/,
                       int32_t *img_id, float *rays_o, float *rays_d, float *target /*[n,3] or NULL*/);
 
+/* ---- one training iteration's launch sequence, issued from native code -------------------------------------------------------------------
+ * The body of Runner.train for one already-sampled batch (runner/runner.py:71-76: model(pos, dir) -> sampler.rays2rgb -> HuberLoss ->
+ * optimizer.step -> ema_optimizer.ema_step), i.e. exactly these calls in this order on `stream`:
+ *   ngp_field_pack_weights, ngp_hash_encode_fwd, ngp_field_fwd, ngp_composite_fwd_huber, ngp_composite_bwd, ngp_field_bwd, ngp_reduce_slabs,
+ *   ngp_hash_encode_bwd_ws, then (run_optimizer != 0) ngp_adam_ema_step for each of the n_opt parameter tensors.
+ * It exists because eleven separate FFI crossings per iteration cost the host more than the GPU needs for the work; it adds no arithmetic
+ * of its own.  fp16 network, level-major features.  Data-parallel callers pass run_optimizer = 0, all-reduce the gradients, and sweep afterwards. */
+typedef struct NgpTrainStep {
+	uint32_t n;                 /* sample capacity of the batch buffers (2^18) */
+	uint32_t n_rays;
+	int32_t cascades;
+	int32_t run_optimizer;
+	/* the sampled batch (ngp_march_rays_compacted_pos, ngp_generate_rays) */
+	const float *coords;        /* [n,7] */
+	const float *pos;           /* [n,3] */
+	const uint32_t *numsteps, *numsteps_compacted;   /* [n_rays,2] */
+	const uint32_t *n_valid;    /* device count of valid samples */
+	const float *bg, *target;   /* [n_rays,3] */
+	const float *density_grid_mean;
+	/* hash grid */
+	const void *table_f16; const uint32_t *level_table_host; float *table_grad; uint64_t n_params; void *hash_workspace; uint64_t hash_workspace_bytes;
+	/* field network */
+	const void *wd_f16, *wc_f16; void *packed_weights; void *feat, *dfeat /* f16 [16][n][2] */; void *out, *dout /* f16 [n,4] */;
+	float *wgrad_slabs; uint32_t n_slabs; uint32_t pad0; float *wgrad_flat /* f32[10240], accumulated into */;
+	/* loss */
+	float huber_delta; float pad1; float *rgb, *loss, *loss_grad;   /* [n_rays,3] */
+	/* optimiser: Adam + EMA over n_opt (<= 4) parameter tensors, see ngp_adam_ema_step */
+	int32_t n_opt; uint32_t step;
+	float lr, beta0, beta1, eps, ema_decay, pad2;
+	float *p[4], *g[4], *m[4], *v[4], *ema[4]; void *p_half[4]; uint64_t numel[4];
+	/* measurement: -1 = none, else the stage to bracket with a HIP event pair on `stream` (NGP_STAGE_*); durations are read with ngp_train_step_timings */
+	int32_t timed_stage; int32_t pad3;
+} NgpTrainStep;
+enum { NGP_STAGE_PACK = 0, NGP_STAGE_HASH_FWD, NGP_STAGE_FIELD_FWD, NGP_STAGE_COMPOSITE_FWD, NGP_STAGE_COMPOSITE_BWD, NGP_STAGE_FIELD_BWD, NGP_STAGE_REDUCE_SLABS,
+       NGP_STAGE_HASH_BWD, NGP_STAGE_ADAM /* the largest parameter tensor's sweep */ };
+int ngp_train_step(void *stream, const NgpTrainStep *args_host);
+/* waits for the bracketed launches of earlier ngp_train_step calls (this thread's device) and writes up to `max` durations in milliseconds, oldest first;
+ * returns how many were written (<0 on error) and forgets them */
+int ngp_train_step_timings(float *ms_out_host, int max);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,8 +12,24 @@ _lib = None
 
 F32, F16 = 0, 1
 LAYOUT_AOS, LAYOUT_SOA = 0, 1
+STAGES = {"field_pack": 0, "hash_fwd": 1, "field_fwd": 2, "composite_fwd": 3, "composite_bwd": 4, "field_bwd": 5, "reduce_slabs": 6, "hash_bwd": 7, "adam_ema": 8}   # NGP_STAGE_*
 
 _vp, _u32, _u64, _i32, _f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
+
+
+class NgpTrainStep(C.Structure):
+    """mirror of `struct NgpTrainStep` in include/ngp_hip.h (argument block of ngp_train_step)"""
+    _fields_ = [("n", _u32), ("n_rays", _u32), ("cascades", _i32), ("run_optimizer", _i32),
+                ("coords", _vp), ("pos", _vp), ("numsteps", _vp), ("numsteps_compacted", _vp), ("n_valid", _vp), ("bg", _vp), ("target", _vp), ("density_grid_mean", _vp),
+                ("table_f16", _vp), ("level_table_host", _vp), ("table_grad", _vp), ("n_params", _u64), ("hash_workspace", _vp), ("hash_workspace_bytes", _u64),
+                ("wd_f16", _vp), ("wc_f16", _vp), ("packed_weights", _vp), ("feat", _vp), ("dfeat", _vp), ("out", _vp), ("dout", _vp),
+                ("wgrad_slabs", _vp), ("n_slabs", _u32), ("pad0", _u32), ("wgrad_flat", _vp),
+                ("huber_delta", _f32), ("pad1", _f32), ("rgb", _vp), ("loss", _vp), ("loss_grad", _vp),
+                ("n_opt", _i32), ("step", _u32), ("lr", _f32), ("beta0", _f32), ("beta1", _f32), ("eps", _f32), ("ema_decay", _f32), ("pad2", _f32),
+                ("p", _vp * 4), ("g", _vp * 4), ("m", _vp * 4), ("v", _vp * 4), ("ema", _vp * 4), ("p_half", _vp * 4), ("numel", _u64 * 4),
+                ("timed_stage", _i32), ("pad3", _i32)]
+
+
 SIGNATURES = {
     "ngp_abi_version": (C.c_int, []),
     "ngp_last_error": (C.c_char_p, []),
@@ -47,6 +63,8 @@ SIGNATURES = {
     "ngp_grid_splat_max": (C.c_int, [_vp, _u32, _vp, _vp, _i32, _vp]),
     "ngp_grid_ema": (C.c_int, [_vp, _u32, _f32, _vp, _vp]),
     "ngp_grid_update_bitfield": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "ngp_train_step": (C.c_int, [_vp, C.POINTER(NgpTrainStep)]),
+    "ngp_train_step_timings": (C.c_int, [_vp, _i32]),
     "ngp_grad_to_half": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _i32]),
     "ngp_adam_ema_step": (C.c_int, [_vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _f32, _i32]),
     "ngp_generate_rays": (C.c_int, [_vp, _u32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -67,6 +67,8 @@ class _RayDatasetBase:
             self._reshuffle()
         index = self.shuffle_index[self.idx_now:self.idx_now + self.batch_size]
         self.idx_now += self.batch_size
+        if index.is_cuda:
+            index.record_stream(torch.cuda.current_stream())       # the permutation may have been drawn on another (side) stream
         return ops.generate_rays(index, self.W, self.H, self.focal_lengths, self.metadata, self.transforms_gpu, images=self.image_data, bg=bg)
 
     def generate_random_data(self, index, bs):

@@ -3,7 +3,10 @@ DensityGridSampler + HuberLoss + Adam/ExpDecay/EMA).  Launches exactly the kerne
 encoders.py / network.py / sampler.py / losses.py), in the same order, on the same buffers — it only removes the per-launch Python
 overhead of nn.Module.__call__ / autograd graph construction, which at ~1 ms per iteration had become the bottleneck.
 Runner.train_step uses it automatically; `fast_path = False` in the config (or any non-standard component) selects the module path."""
+import ctypes as C
 import torch
+import torch.distributed as dist
+from . import _lib as L
 from . import ops
 
 
@@ -30,6 +33,11 @@ class FusedTrainStep:
         self.out = torch.empty((n, 4), dtype=torch.float16, device=dev)
         self.dout = torch.empty((n, 4), dtype=torch.float16, device=dev)
         self._per_rays = {}
+        # single-GPU runs issue the whole sequence with ONE call into the library (ngp_train_step); data-parallel runs keep the per-stage calls below
+        # because the gradient all-reduce sits between backward and the sweep
+        self.timed_stage = None         # name from _lib.STAGES: the library brackets that stage of every native step with HIP events (bench.py)
+        self.native = runner.cfg.native_step is not False and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self._args = None
 
     def _ray_bufs(self, nr, dev):
         b = self._per_rays.get(nr)
@@ -39,7 +47,73 @@ class FusedTrainStep:
             b = self._per_rays[nr] = tuple(torch.empty((nr, 3), dtype=torch.float32, device=dev) for _ in range(3))
         return b
 
+    def _native_args(self, dev):
+        """the argument block of ngp_train_step: everything that does not change from step to step is filled in once"""
+        r, s, enc, m = self.r, self.s, self.enc, self.r.model
+        adam, ema = r.optimizer._nested_optimizer, r.ema_optimizer
+        a = L.NgpTrainStep()
+        n = self.n
+        P = lambda t: None if t is None else t.data_ptr()
+        a.n, a.cascades, a.run_optimizer = n, s.NERF_CASCADES, 1
+        a.density_grid_mean = P(s.density_grid_mean)
+        self._level_table = ops._tbl(enc.level_table)                  # keeps the host array alive
+        a.level_table_host = self._level_table
+        a.table_grad, a.n_params = P(enc.grad_buffer()), enc.n_params
+        need = ops.hash_bwd_workspace_bytes(enc.level_table, n)
+        if enc._bwd_ws is None or enc._bwd_ws.numel() < need:
+            enc._bwd_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        a.hash_workspace, a.hash_workspace_bytes = P(enc._bwd_ws), enc._bwd_ws.numel()
+        dfeat, slabs, _ = m._bwd_buffers(n)
+        a.feat, a.dfeat, a.out, a.dout = P(m._feat_buffer(n)), P(dfeat), P(self.out), P(self.dout)
+        a.wgrad_slabs, a.n_slabs, a.wgrad_flat = P(slabs), slabs.shape[0], P(m._flat_weight_grad())
+        if getattr(m, "_packed", None) is None:
+            m._packed = torch.empty(ops.PACKED_WEIGHT_HALVES, dtype=torch.float16, device=dev)
+        a.packed_weights = P(m._packed)
+        a.huber_delta = r.loss_func.delta
+        pg, eg = adam.param_groups[0], ema.param_groups[0]
+        a.n_opt = len(pg["params"])
+        assert a.n_opt <= 4
+        for i, p in enumerate(pg["params"]):
+            assert p.grad is not None and p.grad.dtype == torch.float32
+            a.p[i], a.g[i], a.m[i], a.v[i], a.ema[i] = P(p.data), P(p.grad), P(pg["m"][i]), P(pg["values"][i]), P(eg["values"][i])
+            a.p_half[i], a.numel[i] = P(adam._half.get(id(p))), p.numel()
+        a.beta0, a.beta1, a.eps, a.ema_decay = adam.betas[0], adam.betas[1], adam.eps, ema.decay
+        self._keep = (dfeat, slabs)
+        return a
+
+    def _call_native(self, b):
+        r, s, enc, m = self.r, self.s, self.enc, self.r.model
+        coords, numsteps, numsteps_c = s._coords, s._rays_numsteps, s._rays_numsteps_compacted
+        nr = numsteps.shape[0]
+        rgb, loss, lgrad = self._ray_bufs(nr, coords.device)
+        wd, wc = self.dm.half_weights(), self.cm.half_weights()
+        table = enc.table_for_kernels()
+        if self._args is None:
+            self._args = self._native_args(coords.device)
+        a = self._args
+        ed, adam, ema = r.optimizer, r.optimizer._nested_optimizer, r.ema_optimizer
+        ed.advance_schedule()                       # == ExpDecay.step / Adam.step / EMA.ema_step bookkeeping; the sweep itself is launched by the library
+        adam.n_step += 1; ed.steps += 1; ema.steps += 1
+        a.n_rays, a.step, a.lr = nr, adam.n_step, adam.lr
+        a.timed_stage = -1 if self.timed_stage is None else L.STAGES[self.timed_stage]
+        a.coords, a.pos, a.numsteps, a.numsteps_compacted, a.n_valid = coords.data_ptr(), s._pos_train.data_ptr(), numsteps.data_ptr(), numsteps_c.data_ptr(), s._n_valid.data_ptr()
+        a.bg, a.target = b["bg"].data_ptr(), b["target"].data_ptr()
+        a.table_f16, a.wd_f16, a.wc_f16 = table.data_ptr(), wd.data_ptr(), wc.data_ptr()
+        a.rgb, a.loss, a.loss_grad = rgb.data_ptr(), loss.data_ptr(), lgrad.data_ptr()
+        L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step")
+        return loss
+
+    def stage_timings(self, max_n=1 << 16):
+        """milliseconds of the bracketed stage for every native step since the last call (synchronises)"""
+        buf = (C.c_float * max_n)()
+        n = L.lib().ngp_train_step_timings(buf, max_n)
+        if n < 0:
+            L.check(n, "ngp_train_step_timings")
+        return [buf[i] for i in range(n)]
+
     def __call__(self, b):
+        if self.native and ops.PROFILE is None:     # (the per-kernel HIP-event brackets of bench.py's probe phase live in the per-stage wrappers)
+            return self._call_native(b)
         r, s, enc, m = self.r, self.s, self.enc, self.r.model
         coords, numsteps, numsteps_c, n_valid = s._coords, s._rays_numsteps, s._rays_numsteps_compacted, s._n_valid
         n = self.n

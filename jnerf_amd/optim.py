@@ -185,10 +185,14 @@ class ExpDecay:
         self.steps = 0
         self.m_learning_rate_factor = 1
 
-    def step(self, loss=None):
+    def advance_schedule(self):
+        """the learning-rate part of step() (expdecay.py:20-23)"""
         if self.steps >= self.decay_start and (self.steps - self.decay_start) % self.decay_interval == 0 and self.steps <= self.decay_end:
             self.m_learning_rate_factor *= self.decay_base
         self._nested_optimizer.lr = self.base_lr * self.m_learning_rate_factor
+
+    def step(self, loss=None):
+        self.advance_schedule()
         self._nested_optimizer.step(loss)
         self.steps += 1
 

@@ -47,7 +47,8 @@ class Runner:
         cfg.m_training_step = 0
         self.val_freq = 4096
         self.pipeline = cfg.pipeline_sampling is not False      # `pipeline_sampling = False` in the config restores the strictly sequential loop
-        self._next, self._side, self._done_valid, self._fast = None, None, False, None
+        self._queue, self._sides, self._done_steps, self._fast, self._rays_event = {}, [], set(), None, None
+        self.pipeline_depth = int(cfg.pipeline_depth or 2)          # batches marched ahead of the one being trained on
         self.render_chunk = int(cfg.render_chunk or 32768)       # rays per inference pass (the reference: n_rays_per_batch = 4096)
         self.W, self.H = self.dataset["train"].resolution
 
@@ -66,9 +67,9 @@ class Runner:
 
     def drain(self):
         """wait for a batch that was marched ahead on the side stream (call before dropping the Runner or touching its buffers from elsewhere)"""
-        if self._side is not None:
-            self._side.synchronize()
-        self._next = None
+        for st in self._sides:
+            st.synchronize()
+        self._queue.clear()
 
     def __del__(self):
         try:
@@ -82,6 +83,9 @@ class Runner:
         current stream"""
         self.cfg.m_training_step = step
         ds = self.dataset["train"]
+        cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        if cur is not None and self._rays_event is not None:
+            cur.wait_event(self._rays_event)    # batches are generated on alternating streams: the dataset's permutation / cursor state is handed on in order
         if hasattr(ds, "next_fused"):       # same values as the three lines of runner.py:65-68, one kernel
             bg = torch.rand((ds.batch_size, 3), device=ds.device)
             img_ids, rays_o, rays_d, rgb_target = ds.next_fused(bg)
@@ -89,23 +93,31 @@ class Runner:
             img_ids, rays_o, rays_d, rgb_target = next(ds)
             bg = torch.rand((rgb_target.shape[0], 3), device=rgb_target.device)
             rgb_target = rgb_target[..., :3] * rgb_target[..., 3:] + bg * (1 - rgb_target[..., 3:])
+        if cur is not None:
+            if self._rays_event is None:
+                self._rays_event = torch.cuda.Event()
+            self._rays_event.record(cur)        # (before the march: only the short ray-generation part is serialised between the streams)
         pos, dirs = self.sampler.sample(img_ids, rays_o, rays_d, is_training=True)
         return {"step": step, "bg": bg, "target": rgb_target, "pos": pos, "dirs": dirs, "state": self.sampler.export_batch_state(),
                 "keep": (img_ids, rays_o, rays_d)}
 
     def train_step(self, i):
-        """Software-pipelined: batch i+1's ray generation + marching only read the dataset and the occupancy bitfield, so they are issued on a
-        side stream while batch i goes through the network / backward / optimiser (the marcher is a dependent-latency kernel that leaves
-        the chip almost idle).  Not possible on steps that refresh the occupancy grid (every update_den_freq-th), which need the new weights."""
+        """Software-pipelined: the ray generation + marching of batches i+1 .. i+depth only read the dataset and the occupancy bitfield, so they are
+        issued on side streams while batch i goes through the network / backward / optimiser.  The marcher is a dependent-latency kernel (its
+        duration is the longest ray's serial chain, ~0.4 ms, while the chip is almost idle), as long as a whole training step: with `pipeline_depth`
+        = 2 two marches overlap each other on two side streams and the step rate is set by the main stream alone.  Batches are never marched across
+        an occupancy-grid refresh (every update_den_freq-th step needs the new weights, and the batches after it the refreshed grid)."""
         cfg = self.cfg
         main = torch.cuda.current_stream() if torch.cuda.is_available() else None
-        b = self._next
-        self._next = None
-        if b is not None and b["step"] == i:
+        b = self._queue.pop(i, None)
+        if b is not None:
             main.wait_event(b["ready"])
             self.sampler.import_batch_state(b["state"])
         else:
-            b = self._make_batch(i)
+            b = self._make_batch(i)                      # on the main stream: first step, refresh steps, pipeline off
+            if self._sides and self.sampler.grid_updated_in_last_sample:
+                self._grid_event.record(main)            # side streams must not read the bitfield before this refresh has finished
+                self._grid_valid = True
         cfg.m_training_step = i
         if self._fast is None:
             from .fastpath import FusedTrainStep
@@ -118,32 +130,45 @@ class Runner:
             loss = self.loss_func(rgb, b["target"])
             self.optimizer.step(loss)
             self.ema_optimizer.ema_step()
-        # ---- batch i+1 on the side stream.  Issued AFTER step i's own launches: every 16th prefetch ends in update_batch_rays' host read-back, and
-        # the main stream should have step i queued while the host waits for it.
-        nxt = i + 1
-        if self.pipeline and main is not None and nxt < self.tot_train_steps and nxt % self.sampler.update_den_freq != 0:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-                self._events = tuple(torch.cuda.Event() for _ in range(4))      # ready[2], done[2]: persistent, re-recorded (no create/destroy per step)
-            self._events[2 + (i & 1)].record(main)           # done(i)
-            if self._done_valid:
-                self._side.wait_event(self._events[2 + ((i - 1) & 1)])          # the buffer set batch i+1 writes was last read by step i-1
-            cur_state = self.sampler.export_batch_state()
-            with torch.cuda.stream(self._side):
-                nb = self._make_batch(nxt)
-                nb["ready"] = self._events[nxt & 1]
-                nb["ready"].record(self._side)
+        if not (self.pipeline and main is not None):
+            return loss
+        # ---- batches i+1 .. i+depth on the side streams.  Issued AFTER step i's own launches: every 16th prefetch ends in update_batch_rays' host
+        # read-back, and the main stream should have step i queued while the host waits for it.
+        n_sets = len(self.sampler._sets)
+        if not self._sides:
+            self._sides = [torch.cuda.Stream() for _ in range(2)]
+            self._ready = [torch.cuda.Event() for _ in range(n_sets)]            # persistent events, re-recorded (no create/destroy per step)
+            self._done = [torch.cuda.Event() for _ in range(n_sets + 1)]
+            self._grid_event, self._grid_valid = torch.cuda.Event(), False
+            if self.sampler.grid_updated_in_last_sample:
+                self._grid_event.record(main); self._grid_valid = True
+        self._done[i % (n_sets + 1)].record(main)        # done(i)
+        self._done_steps.add(i)
+        self._done_steps.discard(i - n_sets - 1)
+        cur_state = None
+        for k in range(i + 1, i + 1 + self.pipeline_depth):
+            if k >= self.tot_train_steps or k % self.sampler.update_den_freq == 0:
+                break                                    # never across a refresh
+            if k in self._queue:
+                continue
+            side = self._sides[k & 1]
+            if (k - n_sets) in self._done_steps:
+                side.wait_event(self._done[(k - n_sets) % (n_sets + 1)])         # the buffer set batch k writes was last read by step k - n_sets
+            if self._grid_valid:
+                side.wait_event(self._grid_event)
+            if cur_state is None:
+                cur_state = self.sampler.export_batch_state()
+            with torch.cuda.stream(side):
+                nb = self._make_batch(k)
+                nb["ready"] = self._ready[k % n_sets]
+                nb["ready"].record(side)
             for t in (nb["bg"], nb["target"]) + tuple(nb["keep"]):
                 if torch.is_tensor(t):
                     t.record_stream(main)
-            self._next = nb
+            self._queue[k] = nb
+        if cur_state is not None:
             self.sampler.import_batch_state(cur_state)
             cfg.m_training_step = i
-            self._done_valid = True
-        else:
-            if self._side is not None and main is not None:
-                self._events[2 + (i & 1)].record(main)
-                self._done_valid = True
         return loss
 
     def train(self):

@@ -31,7 +31,10 @@ class _Composite(torch.autograd.Function):
     def backward(ctx, grad_rgb):
         net_out, rgb = ctx.saved_tensors
         s = ctx.s
-        dout = ops.composite_bwd(net_out, ctx.coords, ctx.nsc, grad_rgb.contiguous(), rgb, s.density_grid_mean, s.NERF_CASCADES, dout=s._dout_buffer(net_out), zero_first=s._n_valid is None)   # rows < n_valid are all written by their rays; rows beyond are never read
+        dout = ops.composite_bwd(net_out, ctx.coords, ctx.nsc, grad_rgb.contiguous(), rgb, s.density_grid_mean, s.NERF_CASCADES, dout=s._dout_buffer(net_out),
+                                 zero_first=s._n_valid is None or not getattr(s.model, "fused", False))
+        # rows < n_valid are all written by their rays.  The fused field network never reads the rows beyond (device-side n_valid); the generic
+        # nn.Linear path back-propagates every row of the fixed-capacity buffer, so there the stale tail must be zero (the reference's buffer is zero-padded)
         return dout, None, None
 
 
@@ -83,10 +86,10 @@ class DensityGridSampler(nn.Module):
             pcg32_advance(self.rng_state, rank << 40)
         self.measured_batch_size = torch.zeros(1, dtype=torch.int32, device=dev)
         cap_r = 1 << 18
-        # two buffer sets: the Runner marches batch i+1 on a side stream while batch i is still being trained on (software pipelining)
+        # three buffer sets: the Runner marches up to two batches ahead on side streams while batch i is still being trained on (software pipelining)
         self._sets = [dict(numsteps=torch.empty((cap_r, 2), dtype=torch.int32, device=dev), numsteps_c=torch.empty((cap_r, 2), dtype=torch.int32, device=dev),
                            counters=torch.zeros(4, dtype=torch.int32, device=dev), coords=torch.zeros((self.target_batch_size, 7), dtype=torch.float32, device=dev),
-                           pos=torch.zeros((self.target_batch_size, 3), dtype=torch.float32, device=dev), scratch=None) for _ in range(2)]
+                           pos=torch.zeros((self.target_batch_size, 3), dtype=torch.float32, device=dev), scratch=None) for _ in range(3)]
         self._set_idx = 0
         self._numsteps_buf, self._numsteps_c_buf = self._sets[0]["numsteps"], self._sets[0]["numsteps_c"]
         self._counters = self._sets[0]["counters"]
@@ -95,6 +98,8 @@ class DensityGridSampler(nn.Module):
         self._dout = None
         self._coords = None
         self._n_valid = None
+        self._order_event = None
+        self.grid_updated_in_last_sample = False
         self.sync_free_inference = False        # Runner.render_img switches it on (large ray chunks, no .item() per chunk)
 
     # ------------------------------------------------------------------ hot path
@@ -110,8 +115,10 @@ class DensityGridSampler(nn.Module):
         return self._dout
 
     def sample(self, img_ids, rays_o, rays_d, rgb_target=None, is_training=False):
+        self.grid_updated_in_last_sample = False
         if is_training and self.cfg.m_training_step % self.update_den_freq == 0:
             self.update_density_grid()
+            self.grid_updated_in_last_sample = True
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
         n = rays_o.shape[0]
         if not is_training:
@@ -143,7 +150,7 @@ class DensityGridSampler(nn.Module):
             self._rays_numsteps = numsteps
             self._n_valid = None
             return self._coords[:, :3], self._coords[:, 4:]
-        self._set_idx ^= 1
+        self._set_idx = (self._set_idx + 1) % len(self._sets)
         bs = self._sets[self._set_idx]
         self._coords_train, self._counters = bs["coords"], bs["counters"]
         numsteps, numsteps_c = bs["numsteps"][:n], bs["numsteps_c"][:n]
@@ -155,9 +162,18 @@ class DensityGridSampler(nn.Module):
                                  self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
                                  coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=bs["scratch"], pos_out=bs["pos"])
         self._pos_train = bs["pos"]                                    # compact [n,3] copy of coords[:, :3], written by the marcher's write pass
+        # two side streams may be marching at once: their read-modify-writes of the running sample count are ordered by an event chain
+        # (the wait sits AFTER this batch's march kernels in stream order, so the marches themselves still overlap)
+        on_gpu = self.measured_batch_size.is_cuda
+        if on_gpu and self._order_event is not None:
+            torch.cuda.current_stream().wait_event(self._order_event)
         self.measured_batch_size += self._counters[2:3]                # density_grid_sampler.py:155
         if self.cfg.m_training_step % self.update_den_freq == (self.update_den_freq - 1):
             self.update_batch_rays()
+        if on_gpu:
+            if self._order_event is None:
+                self._order_event = torch.cuda.Event()
+            self._order_event.record()
         self._coords = self._coords_train
         self._rays_numsteps, self._rays_numsteps_compacted = numsteps, numsteps_c
         self._n_valid = self._counters[3:4]

@@ -20,8 +20,8 @@ def test_smoke_entry():
     g.smoke()
 
 
-@pytest.mark.parametrize("fp16,aabb_scale,const_dt,min_psnr", [(True, 1, True, 30.0), (False, 1, True, 20.0), (True, 4, False, 17.0)])
-def test_training_converges(fp16, aabb_scale, const_dt, min_psnr, tmp_path):
+@pytest.mark.parametrize("fp16,aabb_scale,const_dt,min_psnr,max_loss_ratio", [(True, 1, True, 30.0, 0.5), (False, 1, True, 28.0, 0.5), (True, 4, False, 17.0, 0.7)])
+def test_training_converges(fp16, aabb_scale, const_dt, min_psnr, max_loss_ratio, tmp_path):
     # (fused fp16-MFMA path | fp32 path the reference's ngp_base.py takes | fox-style aabb 4 + cone stepping, which carves 8 tiny views slowly in any precision)
     r = _runner(fp16=fp16, aabb_scale=aabb_scale, const_dt=const_dt, log_dir=str(tmp_path))
     from jnerf_amd.utils.registry import build_from_cfg, DATASETS
@@ -30,7 +30,7 @@ def test_training_converges(fp16, aabb_scale, const_dt, min_psnr, tmp_path):
         l = r.train_step(i)
         if i % 50 == 0:
             losses.append(float(l.mean().item()))
-    assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
+    assert np.isfinite(losses).all() and losses[-1] < max_loss_ratio * losses[0], losses
     r.dataset["test"] = build_from_cfg(r.cfg.dataset.test, DATASETS)
     img, _, tar = r.render_img("test", 0)
     psnr = -10 * np.log10(np.mean((img - tar) ** 2))

@@ -8,8 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jnerf_amd.presets import ngp_cfg
 from jnerf_amd.runner import Runner
 
-for tb in (1 << 12, 1 << 18):
-    ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0", target_batch_size=tb, n_rays_per_batch=64 if tb < 1 << 18 else 4096)
+for tb in (1 << 16, 1 << 17, 1 << 18):
+    ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0", target_batch_size=tb, n_rays_per_batch=4096 * tb >> 18)
     r = Runner()
     step = 0
     for _ in range(200):
