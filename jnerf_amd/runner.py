@@ -70,6 +70,8 @@ class Runner:
         for st in self._sides:
             st.synchronize()
         self._queue.clear()
+        if hasattr(self.sampler, "finish_batch_rays_update"):
+            self.sampler.finish_batch_rays_update()
 
     def __del__(self):
         try:
@@ -83,6 +85,8 @@ class Runner:
         current stream"""
         self.cfg.m_training_step = step
         ds = self.dataset["train"]
+        if hasattr(self.sampler, "finish_batch_rays_update"):
+            self.sampler.finish_batch_rays_update()       # the adaptive ray count decided after the previous 16-batch window (read back lazily)
         cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
         if cur is not None and self._rays_event is not None:
             cur.wait_event(self._rays_event)    # batches are generated on alternating streams: the dataset's permutation / cursor state is handed on in order

@@ -99,6 +99,7 @@ class DensityGridSampler(nn.Module):
         self._coords = None
         self._n_valid = None
         self._order_event = None
+        self._pending_rays_update, self._measured_host = None, None
         self.grid_updated_in_last_sample = False
         self.sync_free_inference = False        # Runner.render_img switches it on (large ray chunks, no .item() per chunk)
 
@@ -236,17 +237,41 @@ class DensityGridSampler(nn.Module):
             self.update_density_grid_nerf(alpha, G3 * n_cascades // 4, G3 * n_cascades // 4)
 
     def update_batch_rays(self):
+        """density_grid_sampler.py:266-271, split in two: the running sample count is copied to pinned host memory asynchronously here (in stream order
+        after the 16th batch's march) and turned into the new ray count by finish_batch_rays_update() when the NEXT batch is about to be generated -
+        the only consumer.  A blocking read-back at this point would stall the host two batches ahead of the training stream and drain the pipeline."""
         measured = self.measured_batch_size
         if self.cfg.world_size and self.cfg.world_size > 1:
             import torch.distributed as dist
             m = measured.float()
             dist.all_reduce(m)                                          # every rank must pick the same ray count
-            measured_val = m.item() / self.cfg.world_size
+            src, scale = m, 1.0 / self.cfg.world_size
         else:
-            measured_val = measured.item()
+            src, scale = measured, 1.0
+        if measured.is_cuda:
+            if self._measured_host is None:
+                self._measured_host = {}
+            host = self._measured_host.get(src.dtype)
+            if host is None:
+                host = self._measured_host[src.dtype] = torch.empty(1, dtype=src.dtype, pin_memory=True)
+            host.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending_rays_update = (host, ev, scale)
+        else:
+            self._pending_rays_update = (src.clone(), None, scale)
+        self.measured_batch_size.zero_()
+
+    def finish_batch_rays_update(self):
+        if self._pending_rays_update is None:
+            return
+        host, ev, scale = self._pending_rays_update
+        self._pending_rays_update = None
+        if ev is not None:
+            ev.synchronize()
+        measured_val = float(host.item()) * scale
         measured_batch_size = max(measured_val / 16, 1)                 # density_grid_sampler.py:266-271
         rays_per_batch = int(self.n_rays_per_batch * self.target_batch_size / measured_batch_size)
         self.n_rays_per_batch = int(min((int(rays_per_batch) + 127) // 128 * 128, self.target_batch_size))
-        self.measured_batch_size.zero_()
         self.dataset.batch_size = self.n_rays_per_batch
         self.n_ray_count_updates = getattr(self, "n_ray_count_updates", 0) + 1

@@ -38,6 +38,7 @@ def test_training_converges(fp16, aabb_scale, const_dt, min_psnr, max_loss_ratio
     psnr_tr = -10 * np.log10(np.mean((img_tr - tar_tr) ** 2))
     print(f"fp16={fp16} aabb={aabb_scale} const_dt={const_dt}: loss {losses[0]:.4f} -> {losses[-1]:.4f}, PSNR train view {psnr_tr:.1f} dB, held-out view {psnr:.1f} dB (8 images of 96x96, 400 steps)")
     assert psnr_tr > min_psnr and psnr > 14.0, (psnr_tr, psnr)
+    r.drain()
     assert r.sampler.n_ray_count_updates == 400 // 16 and r.sampler.n_rays_per_batch % 128 == 0          # update_batch_rays adapted the ray count every 16 steps
     # checkpoint round trip (runner.py:123-151 keys)
     p = str(tmp_path / "params.pkl")

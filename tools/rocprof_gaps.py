@@ -1,0 +1,28 @@
+"""Largest idle gaps of the busiest stream in a rocprofv3 kernel trace (rocpd database), and the busy fraction over the last `n` training steps."""
+import sqlite3, sys
+db = sys.argv[1]; nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+c = sqlite3.connect(db)
+rows = list(c.execute("select d.start, d.end, d.stream_id, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id order by d.start"))
+marks = [i for i, r in enumerate(rows) if "k_field_fwdI6__halfLi1ELb0" in r[3]]
+a, b = marks[-nsteps - 1], marks[-1]
+seg = rows[a:b]
+main = seg[0][2]
+t0, t1 = seg[0][0], rows[b][0]
+ms = [r for r in seg if r[2] == main]
+busy = sum(r[1] - r[0] for r in ms)
+print(f"{nsteps} steps: {(t1 - t0) / nsteps / 1e3:.1f} us/step, main stream busy {busy / nsteps / 1e3:.1f} us/step ({100 * busy / (t1 - t0):.0f} %)")
+gaps = []
+for p, q in zip(ms, ms[1:]):
+    g = q[0] - p[1]
+    if g > 15000:
+        gaps.append((g, p, q))
+tot = sum(g for g, _, _ in gaps)
+print(f"gaps > 15 us: {len(gaps)} totalling {tot / nsteps / 1e3:.1f} us/step")
+for g, p, q in sorted(gaps, key=lambda x: -x[0])[:14]:
+    print(f"  {g / 1e3:8.1f} us  after {p[3][:48]:48s} before {q[3][:48]}")
+# which kernels fill the busy time, per step
+agg = {}
+for r in ms:
+    agg[r[3][:60]] = agg.get(r[3][:60], 0) + (r[1] - r[0])
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:16]:
+    print(f"  {v / nsteps / 1e3:7.1f} us/step  {k}")
