@@ -27,6 +27,21 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == syms
 
 
+def test_train_step_argument_block_layout(tmp_path):
+    """the ctypes mirror of `struct NgpTrainStep` must have the C compiler's size and field offsets (the header is plain C: gcc compiles it)"""
+    fields = [name for name, _ in _lib.NgpTrainStep._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "ngp_hip.h"', 'int main(void) {', '  printf("%zu\\n", sizeof(NgpTrainStep));']
+    prog += [f'  printf("%zu\\n", offsetof(NgpTrainStep, {f}));' for f in fields]
+    prog += ['  return 0;', '}']
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(prog))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
+    import ctypes as C
+    assert out[0] == C.sizeof(_lib.NgpTrainStep)
+    assert out[1:] == [getattr(_lib.NgpTrainStep, f).offset for f in fields]
+
+
 def test_no_torch_types_or_cuda_compat_in_the_abi():
     src = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
     assert "torch" not in src.lower().replace("pytorch-rocm allocator", "") and "at::" not in src and "cuda" not in src.lower()
