@@ -1,0 +1,48 @@
+"""PSNR-vs-wall-time of the FULL reference schedule (40 000 iterations, ExpDecay at 20 k / 30 k) on the bench scene: BASELINE.json's second headline
+("PSNR@5min") restated for a scene that exists on the GPU box.  Writes a markdown table.  usage: train_curve.py out.md [steps]"""
+import os
+import sys
+import time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jnerf_amd.presets import ngp_cfg
+from jnerf_amd.runner import Runner
+from jnerf_amd.utils.registry import build_from_cfg, DATASETS
+
+out = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
+torch.manual_seed(1234)
+ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0", tot_train_steps=steps)
+r = Runner()
+r.dataset["test"] = build_from_cfg(r.cfg.dataset.test, DATASETS)
+marks = [m for m in (100, 250, 500, 1000, 2000, 5000, 10000, 20000, 30000, 40000) if m <= steps]
+
+
+def psnr_now():
+    vals = []
+    for v in range(r.dataset["test"].n_images):
+        img, _, tar = r.render_img("test", v)
+        vals.append(-10 * np.log10(np.mean((img - tar) ** 2)))
+    return float(np.mean(vals))
+
+
+rows, train_s = [], 0.0
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    r.train_step(i)
+    if i + 1 in marks:
+        r.drain(); torch.cuda.synchronize()
+        train_s += time.perf_counter() - t0
+        rows.append((i + 1, train_s, psnr_now(), r.optimizer._nested_optimizer.lr, r.sampler.n_rays_per_batch))
+        print(rows[-1], flush=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+with open(out, "w") as f:
+    f.write("# Full training schedule on one MI355X (bench scene: procedural 50 x 400 x 400 RGBA, fox hyper-parameters, fp16)\n\n")
+    f.write(f"`python tools/train_curve.py` - {steps} iterations of 2^18 samples, ExpDecay x0.33 at 20 k and 30 k (ngp_base.py:31-37); PSNR = mean over the held-out test views;\n")
+    f.write("training time excludes the evaluation renders.\n\n| iteration | training seconds | it/s so far | test PSNR (dB) | lr | rays / batch |\n|---|---|---|---|---|---|\n")
+    for it, s, p, lr, nr in rows:
+        f.write(f"| {it} | {s:.2f} | {it / s:.0f} | {p:.2f} | {lr:.4g} | {nr} |\n")
+print(open(out).read())
