@@ -38,21 +38,29 @@ def cpu_baseline(n_samples=1 << 18, n_rays=4096, n_march_rays=39424):
     m_rays = int(n_march_rays * frac)
     _, ro, rd, _ = synth.rays_from_cameras(xf, focal, meta, 400, 400, m_rays, seed=1)
     bits = synth.shell_bitfield()
+    stages = {}
+
+    def timed(name, fn):
+        ts = time.perf_counter()
+        r = fn()
+        stages[name] = round((time.perf_counter() - ts) * 1e3, 1)
+        return r
+
     t0 = time.perf_counter()
-    O.march_rays(ro, rd, bits, (-1.5, 2.5), O.PCG32(1337), 4096 * 1024, const_dt=False)       # the batch's ray count through the two-pass marcher
-    feat = O.hash_encode_fwd(x, grid, table)
-    sh = O.sh_encode(d, np.float32)
-    out = O.field_fwd(feat.astype(np.float32), sh, wd, wc)
-    rgb = O.composite_fwd(out, coords, ns, ns, bg)
+    timed("march", lambda: O.march_rays(ro, rd, bits, (-1.5, 2.5), O.PCG32(1337), 4096 * 1024, const_dt=False))       # the batch's ray count through the two-pass marcher
+    feat = timed("hash_fwd", lambda: O.hash_encode_fwd(x, grid, table))
+    sh = timed("sh", lambda: O.sh_encode(d, np.float32))
+    out = timed("field_fwd", lambda: O.field_fwd(feat.astype(np.float32), sh, wd, wc))
+    rgb = timed("composite_fwd", lambda: O.composite_fwd(out, coords, ns, ns, bg))
     _, G = O.huber(rgb, bg)
-    dout = O.composite_bwd(out, coords, ns, G, rgb, 0.001)
-    dfeat, dwd, dwc = O.field_bwd(feat.astype(np.float32), sh, wd, wc, dout)
-    g = O.hash_encode_bwd(x, dfeat.astype(np.float16), table, n_params)
+    dout = timed("composite_bwd", lambda: O.composite_bwd(out, coords, ns, G, rgb, 0.001))
+    dfeat, dwd, dwc = timed("field_bwd", lambda: O.field_bwd(feat.astype(np.float32), sh, wd, wc, dout))
+    g = timed("hash_bwd", lambda: O.hash_encode_bwd(x, dfeat.astype(np.float16), table, n_params))
     npar = int(n_params * frac) // 4 * 4
     p = np.zeros(npar, np.float32); m = np.zeros_like(p); v = np.zeros_like(p); e = np.zeros_like(p)
-    O.adam_ema_step(p, g[:npar].astype(np.float32), m, v, e, 0.1, 1)
+    timed("adam_ema", lambda: O.adam_ema_step(p, g[:npar].astype(np.float32), m, v, e, 0.1, 1))
     t = time.perf_counter() - t0
-    return {"value": round(frac / t, 4), "unit": "iters/s", "cores": 1, "kind": "port",
+    return {"value": round(frac / t, 4), "unit": "iters/s", "cores": 1, "kind": "port", "stage_ms": stages,
             "sample": f"{'one' if frac == 1 else f'1/{int(1 / frac)} of one'} training iteration: {m_rays} rays marched, {n_samples} samples through hash fwd/bwd, SH, both MLPs fwd/bwd, "
                       f"compositing fwd/bwd, Huber; Adam+EMA on {npar} of {n_params} parameters (occupancy-grid refresh not included); {t:.1f} s on 1 core"}
 
