@@ -190,7 +190,8 @@ typedef struct NgpTrainStep {
 	int32_t timed_stage; int32_t pad3;
 } NgpTrainStep;
 enum { NGP_STAGE_PACK = 0, NGP_STAGE_HASH_FWD, NGP_STAGE_FIELD_FWD, NGP_STAGE_COMPOSITE_FWD, NGP_STAGE_COMPOSITE_BWD, NGP_STAGE_FIELD_BWD, NGP_STAGE_REDUCE_SLABS,
-       NGP_STAGE_HASH_BWD, NGP_STAGE_ADAM /* the largest parameter tensor's sweep */ };
+       NGP_STAGE_HASH_BWD, NGP_STAGE_ADAM /* the largest parameter tensor's sweep */,
+       NGP_STAGE_BOUNDARY /* not a stage: from the end of one call's last launch to the start of the next call's first launch (main-stream idle + waits) */ };
 int ngp_train_step(void *stream, const NgpTrainStep *args_host);
 /* waits for the bracketed launches of earlier ngp_train_step calls (this thread's device) and writes up to `max` durations in milliseconds, oldest first;
  * returns how many were written (<0 on error) and forgets them */

@@ -12,7 +12,7 @@ _lib = None
 
 F32, F16 = 0, 1
 LAYOUT_AOS, LAYOUT_SOA = 0, 1
-STAGES = {"field_pack": 0, "hash_fwd": 1, "field_fwd": 2, "composite_fwd": 3, "composite_bwd": 4, "field_bwd": 5, "reduce_slabs": 6, "hash_bwd": 7, "adam_ema": 8}   # NGP_STAGE_*
+STAGES = {"field_pack": 0, "hash_fwd": 1, "field_fwd": 2, "composite_fwd": 3, "composite_bwd": 4, "field_bwd": 5, "reduce_slabs": 6, "hash_bwd": 7, "adam_ema": 8, "boundary": 9}   # NGP_STAGE_*
 
 _vp, _u32, _u64, _i32, _f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
 

@@ -9,6 +9,7 @@
 namespace {
 std::mutex g_mu;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pending, g_free;
+std::pair<hipEvent_t, hipEvent_t> g_boundary{nullptr, nullptr};   // open bracket: first = end of the previous call
 struct Bracket {                                       // HIP event pair around one stage, on the stream the stage is launched on
 	hipStream_t s; bool on; std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
 	Bracket(hipStream_t s_, bool on_) : s(s_), on(on_) {
@@ -53,6 +54,10 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	const float *dirs = a->coords + 4;                       // NerfCoordinate = {pos[3], dt, dir[3]}: directions at stride 7
 	int rc;
 	hipStream_t hs = (hipStream_t)stream;
+	if (a->timed_stage == NGP_STAGE_BOUNDARY) {              // close the bracket opened at the end of the previous call
+		std::lock_guard<std::mutex> lk(g_mu);
+		if (g_boundary.first) { hipEventRecord(g_boundary.second, hs); g_pending.push_back(g_boundary); g_boundary = {nullptr, nullptr}; }
+	}
 #define STAGE(id, call) do { Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
 	STAGE(NGP_STAGE_PACK, ngp_field_pack_weights(stream, a->wd_f16, a->wc_f16, a->packed_weights));
 	STAGE(NGP_STAGE_HASH_FWD, ngp_hash_encode_fwd(stream, a->n, a->pos, 3, a->table_f16, a->level_table_host, a->feat, NGP_F16, NGP_LAYOUT_SOA, a->n_valid));
@@ -74,5 +79,11 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		}
 	}
 #undef STAGE
+	if (a->timed_stage == NGP_STAGE_BOUNDARY) {
+		std::lock_guard<std::mutex> lk(g_mu);
+		if (!g_free.empty()) { g_boundary = g_free.back(); g_free.pop_back(); }
+		else if (hipEventCreate(&g_boundary.first) != hipSuccess || hipEventCreate(&g_boundary.second) != hipSuccess) g_boundary = {nullptr, nullptr};
+		if (g_boundary.first) hipEventRecord(g_boundary.first, hs);
+	}
 	return 0;
 }
