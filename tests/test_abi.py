@@ -42,6 +42,27 @@ def test_train_step_argument_block_layout(tmp_path):
     assert out[1:] == [getattr(_lib.NgpTrainStep, f).offset for f in fields]
 
 
+def test_argument_errors_are_reported_before_any_launch():
+    """error behaviour of the boundary: bad arguments give a negative NGP_E_* code and a message in ngp_last_error(), without touching the device
+    (so this runs on a machine without a GPU)"""
+    import ctypes as C
+    lib = _lib.lib()
+    tbl = np.zeros(64, np.uint32)
+    tp = tbl.ctypes.data_as(C.c_void_p)
+    one = C.c_void_p(16)                      # any non-null, 16-byte aligned address: the calls below must fail before dereferencing it
+    assert lib.ngp_hash_encode_fwd(None, 4, one, 3, one, tp, one, 7, 0, None) == -2 and b"dtype" in lib.ngp_last_error()          # NGP_E_DTYPE
+    assert lib.ngp_hash_encode_fwd(None, 4, None, 3, one, tp, one, 0, 0, None) == -1 and b"null" in lib.ngp_last_error()          # NGP_E_ARG
+    assert lib.ngp_hash_encode_fwd(None, 4, one, 2, one, tp, one, 0, 0, None) == -1 and b"stride" in lib.ngp_last_error()
+    assert lib.ngp_hash_encode_fwd(None, 0, None, 3, None, None, None, 0, 0, None) == 0                                            # empty batch: nothing to do
+    assert lib.ngp_field_fwd(None, 4, C.c_void_p(8), 1, one, 3, one, one, one, 1, None) == -3 and b"aligned" in lib.ngp_last_error()   # NGP_E_ALIGN
+    assert lib.ngp_field_fwd(None, 4, one, 5, one, 3, one, one, one, 1, None) == -1 and b"layout" in lib.ngp_last_error()
+    assert lib.ngp_march_rays_compacted(None, (1 << 18) + 1, one, one, one, 0.0, 1.0, 0.2, 0.0, 1, 5, one, 16, 16, one, one, one, one, one) == -4   # NGP_E_CAPACITY
+    assert lib.ngp_adam_ema_step(None, 6, one, one, 0, one, one, None, None, 0.1, 0.9, 0.99, 1e-15, 1, 0.95, 1) == -3 and b"multiple of 4" in lib.ngp_last_error()
+    assert lib.ngp_adam_ema_step(None, 8, one, one, 0, one, one, None, None, 0.1, 0.9, 0.99, 1e-15, 0, 0.95, 1) == -1            # step is 1-based
+    assert lib.ngp_train_step(None, None) == -1
+    assert lib.ngp_grad_to_half(None, 12, one, one, 1) == -3
+
+
 def test_no_torch_types_or_cuda_compat_in_the_abi():
     src = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
     assert "torch" not in src.lower().replace("pytorch-rocm allocator", "") and "at::" not in src and "cuda" not in src.lower()
