@@ -17,37 +17,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(n_samples=1 << 18, n_rays=4096, n_march_rays=39424):
-    """the oracle (plain-C port of the reference's kernels, 1 thread) on a bounded slice of one training iteration: every hot-path stage on
-    n_samples of the 2^18 samples and the parameter update on the same fraction of the 13 M parameters; scaled to iterations/s"""
+def _cpu_inputs(n_samples, n_rays, m_rays, seed):
+    """synthetic inputs of one (slice of a) training iteration for the CPU port"""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import oracle as O
     import synth
-    frac = n_samples / float(1 << 18)
-    table, offsets, n_params = O.level_table(4)
-    grid = synth.table(n_params, np.float16, amp=2e-4)
-    x = synth.uniform_positions(n_samples)
+    x = synth.uniform_positions(n_samples, seed=seed) if "seed" in synth.uniform_positions.__code__.co_varnames else synth.uniform_positions(n_samples)
     d = synth.unit_dirs01(n_samples)
-    wd, wc = synth.mlp_weights()
     coords = np.zeros((n_samples, 7), np.float32); coords[:, :3] = x; coords[:, 4:] = d
     per = n_samples // n_rays
     ns = np.stack([np.full(n_rays, per, np.uint32), (np.arange(n_rays) * per).astype(np.uint32)], 1)
-    bg = np.random.default_rng(0).random((n_rays, 3), dtype=np.float32)
+    bg = np.random.default_rng(seed).random((n_rays, 3), dtype=np.float32)
     xf, focal, meta = synth.camera_ring(8, radius=1.3)
-    m_rays = int(n_march_rays * frac)
-    _, ro, rd, _ = synth.rays_from_cameras(xf, focal, meta, 400, 400, m_rays, seed=1)
-    bits = synth.shell_bitfield()
-    stages = {}
+    _, ro, rd, _ = synth.rays_from_cameras(xf, focal, meta, 400, 400, m_rays, seed=1 + seed)
+    return dict(x=x, d=d, coords=coords, ns=ns, bg=bg, ro=ro, rd=rd)
+
+
+def _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar, stages=None):
+    """every hot-path stage of one iteration through the plain-C oracle (ctypes releases the GIL inside each call)"""
+    import numpy as np
 
     def timed(name, fn):
         ts = time.perf_counter()
         r = fn()
-        stages[name] = round((time.perf_counter() - ts) * 1e3, 1)
+        if stages is not None:
+            stages[name] = round((time.perf_counter() - ts) * 1e3, 1)
         return r
 
-    t0 = time.perf_counter()
-    timed("march", lambda: O.march_rays(ro, rd, bits, (-1.5, 2.5), O.PCG32(1337), 4096 * 1024, const_dt=False))       # the batch's ray count through the two-pass marcher
+    x, d, coords, ns, bg = inp["x"], inp["d"], inp["coords"], inp["ns"], inp["bg"]
+    timed("march", lambda: O.march_rays(inp["ro"], inp["rd"], bits, (-1.5, 2.5), O.PCG32(1337), 4096 * 1024, const_dt=False))   # the batch's ray count through the two-pass marcher
     feat = timed("hash_fwd", lambda: O.hash_encode_fwd(x, grid, table))
     sh = timed("sh", lambda: O.sh_encode(d, np.float32))
     out = timed("field_fwd", lambda: O.field_fwd(feat.astype(np.float32), sh, wd, wc))
@@ -56,13 +53,43 @@ def cpu_baseline(n_samples=1 << 18, n_rays=4096, n_march_rays=39424):
     dout = timed("composite_bwd", lambda: O.composite_bwd(out, coords, ns, G, rgb, 0.001))
     dfeat, dwd, dwc = timed("field_bwd", lambda: O.field_bwd(feat.astype(np.float32), sh, wd, wc, dout))
     g = timed("hash_bwd", lambda: O.hash_encode_bwd(x, dfeat.astype(np.float16), table, n_params))
-    npar = int(n_params * frac) // 4 * 4
     p = np.zeros(npar, np.float32); m = np.zeros_like(p); v = np.zeros_like(p); e = np.zeros_like(p)
     timed("adam_ema", lambda: O.adam_ema_step(p, g[:npar].astype(np.float32), m, v, e, 0.1, 1))
-    t = time.perf_counter() - t0
-    return {"value": round(frac / t, 4), "unit": "iters/s", "cores": 1, "kind": "port", "stage_ms": stages,
+
+
+def cpu_baseline(n_samples=1 << 18, n_rays=4096, n_march_rays=39424):
+    """The oracle (plain-C port of the reference's kernels) on ONE training iteration of the bench workload, on this host's cores: the iteration is split
+    into `cores` independent ray/sample slices that run concurrently (one thread each; the hash-table gradient and the parameter sweep are sliced the same
+    way), plus the same iteration on a single core for the per-stage times.  `value` is iterations/s on `cores` cores."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    import synth
+    frac = n_samples / float(1 << 18)
+    table, offsets, n_params = O.level_table(4)
+    grid = synth.table(n_params, np.float16, amp=2e-4)
+    wd, wc = synth.mlp_weights()
+    bits = synth.shell_bitfield()
+    m_rays = int(n_march_rays * frac)
+    npar = int(n_params * frac) // 4 * 4
+    cores = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    # (a) `cores` slices in parallel
+    parts = [_cpu_inputs(n_samples // cores, max(n_rays // cores, 1), max(m_rays // cores, 1), seed=k) for k in range(cores)]
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(lambda inp: _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar // cores // 4 * 4), parts))
+        t_par = time.perf_counter() - t0
+    # (b) the whole iteration on one core, stage by stage
+    stages = {}
+    whole = _cpu_inputs(n_samples, n_rays, m_rays, seed=0)
+    t0 = time.perf_counter()
+    _cpu_iteration(O, whole, table, n_params, grid, wd, wc, bits, npar, stages)
+    t_one = time.perf_counter() - t0
+    return {"value": round(frac / t_par, 4), "unit": "iters/s", "cores": cores, "kind": "port", "single_core_value": round(frac / t_one, 4), "single_core_stage_ms": stages,
             "sample": f"{'one' if frac == 1 else f'1/{int(1 / frac)} of one'} training iteration: {m_rays} rays marched, {n_samples} samples through hash fwd/bwd, SH, both MLPs fwd/bwd, "
-                      f"compositing fwd/bwd, Huber; Adam+EMA on {npar} of {n_params} parameters (occupancy-grid refresh not included); {t:.1f} s on 1 core"}
+                      f"compositing fwd/bwd, Huber; Adam+EMA on {npar} of {n_params} parameters (occupancy-grid refresh not included); "
+                      f"{t_par:.1f} s on {cores} cores ({cores} concurrent slices), {t_one:.1f} s on 1 core"}
 
 
 def main():
