@@ -73,7 +73,7 @@ def cpu_baseline(n_samples=1 << 18, n_rays=4096, n_march_rays=39424):
     bits = synth.shell_bitfield()
     m_rays = int(n_march_rays * frac)
     npar = int(n_params * frac) // 4 * 4
-    cores = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    cores = max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     # (a) `cores` slices in parallel
     parts = [_cpu_inputs(n_samples // cores, max(n_rays // cores, 1), max(m_rays // cores, 1), seed=k) for k in range(cores)]
     with ThreadPoolExecutor(cores) as ex:
