@@ -192,20 +192,16 @@ __global__ __launch_bounds__(256) void k_field_fwd(uint32_t n, const _Float16 *_
 }
 
 // ---------------------------------------------------------------------------------------------------------------- backward
-#define BT 64                 // samples per workgroup tile
-#define RS (BT + 8)           // LDS row stride in halves (144 B: 16-B aligned rows, breaks the 128-B bank period)
-// LDS rows: inputs  F 0..31 | H 32..95 | IN2 96..127 | G0 128..191 | G1 192..255 ; grads dH 256..319 | dD 320..335 | dG0 336..399 | dG1 400..463 | dO 464..479
-#define R_F 0
-#define R_H 32
-#define R_IN2 96
-#define R_G0 128
-#define R_G1 192
-#define R_DH 256
-#define R_DD 320
-#define R_DG0 336
-#define R_DG1 400
-#define R_DO 464
-#define N_ROWS 480
+#define BT 128                // samples per workgroup tile: 8 waves x 16 samples
+#define RS (BT + 8)           // LDS row stride in halves (272 B: 16-B aligned rows, breaks the 128-B bank period)
+// The weight-gradient contraction is staged in three phases that reuse one 192-row region (each phase: 8 waves write their 16 sample columns, barrier,
+// every wave accumulates its share of the phase's 16x16 tiles over the 128 samples, barrier).  A single 480-row region for everything would cost 130 KB and
+// leave room for only four waves per CU; with 52 KB the workgroup has eight waves = two per SIMD, which is what hides the latency of the 42 dependent
+// MFMA steps of the forward-recompute + dgrad chain (97 % of this kernel's time with one wave per SIMD).
+//   phase A: dG1 0..63 | G0 64..127                      -> V1  (16 tiles, two per wave)
+//   phase B: dH 0..63 | F 64..95 | dG0 96..159 | IN2 160..191   -> W0, V0 (8 + 8 tiles, one of each per wave)
+//   phase C: dD 0..15 | H 16..79 | dO 80..95 | G1 96..159       -> W1 (waves 0-3), V2 (waves 4-7)
+#define N_ROWS 192
 
 __device__ __forceinline__ void st_rows64(_Float16 *stage, int row0, int col, int g, half8 lo, half8 hi) {   // two k64 fragments = 64 neurons
 #pragma unroll
@@ -218,7 +214,7 @@ template <> __device__ __forceinline__ void load_dout<float>(const float *p, flo
 template <> __device__ __forceinline__ void load_dout<__half>(const __half *p, float o[4]) { half4 v = *reinterpret_cast<const half4 *>(p); o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
 
 template <typename T, int LAYOUT>
-__global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+__global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                       const _Float16 *__restrict__ packed, const T *__restrict__ dout,
                                                       _Float16 *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid) {
 	extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
@@ -230,8 +226,9 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16
 	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
 	const uint32_t n_bt = (lim + BT - 1) / BT;
 	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-	// this wave's 10 weight-gradient tiles: V1 (to=w, ti=0..3) | W0 (to=w, ti=0,1) | V0 (to=w, ti=0,1) | W1 (ti=w) | V2 (ti=w)
-	floatx4 aV1[4] = {z, z, z, z}, aW0[2] = {z, z}, aV0[2] = {z, z}, aW1 = z, aV2 = z;
+	// this wave's 5 weight-gradient tiles: V1 (to, ti0), (to, ti0+1) | W0 (to, tj) | V0 (to, tj) | W1 (ti=w) for waves 0-3, V2 (ti=w-4) for waves 4-7
+	const int to = w >> 1, ti0 = 2 * (w & 1), tj = w & 1;
+	floatx4 aV1[2] = {z, z}, aW0 = z, aV0 = z, aX = z;
 	__syncthreads();
 	// the next tile's inputs are requested while the current tile is in its MFMA / LDS phases (one workgroup per CU: nothing else hides the HBM round trip)
 	struct Inputs { half8 f; float d3[3]; float go[4]; };
@@ -291,33 +288,44 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16
 					else *reinterpret_cast<half2v *>(dfeat + (size_t)i * 32 + 2 * level) = v;
 				}
 		}
-		// ---- stage activations and gradients as [neuron][sample] for the weight-gradient contraction over samples
-		const int col = 16 * w + s;
-#pragma unroll
-		for (int j = 0; j < 8; ++j) {
-			stage[(R_F + k32(g, j)) * RS + col] = st.feat[j];
-			stage[(R_IN2 + k64(0, g, j)) * RS + col] = st.in2[j];
-			if (j < 4) { stage[(R_DD + 4 * g + j) * RS + col] = dDf[j]; stage[(R_DO + 4 * g + j) * RS + col] = dO[j]; }
-		}
-		st_rows64(stage, R_H, col, g, st.hfrag[0], st.hfrag[1]);
-		st_rows64(stage, R_G0, col, g, st.g0[0], st.g0[1]);
-		st_rows64(stage, R_G1, col, g, st.g1[0], st.g1[1]);
-		st_rows64(stage, R_DH, col, g, dHlo, dHhi);
-		st_rows64(stage, R_DG0, col, g, dG0lo, dG0hi);
-		st_rows64(stage, R_DG1, col, g, dG1lo, dG1hi);
+		// ---- weight gradients: dW[o][i] += sum_s dY[s][o] X[s][i]   (A = dY^T rows o, B = X columns i, k = sample), three staging phases
+		const int col = 16 * w + s, o = lane & 15;
+		// phase A
+		st_rows64(stage, 0, col, g, dG1lo, dG1hi);
+		st_rows64(stage, 64, col, g, st.g0[0], st.g0[1]);
 		__syncthreads();
-		// ---- weight gradients: dW[o][i] += sum_s dY[s][o] X[s][i]   (A = dY^T rows o, B = X columns i, k = sample)
 #pragma unroll
 		for (int kb = 0; kb < BT / 32; ++kb) {
-			const int cs = 32 * kb + 8 * g, o = lane & 15;
-			const half8 a_dg1 = ld_rows(stage, R_DG1 + 16 * w + o, cs), a_dh = ld_rows(stage, R_DH + 16 * w + o, cs), a_dg0 = ld_rows(stage, R_DG0 + 16 * w + o, cs);
-			const half8 a_dd = ld_rows(stage, R_DD + o, cs), a_do = ld_rows(stage, R_DO + o, cs);
+			const int cs = 32 * kb + 8 * g;
+			const half8 a_dg1 = ld_rows(stage, 16 * to + o, cs);
+			aV1[0] = MFMA(a_dg1, ld_rows(stage, 64 + 16 * ti0 + o, cs), aV1[0]);
+			aV1[1] = MFMA(a_dg1, ld_rows(stage, 64 + 16 * (ti0 + 1) + o, cs), aV1[1]);
+		}
+		__syncthreads();
+		// phase B
+		st_rows64(stage, 0, col, g, dHlo, dHhi);
+		st_rows64(stage, 96, col, g, dG0lo, dG0hi);
 #pragma unroll
-			for (int ti = 0; ti < 4; ++ti) aV1[ti] = MFMA(a_dg1, ld_rows(stage, R_G0 + 16 * ti + o, cs), aV1[ti]);
+		for (int j = 0; j < 8; ++j) { stage[(64 + k32(g, j)) * RS + col] = st.feat[j]; stage[(160 + k64(0, g, j)) * RS + col] = st.in2[j]; }
+		__syncthreads();
 #pragma unroll
-			for (int ti = 0; ti < 2; ++ti) { aW0[ti] = MFMA(a_dh, ld_rows(stage, R_F + 16 * ti + o, cs), aW0[ti]); aV0[ti] = MFMA(a_dg0, ld_rows(stage, R_IN2 + 16 * ti + o, cs), aV0[ti]); }
-			aW1 = MFMA(a_dd, ld_rows(stage, R_H + 16 * w + o, cs), aW1);
-			aV2 = MFMA(a_do, ld_rows(stage, R_G1 + 16 * w + o, cs), aV2);
+		for (int kb = 0; kb < BT / 32; ++kb) {
+			const int cs = 32 * kb + 8 * g;
+			aW0 = MFMA(ld_rows(stage, 16 * to + o, cs), ld_rows(stage, 64 + 16 * tj + o, cs), aW0);
+			aV0 = MFMA(ld_rows(stage, 96 + 16 * to + o, cs), ld_rows(stage, 160 + 16 * tj + o, cs), aV0);
+		}
+		__syncthreads();
+		// phase C
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { stage[(4 * g + j) * RS + col] = dDf[j]; stage[(80 + 4 * g + j) * RS + col] = dO[j]; }
+		st_rows64(stage, 16, col, g, st.hfrag[0], st.hfrag[1]);
+		st_rows64(stage, 96, col, g, st.g1[0], st.g1[1]);
+		__syncthreads();
+#pragma unroll
+		for (int kb = 0; kb < BT / 32; ++kb) {
+			const int cs = 32 * kb + 8 * g;
+			if (w < 4) aX = MFMA(ld_rows(stage, o, cs), ld_rows(stage, 16 + 16 * w + o, cs), aX);               // W1: dD^T x H tile w
+			else aX = MFMA(ld_rows(stage, 80 + o, cs), ld_rows(stage, 96 + 16 * (w - 4) + o, cs), aX);           // V2: dO^T x G1 tile w-4
 		}
 		__syncthreads();
 		if (more) cur = nxt;
@@ -329,11 +337,11 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(uint32_t n, const _Float16
 	for (int r = 0; r < 4; ++r) {
 		const int ro = 4 * g + r;
 #pragma unroll
-		for (int ti = 0; ti < 4; ++ti) slab[3072 + 2048 + (16 * w + ro) * 64 + 16 * ti + ci] = aV1[ti][r];
-#pragma unroll
-		for (int ti = 0; ti < 2; ++ti) { slab[(16 * w + ro) * 32 + 16 * ti + ci] = aW0[ti][r]; slab[3072 + (16 * w + ro) * 32 + 16 * ti + ci] = aV0[ti][r]; }
-		slab[2048 + ro * 64 + 16 * w + ci] = aW1[r];
-		slab[3072 + 6144 + ro * 64 + 16 * w + ci] = aV2[r];
+		for (int q = 0; q < 2; ++q) slab[3072 + 2048 + (16 * to + ro) * 64 + 16 * (ti0 + q) + ci] = aV1[q][r];
+		slab[(16 * to + ro) * 32 + 16 * tj + ci] = aW0[r];
+		slab[3072 + (16 * to + ro) * 32 + 16 * tj + ci] = aV0[r];
+		if (w < 4) slab[2048 + ro * 64 + 16 * w + ci] = aX[r];
+		else slab[3072 + 6144 + ro * 64 + 16 * (w - 4) + ci] = aX[r];
 	}
 }
 
@@ -464,7 +472,7 @@ NGP_API int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int layout
 	NGP_REQUIRE((int)n_slabs == ngp_field_bwd_slabs(n), NGP_E_ARG, "ngp_field_bwd: n_slabs %u != ngp_field_bwd_slabs(%u)", n_slabs, n);
 	if (n == 0) return 0;
 	const size_t shmem = ((N_FWD_FRAGS + N_BWD_FRAGS) * 512 + N_ROWS * RS) * sizeof(_Float16);
-	const dim3 grid(n_slabs), block(256);
+	const dim3 grid(n_slabs), block(512);
 	hipStream_t s = (hipStream_t)stream;
 	const _Float16 *packed = pack_weights("ngp_field_bwd", s, wd, wc, N_FWD_FRAGS + N_BWD_FRAGS, layout_flags); if (!packed) return NGP_E_ARG;
 #define GO(T, L) do { \
