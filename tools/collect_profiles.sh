@@ -13,7 +13,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf/fs -o fs -- $CMD --steps 40
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pf/ws -o ws -- $CMD --steps 40 --warmup 80 > /tmp/pf/ws.log 2>&1
 cd $R
 KT=$(find /tmp/pf/kt -name "*.db" | head -1); FS=$(find /tmp/pf/fs -name "*.db" | head -1); WS=$(find /tmp/pf/ws -name "*.db" | head -1)
-python tools/rocprof_summary.py "$KT" gpurun_out/${TAG}_kernel_trace.md "bench.py (N=1, 300 warm-up + 200 timed steps), rocprofv3 --kernel-trace --stats" 200
+python tools/rocprof_summary.py "$KT" gpurun_out/${TAG}_kernel_trace.md "bench.py (N=1, default warm-up + 200 timed steps), rocprofv3 --kernel-trace --stats" 200
 python tools/rocprof_pmc.py "$FS" gpurun_out/${TAG}_pmc_fetch_size.md "bench.py --steps 40 --warmup 80, rocprofv3 --pmc FETCH_SIZE --kernel-trace"
 python tools/rocprof_pmc.py "$WS" gpurun_out/${TAG}_pmc_write_size.md "bench.py --steps 40 --warmup 80, rocprofv3 --pmc WRITE_SIZE --kernel-trace"
 python tools/rocprof_pmc_json.py "$FS" "$WS" gpurun_out/${TAG}_pmc.json "python bench.py --no-cpu-baseline --no-psnr --steps 40 --warmup 80"

@@ -13,10 +13,22 @@ def main(db, out, title, last_steps=0):
         if len(marks) > last_steps:
             cutoff = marks[-last_steps]
             title += f" — last {last_steps} training steps only"
-    q = f"""select s.kernel_name, count(*), sum(d.end-d.start)/1e3, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3, max(d.end-d.start)/1e3,
-                  max(s.arch_vgpr_count), max(s.sgpr_count), max(d.group_segment_size), max(d.grid_size_x), max(d.workgroup_size_x)
-           from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id where d.start >= {cutoff} group by s.kernel_name order by 3 desc"""
-    rows = list(c.execute(q))
+    # one row per (kernel, launch size class): the same kernel serves the 2^18-sample training batch and e.g. the 3 M-point occupancy-grid refresh, or the
+    # 13 M-parameter table and the 3 k-parameter weight packs - averaging those together would say nothing.  Size class = grid size within a factor of 2^(1/2).
+    import math
+    raw = list(c.execute(f"""select s.kernel_name, d.end-d.start, s.arch_vgpr_count, s.sgpr_count, d.group_segment_size, d.grid_size_x, d.workgroup_size_x
+                             from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id where d.start >= {cutoff}"""))
+    groups = {}
+    for name, dur, vg, sg, lds, grid, wg in raw:
+        key = (name, round(math.log2(max(grid, 1)) * 2))
+        g = groups.setdefault(key, [name, 0, 0.0, 0.0, 1e30, 0.0, 0, 0, 0, 0, 0])
+        g[1] += 1; g[2] += dur / 1e3; g[4] = min(g[4], dur / 1e3); g[5] = max(g[5], dur / 1e3)
+        g[6] = max(g[6], vg or 0); g[7] = max(g[7], sg or 0); g[8] = max(g[8], lds or 0); g[9] = max(g[9], grid); g[10] = max(g[10], wg)
+    rows = []
+    for g in groups.values():
+        g[3] = g[2] / g[1]
+        rows.append(tuple(g))
+    rows.sort(key=lambda r: -r[2])
     tot = sum(r[2] for r in rows)
     with open(out, "w") as f:
         f.write(f"# {title}\n\nsource: `rocprofv3 --kernel-trace --stats` (rocpd database), all durations in microseconds\n\n")
