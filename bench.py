@@ -1,12 +1,23 @@
 #!/usr/bin/env python
-"""bench.py — Instant-NGP training throughput on MI355X (BASELINE.json metric "training iters/s", config[1]: fox-config
-Instant-NGP, L=16 hash levels, T=2^19, fp16 fused MLP, 2^18-sample batches; synthetic procedural scene, random-init weights).
+"""bench.py — Instant-NGP training throughput on MI355X.
 
-One "step" = one full training iteration of Runner.train (ray generation + random background, occupancy-grid marching/compaction,
-hash encode, fused MLP, compositing, Huber, backward, fused Adam+EMA; occupancy-grid update every 16th step) over one 2^18-sample batch.
-`value` = (n_gpus * steps) / seconds: iterations per second where every rank trains its own 2^18-sample ray batch and the hash-table /
-MLP gradients are all-reduced over RCCL each step (weak scaling; at n_gpus=1 this is exactly the reference's it/s).
-Prints ONE JSON line on rank 0."""
+Headline workload (BASELINE.json metric "training iters/s ... on lego"): the reference's projects/ngp/configs/ngp_base.py hyper-parameters AS COMMITTED —
+aabb_scale 1 (NeRF-synthetic), const_dt = True, fp32 hash table + fp32 field network (ngp_base.py leaves `fp16` unset, models/networks/ngp_network.py:57-67),
+L=16, F=2, T=2^19, Adam lr 1e-1 / eps 1e-15 / betas (0.9, 0.99), EMA 0.95, Huber 0.1, 4096 initial rays, 2^18-sample batches, occupancy refresh every 16 steps —
+on a procedural 100 x 800 x 800 RGBA scene (lego itself is not on the GPU box and cannot be downloaded; SURVEY.md §8d names this stand-in), random-init weights.
+
+One "step" = one full training iteration of Runner.train (ray generation + random background, occupancy-grid marching + compaction, hash encode, field
+network, compositing, Huber, backward, fused Adam+EMA; occupancy-grid refresh on every 16th step) over one 2^18-sample batch.
+
+Regime: a FIXED burn-in of --burn-in (1024) untimed steps brings the occupancy grid and the adaptive ray count to steady state regardless of --warmup; then
+--warmup untimed steps, then exactly --steps timed steps between barrier + synchronize.  The last 32 burn-in steps run with an event pair around EVERY kernel
+launch of the library (csrc/prof.hip, on each launch's own stream) to find the kernel with the largest share of GPU time; in the timed region only that kernel
+keeps its bracket, and `roofline` is computed from those live durations.
+
+`value` = (n_gpus * steps) / seconds (weak scaling: every rank trains its own 2^18-sample ray batch, hash-table / MLP gradients all-reduced over RCCL each step);
+--scaling strong splits ONE 2^18-sample iteration over the ranks (2^18 / n_gpus samples per rank), value = steps / seconds.
+--config fox runs the ngp_fox.py hyper-parameters (aabb 4, cone stepping, fp16 fused MLP) instead; the default run reports that configuration on the REAL fox
+images (data/fox, copied from the reference checkout by __graft_entry__.build()) under `extra.fox`.  Prints ONE JSON line on rank 0."""
 import argparse
 import json
 import os
@@ -16,12 +27,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+BURN_IN_DEFAULT = 1024
+PROBE_STEPS = 32
 
-def _cpu_inputs(n_samples, n_rays, m_rays, seed):
+
+# ---------------------------------------------------------------------------------------------------------------- CPU baseline (oracle port; rank 0, N=1 only)
+def _cpu_inputs(n_samples, n_rays, m_rays, seed, aabb):
     """synthetic inputs of one (slice of a) training iteration for the CPU port"""
     import numpy as np
     import synth
-    x = synth.uniform_positions(n_samples, seed=seed) if "seed" in synth.uniform_positions.__code__.co_varnames else synth.uniform_positions(n_samples)
+    x = synth.uniform_positions(n_samples, seed=seed)
     d = synth.unit_dirs01(n_samples)
     coords = np.zeros((n_samples, 7), np.float32); coords[:, :3] = x; coords[:, 4:] = d
     per = n_samples // n_rays
@@ -29,10 +44,10 @@ def _cpu_inputs(n_samples, n_rays, m_rays, seed):
     bg = np.random.default_rng(seed).random((n_rays, 3), dtype=np.float32)
     xf, focal, meta = synth.camera_ring(8, radius=1.3)
     _, ro, rd, _ = synth.rays_from_cameras(xf, focal, meta, 400, 400, m_rays, seed=1 + seed)
-    return dict(x=x, d=d, coords=coords, ns=ns, bg=bg, ro=ro, rd=rd)
+    return dict(x=x, d=d, coords=coords, ns=ns, bg=bg, ro=ro, rd=rd, aabb=aabb)
 
 
-def _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar, stages=None):
+def _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar, fp16, const_dt, stages=None):
     """every hot-path stage of one iteration through the plain-C oracle (ctypes releases the GIL inside each call)"""
     import numpy as np
 
@@ -44,7 +59,7 @@ def _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar, stages=Non
         return r
 
     x, d, coords, ns, bg = inp["x"], inp["d"], inp["coords"], inp["ns"], inp["bg"]
-    timed("march", lambda: O.march_rays(inp["ro"], inp["rd"], bits, (-1.5, 2.5), O.PCG32(1337), 4096 * 1024, const_dt=False))   # the batch's ray count through the two-pass marcher
+    timed("march", lambda: O.march_rays(inp["ro"], inp["rd"], bits, inp["aabb"], O.PCG32(1337), 4096 * 1024, const_dt=const_dt))
     feat = timed("hash_fwd", lambda: O.hash_encode_fwd(x, grid, table))
     sh = timed("sh", lambda: O.sh_encode(d, np.float32))
     out = timed("field_fwd", lambda: O.field_fwd(feat.astype(np.float32), sh, wd, wc))
@@ -52,13 +67,13 @@ def _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar, stages=Non
     _, G = O.huber(rgb, bg)
     dout = timed("composite_bwd", lambda: O.composite_bwd(out, coords, ns, G, rgb, 0.001))
     dfeat, dwd, dwc = timed("field_bwd", lambda: O.field_bwd(feat.astype(np.float32), sh, wd, wc, dout))
-    g = timed("hash_bwd", lambda: O.hash_encode_bwd(x, dfeat.astype(np.float16), table, n_params))
+    g = timed("hash_bwd", lambda: O.hash_encode_bwd(x, dfeat.astype(np.float16 if fp16 else np.float32), table, n_params))
     p = np.zeros(npar, np.float32); m = np.zeros_like(p); v = np.zeros_like(p); e = np.zeros_like(p)
     timed("adam_ema", lambda: O.adam_ema_step(p, g[:npar].astype(np.float32), m, v, e, 0.1, 1))
 
 
-def cpu_baseline(n_samples=1 << 18, n_rays=4096, n_march_rays=39424):
-    """The oracle (plain-C port of the reference's kernels) on ONE training iteration of the bench workload, on this host's cores: the iteration is split
+def cpu_baseline(aabb_scale, fp16, const_dt, n_samples=1 << 18, n_rays=4096, n_march_rays=4096):
+    """The oracle (plain-C port of the reference's kernels) on ONE training iteration of the bench workload's shape, on this host's cores: the iteration is split
     into `cores` independent ray/sample slices that run concurrently (one thread each; the hash-table gradient and the parameter sweep are sliced the same
     way), plus the same iteration on a single core for the per-stage times.  `value` is iterations/s on `cores` cores."""
     import numpy as np
@@ -67,41 +82,71 @@ def cpu_baseline(n_samples=1 << 18, n_rays=4096, n_march_rays=39424):
     from oracle import oracle as O
     import synth
     frac = n_samples / float(1 << 18)
-    table, offsets, n_params = O.level_table(4)
-    grid = synth.table(n_params, np.float16, amp=2e-4)
+    table, offsets, n_params = O.level_table(aabb_scale)
+    grid = synth.table(n_params, np.float16 if fp16 else np.float32, amp=2e-4)
     wd, wc = synth.mlp_weights()
     bits = synth.shell_bitfield()
+    aabb = (0.5 - aabb_scale / 2, 0.5 + aabb_scale / 2)
     m_rays = int(n_march_rays * frac)
     npar = int(n_params * frac) // 4 * 4
     cores = max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-    # (a) `cores` slices in parallel
-    parts = [_cpu_inputs(n_samples // cores, max(n_rays // cores, 1), max(m_rays // cores, 1), seed=k) for k in range(cores)]
+    parts = [_cpu_inputs(n_samples // cores, max(n_rays // cores, 1), max(m_rays // cores, 1), seed=k, aabb=aabb) for k in range(cores)]
     with ThreadPoolExecutor(cores) as ex:
         t0 = time.perf_counter()
-        list(ex.map(lambda inp: _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar // cores // 4 * 4), parts))
+        list(ex.map(lambda inp: _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar // cores // 4 * 4, fp16, const_dt), parts))
         t_par = time.perf_counter() - t0
-    # (b) the whole iteration on one core, stage by stage
     stages = {}
-    whole = _cpu_inputs(n_samples, n_rays, m_rays, seed=0)
+    whole = _cpu_inputs(n_samples, n_rays, m_rays, seed=0, aabb=aabb)
     t0 = time.perf_counter()
-    _cpu_iteration(O, whole, table, n_params, grid, wd, wc, bits, npar, stages)
+    _cpu_iteration(O, whole, table, n_params, grid, wd, wc, bits, npar, fp16, const_dt, stages)
     t_one = time.perf_counter() - t0
     return {"value": round(frac / t_par, 4), "unit": "iters/s", "cores": cores, "kind": "port", "single_core_value": round(frac / t_one, 4), "single_core_stage_ms": stages,
-            "sample": f"{'one' if frac == 1 else f'1/{int(1 / frac)} of one'} training iteration: {m_rays} rays marched, {n_samples} samples through hash fwd/bwd, SH, both MLPs fwd/bwd, "
-                      f"compositing fwd/bwd, Huber; Adam+EMA on {npar} of {n_params} parameters (occupancy-grid refresh not included); "
-                      f"{t_par:.1f} s on {cores} cores ({cores} concurrent slices), {t_one:.1f} s on 1 core"}
+            "sample": f"one training iteration of the bench workload's shape ({'fp16' if fp16 else 'fp32'} table, aabb_scale {aabb_scale}, const_dt {const_dt}): {m_rays} rays marched through a "
+                      f"shell bitfield, {n_samples} samples through hash fwd/bwd, SH, both MLPs fwd/bwd, compositing fwd/bwd, Huber; Adam+EMA on {npar} of {n_params} parameters "
+                      f"(occupancy-grid refresh not included); {t_par:.1f} s on {cores} cores ({cores} concurrent slices), {t_one:.1f} s on 1 core"}
+
+
+# ---------------------------------------------------------------------------------------------------------------- roofline bookkeeping
+def alg_bytes_table(n, P, R, n_refresh, fp16):
+    """ALGORITHMIC bytes (and flops) per launch of every hot-path kernel: per-unit figure x units one launch processes.
+    n = samples in the batch, P = hash-table parameters, R = rays in the batch, n_refresh = points of one occupancy-grid refresh launch, T/F = bytes per table / feature element."""
+    T = 2 if fp16 else 4
+    hf = 12 + 16 * 8 * 2 * T + 32 * T                      # hash fwd per sample: pos + 128 corner values + 32 features out (588 | 1164)
+    fio = 32 * T + 12 + 4 * T                              # field fwd per sample: features + direction + 4 outputs
+    d = {
+        "k_hash_fwd": n * hf, "k_field_fwd": n * fio, "k_field_bwd": n * (fio + 32 * T),
+        "k_field32_fwd": n * fio, "k_field32_bwd": n * (fio + 32 * T),
+        "k_composite_fwd": n * (4 * T + 28), "k_composite_bwd": n * (4 * T + 28 + 4 * T),
+        "k_adam_ema": P * (34 if fp16 else 32),
+        # hash backward: the stage's necessary traffic is pos 12 + dL/dy 32*T + 128 scattered fp32 updates (4 B each as one write); attributed to the kernels that do each part
+        "k_level_absmax": n * 32 * T, "k_bin_records": n * (12 + 32 * T) * 12 / 16, "k_bin_accumulate": n * 12 * 8 * 2 * 4, "k_hash_bwd_owner": n * ((12 + 32 * T) * 4 / 16 + 4 * 8 * 2 * 4),
+        "k_reduce_dense": 0, "k_reduce_slabs": 10240 * 4, "k_pack_frags": 21504 * 2 * 2,
+        # sampling: ray in (24 B) + one 28-byte record and one 12-byte position out per sample
+        "k_march_count": R * 24 + n * 4, "k_march_scan": R * 20, "k_march_write_cached": n * (4 + 40), "k_march": R * 24 + n * 40,
+        "k_generate_rays": R * (8 + 16 + 12 + 40),
+        # occupancy refresh (one launch over all points)
+        "k_grid_generate": n_refresh * (4 + 16), "k_grid_splat": n_refresh * (4 + T + 4), "k_grid_ema": 5 * 128 ** 3 * 12, "k_grid_mean": 128 ** 3 * 4, "k_grid_to_bitfield": 5 * 128 ** 3 * 4.125,
+        "k_bitfield_max_pool": 128 ** 3 / 8 * 1.125, "k_refresh_fused": n_refresh * (4 + 16 * 8 * 2 * T + 4),
+    }
+    flops = {"k_field_fwd": 20480.0 * n, "k_field_bwd": 61440.0 * n, "k_field32_fwd": 20480.0 * n, "k_field32_bwd": 61440.0 * n}
+    return d, flops
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--burn-in", type=int, default=BURN_IN_DEFAULT, help="fixed number of untimed steps BEFORE --warmup (occupancy grid + adaptive ray count reach steady state)")
+    ap.add_argument("--config", default="lego", choices=["lego", "fox"], help="lego = ngp_base.py hyper-parameters (headline); fox = ngp_fox.py hyper-parameters")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
-    ap.add_argument("--images", type=int, default=50)
-    ap.add_argument("--res", type=int, default=400)
+    ap.add_argument("--no-fox", action="store_true", help="skip the real-fox leg (extra.fox)")
+    ap.add_argument("--images", type=int, default=0)
+    ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event brackets (then no roofline object)")
+    ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: still create the process group and run the data-parallel sequence (RCCL all-reduce at world size 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     args = ap.parse_args()
 
@@ -113,8 +158,11 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})"
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -123,99 +171,116 @@ def main():
     from jnerf_amd.presets import ngp_cfg
     from jnerf_amd.runner import Runner
     torch.manual_seed(1234 + rank)
-    ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=args.images, W=args.res, H=args.res, device=f"cuda:{local_rank}", rank=rank, world_size=world)
+    lego = args.config == "lego"
+    fp16, aabb_scale, const_dt = (False, 1, True) if lego else (True, 4, False)
+    n_images = args.images or (100 if lego else 50)
+    res = args.res or (800 if lego else 400)
+    share = world if args.scaling == "strong" else 1
+    ngp_cfg(fp16=fp16, aabb_scale=aabb_scale, const_dt=const_dt, n_images=n_images, W=res, H=res, device=f"cuda:{local_rank}", rank=rank, world_size=world,
+            target_batch_size=(1 << 18) // share, n_rays_per_batch=4096 // share, dp_force_collectives=bool(args.force_dist))
     runner = Runner()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     step = 0
-    probe = min(32, args.warmup // 2)
-    for _ in range(args.warmup - probe):
+    probe = 0 if args.no_kernel_events else min(PROBE_STEPS, args.burn_in // 2)
+    for _ in range(args.burn_in - probe):
         runner.train_step(step); step += 1
-    # last `probe` warm-up steps: HIP-event brackets around every hot-path launch to find the dominant kernel and the per-step breakdown ...
-    ops.PROFILE = None if args.no_kernel_events else {}
+    # ---- last `probe` burn-in steps: an event pair around EVERY kernel launch of the library (each on its own stream)
+    if probe:
+        ops.prof_enable("*")
     valid_sum = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rays_sum = 0
     for _ in range(probe):
         runner.train_step(step); step += 1
         valid_sum += runner.sampler._counters[3]            # samples in the batch just trained on (device-side count; read back once, after the run)
-    torch.cuda.synchronize()
-    probe_prof, ops.PROFILE = (ops.PROFILE or {}), None
-    # what an empty event pair measures on this stream (the two timestamp packets themselves): subtracted from every bracket below
+        rays_sum += int(runner.sampler._rays_numsteps.shape[0])
+    ops.prof_enable("")
+    probe_ms = ops.prof_read() if probe else {}
+    # what an empty event pair measures on a stream (the two timestamp packets themselves): subtracted from every bracket
     pairs = []
     for _ in range(64):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); b.record(); pairs.append((a, b))
     torch.cuda.synchronize()
     ev_overhead = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
-    single = ("hash_fwd", "field_fwd", "field_bwd", "composite_fwd", "composite_bwd", "adam_ema")          # brackets that contain exactly one kernel
-    breakdown = {k: sum(max(a.elapsed_time(b) - ev_overhead, 0.0) for a, b in v) / max(probe, 1) for k, v in probe_prof.items()}
-    dom = max((k for k in breakdown if k in single), key=lambda k: breakdown[k]) if breakdown else None
-    # ... in the timed region only that kernel keeps its bracket (an event pair per launch costs ~2-3 us; eight of them per step were ~5 %).
-    # Single-GPU runs issue the step through ngp_train_step, which records the pair itself; data-parallel runs keep the Python-side bracket.
-    fast = runner._fast if getattr(runner, "_fast", None) else None
-    native = bool(fast and fast.native)
-    ops.PROFILE_ONLY = dom
-    if native:
-        fast.timed_stage = None if (args.no_kernel_events or dom is None) else dom
-        fast.stage_timings()                                  # drop anything recorded so far
-        ops.PROFILE = None
-    else:
-        ops.PROFILE = None if (args.no_kernel_events or dom is None) else {}
+    mean_valid = float(valid_sum.item()) / max(probe, 1) if probe else float(1 << 18) / share
+    mean_rays = rays_sum / max(probe, 1) if probe else float(runner.sampler.n_rays_per_batch)
+    per_step = {k: sum(max(x - ev_overhead, 0.0) for x in v) / probe for k, v in probe_ms.items()} if probe else {}
+    # one kernel can serve launches of very different sizes (k_hash_fwd: the training batch vs the occupancy-grid refresh; k_adam_ema: the table vs the weight
+    # packs): the roofline uses the TRAINING-BATCH class = the launches whose duration is within 2x of the median of the kernel's most frequent class
+    def batch_class(v):
+        s = sorted(v)
+        med = s[len(s) // 2]
+        return [x for x in v if 0.5 * med <= x <= 2.0 * med] or v
+    dom = max(per_step, key=lambda k: per_step[k]) if per_step else None
+    # ---- warm-up + timed region: only the dominant kernel keeps its bracket
+    for _ in range(args.warmup):
+        runner.train_step(step); step += 1
+    if dom is not None:
+        ops.prof_enable(dom)
     barrier()
     t0 = time.perf_counter()
     loss = None
     for _ in range(args.steps):
         loss = runner.train_step(step); step += 1
     barrier()
-    last_loss = loss.mean().item() if loss is not None else float("nan")
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = (ops.PROFILE or {}), None
-    dom_ms = [a.elapsed_time(b) for a, b in prof.get(dom, [])] if dom else []
-    if native and fast.timed_stage is not None:
-        dom_ms = fast.stage_timings()
-        fast.timed_stage = None
+    last_loss = loss.mean().item() if loss is not None else float("nan")
+    runner.drain()
+    torch.cuda.synchronize()
+    ops.prof_enable("")
+    dom_ms = ops.prof_read().get(dom, []) if dom is not None else []
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    mean_valid = float(valid_sum.item()) / max(probe, 1)          # mean samples per batch over the probe steps (the adaptive ray count keeps it within ~1 % of 2^18)
 
-    # ---- roofline of the dominant single kernel: HIP-event durations over the timed region, algorithmic bytes per launch
+    # ---- roofline of the dominant kernel: live HIP-event durations over the timed region, algorithmic bytes per launch
     P = runner.model.pos_encoder.n_params
-    alg_bytes = {"hash_fwd": mean_valid * (12 + 16 * 8 * 4 + 64), "field_fwd": mean_valid * (64 + 12 + 8), "field_bwd": mean_valid * (64 + 12 + 8 + 64),
-                 "composite_fwd": mean_valid * 36, "composite_bwd": mean_valid * 44, "adam_ema": P * 34}
+    n_refresh = 128 ** 3 * (runner.sampler.max_cascade + 1) // 2
+    alg, flops = alg_bytes_table(mean_valid, P, mean_rays, n_refresh, fp16)
     roof = None
     if dom is not None and dom_ms:
-        ms = dom_ms
-        avg_raw = sum(ms) / len(ms)
+        cls = batch_class(dom_ms)
+        avg_raw = sum(cls) / len(cls)
         avg_ms = max(avg_raw - ev_overhead, 1e-6)
-        nbytes = alg_bytes[dom]
+        nbytes = float(alg.get(dom, 0.0))
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
-        flops = {"field_fwd": 20480.0, "field_bwd": 61440.0}.get(dom)      # per sample: 20 MFMA 16x16x32 per 16 samples forward; recompute + dgrad + wgrad backward
-        traffic = None      # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        traffic = None      # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside this process): profiles/r02_pmc.json
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            traffic = pm.get(dom, {}).get("hbm_bytes_per_launch")
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+            traffic = pm.get(args.config, {}).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
-        kname = {"hash_fwd": "k_hash_fwd", "field_fwd": "k_field_fwd", "field_bwd": "k_field_bwd", "composite_fwd": "k_composite_fwd",
-                 "composite_bwd": "k_composite_bwd", "adam_ema": "k_adam_ema"}[dom]
         hbm = {"achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4)}
-        if flops is None:
+        if dom in flops:    # the fused field kernels are MFMA work (fp16 16x16x32: dense peak 2.5 PFLOP/s; fp32 16x16x4: 157.3 TFLOP/s); their HBM side is reported next to it
+            peak = 2500.0 if fp16 else 157.3
+            tf = flops[dom] / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "hbm": hbm}
+        else:
             roof = dict(bound="hbm", **hbm)
-        else:       # the fused MLP kernels are MFMA work (fp16 16x16x32, dense peak 2.5 PFLOP/s); their HBM side is reported next to it
-            tf = flops * mean_valid / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "hbm": hbm}
-        roof.update({"kernel": kname, "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_raw": round(avg_raw, 4), "event_pair_overhead_ms": round(ev_overhead, 4), "launches_timed": len(ms), "alg_bytes_per_launch": int(nbytes),
-                     "ms_per_step_by_launch_group": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])}})
+        roof.update({"kernel": dom, "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_raw": round(avg_raw, 4), "event_pair_overhead_ms": round(ev_overhead, 4),
+                     "launches_timed": len(cls), "launches_other_size_class": len(dom_ms) - len(cls), "alg_bytes_per_launch": int(nbytes),
+                     "share_of_kernel_time": round(per_step[dom] / max(sum(per_step.values()), 1e-9), 4),
+                     "ms_per_step_by_kernel": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}})
 
-    extra = {"mean_samples_per_batch": round(mean_valid, 1), "rays_per_batch": runner.sampler.n_rays_per_batch}
-    if breakdown:       # every single-kernel bracket against the HBM roofline, from the probe steps (algorithmic bytes / HIP-event duration)
-        extra["probe_kernels"] = {k: {"avg_launch_ms": round(breakdown[k], 4), "alg_GBps": round(alg_bytes[k] / (breakdown[k] * 1e-3) / 1e9, 1),
-                                      "frac_hbm": round(alg_bytes[k] / (breakdown[k] * 1e-3) / 8e12, 4)} for k in single if breakdown.get(k)}
+    extra = {"mean_samples_per_batch": round(mean_valid, 1), "rays_per_batch": runner.sampler.n_rays_per_batch, "burn_in_steps": args.burn_in, "probe_steps": probe,
+             "native_step": bool(getattr(runner, "_fast", None) and runner._fast.native), "fast_path": bool(getattr(runner, "_fast", None))}
+    if probe_ms:        # every kernel against its roofline, from the probe steps (training-batch size class)
+        pk = {}
+        for k, v in probe_ms.items():
+            cls = batch_class(v)
+            ms = max(sum(cls) / len(cls) - ev_overhead, 1e-6)
+            row = {"avg_launch_ms": round(ms, 4), "launches_per_step": round(len(v) / probe, 2), "alg_GBps": round(alg.get(k, 0.0) / (ms * 1e-3) / 1e9, 1),
+                   "frac_hbm": round(alg.get(k, 0.0) / (ms * 1e-3) / 8e12, 4)}
+            if k in flops:
+                row["TFLOPs"] = round(flops[k] / (ms * 1e-3) / 1e12, 1)
+            pk[k] = row
+        extra["probe_kernels"] = pk
     if not args.no_psnr and rank == 0:
         import numpy as np
         from jnerf_amd.utils.registry import build_from_cfg, DATASETS
@@ -229,28 +294,77 @@ def main():
             n_s += runner.n_samples_rendered
         torch.cuda.synchronize(); tr = time.perf_counter() - tr0
         extra["render_Msamples_per_s"] = round(n_s / tr / 1e6, 2)
-        extra["render_ms_per_%dx%d_view" % (args.res, args.res)] = round(tr / 4 * 1e3, 2)
-    if world > 1:
+        extra["render_ms_per_%dx%d_view" % (res, res)] = round(tr / 4 * 1e3, 2)
+    if use_dist:
+        extra["dist_backend"] = dist.get_backend()
         # data-parallel invariant: every rank must hold bit-identical parameters (identical summed gradients + a deterministic sweep)
         from jnerf_amd import optim as _optim
         _optim.flush_all()
-        enc = runner.model.pos_encoder
-        sig = torch.stack([enc.m_grid.detach().double().sum(), enc.m_grid.detach().double().abs().sum(),
-                           runner.model.density_mlp.con_weights.detach().double().sum(), runner.model.rgb_mlp.con_weights.detach().double().sum()])
+        sig = torch.stack([p.detach().double().sum() for p in runner.model.parameters()] + [p.detach().double().abs().sum() for p in runner.model.parameters()])
         sigs = [torch.empty_like(sig) for _ in range(world)]
         dist.all_gather(sigs, sig)
         extra["replicas_identical"] = bool(all(torch.equal(sigs[0], x) for x in sigs))
         dist.barrier()
+    if rank == 0 and not use_dist and not args.no_fox:
+        del runner
+        torch.cuda.empty_cache()
+        extra["fox"] = fox_leg()
     if rank == 0:
-        line = {"metric": "training iters/s", "value": round(world * args.steps / dt, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic", "loss": round(float(last_loss), 6),
-                "config": {"workload": "Instant-NGP fox config (ngp_fox.py hyper-parameters: aabb_scale 4, L=16, T=2^19, F=2, fp16 fused MLP, const_dt=False, 2^18-sample batches), "
-                                       f"procedural scene {args.images}x{args.res}x{args.res} RGBA, random-init weights",
-                           "samples_per_iter_per_gpu": 1 << 18, "parallelism": f"ray-batch dp{world}" if world > 1 else "single"},
-                "roofline": roof, "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(), "extra": extra}
+        wl = ("Instant-NGP lego config (projects/ngp/configs/ngp_base.py hyper-parameters: aabb_scale 1, L=16, T=2^19, F=2, fp32 table + fp32 field network, const_dt=True, 2^18-sample batches), "
+              if lego else "Instant-NGP fox config (ngp_fox.py hyper-parameters: aabb_scale 4, L=16, T=2^19, F=2, fp16 fused MLP, const_dt=False, 2^18-sample batches), ")
+        line = {"metric": "training iters/s", "value": round((world if args.scaling == "weak" else 1) * args.steps / dt, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16" if fp16 else "f32",
+                "data": "synthetic", "loss": round(float(last_loss), 6),
+                "config": {"workload": wl + f"procedural scene {n_images}x{res}x{res} RGBA, random-init weights, {args.burn_in}-step burn-in before warm-up",
+                           "samples_per_iter_per_gpu": (1 << 18) // share, "parallelism": f"ray-batch dp{world} ({args.scaling} scaling)" if world > 1 else "single"},
+                "roofline": roof, "cpu_baseline": None if (args.no_cpu_baseline or use_dist) else cpu_baseline(aabb_scale, fp16, const_dt), "extra": extra}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+
+
+def fox_leg(burn_in=1024, timed=200, total=3000):
+    """BASELINE config [1] on the REAL scene: projects/ngp/configs/ngp_fox.py unchanged (fp16 fused MLP, aabb_scale 4, cone stepping) on data/fox
+    (50 photographs 1080x1920, copied from the reference checkout by build()): iters/s in steady state and PSNR on the scene's own test split."""
+    import numpy as np
+    import torch
+    root = os.path.join(ROOT, "data", "fox")
+    if not os.path.isfile(os.path.join(root, "transforms_train.json")):
+        return {"skipped": "data/fox is not in the tree (run __graft_entry__.build() where /root/reference exists)"}
+    from jnerf_amd.utils.config import init_cfg, get_cfg
+    from jnerf_amd.runner import Runner
+    cwd = os.getcwd()
+    os.chdir(ROOT)                          # the config names the dataset relative to the project root, like the reference's
+    try:
+        t0 = time.perf_counter()
+        init_cfg(os.path.join(ROOT, "projects", "ngp", "configs", "ngp_fox.py"))
+        cfg = get_cfg()
+        cfg.log_dir = os.path.join(ROOT, "gpurun_out", "logs")
+        torch.manual_seed(7)
+        r = Runner()
+        t_load = time.perf_counter() - t0
+        for i in range(burn_in):
+            r.train_step(i)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(burn_in, burn_in + timed):
+            r.train_step(i)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        for i in range(burn_in + timed, total):
+            r.train_step(i)
+        r.drain()
+        from jnerf_amd.utils.registry import build_from_cfg, DATASETS
+        r.dataset["test"] = build_from_cfg(cfg.dataset.test, DATASETS)
+        ps = []
+        for v in range(r.dataset["test"].n_images):
+            img, _, tar = r.render_img("test", v)
+            ps.append(float(-10 * np.log10(np.mean((img - tar) ** 2))))
+        out = {"config": "projects/ngp/configs/ngp_fox.py (unchanged), data/fox: %d images %dx%d" % (r.dataset["train"].n_images, r.W, r.H), "iters_per_s": round(timed / dt, 1),
+               "ms_per_step": round(dt / timed * 1e3, 4), "steps_timed": timed, "burn_in_steps": burn_in, "psnr_test_split_after_%d_steps" % total: round(float(np.mean(ps)), 2),
+               "rays_per_batch": r.sampler.n_rays_per_batch, "load_s": round(t_load, 1), "dtype": "f16"}
+        del r
+        return out
+    finally:
+        os.chdir(cwd)
 
 
 if __name__ == "__main__":

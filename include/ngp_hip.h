@@ -197,6 +197,13 @@ int ngp_train_step(void *stream, const NgpTrainStep *args_host);
  * returns how many were written (<0 on error) and forgets them */
 int ngp_train_step_timings(float *ms_out_host, int max);
 
+/* ---- measurement: per-kernel HIP-event brackets (bench.py's `roofline` object; the reference has no profiler hooks) --------------------
+ * names: "" = off, "*" = every kernel, else comma-separated kernel base names ("k_hash_fwd,k_field_bwd").  While enabled, every launch of a named kernel is
+ * bracketed by an event pair on the stream it is launched on.  ngp_prof_read(index, ...) waits for and returns the durations (ms, oldest first) recorded for
+ * the index-th registered kernel since the last read and writes its name; returns the count, or -1 when index is past the last registered kernel. */
+int ngp_prof_enable(const char *names);
+int ngp_prof_read(int index, char *name_out_host, int name_cap, float *ms_out_host, int max);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,7 +105,7 @@ __global__ void k_bitfield_max_pool(uint32_t n, const uint8_t *__restrict__ prev
 NGP_API int ngp_grid_mark_untrained(void *stream, uint32_t n_elements, float *grid, uint32_t n_images, const float *focal, const float *xforms, int W, int H) {
 	NGP_REQUIRE(grid && focal && xforms, NGP_E_ARG, "ngp_grid_mark_untrained: null pointer");
 	if (n_elements == 0) return 0;
-	hipLaunchKernelGGL(k_grid_mark, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, grid, n_images, focal, xforms, W * 0.5f, H * 0.5f);
+	NGP_LAUNCH(k_grid_mark, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, grid, n_images, focal, xforms, W * 0.5f, H * 0.5f);
 	NGP_LAUNCH_CHECK("ngp_grid_mark_untrained");
 	return 0;
 }
@@ -115,7 +115,7 @@ NGP_API int ngp_grid_generate_samples(void *stream, uint32_t n, uint64_t *rng_st
 	Pcg32 rng{rng_state_host[0], rng_state_host[1]};
 	Pcg32 adv = rng; adv.advance(1ull << 32); rng_state_host[0] = adv.state;          // generate_grid_samples_nerf_nonuniform.py:44
 	if (n == 0) return 0;
-	hipLaunchKernelGGL(k_grid_generate, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, rng, ema_step, aabb0, aabb1, grid, positions, indices, n_cascades, thresh);
+	NGP_LAUNCH(k_grid_generate, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, rng, ema_step, aabb0, aabb1, grid, positions, indices, n_cascades, thresh);
 	NGP_LAUNCH_CHECK("ngp_grid_generate_samples");
 	return 0;
 }
@@ -123,15 +123,15 @@ NGP_API int ngp_grid_splat_max(void *stream, uint32_t n, const uint32_t *indices
 	NGP_REQUIRE(indices && density && grid_tmp, NGP_E_ARG, "ngp_grid_splat_max: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_grid_splat_max: bad dtype %d", dtype);
 	if (n == 0) return 0;
-	if (dtype == NGP_F32) hipLaunchKernelGGL(k_grid_splat<float>, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, indices, (const float *)density, grid_tmp);
-	else hipLaunchKernelGGL(k_grid_splat<__half>, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, indices, (const __half *)density, grid_tmp);
+	if (dtype == NGP_F32) NGP_LAUNCH(k_grid_splat<float>, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, indices, (const float *)density, grid_tmp);
+	else NGP_LAUNCH(k_grid_splat<__half>, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, indices, (const __half *)density, grid_tmp);
 	NGP_LAUNCH_CHECK("ngp_grid_splat_max");
 	return 0;
 }
 NGP_API int ngp_grid_ema(void *stream, uint32_t n_elements, float decay, float *grid, const float *grid_tmp) {
 	NGP_REQUIRE(grid && grid_tmp, NGP_E_ARG, "ngp_grid_ema: null pointer");
 	if (n_elements == 0) return 0;
-	hipLaunchKernelGGL(k_grid_ema, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, decay, grid, grid_tmp);
+	NGP_LAUNCH(k_grid_ema, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, decay, grid, grid_tmp);
 	NGP_LAUNCH_CHECK("ngp_grid_ema");
 	return 0;
 }
@@ -141,10 +141,10 @@ NGP_API int ngp_grid_update_bitfield(void *stream, const float *grid, int cascad
 	hipStream_t s = (hipStream_t)stream;
 	hipError_t e = hipMemsetAsync(mean, 0, 4, s);
 	if (e != hipSuccess) { ngp_set_error("ngp_grid_update_bitfield: %s", hipGetErrorString(e)); return (int)e; }
-	hipLaunchKernelGGL(k_grid_mean, dim3(G3 / 4 / 256), dim3(256), 0, s, grid, mean);
-	hipLaunchKernelGGL(k_grid_to_bitfield, dim3(div_up(G3 / 8 * cascades, 256)), dim3(256), 0, s, G3 / 8 * (uint32_t)cascades, grid, bitfield, (const float *)mean);
+	NGP_LAUNCH(k_grid_mean, dim3(G3 / 4 / 256), dim3(256), 0, s, grid, mean);
+	NGP_LAUNCH(k_grid_to_bitfield, dim3(div_up(G3 / 8 * cascades, 256)), dim3(256), 0, s, G3 / 8 * (uint32_t)cascades, grid, bitfield, (const float *)mean);
 	for (int level = 1; level < cascades; ++level)
-		hipLaunchKernelGGL(k_bitfield_max_pool, dim3(div_up(G3 / 64, 256)), dim3(256), 0, s, G3 / 64, (const uint8_t *)(bitfield + (size_t)G3 * (level - 1) / 8), bitfield + (size_t)G3 * level / 8);
+		NGP_LAUNCH(k_bitfield_max_pool, dim3(div_up(G3 / 64, 256)), dim3(256), 0, s, G3 / 64, (const uint8_t *)(bitfield + (size_t)G3 * (level - 1) / 8), bitfield + (size_t)G3 * level / 8);
 	NGP_LAUNCH_CHECK("ngp_grid_update_bitfield");
 	return 0;
 }

@@ -419,7 +419,7 @@ static const _Float16 *pack_weights(const char *fn, hipStream_t s, const void *w
 		if (!slot) { hipError_t e = hipMalloc((void **)&slot, (size_t)(N_FWD_FRAGS + N_BWD_FRAGS) * 512 * sizeof(_Float16)); if (e != hipSuccess) { slot = nullptr; ngp_set_error("%s: hipMalloc(fragment scratch): %s", fn, hipGetErrorString(e)); return nullptr; } }
 		buf = slot;
 	}
-	hipLaunchKernelGGL(k_pack_frags, dim3(div_up((uint32_t)n_frags * 512u, 256u)), dim3(256), 0, s, (const _Float16 *)wd, (const _Float16 *)wc, buf, n_frags);
+	NGP_LAUNCH(k_pack_frags, dim3(div_up((uint32_t)n_frags * 512u, 256u)), dim3(256), 0, s, (const _Float16 *)wd, (const _Float16 *)wc, buf, n_frags);
 	return buf;
 }
 static uint32_t fwd_grid(uint32_t n) { uint32_t b = div_up(div_up(n, 16), 4); return b < 2048 ? (b ? b : 1) : 2048; }
@@ -433,7 +433,7 @@ NGP_API int ngp_field_fwd(void *stream, uint32_t n, const void *feat, int layout
 	const dim3 grid(fwd_grid(n)), block(256);
 	hipStream_t s = (hipStream_t)stream;
 	const _Float16 *packed = pack_weights("ngp_field_fwd", s, wd, wc, N_FWD_FRAGS, layout_flags); if (!packed) return NGP_E_ARG;
-#define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, false>), grid, block, 0, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (T *)out, n_valid)
+#define GO(T, L) NGP_LAUNCH((k_field_fwd<T, L, false>), grid, block, 0, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (T *)out, n_valid)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO
@@ -448,7 +448,7 @@ NGP_API int ngp_density_fwd(void *stream, uint32_t n, const void *feat, int layo
 	const dim3 grid(fwd_grid(n)), block(256);
 	hipStream_t s = (hipStream_t)stream;
 	const _Float16 *packed = pack_weights("ngp_density_fwd", s, wd, wd, 6, layout_flags); if (!packed) return NGP_E_ARG;
-#define GO(T, L) hipLaunchKernelGGL((k_field_fwd<T, L, true>), grid, block, 0, s, n, (const _Float16 *)feat, (const float *)nullptr, 3u, packed, (T *)out, (const uint32_t *)nullptr)
+#define GO(T, L) NGP_LAUNCH((k_field_fwd<T, L, true>), grid, block, 0, s, n, (const _Float16 *)feat, (const float *)nullptr, 3u, packed, (T *)out, (const uint32_t *)nullptr)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO
@@ -459,7 +459,7 @@ NGP_API int ngp_field_pack_weights(void *stream, const void *wd, const void *wc,
 	NGP_REQUIRE(wd && wc && packed_out, NGP_E_ARG, "ngp_field_pack_weights: null pointer");
 	NGP_REQUIRE(((uintptr_t)packed_out & 15) == 0, NGP_E_ALIGN, "ngp_field_pack_weights: output must be 16-byte aligned");
 	const int n_frags = N_FWD_FRAGS + N_BWD_FRAGS;
-	hipLaunchKernelGGL(k_pack_frags, dim3(div_up((uint32_t)n_frags * 512u, 256u)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)wd, (const _Float16 *)wc, (_Float16 *)packed_out, n_frags);
+	NGP_LAUNCH(k_pack_frags, dim3(div_up((uint32_t)n_frags * 512u, 256u)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)wd, (const _Float16 *)wc, (_Float16 *)packed_out, n_frags);
 	NGP_LAUNCH_CHECK("ngp_field_pack_weights");
 	return 0;
 }
@@ -479,7 +479,7 @@ NGP_API int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int layout
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field_bwd<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	hipLaunchKernelGGL((k_field_bwd<T, L>), grid, block, shmem, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid); } while (0)
+	NGP_LAUNCH((k_field_bwd<T, L>), grid, block, shmem, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid); } while (0)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO
@@ -488,7 +488,7 @@ NGP_API int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int layout
 }
 NGP_API int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out, int accumulate) {
 	NGP_REQUIRE(slabs && out, NGP_E_ARG, "ngp_reduce_slabs: null pointer");
-	hipLaunchKernelGGL(k_reduce_slabs, dim3(div_up(width, 64)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, width, out, accumulate);
+	NGP_LAUNCH(k_reduce_slabs, dim3(div_up(width, 64)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, width, out, accumulate);
 	NGP_LAUNCH_CHECK("ngp_reduce_slabs");
 	return 0;
 }
@@ -496,8 +496,8 @@ NGP_API int ngp_sh_encode(void *stream, uint32_t n, const float *dir, uint32_t s
 	NGP_REQUIRE(dir && out && stride >= 3, NGP_E_ARG, "ngp_sh_encode: bad arguments");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_sh_encode: bad dtype %d", dtype);
 	if (n == 0) return 0;
-	if (dtype == NGP_F32) hipLaunchKernelGGL(k_sh<float>, dim3(div_up(n, 128)), dim3(128), 0, (hipStream_t)stream, n, dir, stride, (float *)out);
-	else hipLaunchKernelGGL(k_sh<__half>, dim3(div_up(n, 128)), dim3(128), 0, (hipStream_t)stream, n, dir, stride, (__half *)out);
+	if (dtype == NGP_F32) NGP_LAUNCH(k_sh<float>, dim3(div_up(n, 128)), dim3(128), 0, (hipStream_t)stream, n, dir, stride, (float *)out);
+	else NGP_LAUNCH(k_sh<__half>, dim3(div_up(n, 128)), dim3(128), 0, (hipStream_t)stream, n, dir, stride, (__half *)out);
 	NGP_LAUNCH_CHECK("ngp_sh_encode");
 	return 0;
 }
@@ -505,7 +505,7 @@ NGP_API int ngp_selftest_mfma(void *stream, uint32_t *result) {
 	NGP_REQUIRE(result, NGP_E_ARG, "ngp_selftest_mfma: null pointer");
 	hipError_t e = hipMemsetAsync(result, 0, 16, (hipStream_t)stream);
 	if (e != hipSuccess) { ngp_set_error("ngp_selftest_mfma: %s", hipGetErrorString(e)); return (int)e; }
-	hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, result);
+	NGP_LAUNCH(k_selftest_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, result);
 	NGP_LAUNCH_CHECK("ngp_selftest_mfma");
 	return 0;
 }

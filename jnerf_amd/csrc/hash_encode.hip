@@ -476,7 +476,7 @@ NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint
 	const dim3 grid(16 * nblk), block(256);
 	const LevelTable lt = load_table(level_table_host);
 	hipStream_t s = (hipStream_t)stream;
-#define GO(T, L) hipLaunchKernelGGL((k_hash_fwd<T, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)table, lt, (T *)out, nblk, n_valid)
+#define GO(T, L) NGP_LAUNCH((k_hash_fwd<T, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)table, lt, (T *)out, nblk, n_valid)
 	if (dtype == NGP_F32) { if (out_layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (out_layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO
@@ -663,15 +663,22 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	}
 }
 
+// A level takes the binned path only if it is REALLY hashed: k_bin_records indexes with (x ^ y*p1 ^ z*p2) & (size - 1).  A dense level whose table is large
+// enough for 32 slices (res 80: 512000 entries, reachable with non-power-of-two aabb scales) must stay on the owner-computes scan (chunked, with slabs).
+static bool level_dense_host(uint32_t size, uint32_t res) { uint32_t stride = 1; for (int d = 0; d < 3; ++d) if (stride <= size) stride *= res; return !(size < stride); }
+static bool level_binned(const LevelTable &lt, int l) {
+	const uint32_t size = lt.v[4 * l + 1], res = lt.v[4 * l + 2];
+	return div_up(size, OWN_SLICE) >= 32 && (size & (size - 1)) == 0 && !level_dense_host(size, res);
+}
 static uint64_t hash_bwd_workspace_bytes(const LevelTable &lt) {           // dense-level slabs only
 	uint64_t entries = 0;
-	for (int l = 0; l < 16; ++l) if (div_up(lt.v[4 * l + 1], OWN_SLICE) < 32) entries += (uint64_t)32u * lt.v[4 * l + 1];
+	for (int l = 0; l < 16; ++l) if (!level_binned(lt, l)) entries += (uint64_t)32u * lt.v[4 * l + 1];
 	return (entries * sizeof(float2) + 255) & ~(uint64_t)255;
 }
 static uint32_t bin_capacity(uint32_t n) { uint32_t c = (n / 2 + 1u) & ~1u; return c < 4096u ? 4096u : c; }   // 4x the expected n*8/64 records per bin
 static uint64_t hash_bwd_workspace_bytes_binned(const LevelTable &lt, uint32_t n) {
 	uint32_t n_hashed = 0;
-	for (int l = 0; l < 16; ++l) if (div_up(lt.v[4 * l + 1], OWN_SLICE) >= 32) ++n_hashed;
+	for (int l = 0; l < 16; ++l) if (level_binned(lt, l)) ++n_hashed;
 	return hash_bwd_workspace_bytes(lt) + 4096 /*cursors u32[16*64]*/ + 256 /*absmax u32[16]*/ + (uint64_t)n_hashed * BINS_PER_LEVEL * bin_capacity(n) * sizeof(uint2);
 }
 NGP_API uint64_t ngp_hash_bwd_workspace_bytes(const uint32_t *level_table_host, uint32_t n) { return hash_bwd_workspace_bytes_binned(load_table(level_table_host), n); }
@@ -709,7 +716,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		if (n == 0) return 0;
 		const uint32_t nblk = div_up(n, 256);
 		const dim3 grid(16 * nblk), block(256);
-#define GO(T, G, L) hipLaunchKernelGGL((k_hash_bwd<T, G, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)dLdy, lt, (G *)grad, nblk, n_valid)
+#define GO(T, G, L) NGP_LAUNCH((k_hash_bwd<T, G, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)dLdy, lt, (G *)grad, nblk, n_valid)
 		if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, float, NGP_LAYOUT_SOA); else GO(float, float, NGP_LAYOUT_AOS); }
 		else if (grad_dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(__half, float, NGP_LAYOUT_SOA); else GO(__half, float, NGP_LAYOUT_AOS); }
 		else { if (in_layout == NGP_LAYOUT_SOA) GO(__half, __half, NGP_LAYOUT_SOA); else GO(__half, __half, NGP_LAYOUT_AOS); }
@@ -726,12 +733,12 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	const bool use_bins = use_slabs && !level_scratch && dtype == NGP_F16 && grad_dtype == NGP_F32 && workspace_bytes >= hash_bwd_workspace_bytes_binned(lt, n) && getenv("NGP_HASH_BWD_NO_BINS") == nullptr;
 	uint64_t slab_cursor = 0;
 	bool any_binned = false;
-	for (int l = 0; l < 16; ++l) any_binned |= div_up(lt.v[4 * l + 1], OWN_SLICE) >= 32;
+	for (int l = 0; l < 16; ++l) any_binned |= level_binned(lt, l);
 	const bool fx64 = use_bins && any_binned;                             // the abs-max pass runs -> dense levels can use the 64-bit integer sums
 	for (int l = 0; l < 16; ++l) {
 		slices[l] = div_up(lt.v[4 * l + 1], OWN_SLICE);
 		plan.slab_off[l] = ~0u;
-		if (slices[l] >= 32) { plan.chunks[l] = 1u; continue; }
+		if (level_binned(lt, l)) { plan.chunks[l] = 1u; continue; }
 		if (use_slabs) { plan.chunks[l] = 32u; plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)32u * lt.v[4 * l + 1]; }   // 32 sample chunks per slice, partial slabs
 		else plan.chunks[l] = 32u / slices[l] ? 32u / slices[l] : 1u;
 	}
@@ -773,23 +780,23 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_hash_bwd_owner<T, G, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	if (level_scratch) hipLaunchKernelGGL((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
+	if (level_scratch) NGP_LAUNCH((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
 	if (use_bins && bp.n_levels) { \
 		static bool attr2 = false; \
 		if (!attr2) { hipError_t e = hipFuncSetAttribute((const void *)k_bin_records<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIN_STAGE_BYTES); \
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
 			e = hipFuncSetAttribute((const void *)k_bin_accumulate<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_ENTRIES * 16)); \
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr2 = true; } \
-		hipLaunchKernelGGL((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
+		NGP_LAUNCH((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
 		if (units && side.ok) hipEventRecord(side.fork, s);   /* fork point: the dense-level kernel needs the abs-max too */ \
 		if (!probe_skip_bins) { \
-		hipLaunchKernelGGL((k_bin_records<T, L>), dim3(div_up(n, 1024), bp.n_levels), dim3(1024), BIN_STAGE_BYTES, s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, records, (float *)grad, n_valid); \
-		hipLaunchKernelGGL((k_bin_accumulate<G>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const uint2 *)records, (G *)grad); } \
+		NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, 1024), bp.n_levels), dim3(1024), BIN_STAGE_BYTES, s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, records, (float *)grad, n_valid); \
+		NGP_LAUNCH((k_bin_accumulate<G>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const uint2 *)records, (G *)grad); } \
 	} \
 	hipStream_t sd = s; \
 	if (use_bins && bp.n_levels && units && side.ok) { sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* dense levels run beside the binning kernels */ \
-	if (units) hipLaunchKernelGGL((k_hash_bwd_owner<T, G, L>), grid, block, shmem, sd, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr, fx64 ? (const uint32_t *)absmax : (const uint32_t *)nullptr); \
-	if (use_slabs) hipLaunchKernelGGL((k_reduce_dense<G>), dim3(1024, 16), dim3(256), 0, sd, lt, plan, (const float2 *)workspace, (G *)grad, accumulate & 1); \
+	if (units) NGP_LAUNCH((k_hash_bwd_owner<T, G, L>), grid, block, shmem, sd, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr, fx64 ? (const uint32_t *)absmax : (const uint32_t *)nullptr); \
+	if (use_slabs) NGP_LAUNCH((k_reduce_dense<G>), dim3(1024, 16), dim3(256), 0, sd, lt, plan, (const float2 *)workspace, (G *)grad, accumulate & 1); \
 	if (sd != s) { hipEventRecord(side.join, sd); hipStreamWaitEvent(s, side.join, 0); } } while (0)
 	if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, float, NGP_LAYOUT_SOA); else GO(float, float, NGP_LAYOUT_AOS); }
 	else if (grad_dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(__half, float, NGP_LAYOUT_SOA); else GO(__half, float, NGP_LAYOUT_AOS); }
@@ -851,7 +858,7 @@ NGP_API int ngp_x_probe_hash_bwd(void *stream, uint32_t n, const float *pos, con
 	const LevelTable lt = load_table(level_table_host);
 	const dim3 grid(div_up(n, 256)), block(256);
 	hipStream_t s = (hipStream_t)stream;
-#define GO(S, P) hipLaunchKernelGGL((k_probe_bwd<S, P>), grid, block, 0, s, n, pos, (const __half2 *)dy, lt, grad, level)
+#define GO(S, P) NGP_LAUNCH((k_probe_bwd<S, P>), grid, block, 0, s, n, pos, (const __half2 *)dy, lt, grad, level)
 	if (scope == 0) { if (pk16) GO(0, true); else GO(0, false); } else { if (pk16) GO(1, true); else GO(1, false); }
 #undef GO
 	NGP_LAUNCH_CHECK("ngp_x_probe_hash_bwd");

@@ -14,6 +14,16 @@ void ngp_set_error(const char *fmt, ...);
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// Every kernel launch goes through NGP_LAUNCH: identical to hipLaunchKernelGGL unless the kernel was enabled with ngp_prof_enable, in which case the launch is
+// bracketed by a HIP event pair on its own stream (csrc/prof.hip).
+extern int g_ngp_prof_on;
+int ngp_prof_register(const char *kernel_expr);
+struct NgpProfScope { int id; hipStream_t s; hipEvent_t a, b; NgpProfScope(int id, hipStream_t s); ~NgpProfScope(); };
+#define NGP_LAUNCH(kernel, grid, block, shmem, stream, ...) do { \
+	static const int ngp_kid_ = ngp_prof_register(#kernel); \
+	NgpProfScope ngp_ps_(ngp_kid_, (hipStream_t)(stream)); \
+	hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
+
 struct LevelTable { uint32_t v[64]; };   // [16][4] = offset, size, res, scale bits — passed by value (256 B of kernarg)
 
 // ------------------------------------------------------------------ pcg32 (ops/op_include/pcg32/pcg32.h semantics)

@@ -61,7 +61,7 @@ NGP_API int ngp_grad_to_half(void *stream, uint64_t n, float *grad_f32, void *gr
 	if (n == 0) return 0;
 	const uint64_t n8 = n / 8;
 	uint32_t blocks = (uint32_t)((n8 + 255) / 256); if (blocks > 2048 * 4) blocks = 2048 * 4;
-	hipLaunchKernelGGL(k_grad_to_half, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n8, (float4 *)grad_f32, (uint4 *)grad_f16, zero_src);
+	NGP_LAUNCH(k_grad_to_half, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n8, (float4 *)grad_f32, (uint4 *)grad_f16, zero_src);
 	NGP_LAUNCH_CHECK("ngp_grad_to_half");
 	return 0;
 }
@@ -81,7 +81,7 @@ NGP_API int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g
 	const uint64_t n4 = n / 4;
 	uint32_t blocks = (uint32_t)((n4 + 255) / 256); if (blocks > 2048 * 4) blocks = 2048 * 4;
 	hipStream_t s = (hipStream_t)stream;
-#define GO(G, E, H, Z) hipLaunchKernelGGL((k_adam_ema<G, E, H, Z>), dim3(blocks), dim3(256), 0, s, n4, (float4 *)p, (G *)g, (float4 *)m, (float4 *)v, (float4 *)ema, (uint2 *)p_half, c)
+#define GO(G, E, H, Z) NGP_LAUNCH((k_adam_ema<G, E, H, Z>), dim3(blocks), dim3(256), 0, s, n4, (float4 *)p, (G *)g, (float4 *)m, (float4 *)v, (float4 *)ema, (uint2 *)p_half, c)
 #define GO_Z(G, E, H) do { if (zero_grad) GO(G, E, H, true); else GO(G, E, H, false); } while (0)
 #define GO_H(G, E) do { if (p_half) GO_Z(G, E, true); else GO_Z(G, E, false); } while (0)
 #define GO_E(G) do { if (ema == p) GO_H(G, 2); else if (ema) GO_H(G, 1); else GO_H(G, 0); } while (0)
@@ -120,7 +120,7 @@ NGP_API int ngp_generate_rays(void *stream, uint32_t n, const int64_t *pixel_ind
 	NGP_REQUIRE(pixel_index && focal && metadata && xforms && img_id && rays_o && rays_d, NGP_E_ARG, "ngp_generate_rays: null pointer");
 	NGP_REQUIRE(!target || (images && bg), NGP_E_ARG, "ngp_generate_rays: target requested without images/bg");
 	if (n == 0) return 0;
-	hipLaunchKernelGGL(k_generate_rays, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, pixel_index, W, H, focal, metadata, xforms, images, bg, img_id, rays_o, rays_d, target);
+	NGP_LAUNCH(k_generate_rays, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, pixel_index, W, H, focal, metadata, xforms, images, bg, img_id, rays_o, rays_d, target);
 	NGP_LAUNCH_CHECK("ngp_generate_rays");
 	return 0;
 }

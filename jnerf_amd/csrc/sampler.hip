@@ -266,9 +266,9 @@ NGP_API int ngp_march_rays(void *stream, uint32_t n_rays, const float *rays_o, c
 	const MarchParams p = make_params(aabb0, aabb1, near_distance, cone_angle, const_dt, cascades, rng_state_host);
 	if (zero_coords && coords) { hipError_t e = hipMemsetAsync(coords, 0, (size_t)max_samples * 28, s); if (e != hipSuccess) { ngp_set_error("ngp_march_rays memset: %s", hipGetErrorString(e)); return (int)e; } }
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 8, s); return 0; }
-	hipLaunchKernelGGL(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, (float *)nullptr);
-	hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, n_rays, max_samples, 0u, (const uint32_t *)scratch, numsteps, (uint32_t *)nullptr, ray_indices, counters, 2);
-	hipLaunchKernelGGL(k_march_write<false>, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, (const uint32_t *)numsteps, coords);
+	NGP_LAUNCH(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, (float *)nullptr);
+	NGP_LAUNCH(k_march_scan, dim3(1), dim3(1024), 0, s, n_rays, max_samples, 0u, (const uint32_t *)scratch, numsteps, (uint32_t *)nullptr, ray_indices, counters, 2);
+	NGP_LAUNCH(k_march_write<false>, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, (const uint32_t *)numsteps, coords);
 	NGP_LAUNCH_CHECK("ngp_march_rays");
 	return 0;
 }
@@ -294,9 +294,9 @@ NGP_API int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const fl
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 16, s); return 0; }
 	// scratch = steps[n_rays] | pad to 1024 | t-cache[NGP_TCACHE][n_rays]  (ngp_march_scratch_elems(n_rays) u32 elements)
 	float *tcache = reinterpret_cast<float *>(scratch + ((n_rays + 1023u) & ~1023u));
-	hipLaunchKernelGGL(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
-	hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, s, n_rays, max_samples, cap, (const uint32_t *)scratch, numsteps, numsteps_compacted, (int32_t *)nullptr, counters, 4);
-	hipLaunchKernelGGL(k_march_write_cached, dim3(div_up(cap, 256)), dim3(256), 0, s, n_rays, p, rays_o, rays_d, (const uint32_t *)numsteps_compacted,
+	NGP_LAUNCH(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
+	NGP_LAUNCH(k_march_scan, dim3(1), dim3(1024), 0, s, n_rays, max_samples, cap, (const uint32_t *)scratch, numsteps, numsteps_compacted, (int32_t *)nullptr, counters, 4);
+	NGP_LAUNCH(k_march_write_cached, dim3(div_up(cap, 256)), dim3(256), 0, s, n_rays, p, rays_o, rays_d, (const uint32_t *)numsteps_compacted,
 	                   (const uint32_t *)counters, 3u, (const float *)tcache, coords_out, pos_out);
 	NGP_LAUNCH_CHECK("ngp_march_rays_compacted");
 	return 0;
@@ -338,8 +338,8 @@ NGP_API int ngp_compact_coords(void *stream, uint32_t n_rays, uint32_t cap, cons
 	hipError_t e = hipMemsetAsync(coords_out, 0, (size_t)cap * 28, s);               // compacted_coord.py:38 zero-fills
 	if (e != hipSuccess) { ngp_set_error("ngp_compact_coords memset: %s", hipGetErrorString(e)); return (int)e; }
 	if (n_rays == 0) { hipMemsetAsync(counter, 0, 4, s); return 0; }
-	hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, s, n_rays, cap, numsteps_in, numsteps_out, counter);
-	hipLaunchKernelGGL(k_compact_copy, dim3(div_up(n_rays * 64, 256)), dim3(256), 0, s, n_rays, coords_in, numsteps_in, (const uint32_t *)numsteps_out, coords_out);
+	NGP_LAUNCH(k_compact_scan, dim3(1), dim3(1024), 0, s, n_rays, cap, numsteps_in, numsteps_out, counter);
+	NGP_LAUNCH(k_compact_copy, dim3(div_up(n_rays * 64, 256)), dim3(256), 0, s, n_rays, coords_in, numsteps_in, (const uint32_t *)numsteps_out, coords_out);
 	NGP_LAUNCH_CHECK("ngp_compact_coords");
 	(void)scratch;
 	return 0;
@@ -510,8 +510,8 @@ static int composite_fwd_impl(void *stream, uint32_t n_rays, const void *net, in
 	if (n_rays == 0) return 0;
 	const dim3 grid(div_up(n_rays, 256u / CG_TRAIN)), block(256);
 	hipStream_t s = (hipStream_t)stream;
-	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, false>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
-	else hipLaunchKernelGGL((k_composite_fwd<__half, false>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
+	if (dtype == NGP_F32) NGP_LAUNCH((k_composite_fwd<float, false>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
+	else NGP_LAUNCH((k_composite_fwd<__half, false>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
 	NGP_LAUNCH_CHECK("ngp_composite_fwd");
 	return 0;
 }
@@ -522,8 +522,8 @@ NGP_API int ngp_composite_inference(void *stream, uint32_t n_rays, const void *n
 	if (n_rays == 0) return 0;
 	const dim3 grid(div_up(n_rays, 256u / CG_INFER)), block(256);
 	hipStream_t s = (hipStream_t)stream;
-	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_fwd<float, true>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
-	else hipLaunchKernelGGL((k_composite_fwd<__half, true>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
+	if (dtype == NGP_F32) NGP_LAUNCH((k_composite_fwd<float, true>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
+	else NGP_LAUNCH((k_composite_fwd<__half, true>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
 	NGP_LAUNCH_CHECK("ngp_composite_inference");
 	return 0;
 }
@@ -535,8 +535,8 @@ NGP_API int ngp_composite_bwd(void *stream, uint32_t n_rays, uint32_t n_elems, c
 	if (zero_first) { hipError_t e = hipMemsetAsync(dout, 0, (size_t)n_elems * 4 * (dtype == NGP_F16 ? 2 : 4), s); if (e != hipSuccess) { ngp_set_error("ngp_composite_bwd memset: %s", hipGetErrorString(e)); return (int)e; } }
 	if (n_rays == 0) return 0;
 	const dim3 grid(div_up(n_rays, 256u / CG_TRAIN)), block(256);
-	if (dtype == NGP_F32) hipLaunchKernelGGL((k_composite_bwd<float>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (float *)dout);
-	else hipLaunchKernelGGL((k_composite_bwd<__half>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (__half *)dout);
+	if (dtype == NGP_F32) NGP_LAUNCH((k_composite_bwd<float>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (float *)dout);
+	else NGP_LAUNCH((k_composite_bwd<__half>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (__half *)dout);
 	NGP_LAUNCH_CHECK("ngp_composite_bwd");
 	return 0;
 }
@@ -552,7 +552,7 @@ __global__ void k_huber(uint32_t n, const float *__restrict__ x, const float *__
 NGP_API int ngp_huber(void *stream, uint32_t n, const float *x, const float *target, float delta, float *loss, float *grad) {
 	NGP_REQUIRE(x && target && (loss || grad), NGP_E_ARG, "ngp_huber: null pointer");
 	if (n == 0) return 0;
-	hipLaunchKernelGGL(k_huber, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, x, target, delta, loss, grad);
+	NGP_LAUNCH(k_huber, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, x, target, delta, loss, grad);
 	NGP_LAUNCH_CHECK("ngp_huber");
 	return 0;
 }

@@ -36,7 +36,7 @@ class FusedTrainStep:
         # single-GPU runs issue the whole sequence with ONE call into the library (ngp_train_step); data-parallel runs keep the per-stage calls below
         # because the gradient all-reduce sits between backward and the sweep
         self.timed_stage = None         # name from _lib.STAGES: the library brackets that stage of every native step with HIP events (bench.py)
-        self.native = runner.cfg.native_step is not False and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.native = runner.cfg.native_step is not False and not runner.optimizer._nested_optimizer._dp_active()
         self._args = None
 
     def _ray_bufs(self, nr, dev):
@@ -112,7 +112,7 @@ class FusedTrainStep:
         return [buf[i] for i in range(n)]
 
     def __call__(self, b):
-        if self.native and ops.PROFILE is None:     # (the per-kernel HIP-event brackets of bench.py's probe phase live in the per-stage wrappers)
+        if self.native:
             return self._call_native(b)
         r, s, enc, m = self.r, self.s, self.enc, self.r.model
         coords, numsteps, numsteps_c, n_valid = s._coords, s._rays_numsteps, s._rays_numsteps_compacted, s._n_valid

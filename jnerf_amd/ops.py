@@ -8,30 +8,26 @@ from ._lib import F32, F16, LAYOUT_AOS, LAYOUT_SOA, check
 
 CAP_RAYS = 1 << 18
 
-# ------------------------------------------------------------------ optional per-kernel timing (bench.py): HIP events on the launch stream
-PROFILE = None      # None (off) or dict: name -> list of (start_event, end_event)
-PROFILE_ONLY = None  # if set, only this bracket name is recorded
+# ------------------------------------------------------------------ per-kernel timing (bench.py): HIP event pairs recorded inside the library, on each launch's own stream
+def prof_enable(names):
+    """"" = off, "*" = every kernel, else an iterable / comma-separated string of kernel base names (csrc/prof.hip)"""
+    if not isinstance(names, str):
+        names = ",".join(names)
+    check(L.lib().ngp_prof_enable(names.encode()), "ngp_prof_enable")
 
 
-class timed:
-    """`with ops.timed("hash_bwd"): launch(...)` records a HIP event pair on the current stream when ops.PROFILE is a dict"""
-    __slots__ = ("name", "ev")
-
-    def __init__(self, name):
-        self.name = name
-
-    def __enter__(self):
-        self.ev = None
-        if PROFILE is not None and (PROFILE_ONLY is None or PROFILE_ONLY == self.name):
-            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            self.ev[0].record()
-        return self
-
-    def __exit__(self, *a):
-        if self.ev is not None:
-            self.ev[1].record()
-            PROFILE.setdefault(self.name, []).append(self.ev)
-        return False
+def prof_read(max_n=1 << 16):
+    """-> {kernel name: [ms per launch since the last read]} (synchronises on the recorded events)"""
+    out, idx = {}, 0
+    name = C.create_string_buffer(128)
+    buf = (C.c_float * max_n)()
+    while True:
+        n = L.lib().ngp_prof_read(idx, name, 128, buf, max_n)
+        if n < 0:
+            return out
+        if n:
+            out[name.value.decode()] = [buf[i] for i in range(n)]
+        idx += 1
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -104,8 +100,7 @@ def hash_encode_fwd(pos, table, level_tbl, out=None, layout=LAYOUT_AOS, n_valid=
     n = pos.shape[0]
     if out is None:
         out = torch.empty((n, 32) if layout == LAYOUT_AOS else (16, n, 2), dtype=table.dtype, device=pos.device)
-    with timed("hash_fwd" if n_valid is not None else "hash_fwd_aux"):     # aux = occupancy-grid refresh / standalone encoder calls
-        check(L.lib().ngp_hash_encode_fwd(_stream(), n, _p(pos), stride, _p(table), _tbl(level_tbl), _p(out), _dt(table), layout, _p(n_valid)), "ngp_hash_encode_fwd")
+    check(L.lib().ngp_hash_encode_fwd(_stream(), n, _p(pos), stride, _p(table), _tbl(level_tbl), _p(out), _dt(table), layout, _p(n_valid)), "ngp_hash_encode_fwd")
     return out
 
 
@@ -117,16 +112,15 @@ def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, 
     assert dLdy.is_contiguous()
     if grad is None:
         grad = torch.empty(n_params, dtype=grad_dtype or dLdy.dtype, device=pos.device)
-    with timed("hash_bwd"):
-        if workspace is not None:
-            check(L.lib().ngp_hash_encode_bwd_ws(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
-                                                 int(zero_first), _p(n_valid), _p(fixed_point_scratch), _p(workspace), workspace.numel() * workspace.element_size()), "ngp_hash_encode_bwd_ws")
-        elif fixed_point_scratch is not None:
-            check(L.lib().ngp_hash_encode_bwd_fx(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
-                                                 int(zero_first), _p(n_valid), _p(fixed_point_scratch)), "ngp_hash_encode_bwd_fx")
-        else:
-            check(L.lib().ngp_hash_encode_bwd(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
-                                              int(zero_first), _p(n_valid)), "ngp_hash_encode_bwd")
+    if workspace is not None:
+        check(L.lib().ngp_hash_encode_bwd_ws(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
+                                             int(zero_first), _p(n_valid), _p(fixed_point_scratch), _p(workspace), workspace.numel() * workspace.element_size()), "ngp_hash_encode_bwd_ws")
+    elif fixed_point_scratch is not None:
+        check(L.lib().ngp_hash_encode_bwd_fx(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
+                                             int(zero_first), _p(n_valid), _p(fixed_point_scratch)), "ngp_hash_encode_bwd_fx")
+    else:
+        check(L.lib().ngp_hash_encode_bwd(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
+                                          int(zero_first), _p(n_valid)), "ngp_hash_encode_bwd")
     return grad
 
 
@@ -151,8 +145,7 @@ def field_pack_weights(wd, wc, out=None):
     assert wd.dtype == torch.float16 and wc.dtype == torch.float16 and wd.numel() == 3072 and wc.numel() == 7168
     if out is None:
         out = torch.empty(PACKED_WEIGHT_HALVES, dtype=torch.float16, device=wd.device)
-    with timed("field_pack"):
-        check(L.lib().ngp_field_pack_weights(_stream(), _p(wd), _p(wc), _p(out)), "ngp_field_pack_weights")
+    check(L.lib().ngp_field_pack_weights(_stream(), _p(wd), _p(wc), _p(out)), "ngp_field_pack_weights")
     return out
 
 
@@ -166,8 +159,7 @@ def field_fwd(feat, d, wd, wc, layout=LAYOUT_AOS, out_dtype=torch.float16, out=N
     n = d.shape[0]
     if out is None:
         out = torch.empty((n, 4), dtype=out_dtype, device=d.device)
-    with timed("field_fwd"):
-        check(L.lib().ngp_field_fwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(out), _dt(out), _p(n_valid)), "ngp_field_fwd")
+    check(L.lib().ngp_field_fwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(out), _dt(out), _p(n_valid)), "ngp_field_fwd")
     return out
 
 
@@ -197,8 +189,7 @@ def field_bwd(feat, d, wd, wc, dLdout, layout=LAYOUT_AOS, dfeat=None, slabs=None
         dfeat = torch.zeros_like(feat)
     if slabs is None:
         slabs = torch.empty((ns, 10240), dtype=torch.float32, device=d.device)
-    with timed("field_bwd"):
-        check(L.lib().ngp_field_bwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(dLdout), _dt(dLdout), _p(dfeat), _p(slabs), ns, _p(n_valid)), "ngp_field_bwd")
+    check(L.lib().ngp_field_bwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(dLdout), _dt(dLdout), _p(dfeat), _p(slabs), ns, _p(n_valid)), "ngp_field_bwd")
     return dfeat, slabs
 
 
@@ -259,10 +250,9 @@ def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng_state, max_samples,
     if scratch is None:
         scratch = torch.empty(need, dtype=torch.int32, device=dev)
     assert scratch.numel() >= need, "march scratch too small: use ops.march_scratch_elems(n_rays)"
-    with timed("march"):
-        check(L.lib().ngp_march_rays_compacted_pos(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
-                                                   rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch),
-                                                   _p(pos_out)), "ngp_march_rays_compacted_pos")
+    check(L.lib().ngp_march_rays_compacted_pos(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
+                                               rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch),
+                                               _p(pos_out)), "ngp_march_rays_compacted_pos")
     return coords_out, numsteps, numsteps_c, counters
 
 
@@ -271,8 +261,7 @@ def composite_fwd(net, coords, numsteps, numsteps_c, bg, cascades=5, out=None):
     assert net.is_contiguous() and coords.is_contiguous() and bg.is_contiguous()
     if out is None:
         out = torch.empty((n, 3), dtype=torch.float32, device=net.device)
-    with timed("composite_fwd"):
-        check(L.lib().ngp_composite_fwd(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out)), "ngp_composite_fwd")
+    check(L.lib().ngp_composite_fwd(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out)), "ngp_composite_fwd")
     return out
 
 
@@ -284,9 +273,8 @@ def composite_fwd_huber(net, coords, numsteps, numsteps_c, bg, target, delta, ca
     out = torch.empty((n, 3), dtype=torch.float32, device=dev) if out is None else out
     loss = torch.empty((n, 3), dtype=torch.float32, device=dev) if loss is None else loss
     grad = torch.empty((n, 3), dtype=torch.float32, device=dev) if grad is None else grad
-    with timed("composite_fwd"):
-        check(L.lib().ngp_composite_fwd_huber(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out), _p(target), delta, _p(loss), _p(grad)),
-              "ngp_composite_fwd_huber")
+    check(L.lib().ngp_composite_fwd_huber(_stream(), n, _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out), _p(target), delta, _p(loss), _p(grad)),
+          "ngp_composite_fwd_huber")
     return out, loss, grad
 
 
@@ -295,9 +283,8 @@ def composite_bwd(net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean
     assert net.is_contiguous() and loss_grad.is_contiguous() and rgb_ray.is_contiguous()
     if dout is None:
         dout = torch.empty_like(net)
-    with timed("composite_bwd"):
-        check(L.lib().ngp_composite_bwd(_stream(), n, net.shape[0], _p(net), _dt(net), _p(coords), _p(numsteps_c), _p(loss_grad), _p(rgb_ray), _p(density_grid_mean), cascades, _p(dout), int(zero_first)),
-              "ngp_composite_bwd")
+    check(L.lib().ngp_composite_bwd(_stream(), n, net.shape[0], _p(net), _dt(net), _p(coords), _p(numsteps_c), _p(loss_grad), _p(rgb_ray), _p(density_grid_mean), cascades, _p(dout), int(zero_first)),
+          "ngp_composite_bwd")
     return dout
 
 
@@ -364,8 +351,7 @@ def grad_to_half(g32, g16, zero_src=True):
 
 
 def adam_ema_step(p, g, m, v, ema, p_half, lr, step, b0=0.9, b1=0.99, eps=1e-15, ema_decay=0.95, zero_grad=True):
-    with timed("adam_ema" if p.numel() >= (1 << 20) else "adam_ema_small"):          # the hash table vs the two MLP weight packs
-        check(L.lib().ngp_adam_ema_step(_stream(), p.numel(), _p(p), _p(g), _dt(g), _p(m), _p(v), _p(ema), _p(p_half), lr, b0, b1, eps, step, ema_decay, int(zero_grad)), "ngp_adam_ema_step")
+    check(L.lib().ngp_adam_ema_step(_stream(), p.numel(), _p(p), _p(g), _dt(g), _p(m), _p(v), _p(ema), _p(p_half), lr, b0, b1, eps, step, ema_decay, int(zero_grad)), "ngp_adam_ema_step")
 
 
 def generate_rays(pixel_index, W, H, focal, metadata, xforms, images=None, bg=None):

@@ -23,6 +23,8 @@ def flush_all():
 @OPTIMS.register_module()
 class Adam:
     def __init__(self, params, lr=1e-1, eps=1e-15, betas=(0.9, 0.99), **kwargs):
+        if kwargs:      # jt.nn.Adam also takes weight_decay; the fused sweep does not implement it, and silently training without it would be worse than failing
+            raise TypeError(f"Adam: unsupported arguments {sorted(kwargs)} (supported: lr, eps, betas)")
         self.lr, self.eps, self.betas = lr, eps, tuple(betas)
         params = [p for p in params]
         self.param_groups = [{"params": params, "values": [torch.zeros_like(p) for p in params], "m": [torch.zeros_like(p) for p in params]}]
@@ -65,12 +67,21 @@ class Adam:
     def _world():
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
+    @staticmethod
+    def _dp_active():
+        """gradients go through the collectives: more than one rank, or `dp_force_collectives = True` in the config (a single-rank process group then runs the
+        complete data-parallel sequence - fp16 conversion, RCCL all-reduce on the comm stream, deferred sweep - which is how the RCCL path is tested on a 1-GPU box)"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        from .utils.config import get_cfg
+        return dist.get_world_size() > 1 or get_cfg().dp_force_collectives is True
+
     def allreduce_grads(self):
         """Ray-batch data parallelism: SUM the hash-table gradient (49.9 MB fp32) and the two MLP gradients over ranks — RCCL over xGMI on
         the GPUs, gloo in the CPU unit tests.  On the GPU the collectives are issued on a side stream right after backward and are only
         waited for when the parameters are next READ (flush()): the next iteration's ray generation and occupancy-grid marching — which
         do not depend on the parameters — run underneath the all-reduce."""
-        if self._world() == 1:
+        if not self._dp_active():
             return
         grads = [p.grad for p in self.param_groups[0]["params"] if p.grad is not None]
         # gradients that are views tiling one flat buffer (the two MLP packs, network.py:_flat_weight_grad) travel as ONE collective

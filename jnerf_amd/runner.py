@@ -184,8 +184,13 @@ class Runner:
                 psnr = mse2psnr(self.val_img(i))
                 print("STEP={} | LOSS={} | VAL PSNR={}".format(i, loss.mean().item(), psnr))
         self.drain()
-        self.save_ckpt(os.path.join(self.save_path, "params.pkl"))
-        self.test()
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi or dist.get_rank() == 0:           # replicas are bit-identical: one writer (every rank writing the same files would race)
+            self.save_ckpt(os.path.join(self.save_path, "params.pkl"))
+            self.test()
+        if multi:
+            dist.barrier()
 
     def test(self, load_ckpt=False):
         if load_ckpt:
@@ -211,7 +216,14 @@ class Runner:
 
     def load_ckpt(self, path):
         print("Loading ckpt from:", path)
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        try:
+            ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        except Exception as e:
+            raise RuntimeError(f"{path} is not a checkpoint written by this Runner (torch.save container).  Checkpoints pickled by the reference's Jittor Runner "
+                               f"(jt.save, runner/runner.py:123-135) hold jittor.Var payloads and need Jittor to unpickle; convert them with tools/convert_ckpt.py "
+                               f"on a machine that has Jittor.  Original error: {e!r}") from e
+        if not (isinstance(ckpt, dict) and "model" in ckpt and "global_step" in ckpt):
+            raise RuntimeError(f"{path}: unexpected checkpoint layout (keys {list(ckpt)[:8] if isinstance(ckpt, dict) else type(ckpt)}); expected the keys of runner/runner.py:123-135")
         self.start = ckpt["global_step"]
         self.model.load_state_dict(ckpt["model"])
         self.sampler.load_state_dict(ckpt["sampler"])
@@ -255,20 +267,27 @@ class Runner:
         dev = rays_o_total.device
         imgs = torch.empty((n, 3), device=dev)
         alphas = torch.empty((n, 1), device=dev)
-        counts = torch.zeros(1, dtype=torch.int64, device=dev)
+        counts = torch.zeros(2, dtype=torch.int64, device=dev)      # [samples rendered, chunks whose requested samples exceeded the capacity]
         self.sampler.sync_free_inference = True
         try:
             for pixel in range(0, n, chunk):
                 rays_o, rays_d = rays_o_total[pixel:pixel + chunk], rays_d_total[pixel:pixel + chunk]
                 pos, dirs = self.sampler.sample(img_ids, rays_o, rays_d)
-                counts += self.sampler._inference_counter[3]
+                cnt = self.sampler._inference_counter
+                counts[0] += cnt[3]
+                counts[1] += (cnt[1].to(torch.int64) & 0xffffffff) > self.sampler.max_samples
                 network_outputs = self.model(pos, dirs)
                 rgb, alpha = self.sampler.rays2rgb(network_outputs, inference=True)
                 imgs[pixel:pixel + chunk] = rgb
                 alphas[pixel:pixel + chunk] = alpha
         finally:
             self.sampler.sync_free_inference = False
-        self.n_samples_rendered = int(counts.item())
+        host = counts.tolist()                              # ONE read-back per image: samples rendered + overflow flag
+        self.n_samples_rendered = int(host[0])
+        if host[1] and chunk > self.sampler.max_samples // self.sampler.MAX_STEP:
+            # a chunk asked for more than the sampler's fixed 4096*1024-sample capacity (ray_sampler.py:15): its trailing rays came back empty.  Re-render with
+            # the reference's chunk size (capacity / MAX_STEP = 4096 rays can never overflow) instead of returning black pixels.
+            return self._render_rays(img_ids, rays_o_total, rays_d_total, self.sampler.max_samples // self.sampler.MAX_STEP)
         return imgs, alphas
 
     @torch.no_grad()

@@ -82,6 +82,30 @@ def test_hash_bwd_vs_oracle(H, dtype, grad_dtype):
     GC.close(H.N(g).astype(np.float64) / 2, ref, what="hash bwd workspace accumulate", atol=tol["atol"] * 2, rtol=tol["rtol"] * 2)
 
 
+@pytest.mark.parametrize("aabb_scale", [1, 2, 16, 23.4])
+def test_hash_bwd_workspace_other_level_tables(H, aabb_scale):
+    """levels are routed to the binned path only if they are really hashed.  aabb_scale 23.4 has a DENSE level with res 80 = 512000
+    entries (32 slices of 16384) that the size-only predicate used to bin with the XOR hash; 2 and 16 (colmap2nerf's usual value) have large dense levels."""
+    from jnerf_amd import ops
+    table, offsets, n_params = O.level_table(aabb_scale)
+    rng = np.random.default_rng(11)
+    n = 4097
+    x = synth.uniform_positions(n, seed=12)
+    dy = (rng.normal(size=(n, 32)) * 1e-2).astype(np.float16)
+    ref = O.hash_encode_bwd(x, dy.astype(np.float32), table, n_params)
+    dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n), dtype=torch.uint8, device="cuda")
+    for gdt, tol in ((torch.float32, dict(atol=2e-5, rtol=1.5e-3)), (torch.float16, dict(atol=1e-4, rtol=2e-2))):
+        g = torch.full((n_params,), 3.0, dtype=gdt, device="cuda")
+        ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
+        out = H.N(g).astype(np.float32)
+        for l in range(16):
+            lo, hi = int(offsets[l]) * 2, int(offsets[l + 1]) * 2
+            GC.close(out[lo:hi], ref[lo:hi], what=f"aabb {aabb_scale} level {l} (res {int(table[l, 2])}, size {int(table[l, 1])}) grad {gdt}", **tol)
+    x32 = H.hash_encode_bwd(x, dy.astype(np.float32), table, n_params)             # fp32 table / fp32 gradient
+    GC.close(x32, ref, atol=1e-7, rtol=1e-5, what=f"aabb {aabb_scale} fp32")
+
+
 def test_hash_bwd_fixed_point_vs_oracle_and_deterministic(H):
     """ngp_hash_encode_bwd_fx: 32-bit fixed-point LDS accumulation with the provable scale 2^30 / L1(level)"""
     from jnerf_amd import ops
