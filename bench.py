@@ -211,11 +211,17 @@ def main():
     mean_rays = rays_sum / max(probe, 1) if probe else float(runner.sampler.n_rays_per_batch)
     per_step = {k: sum(max(x - ev_overhead, 0.0) for x in v) / probe for k, v in probe_ms.items()} if probe else {}
     # one kernel can serve launches of very different sizes (k_hash_fwd: the training batch vs the occupancy-grid refresh; k_adam_ema: the table vs the weight
-    # packs): the roofline uses the TRAINING-BATCH class = the launches whose duration is within 2x of the median of the kernel's most frequent class
+    # packs): durations are clustered (a gap of more than 2x starts a new class) and the roofline uses the class that carries most of the kernel's time
     def batch_class(v):
         s = sorted(v)
-        med = s[len(s) // 2]
-        return [x for x in v if 0.5 * med <= x <= 2.0 * med] or v
+        classes, cur = [], [s[0]]
+        for x in s[1:]:
+            if x > 2.0 * cur[0]:
+                classes.append(cur); cur = [x]
+            else:
+                cur.append(x)
+        classes.append(cur)
+        return max(classes, key=sum)                    # the size class that carries most of the kernel's time
     dom = max(per_step, key=lambda k: per_step[k]) if per_step else None
     # ---- warm-up + timed region: only the dominant kernel keeps its bracket
     for _ in range(args.warmup):

@@ -92,6 +92,19 @@ int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int feat_layout, c
 int ngp_field_bwd_slabs(uint32_t n);                       /* number of slabs ngp_field_bwd writes for capacity n */
 int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out /*[width]*/, int accumulate /*out += sum*/);
 
+/* ---- fp32 field network: NGPNetworks.execute_ when cfg.fp16 is unset (ngp_network.py:57-67 falls back to nn.Linear chains in fp32; this is what
+ * projects/ngp/configs/ngp_base.py - the lego headline - runs).  Same fused structure on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).
+ * wd f32[3072] / wc f32[7168]: the same pack layout as above; feat / dLdfeat f32 in `feat_layout`; out / dLdout f32 [n,4]; slabs as ngp_field_bwd.
+ * ngp_field32_pack_weights builds the MFMA-ordered fragments once per step (f32[NGP_PACKED32_WEIGHT_FLOATS], 16-byte aligned; pass with NGP_WEIGHTS_PACKED). */
+#define NGP_PACKED32_WEIGHT_FLOATS 19456
+int ngp_field32_pack_weights(void *stream, const float *wd, const float *wc, float *packed_out);
+int ngp_field32_fwd(void *stream, uint32_t n, const float *feat, int feat_layout, const float *dir, uint32_t dir_stride_floats,
+                    const float *wd, const float *wc, float *out, const uint32_t *n_valid);
+int ngp_density32_fwd(void *stream, uint32_t n, const float *feat, int feat_layout, const float *wd, float *out /*[n]*/);
+int ngp_field32_bwd(void *stream, uint32_t n, const float *feat, int feat_layout, const float *dir, uint32_t dir_stride_floats,
+                    const float *wd, const float *wc, const float *dLdout, float *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid);
+int ngp_field32_bwd_slabs(uint32_t n);
+
 /* ---- sampler ------------------------------------------------------------------------------------------------------
  * rng_state_host: u64[2] = {state, inc} of the reference's global pcg32{1337} (ops/code_ops/global_vars.py:13-16); it is advanced
  * by 2^32 on return exactly like `rng.advance()` at ray_sampler.py:61.  cascades = NERF_CASCADES (5), const_dt per cfg.const_dt. */
@@ -175,11 +188,11 @@ typedef struct NgpTrainStep {
 	const uint32_t *n_valid;    /* device count of valid samples */
 	const float *bg, *target;   /* [n_rays,3] */
 	const float *density_grid_mean;
-	/* hash grid */
-	const void *table_f16; const uint32_t *level_table_host; float *table_grad; uint64_t n_params; void *hash_workspace; uint64_t hash_workspace_bytes;
-	/* field network */
-	const void *wd_f16, *wc_f16; void *packed_weights; void *feat, *dfeat /* f16 [16][n][2] */; void *out, *dout /* f16 [n,4] */;
-	float *wgrad_slabs; uint32_t n_slabs; uint32_t pad0; float *wgrad_flat /* f32[10240], accumulated into */;
+	/* hash grid: `table` is what the gather reads - the fp16 shadow (dtype NGP_F16) or the fp32 parameter itself (NGP_F32) */
+	const void *table; const uint32_t *level_table_host; float *table_grad; uint64_t n_params; void *hash_workspace; uint64_t hash_workspace_bytes;
+	/* field network: weight packs, fragment scratch (f16[NGP_PACKED_WEIGHT_HALVES] | f32[NGP_PACKED32_WEIGHT_FLOATS]), features / their gradient T[16][n][2], outputs T[n,4] */
+	const void *wd, *wc; void *packed_weights; void *feat, *dfeat; void *out, *dout;
+	float *wgrad_slabs; uint32_t n_slabs; int32_t dtype /* NGP_F16: fp16 table shadow + fused fp16-MFMA network (ngp_fox.py); NGP_F32: fp32 table + fp32-MFMA network (ngp_base.py) */; float *wgrad_flat /* f32[10240] */;
 	/* loss */
 	float huber_delta; float pad1; float *rgb, *loss, *loss_grad;   /* [n_rays,3] */
 	/* optimiser: Adam + EMA over n_opt (<= 4) parameter tensors, see ngp_adam_ema_step */
@@ -187,7 +200,10 @@ typedef struct NgpTrainStep {
 	float lr, beta0, beta1, eps, ema_decay, pad2;
 	float *p[4], *g[4], *m[4], *v[4], *ema[4]; void *p_half[4]; uint64_t numel[4];
 	/* measurement: -1 = none, else the stage to bracket with a HIP event pair on `stream` (NGP_STAGE_*); durations are read with ngp_train_step_timings */
-	int32_t timed_stage; int32_t pad3;
+	int32_t timed_stage;
+	/* != 0: the gradient buffers are OVERWRITTEN by this step's backward (hash scatter with zero_first, slab reduction without accumulation) and the sweep does
+	 * not zero them afterwards - 4 B/parameter less traffic than accumulate-then-zero.  0: gradients are accumulated into and zeroed by the sweep. */
+	int32_t grad_overwrite;
 } NgpTrainStep;
 enum { NGP_STAGE_PACK = 0, NGP_STAGE_HASH_FWD, NGP_STAGE_FIELD_FWD, NGP_STAGE_COMPOSITE_FWD, NGP_STAGE_COMPOSITE_BWD, NGP_STAGE_FIELD_BWD, NGP_STAGE_REDUCE_SLABS,
        NGP_STAGE_HASH_BWD, NGP_STAGE_ADAM /* the largest parameter tensor's sweep */,

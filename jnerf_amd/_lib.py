@@ -21,13 +21,13 @@ class NgpTrainStep(C.Structure):
     """mirror of `struct NgpTrainStep` in include/ngp_hip.h (argument block of ngp_train_step)"""
     _fields_ = [("n", _u32), ("n_rays", _u32), ("cascades", _i32), ("run_optimizer", _i32),
                 ("coords", _vp), ("pos", _vp), ("numsteps", _vp), ("numsteps_compacted", _vp), ("n_valid", _vp), ("bg", _vp), ("target", _vp), ("density_grid_mean", _vp),
-                ("table_f16", _vp), ("level_table_host", _vp), ("table_grad", _vp), ("n_params", _u64), ("hash_workspace", _vp), ("hash_workspace_bytes", _u64),
-                ("wd_f16", _vp), ("wc_f16", _vp), ("packed_weights", _vp), ("feat", _vp), ("dfeat", _vp), ("out", _vp), ("dout", _vp),
-                ("wgrad_slabs", _vp), ("n_slabs", _u32), ("pad0", _u32), ("wgrad_flat", _vp),
+                ("table", _vp), ("level_table_host", _vp), ("table_grad", _vp), ("n_params", _u64), ("hash_workspace", _vp), ("hash_workspace_bytes", _u64),
+                ("wd", _vp), ("wc", _vp), ("packed_weights", _vp), ("feat", _vp), ("dfeat", _vp), ("out", _vp), ("dout", _vp),
+                ("wgrad_slabs", _vp), ("n_slabs", _u32), ("dtype", _i32), ("wgrad_flat", _vp),
                 ("huber_delta", _f32), ("pad1", _f32), ("rgb", _vp), ("loss", _vp), ("loss_grad", _vp),
                 ("n_opt", _i32), ("step", _u32), ("lr", _f32), ("beta0", _f32), ("beta1", _f32), ("eps", _f32), ("ema_decay", _f32), ("pad2", _f32),
                 ("p", _vp * 4), ("g", _vp * 4), ("m", _vp * 4), ("v", _vp * 4), ("ema", _vp * 4), ("p_half", _vp * 4), ("numel", _u64 * 4),
-                ("timed_stage", _i32), ("pad3", _i32)]
+                ("timed_stage", _i32), ("grad_overwrite", _i32)]
 
 
 SIGNATURES = {
@@ -47,6 +47,11 @@ SIGNATURES = {
     "ngp_field_bwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _u32, _vp, _vp, _vp, _i32, _vp, _vp, _u32, _vp]),
     "ngp_field_bwd_slabs": (C.c_int, [_u32]),
     "ngp_field_pack_weights": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "ngp_field32_pack_weights": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "ngp_field32_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "ngp_density32_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp]),
+    "ngp_field32_bwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "ngp_field32_bwd_slabs": (C.c_int, [_u32]),
     "ngp_reduce_slabs": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _i32]),
     "ngp_march_rays": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _i32]),
     "ngp_compact_coords": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,475 @@
+// fp32 field network for gfx950: what NGPNetworks.execute_ computes when cfg.fp16 is unset (models/networks/ngp_network.py:57-67, 77-84 — the
+// configuration projects/ngp/configs/ngp_base.py, i.e. the lego headline, runs): SH direction encoding + density MLP (32->64->16) + colour MLP
+// (32->64->64->3), no biases, fp32 weights, fp32 activations, fp32 accumulation; forward and backward (dL/dfeatures + the five weight gradients).
+// The reference executes this as five cuBLAS GEMMs + elementwise kernels + three concats forward and twice that backward, with every [n,64]
+// intermediate written to and re-read from memory (2.3 ms per 2^18-sample batch through rocBLAS here).
+//
+// CDNA4 design (same structure as field_mlp.hip, different matrix instruction):
+//  * v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate (an fma chain; no xf32/TF32 exists on gfx950).  157 TFLOP/s dense peak: one 2^18-sample
+//    batch is 5.4 GFLOP forward / 16.1 GFLOP backward, so the kernels are MFMA-issue-bound, not HBM-bound.
+//  * "transposed" formulation: Y^T[neurons x samples] = W[neurons x k] * X^T[k x samples]; A = weights, B = 16 samples of a wave tile.  The C fragment of a
+//    layer (lane = sample lane&15, registers = neurons 4*(lane>>4)+r of every 16-neuron tile) IS the B operand of the next layer's k-steps: k-step (tile t, r)
+//    takes register r of tile t, i.e. lane group g supplies neuron 16t+4g+r.  The matching A operand W[o][16t+4g+r], r = 0..3, is four CONSECUTIVE floats of
+//    a weight row, so every weight fragment is one 16-byte LDS read per lane serving four MFMAs.  Activations never leave registers between layers.
+//  * weights are staged in LDS as pre-permuted 1-KiB fragments (lane-contiguous: conflict-free ds_read_b128), built once per step by k_pack_frags32.
+//  * backward recomputes the forward, runs dgrad with transposed fragments, and contracts the weight gradients over SAMPLES through LDS ([neuron][sample]
+//    rows, five staging phases that reuse one 66-KiB region), one fp32 slab per workgroup, summed by ngp_reduce_slabs (deterministic, no atomics).
+#include "ngp_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define NF32_FWD 40
+#define NF32_BWD 36
+#define NF32_ALL (NF32_FWD + NF32_BWD)          // == NGP_PACKED32_WEIGHT_FLOATS / 256
+
+// value j (0..3) of weight fragment f for lane (s = lane&15: row of the A tile, g = lane>>4: k index of the MFMA).  fp32 packs, (out,in) row-major:
+// wd: W0 @0 [64][32], W1 @2048 [16][64];  wc: V0 @0 [64][32], V1 @2048 [64][64], V2 @6144 [16][64]   (ngp_network.py:21-29)
+__device__ __forceinline__ float frag_value32(const float *__restrict__ wd, const float *__restrict__ wc, int f, int s, int g, int j) {
+	if (f < 8) { const int u = f >> 1, kq = f & 1; return wd[(16 * u + s) * 32 + 8 * g + 4 * kq + j]; }                         // L0: lane group g holds features 8g..8g+7
+	if (f < 12) { const int kq = f - 8; return wd[2048 + s * 64 + 16 * kq + 4 * g + j]; }                                        // L1
+	if (f < 20) { const int u = (f - 12) >> 1, kq = (f - 12) & 1; return wc[(16 * u + s) * 32 + 16 * kq + 4 * g + j]; }           // L2: input = [density(16) | SH(16)]
+	if (f < 36) { const int u = (f - 20) >> 2, kq = (f - 20) & 3; return wc[2048 + (16 * u + s) * 64 + 16 * kq + 4 * g + j]; }    // L3
+	if (f < 40) { const int kq = f - 36; return wc[6144 + s * 64 + 16 * kq + 4 * g + j]; }                                       // L4
+	f -= 40;                                                                                                                   // backward: A = W^T
+	if (f < 4) return wc[6144 + (4 * g + j) * 64 + 16 * f + s];                                                                 // dG1 = V2^T dO
+	if (f < 20) { const int u = (f - 4) >> 2, t = (f - 4) & 3; return wc[2048 + (16 * t + 4 * g + j) * 64 + 16 * u + s]; }       // dG0 = V1^T dG1
+	if (f < 24) { const int t = f - 20; return wc[(16 * t + 4 * g + j) * 32 + s]; }                                             // dD  = (V0^T dG0)[0:16]
+	if (f < 28) { const int u = f - 24; return wd[2048 + (4 * g + j) * 64 + 16 * u + s]; }                                      // dH  = W1^T dD
+	{ const int u = (f - 28) >> 2, t = (f - 28) & 3; return wd[(16 * t + 4 * g + j) * 32 + 16 * u + s]; }                        // dF  = W0^T dH
+}
+__global__ __launch_bounds__(256) void k_pack_frags32(const float *__restrict__ wd, const float *__restrict__ wc, float *__restrict__ out, int n_frags) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= n_frags * 256) return;
+	const int f = idx >> 8, lane = (idx >> 2) & 63, j = idx & 3;
+	out[idx] = frag_value32(wd, wc, f, lane & 15, lane >> 4, j);
+}
+__device__ __forceinline__ void stage_weights32(float *lds, const float *__restrict__ packed, int n_frags) {
+	const float4 *src = reinterpret_cast<const float4 *>(packed);
+	float4 *dst = reinterpret_cast<float4 *>(lds);
+	for (int idx = threadIdx.x; idx < n_frags * 64; idx += blockDim.x) dst[idx] = src[idx];
+}
+__device__ __forceinline__ floatx4 ld_frag32(const float *lds, int f, int lane) { return *reinterpret_cast<const floatx4 *>(lds + f * 256 + lane * 4); }
+
+__device__ __forceinline__ floatx4 relu4(floatx4 a) { floatx4 r; r[0] = fmaxf(a[0], 0.f); r[1] = fmaxf(a[1], 0.f); r[2] = fmaxf(a[2], 0.f); r[3] = fmaxf(a[3], 0.f); return r; }
+// relu'(activation) * grad; the activation is the exact fp32 pre-activation clamped at zero, so act > 0 <=> pre-activation > 0
+__device__ __forceinline__ floatx4 mask4(floatx4 grad, floatx4 act) {
+	floatx4 r;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) r[k] = act[k] > 0.f ? grad[k] : 0.f;
+	return r;
+}
+
+// degree-4 SH of (2d-1), components 4g..4g+3 (SphericalEncode.h:77-95)
+__device__ __forceinline__ void sh4_32(const float d[3], int g, float o[4]) {
+	const float x = d[0] * 2.f - 1.f, y = d[1] * 2.f - 1.f, z = d[2] * 2.f - 1.f;
+	const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+	if (g == 0) { o[0] = 0.28209479177387814f; o[1] = -0.48860251190291987f * y; o[2] = 0.48860251190291987f * z; o[3] = -0.48860251190291987f * x; }
+	else if (g == 1) { o[0] = 1.0925484305920792f * xy; o[1] = -1.0925484305920792f * yz; o[2] = 0.94617469575755997f * z2 - 0.31539156525251999f; o[3] = -1.0925484305920792f * xz; }
+	else if (g == 2) { o[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2; o[1] = 0.59004358992664352f * y * (-3.0f * x2 + y2); o[2] = 2.8906114426405538f * xy * z; o[3] = 0.45704579946446572f * y * (1.0f - 5.0f * z2); }
+	else { o[0] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f); o[1] = 0.45704579946446572f * x * (1.0f - 5.0f * z2); o[2] = 1.4453057213202769f * z * (x2 - y2); o[3] = 0.59004358992664352f * x * (-x2 + 3.0f * y2); }
+}
+
+// features 8g..8g+7 of sample i (levels 4g..4g+3)
+template <int LAYOUT>
+__device__ __forceinline__ void load_feat32(const float *__restrict__ feat, uint32_t n, uint32_t i, int g, float f[8]) {
+	if (LAYOUT == NGP_LAYOUT_SOA) {
+		const float2 *p = reinterpret_cast<const float2 *>(feat);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { const float2 v = p[(size_t)(4 * g + q) * n + i]; f[2 * q] = v.x; f[2 * q + 1] = v.y; }
+	} else {
+		const float4 *p = reinterpret_cast<const float4 *>(feat + (size_t)i * 32 + 8 * g);
+		const float4 a = p[0], b = p[1];
+		f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+	}
+}
+
+struct Fwd32 { floatx4 h[4], den, g0[4], g1[4], rgb; };      // h, g0, g1: post-ReLU activations (C layout: [tile][r] = neuron 16*tile + 4g + r of sample lane&15)
+
+// one layer: acc[u] (NU output tiles) += sum over NK k-groups of 4 k-steps; A fragments f0 + u*NK + kq, B value of k-group kq, step j = b(kq, j)
+template <bool DENSITY_ONLY>
+__device__ __forceinline__ void forward32(const float *wl, int lane, const float feat[8], const float sh[4], Fwd32 &st) {
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	floatx4 acc[4] = {z, z, z, z};
+#pragma unroll
+	for (int kq = 0; kq < 2; ++kq) {                       // L0: 32 -> 64
+		floatx4 a[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 2 * u + kq, lane);
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+#pragma unroll
+			for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], feat[4 * kq + j], acc[u]);
+	}
+#pragma unroll
+	for (int u = 0; u < 4; ++u) st.h[u] = relu4(acc[u]);
+	floatx4 d0 = z, d1 = z;                                // L1: 64 -> 16, two partial accumulators (a single 16-wide output tile would be a 16-deep dependent chain)
+#pragma unroll
+	for (int kq = 0; kq < 4; ++kq) {
+		const floatx4 a = ld_frag32(wl, 8 + kq, lane);
+		d0 = MFMA32(a[0], st.h[kq][0], d0); d1 = MFMA32(a[1], st.h[kq][1], d1);
+		d0 = MFMA32(a[2], st.h[kq][2], d0); d1 = MFMA32(a[3], st.h[kq][3], d1);
+	}
+	st.den = d0 + d1;
+	if (DENSITY_ONLY) return;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) acc[u] = z;
+#pragma unroll
+	for (int kq = 0; kq < 2; ++kq) {                       // L2: [density(16) | SH(16)] -> 64
+		floatx4 a[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 12 + 2 * u + kq, lane);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const float b = kq == 0 ? st.den[j] : sh[j];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], b, acc[u]);
+		}
+	}
+#pragma unroll
+	for (int u = 0; u < 4; ++u) { st.g0[u] = relu4(acc[u]); acc[u] = z; }
+#pragma unroll
+	for (int kq = 0; kq < 4; ++kq) {                       // L3: 64 -> 64
+		floatx4 a[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 20 + 4 * u + kq, lane);
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+#pragma unroll
+			for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], st.g0[kq][j], acc[u]);
+	}
+#pragma unroll
+	for (int u = 0; u < 4; ++u) st.g1[u] = relu4(acc[u]);
+	d0 = z; d1 = z;                                        // L4: 64 -> 16 (3 used)
+#pragma unroll
+	for (int kq = 0; kq < 4; ++kq) {
+		const floatx4 a = ld_frag32(wl, 36 + kq, lane);
+		d0 = MFMA32(a[0], st.g1[kq][0], d0); d1 = MFMA32(a[1], st.g1[kq][1], d1);
+		d0 = MFMA32(a[2], st.g1[kq][2], d0); d1 = MFMA32(a[3], st.g1[kq][3], d1);
+	}
+	st.rgb = d0 + d1;
+}
+
+template <int LAYOUT, bool DENSITY_ONLY>
+__global__ __launch_bounds__(256) void k_field32_fwd(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+                                                     const float *__restrict__ packed, float *__restrict__ out, const uint32_t *__restrict__ n_valid) {
+	__shared__ __attribute__((aligned(16))) float wl[NF32_FWD * 256];
+	stage_weights32(wl, packed, DENSITY_ONLY ? 12 : NF32_FWD);
+	__syncthreads();
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+	const uint32_t n_tiles = (lim + 15u) / 16u;
+	const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+	auto fetch = [&](uint32_t tile, float f[8], float d[3]) {
+		const uint32_t i = tile * 16u + s;
+		const uint32_t ic = i < lim ? i : lim - 1;
+		load_feat32<LAYOUT>(feat, n, ic, g, f);
+		if (!DENSITY_ONLY) { d[0] = dir[(size_t)ic * dir_stride]; d[1] = dir[(size_t)ic * dir_stride + 1]; d[2] = dir[(size_t)ic * dir_stride + 2]; }
+	};
+	float f[8], fn[8], d[3] = {0.f, 0.f, 0.f}, dn[3] = {0.f, 0.f, 0.f};
+	if (wave < n_tiles) fetch(wave, f, d);
+	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+		const uint32_t i = tile * 16u + s;
+		const bool more = tile + n_waves < n_tiles;
+		if (more) fetch(tile + n_waves, fn, dn);                   // the next tile's inputs are in flight during this tile's 160 MFMAs
+		float sh[4] = {0.f, 0.f, 0.f, 0.f};
+		if (!DENSITY_ONLY) sh4_32(d, g, sh);
+		Fwd32 st;
+		forward32<DENSITY_ONLY>(wl, lane, f, sh, st);
+		if (g == 0 && i < lim) {
+			if (DENSITY_ONLY) out[i] = st.den[0];
+			else *reinterpret_cast<float4 *>(out + (size_t)i * 4) = make_float4(st.rgb[0], st.rgb[1], st.rgb[2], st.den[0]);
+		}
+		if (more) {
+#pragma unroll
+			for (int q = 0; q < 8; ++q) f[q] = fn[q];
+			d[0] = dn[0]; d[1] = dn[1]; d[2] = dn[2];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward
+#define BT32 128               // samples per workgroup trip: 8 waves x 16
+#define RS32 (BT32 + 4)        // LDS row stride in floats (528 B: rows 16-byte aligned; consecutive rows shift by one 16-byte slot => ds_read_b128 of 16 rows is conflict-free up to one pair)
+#define N_ROWS32 128           // largest staging phase
+// weight-gradient staging phases (rows of the [neuron][sample] region); every phase: all waves write their 16 sample columns, barrier, every wave accumulates
+// its tiles over the 128 samples (32 MFMAs per 16x16 tile), barrier:
+//   A : dG1 0..63 | G0 64..127     -> V1  (16 tiles: wave w -> (to = w>>1, ti = 2(w&1), 2(w&1)+1))
+//   B1: dH  0..63 | F  64..95      -> W0  ( 8 tiles: wave w -> (to = w>>1, tj = w&1))
+//   B2: dG0 0..63 | IN2 64..95     -> V0  ( 8 tiles: same map)
+//   C1: dD  0..15 | H  16..79      -> W1  ( 4 tiles: wave w -> tile w&3 over samples 64(w>>2) .. +63)
+//   C2: dO  0..15 | G1 16..79      -> V2  ( 4 tiles: same map)
+
+__device__ __forceinline__ void st_tiles(float *stage, int row0, int col, int g, const floatx4 *v) {      // four 16-neuron tiles
+#pragma unroll
+	for (int t = 0; t < 4; ++t)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) stage[(row0 + 16 * t + 4 * g + r) * RS32 + col] = v[t][r];
+}
+__device__ __forceinline__ floatx4 ld_rows32(const float *stage, int row, int col) { return *reinterpret_cast<const floatx4 *>(stage + row * RS32 + col); }
+// acc += A-rows x B-rows over samples [c0, c1) of the staged region (16 samples per step: lanes g = 0..3 take samples 4g..4g+3 of the step, MFMA j uses sample 4g+j)
+__device__ __forceinline__ floatx4 wgrad_tile(const float *stage, int row_a, int row_b, int o, int g, int c0, int c1, floatx4 acc) {
+#pragma unroll 4
+	for (int c = c0; c < c1; c += 16) {
+		const floatx4 a = ld_rows32(stage, row_a + o, c + 4 * g), b = ld_rows32(stage, row_b + o, c + 4 * g);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], b[j], acc);
+	}
+	return acc;
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(512, 1) void k_field32_bwd(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+                                                        const float *__restrict__ packed, const float *__restrict__ dout,
+                                                        float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid) {
+	extern __shared__ __attribute__((aligned(16))) float smem32[];
+	float *wl = smem32;                                   // 76 fragments
+	float *stage = smem32 + NF32_ALL * 256;               // [N_ROWS32][RS32]
+	stage_weights32(wl, packed, NF32_ALL);
+	const float *wb = wl + NF32_FWD * 256;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+	const uint32_t n_bt = (lim + BT32 - 1) / BT32;
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	const int to = w >> 1, ti0 = 2 * (w & 1), tj = w & 1, tx = w & 3, half = w >> 2;
+	floatx4 aV1[2] = {z, z}, aW0 = z, aV0 = z, aW1 = z, aV2 = z;
+	__syncthreads();
+	struct Inputs { float f[8]; float d3[3]; float go[4]; };
+	auto fetch = [&](uint32_t bt, Inputs &in) {
+		const uint32_t i = bt * BT32 + 16u * w + s;
+		const bool valid = i < lim;
+		const uint32_t ic = valid ? i : lim - 1;
+		load_feat32<LAYOUT>(feat, n, ic, g, in.f);
+		in.d3[0] = dir[(size_t)ic * dir_stride]; in.d3[1] = dir[(size_t)ic * dir_stride + 1]; in.d3[2] = dir[(size_t)ic * dir_stride + 2];
+		in.go[0] = in.go[1] = in.go[2] = in.go[3] = 0.f;
+		if (valid) { const float4 v = *reinterpret_cast<const float4 *>(dout + (size_t)i * 4); in.go[0] = v.x; in.go[1] = v.y; in.go[2] = v.z; in.go[3] = v.w; }
+	};
+	Inputs cur, nxt;
+	if (blockIdx.x < n_bt) fetch(blockIdx.x, cur);
+	for (uint32_t bt = blockIdx.x; bt < n_bt; bt += gridDim.x) {
+		const uint32_t i = bt * BT32 + 16u * w + s;
+		const bool valid = i < lim;
+		const bool more = bt + gridDim.x < n_bt;
+		if (more) fetch(bt + gridDim.x, nxt);
+		float sh[4]; sh4_32(cur.d3, g, sh);
+		Fwd32 st;
+		forward32<false>(wl, lane, cur.f, sh, st);
+		// ---- dgrad chain (register resident, transposed weight fragments)
+		floatx4 dO = z;                                          // register j <-> gradient of output neuron 4g+j; only neurons 0..2 (g == 0) are non-zero
+		if (g == 0) { dO[0] = cur.go[0]; dO[1] = cur.go[1]; dO[2] = cur.go[2]; }
+		floatx4 dG1[4], dG0[4], dH[4], dF[2];
+		{
+			floatx4 a[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, u, lane); dG1[u] = z; }
+#pragma unroll
+			for (int j = 0; j < 3; ++j)                           // k-step 3 would contract output neurons 3, 7, 11, 15: all zero-gradient padding rows
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dG1[u] = MFMA32(a[u][j], dO[j], dG1[u]);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) dG1[u] = mask4(dG1[u], st.g1[u]);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) dG0[u] = z;
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			floatx4 a[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wb, 4 + 4 * u + t, lane);
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dG0[u] = MFMA32(a[u][j], dG1[t][j], dG0[u]);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) dG0[u] = mask4(dG0[u], st.g0[u]);
+		floatx4 dD;
+		{
+			floatx4 d0 = z, d1 = z;
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const floatx4 a = ld_frag32(wb, 20 + t, lane);
+				d0 = MFMA32(a[0], dG0[t][0], d0); d1 = MFMA32(a[1], dG0[t][1], d1);
+				d0 = MFMA32(a[2], dG0[t][2], d0); d1 = MFMA32(a[3], dG0[t][3], d1);
+			}
+			dD = d0 + d1;
+			if (g == 0) dD[0] += cur.go[3];                       // out[:,3] = den[:,0]  (ngp_network.py:83)
+		}
+		{
+			floatx4 a[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, 24 + u, lane); dH[u] = z; }
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dH[u] = MFMA32(a[u][j], dD[j], dH[u]);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) dH[u] = mask4(dH[u], st.h[u]);
+		}
+		dF[0] = z; dF[1] = z;
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			const floatx4 a0 = ld_frag32(wb, 28 + t, lane), a1 = ld_frag32(wb, 32 + t, lane);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { dF[0] = MFMA32(a0[j], dH[t][j], dF[0]); dF[1] = MFMA32(a1[j], dH[t][j], dF[1]); }
+		}
+		if (valid) {                                              // feature 16u+4g+r  ->  level 8u+2g+(r>>1), component r&1
+#pragma unroll
+			for (int u = 0; u < 2; ++u)
+#pragma unroll
+				for (int pr = 0; pr < 2; ++pr) {
+					const float2 v = make_float2(dF[u][2 * pr], dF[u][2 * pr + 1]);
+					const uint32_t level = 8 * u + 2 * g + pr;
+					if (LAYOUT == NGP_LAYOUT_SOA) reinterpret_cast<float2 *>(dfeat)[(size_t)level * n + i] = v;
+					else *reinterpret_cast<float2 *>(dfeat + (size_t)i * 32 + 2 * level) = v;
+				}
+		}
+		// ---- weight gradients: dW[o][i] += sum_s dY[s][o] X[s][i]   (A = dY^T rows o, B = X^T rows i, k = sample)
+		const int col = 16 * w + s, o = lane & 15;
+		// phase A: V1
+		st_tiles(stage, 0, col, g, dG1);
+		st_tiles(stage, 64, col, g, st.g0);
+		__syncthreads();
+		aV1[0] = wgrad_tile(stage, 16 * to, 64 + 16 * ti0, o, g, 0, BT32, aV1[0]);
+		aV1[1] = wgrad_tile(stage, 16 * to, 64 + 16 * (ti0 + 1), o, g, 0, BT32, aV1[1]);
+		__syncthreads();
+		// phase B1: W0
+		st_tiles(stage, 0, col, g, dH);
+#pragma unroll
+		for (int q = 0; q < 8; ++q) stage[(64 + 8 * g + q) * RS32 + col] = cur.f[q];
+		__syncthreads();
+		aW0 = wgrad_tile(stage, 16 * to, 64 + 16 * tj, o, g, 0, BT32, aW0);
+		__syncthreads();
+		// phase B2: V0
+		st_tiles(stage, 0, col, g, dG0);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) { stage[(64 + 4 * g + r) * RS32 + col] = st.den[r]; stage[(80 + 4 * g + r) * RS32 + col] = sh[r]; }
+		__syncthreads();
+		aV0 = wgrad_tile(stage, 16 * to, 64 + 16 * tj, o, g, 0, BT32, aV0);
+		__syncthreads();
+		// phase C1: W1 (each tile's samples split between waves w and w+4)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RS32 + col] = dD[r];
+		st_tiles(stage, 16, col, g, st.h);
+		__syncthreads();
+		aW1 = wgrad_tile(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64, aW1);
+		__syncthreads();
+		// phase C2: V2
+#pragma unroll
+		for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RS32 + col] = dO[r];
+		st_tiles(stage, 16, col, g, st.g1);
+		__syncthreads();
+		aV2 = wgrad_tile(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64, aV2);
+		__syncthreads();
+		if (more) cur = nxt;
+	}
+	// ---- W1 / V2 partial sums of waves 4..7 join those of waves 0..3 through LDS, then one fp32 slab per workgroup, packed like the weights
+	// (wd part 0..3071, wc part 3072..10239); C rows = 4g+r (output neuron within the tile), cols = lane&15 (input neuron within the tile)
+	float *xch = stage;                                       // [4 tiles][2][64 lanes][4]
+	if (half == 1) {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) { xch[((tx * 2 + 0) * 64 + lane) * 4 + r] = aW1[r]; xch[((tx * 2 + 1) * 64 + lane) * 4 + r] = aV2[r]; }
+	}
+	__syncthreads();
+	float *slab = slabs + (size_t)blockIdx.x * 10240;
+	const int ci = lane & 15;
+#pragma unroll
+	for (int r = 0; r < 4; ++r) {
+		const int ro = 4 * g + r;
+#pragma unroll
+		for (int q = 0; q < 2; ++q) slab[3072 + 2048 + (16 * to + ro) * 64 + 16 * (ti0 + q) + ci] = aV1[q][r];
+		slab[(16 * to + ro) * 32 + 16 * tj + ci] = aW0[r];
+		slab[3072 + (16 * to + ro) * 32 + 16 * tj + ci] = aV0[r];
+		if (half == 0) {
+			slab[2048 + ro * 64 + 16 * tx + ci] = aW1[r] + xch[((tx * 2 + 0) * 64 + lane) * 4 + r];
+			slab[3072 + 6144 + ro * 64 + 16 * tx + ci] = aV2[r] + xch[((tx * 2 + 1) * 64 + lane) * 4 + r];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------- C ABI
+static int check_field32(const char *fn, const void *feat, const void *wd, const void *wc, int layout) {
+	const bool prepacked = (layout & NGP_WEIGHTS_PACKED) != 0;
+	layout &= ~NGP_WEIGHTS_PACKED;
+	NGP_REQUIRE(feat && wd && (wc || prepacked), NGP_E_ARG, "%s: null pointer", fn);
+	NGP_REQUIRE(!prepacked || ((uintptr_t)wd & 15) == 0, NGP_E_ALIGN, "%s: packed weight buffer must be 16-byte aligned", fn);
+	NGP_REQUIRE(layout == NGP_LAYOUT_AOS || layout == NGP_LAYOUT_SOA, NGP_E_ARG, "%s: bad layout %d", fn, layout);
+	NGP_REQUIRE(((uintptr_t)feat & 15) == 0, NGP_E_ALIGN, "%s: feature pointer must be 16-byte aligned", fn);
+	return 0;
+}
+static const float *pack_weights32(const char *fn, hipStream_t s, const void *wd, const void *wc, int n_frags, int layout_flags) {
+	if (layout_flags & NGP_WEIGHTS_PACKED) return (const float *)wd;
+	static std::mutex mu;
+	static std::map<std::pair<int, hipStream_t>, float *> pool;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { ngp_set_error("%s: hipGetDevice failed", fn); return nullptr; }
+	float *buf;
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		float *&slot = pool[{dev, s}];
+		if (!slot) { hipError_t e = hipMalloc((void **)&slot, (size_t)NF32_ALL * 256 * sizeof(float)); if (e != hipSuccess) { slot = nullptr; ngp_set_error("%s: hipMalloc(fragment scratch): %s", fn, hipGetErrorString(e)); return nullptr; } }
+		buf = slot;
+	}
+	NGP_LAUNCH(k_pack_frags32, dim3(div_up((uint32_t)n_frags * 256u, 256u)), dim3(256), 0, s, (const float *)wd, (const float *)wc, buf, n_frags);
+	return buf;
+}
+static uint32_t fwd32_grid(uint32_t n) { uint32_t b = div_up(div_up(n, 16), 4); return b < 1024 ? (b ? b : 1) : 1024; }
+
+NGP_API int ngp_field32_pack_weights(void *stream, const float *wd, const float *wc, float *packed_out) {
+	NGP_REQUIRE(wd && wc && packed_out, NGP_E_ARG, "ngp_field32_pack_weights: null pointer");
+	NGP_REQUIRE(((uintptr_t)packed_out & 15) == 0, NGP_E_ALIGN, "ngp_field32_pack_weights: output must be 16-byte aligned");
+	NGP_LAUNCH(k_pack_frags32, dim3(div_up((uint32_t)NF32_ALL * 256u, 256u)), dim3(256), 0, (hipStream_t)stream, wd, wc, packed_out, NF32_ALL);
+	NGP_LAUNCH_CHECK("ngp_field32_pack_weights");
+	return 0;
+}
+NGP_API int ngp_field32_fwd(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const float *wd, const float *wc,
+                            float *out, const uint32_t *n_valid) {
+	int rc = check_field32("ngp_field32_fwd", feat, wd, wc, layout); if (rc) return rc;
+	const int layout_flags = layout; layout &= ~NGP_WEIGHTS_PACKED;
+	NGP_REQUIRE(dir && out && dir_stride >= 3, NGP_E_ARG, "ngp_field32_fwd: bad dir/out");
+	if (n == 0) return 0;
+	hipStream_t s = (hipStream_t)stream;
+	const float *packed = pack_weights32("ngp_field32_fwd", s, wd, wc, NF32_FWD, layout_flags); if (!packed) return NGP_E_ARG;
+	const dim3 grid(fwd32_grid(n)), block(256);
+	if (layout == NGP_LAYOUT_SOA) NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_SOA, false>), grid, block, 0, s, n, feat, dir, dir_stride, packed, out, n_valid);
+	else NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_AOS, false>), grid, block, 0, s, n, feat, dir, dir_stride, packed, out, n_valid);
+	NGP_LAUNCH_CHECK("ngp_field32_fwd");
+	return 0;
+}
+NGP_API int ngp_density32_fwd(void *stream, uint32_t n, const float *feat, int layout, const float *wd, float *out) {
+	int rc = check_field32("ngp_density32_fwd", feat, wd, wd, layout); if (rc) return rc;
+	const int layout_flags = layout; layout &= ~NGP_WEIGHTS_PACKED;
+	NGP_REQUIRE(out, NGP_E_ARG, "ngp_density32_fwd: null out");
+	if (n == 0) return 0;
+	hipStream_t s = (hipStream_t)stream;
+	const float *packed = pack_weights32("ngp_density32_fwd", s, wd, wd, 12, layout_flags); if (!packed) return NGP_E_ARG;
+	const dim3 grid(fwd32_grid(n)), block(256);
+	if (layout == NGP_LAYOUT_SOA) NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_SOA, true>), grid, block, 0, s, n, feat, (const float *)nullptr, 3u, packed, out, (const uint32_t *)nullptr);
+	else NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_AOS, true>), grid, block, 0, s, n, feat, (const float *)nullptr, 3u, packed, out, (const uint32_t *)nullptr);
+	NGP_LAUNCH_CHECK("ngp_density32_fwd");
+	return 0;
+}
+NGP_API int ngp_field32_bwd_slabs(uint32_t n) { uint32_t b = div_up(n, BT32); return (int)(b < 256 ? (b ? b : 1) : 256); }
+NGP_API int ngp_field32_bwd(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const float *wd, const float *wc,
+                            const float *dLdout, float *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid) {
+	int rc = check_field32("ngp_field32_bwd", feat, wd, wc, layout); if (rc) return rc;
+	const int layout_flags = layout; layout &= ~NGP_WEIGHTS_PACKED;
+	NGP_REQUIRE(dir && dLdout && dLdfeat && wgrad_slabs && dir_stride >= 3, NGP_E_ARG, "ngp_field32_bwd: null pointer");
+	NGP_REQUIRE((int)n_slabs == ngp_field32_bwd_slabs(n), NGP_E_ARG, "ngp_field32_bwd: n_slabs %u != ngp_field32_bwd_slabs(%u)", n_slabs, n);
+	if (n == 0) return 0;
+	const size_t shmem = ((size_t)NF32_ALL * 256 + (size_t)N_ROWS32 * RS32) * sizeof(float);
+	const dim3 grid(n_slabs), block(512);
+	hipStream_t s = (hipStream_t)stream;
+	const float *packed = pack_weights32("ngp_field32_bwd", s, wd, wc, NF32_ALL, layout_flags); if (!packed) return NGP_E_ARG;
+#define GO(L) do { \
+	static bool attr_set = false; \
+	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
+	NGP_LAUNCH((k_field32_bwd<L>), grid, block, shmem, s, n, feat, dir, dir_stride, packed, dLdout, dLdfeat, wgrad_slabs, n_valid); } while (0)
+	if (layout == NGP_LAYOUT_SOA) GO(NGP_LAYOUT_SOA); else GO(NGP_LAYOUT_AOS);
+#undef GO
+	NGP_LAUNCH_CHECK("ngp_field32_bwd");
+	return 0;
+}

@@ -169,15 +169,15 @@ __device__ __forceinline__ float bin_scale(uint32_t absmax_bits) {     // power 
 // sum = (sum_y << 32) + sum_x in two's complement, decoded exactly at the flush.  The scale is the power of two with scale * L1(level) <= 2^30,
 // where L1(level) = sum over all samples of |dL/dy| bounds any entry's |sum| — overflow is impossible by construction, integer adds commute,
 // so the exclusive slices become bit-reproducible.
-// FX = 2: each feature as its own 64-bit fixed-point sum (two ds_add_u64).  The scale is 2^8 * the power of two that puts the level's largest |dL/dy| in
-// [2^13, 2^14) (k_level_absmax, shared with the binned path): a register-combined run of <= 8 samples converts with ONE v_cvt_i32_f32 (|x| < 2^25), the quantum is
-// max|dL/dy| * 2^-21 per run (the hashed levels round every contribution to fp16, 2^-11 relative), and a 64-bit sum of 2^24 such terms cannot overflow.
+// FX = 2 (fp32 gradients): each feature as its own 64-bit fixed-point sum (two ds_add_u64).  The scale is the power of two that puts the level's largest |dL/dy|
+// (k_level_absmax, shared with the binned path) in [2^37, 2^38): a contribution of that size keeps all 24 bits of its fp32 significand, one 2^-16 of it
+// still keeps 8, and a 64-bit sum of 2^21 register-combined runs of <= 8 samples cannot overflow.  Integer adds commute => bit-reproducible.
 template <int FX>
 __device__ __forceinline__ void acc_add(float *acc, uint32_t l, float vx, float vy, float fx_scale) {
 	if (FX == 2) {
 		unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + 2 * l;
-		__hip_atomic_fetch_add(a, (unsigned long long)(long long)__float2int_rn(vx * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // |v * scale| < 2^22 * run length: one v_cvt_i32_f32
-		__hip_atomic_fetch_add(a + 1, (unsigned long long)(long long)__float2int_rn(vy * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add(a, (unsigned long long)__float2ll_rn(vx * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add(a + 1, (unsigned long long)__float2ll_rn(vy * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	} else if (FX == 1) {
 		const int ix = __float2int_rn(vx * fx_scale), iy = __float2int_rn(vy * fx_scale);
 		const unsigned long long add = (unsigned long long)(long long)ix + ((unsigned long long)(uint32_t)iy << 32);
@@ -202,7 +202,7 @@ __device__ __forceinline__ float2 acc_read(const float *acc, uint32_t e, float f
 	return make_float2(acc[2 * e], acc[2 * e + 1]);
 }
 
-struct OwnerPlan { uint32_t first_unit[17]; uint32_t chunks[16]; uint32_t order[16]; uint32_t slab_off[16]; uint32_t level_mask; uint32_t coarse_res; };   // slab_off: float2 offset of the level's [chunks][size] partial slabs, ~0u = none
+struct OwnerPlan { uint32_t first_unit[17]; uint32_t chunks[16]; uint32_t order[16]; uint32_t slab_off[16]; uint32_t level_mask; uint32_t coarse_res; uint32_t half_slices /* bit l: level l uses 8192-entry slices (FX = 2, 16 B of LDS per entry) */; };   // slab_off: float2 offset of the level's [chunks][size] partial slabs, ~0u = none
 
 template <typename T, typename G, int LAYOUT, bool HASHED, bool COMBINE, int FX>
 __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, const LevelTable &lt, uint32_t level,
@@ -389,18 +389,27 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float
 	const bool coarse = res <= plan.coarse_res;     // cells much longer than a marching step: consecutive samples of a ray share them
 	const bool dense = level_is_dense(size, res);
 #define OWNER_GO(H, C, F, SC) owner_unit<T, G, LAYOUT, H, C, F>(SC, n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc, slab)
-	if (absmax_bits && slab && dense) {                          // dense level with partial slabs: integer sums, both features in ONE ds_add_u64 (two 32-bit fields)
-		// scale: largest |dL/dy| of the level -> [2^13, 2^14) (k_level_absmax, shared with the binned path), times 2^k with k the largest value that keeps
-		// (samples of this chunk) * 2^14 * 2^k <= 2^31: an entry receives at most one corner (weight <= 1) per sample, so a field cannot overflow.
-		const uint32_t per = (lim + n_chunks - 1) / n_chunks + 8u;
-		int k = 17 - (32 - __builtin_clz(per));
-		const float sc = k < -13 ? 0.f : ldexpf(bin_scale(absmax_bits[level]), k);
+	if (absmax_bits && slab && dense) {                          // dense level with partial slabs: integer sums
+		const bool wide = sizeof(T) == 4;                        // fp32 gradients: one 64-bit sum per feature (FX = 2); fp16: both features in ONE ds_add_u64 (two 32-bit fields)
+		float sc;
+		if (wide) {
+			const float m = __uint_as_float(absmax_bits[level]);
+			int ex = 0; if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);
+			sc = (m > 0.f && m < 3.0e38f) ? ldexpf(1.0f, 38 - ex) : 0.f;
+		} else {
+			// scale: largest |dL/dy| of the level -> [2^13, 2^14) (k_level_absmax, shared with the binned path), times 2^k with k the largest value that keeps
+			// (samples of this chunk) * 2^14 * 2^k <= 2^31: an entry receives at most one corner (weight <= 1) per sample, so a field cannot overflow.
+			const uint32_t per = (lim + n_chunks - 1) / n_chunks + 8u;
+			int k = 17 - (32 - __builtin_clz(per));
+			sc = k < -13 ? 0.f : ldexpf(bin_scale(absmax_bits[level]), k);
+		}
 		if (sc == 0.f) {                                         // no gradient on this level: the slab part is zeros
-			const uint32_t lo = slice * OWN_SLICE, cnt = min(OWN_SLICE, size - lo);
+			const uint32_t SL = wide ? OWN_SLICE / 2 : OWN_SLICE;
+			const uint32_t lo = slice * SL, cnt = min(SL, size - lo);
 			for (uint32_t e = threadIdx.x; e < cnt; e += 1024) slab[(size_t)chunk * size + lo + e] = make_float2(0.f, 0.f);
 			return;
 		}
-		OWNER_GO(false, true, 1, sc);
+		if (wide) OWNER_GO(false, true, 2, sc); else OWNER_GO(false, true, 1, sc);
 	} else if (level_l1) {
 		const float l1 = level_l1[level];
 		if (!(l1 > 0.f)) {                                       // nothing to add on this level: write zeros / leave the accumulating buffer alone
@@ -498,16 +507,23 @@ static int hash_bwd_method() {
 //   A  k_bin_records: one thread per (sample, level) computes the eight (entry, weight*gradient) contributions ONCE, and appends each
 //      to the record list of the 8192-entry bin the entry lives in (64 bins per level).  Slots are handed out by an LDS histogram per
 //      workgroup plus ONE global integer atomic per (workgroup, bin) — ~10^5 global atomics per batch instead of 3*10^7.
-//   B  k_bin_accumulate: one workgroup per bin streams its records (coalesced 8-byte reads) into 64-bit INTEGER accumulators in LDS
-//      (ds_add_u64: 16.6 cycles per wave instruction vs 194 for ds_add_f32) and adds the bin to the gradient with plain stores.
-// A record stores the contribution as fp16 after scaling by the power of two that maps the level's max |dL/dy| into [2^13, 2^14): every
-// fp16 value is a multiple of 2^-24, so value * 2^24 is an exact integer < 2^39 and the sum of up to 2^21 records cannot overflow 63 bits.
-// Result: each contribution is rounded once (2^-11 relative, like the `(__half)(grad*weight)` of HashEncode.h:345), the accumulation itself is
-// EXACT and order-independent => bit-reproducible gradients (the reference's fp16 atomics round after every add, in random order).
+//   B  k_bin_accumulate: one workgroup per bin streams its records (coalesced reads) into 64-bit INTEGER accumulators in LDS
+//      (ds_add_u64: 16.6 cycles per wave instruction vs 194 for ds_add_f32) and writes the bin's slice of the gradient with plain stores.
+// A record is a 16-bit entry index inside the bin plus the contribution, kept as two streams (structure of arrays: 2 + 4 bytes for fp16 gradients, 2 + 8 for
+// fp32 - the 8-byte {u32 index, half2} records of round 1 moved a third more bytes).
+//   fp16 dL/dy: the contribution is stored as fp16 after scaling by the power of two that maps the level's max |dL/dy| into [2^13, 2^14): every fp16 value is a
+//     multiple of 2^-24, so value * 2^24 is an exact integer < 2^39 and the sum of up to 2^21 records cannot overflow 63 bits.  Each contribution is rounded once
+//     (2^-11 relative, like the `(__half)(grad*weight)` of HashEncode.h:345).
+//   fp32 dL/dy (ngp_base.py): the contribution is stored as fp32 and converted to fixed point at 2^38 / max|dL/dy| (see acc_add<2>): fp32-exact for every
+//     contribution within 2^-14 of the level's largest, and still 2^-10-relative 14 binades further down.
+// In both cases the accumulation itself is EXACT and order-independent => bit-reproducible gradients (the reference's atomics round after every add, in
+// random order).  A bin that overflows its record capacity (pathological clustering: all samples in a few cells) spills to one shared list that the bin's
+// owner scans before it writes - no float atomics anywhere, still deterministic, just slow in that corner.
 #define BIN_BITS 13u
 #define BIN_ENTRIES (1u << BIN_BITS)
 #define BINS_PER_LEVEL 64u
-struct BinPlan { uint32_t level[16]; uint32_t n_levels; uint32_t cap; };   // hashed levels, records per bin
+struct BinPlan { uint32_t level[16]; uint32_t n_levels; uint32_t cap; uint32_t spill_cap; };   // hashed levels, records per bin, entries of the spill list
+struct SpillEntry { uint32_t key /* hashed-level ordinal << 19 | entry */; float x, y; };       // value in record units (fp16 path: scaled)
 
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__restrict__ dLdy, uint32_t *__restrict__ absmax_bits, const uint32_t *__restrict__ n_valid) {
@@ -541,28 +557,35 @@ __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__res
 	}
 }
 
-// Records are staged in LDS grouped by bin and written out run by run: a wave then stores 64 consecutive records (four full 128-byte lines) instead of 64
-// scattered 8-byte words.  The scattered version was bound by the L2 request rate (2.4e7 partial-line writes ~ one per clock per channel), not by bytes.
-#define BIN_STAGE_BYTES (1024u * 8u * 8u + 3u * BINS_PER_LEVEL * 4u)
+// Records are staged in LDS grouped by bin and written out run by run: a wave then stores 64 consecutive records (full lines) instead of 64
+// scattered words.  The scattered version was bound by the L2 request rate (2.4e7 partial-line writes ~ one per clock per channel), not by bytes.
+template <typename T> struct RecVal;
+template <> struct RecVal<__half> { using type = __half2; };
+template <> struct RecVal<float> { using type = float2; };
+template <typename T> constexpr uint32_t bin_stage_bytes() { return 1024u * 8u * (uint32_t)(sizeof(typename RecVal<T>::type) + 4u) + 3u * BINS_PER_LEVEL * 4u; }
+
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(1024) void k_bin_records(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp,
-                                                      const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ cursors, uint2 *__restrict__ records,
-                                                      float *__restrict__ grad_f32, const uint32_t *__restrict__ n_valid) {
-	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
-	uint2 *stage = reinterpret_cast<uint2 *>(bin_smem);                       // [8192] records, grouped by bin
-	uint32_t *cnt = bin_smem + 1024u * 8u * 2u, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL;
+                                                      const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ cursors, typename RecVal<T>::type *__restrict__ rec_val,
+                                                      uint16_t *__restrict__ rec_idx, uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill,
+                                                      const uint32_t *__restrict__ n_valid) {
 	using P = typename Pair<T>::type;
+	using RV = typename RecVal<T>::type;
+	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
+	RV *stage_val = reinterpret_cast<RV *>(bin_smem);                                   // [8192] contributions, grouped by bin
+	uint32_t *stage_idx = bin_smem + 1024u * 8u * (sizeof(RV) / 4u);                     // [8192] level-wide entry indices
+	uint32_t *cnt = stage_idx + 1024u * 8u, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL;
 	const uint32_t hl = blockIdx.y, level = bp.level[hl];
-	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1];
+	const uint32_t size = lt.v[4 * level + 1];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
-	const float vs = bin_scale(absmax_bits[level]);
+	const float vs = sizeof(T) == 2 ? bin_scale(absmax_bits[level]) : (absmax_bits[level] ? 1.0f : 0.f);       // fp32 records are stored unscaled
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
 	if (vs == 0.f || blockIdx.x * 1024u >= lim) return;                // uniform exit
 	if (threadIdx.x < BINS_PER_LEVEL) cnt[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
 	const P *dy = reinterpret_cast<const P *>(dLdy);
-	uint32_t idx[8], rank[8]; __half2 val[8];
+	uint32_t idx[8], rank[8]; RV val[8];
 	bool live = false;
 	if (i < lim) {
 		const float2 g2 = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level]);
@@ -576,7 +599,7 @@ __global__ __launch_bounds__(1024) void k_bin_records(uint32_t n, const float *_
 				const uint32_t ex = c.g[0] + (q & 1u), ey = ty0 + ((q & 2u) ? 19349663u : 0u), ez = tz0 + ((q & 4u) ? 83492791u : 0u);
 				idx[q] = (ex ^ ey ^ ez) & (size - 1);
 				const float w = ((q & 1u) ? c.w[0] : 1 - c.w[0]) * ((q & 2u) ? c.w[1] : 1 - c.w[1]) * ((q & 4u) ? c.w[2] : 1 - c.w[2]);
-				val[q] = __floats2half2_rn(gx * w, gy * w);
+				from_f2(val[q], make_float2(gx * w, gy * w));
 				rank[q] = atomicAdd(&cnt[idx[q] >> BIN_BITS], 1u);
 			}
 		}
@@ -594,71 +617,111 @@ __global__ __launch_bounds__(1024) void k_bin_records(uint32_t n, const float *_
 	if (live) {
 #pragma unroll
 		for (uint32_t q = 0; q < 8; ++q) {
-			const uint32_t bin = idx[q] >> BIN_BITS;
-			uint2 r; r.x = idx[q]; r.y = *reinterpret_cast<uint32_t *>(&val[q]);          // full level index for now: the copy-out needs the bin
-			stage[loff[bin] + rank[q]] = r;
+			const uint32_t slot = loff[idx[q] >> BIN_BITS] + rank[q];
+			stage_val[slot] = val[q]; stage_idx[slot] = idx[q];
 		}
 	}
 	__syncthreads();
 	const uint32_t total = loff[BINS_PER_LEVEL - 1] + cnt[BINS_PER_LEVEL - 1];
 	for (uint32_t p = threadIdx.x; p < total; p += 1024u) {
-		uint2 r = stage[p];
-		const uint32_t bin = r.x >> BIN_BITS, slot = base[bin] + (p - loff[bin]);
+		const uint32_t e = stage_idx[p];
+		const RV v = stage_val[p];
+		const uint32_t bin = e >> BIN_BITS, slot = base[bin] + (p - loff[bin]);
 		if (slot < bp.cap) {
-			r.x &= BIN_ENTRIES - 1u;
-			records[((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap + slot] = r;
-		} else {                                                        // bin full (pathological clustering): add this contribution directly
-			const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&r.y));
-			atomic_add_pair(grad_f32 + ((size_t)off + r.x) * 2, make_float2(v.x / vs, v.y / vs));
+			const size_t r = ((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap + slot;
+			rec_val[r] = v; rec_idx[r] = (uint16_t)(e & (BIN_ENTRIES - 1u));
+		} else {                                                        // bin full (pathological clustering): the shared spill list, scanned by the bin's owner
+			const uint32_t k = atomicAdd(spill_count, 1u);
+			if (k < bp.spill_cap) { const float2 f = to_f2(v); spill[k] = SpillEntry{(hl << 19) | e, f.x, f.y}; }
 		}
 	}
 }
 
-template <typename G>
+// value of one record in the accumulator's integer unit.  fp16 records: multiples of 2^-24 (exact).  fp32 records: fixed point at `s32` (see acc_add<2>).
+__device__ __forceinline__ void rec_to_fixed(__half2 v, float, long long &ix, long long &iy) {
+	const float2 f = __half22float2(v);
+	ix = (long long)(f.x * 16777216.0f); iy = (long long)(f.y * 16777216.0f);
+}
+__device__ __forceinline__ void rec_to_fixed(float2 v, float s32, long long &ix, long long &iy) { ix = __float2ll_rn(v.x * s32); iy = __float2ll_rn(v.y * s32); }
+
+template <typename G, typename RV>
 __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan bp, const uint32_t *__restrict__ absmax_bits, const uint32_t *__restrict__ cursors,
-                                                         const uint2 *__restrict__ records, G *__restrict__ grad) {
-	extern __shared__ __attribute__((aligned(16))) unsigned long long iacc[];   // [BIN_ENTRIES][2] 64-bit fixed point (units of 2^-24 / scale)
+                                                         const RV *__restrict__ rec_val, const uint16_t *__restrict__ rec_idx, const uint32_t *__restrict__ spill_count,
+                                                         const SpillEntry *__restrict__ spill, G *__restrict__ grad, int overwrite) {
+	extern __shared__ __attribute__((aligned(16))) unsigned long long iacc[];   // [BIN_ENTRIES][2] 64-bit fixed point
 	using GP = typename Pair<G>::type;
+	constexpr bool F32 = sizeof(RV) == 8;
 	const uint32_t hl = blockIdx.x / BINS_PER_LEVEL, bin = blockIdx.x % BINS_PER_LEVEL, level = bp.level[hl];
-	const float vs = bin_scale(absmax_bits[level]);
-	const uint32_t count = min(cursors[hl * BINS_PER_LEVEL + bin], bp.cap);
-	if (vs == 0.f || count == 0) return;                                // nothing to add (the destination is accumulated into, never overwritten)
+	const uint32_t amax = absmax_bits[level];
+	float s32 = 0.f, inv;
+	if (F32) {
+		const float m = __uint_as_float(amax);
+		if (m > 0.f && m < 3.0e38f) { int ex; frexpf(m, &ex); s32 = ldexpf(1.0f, 38 - ex); }
+		inv = s32 > 0.f ? 1.0f / s32 : 0.f;
+	} else {
+		const float vs = bin_scale(amax);
+		s32 = vs;                                                            // (only its zero-ness is used on this path)
+		inv = vs > 0.f ? 1.0f / (vs * 16777216.0f) : 0.f;
+	}
+	const uint32_t raw = cursors[hl * BINS_PER_LEVEL + bin];
+	const uint32_t count = min(raw, bp.cap);
+	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level] + (size_t)bin * BIN_ENTRIES;
+	if (s32 == 0.f || count == 0) {                                      // nothing to add: an accumulating destination is left alone, an overwritten one gets its zeros
+		if (overwrite) { GP zv; from_f2(zv, make_float2(0.f, 0.f)); for (uint32_t e = threadIdx.x; e < BIN_ENTRIES; e += 1024) dst[e] = zv; }
+		return;
+	}
 	for (uint32_t e = threadIdx.x; e < BIN_ENTRIES * 2; e += 1024) iacc[e] = 0ull;
 	__syncthreads();
-	const uint2 *rec = records + ((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap;
-	auto add = [&](uint32_t local, uint32_t packed) {
-		const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&packed));
-		const long long ix = (long long)(v.x * 16777216.0f), iy = (long long)(v.y * 16777216.0f);    // exact: fp16 values are multiples of 2^-24
+	const size_t r0 = ((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap;             // cap % 8 == 0: both streams of a bin start 16-byte aligned
+	auto add = [&](uint32_t local, RV v) {
+		long long ix, iy; rec_to_fixed(v, s32, ix, iy);
 		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		__hip_atomic_fetch_add(&iacc[2 * local + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	};
 	// one workgroup per CU (128 KiB of LDS) and ~32 records per thread: with one load per trip the loop is a chain of HBM round trips.
-	// Eight records (four 16-byte loads) are requested before the first is used.
-	const uint4 *rec2 = reinterpret_cast<const uint4 *>(rec);              // two records per load (bin regions are 16-byte aligned: cap is even)
-	const uint32_t pairs = count >> 1;
+	// Each thread takes K consecutive records per trip (one 16-byte load of values, one 4- or 8-byte load of indices), four trips in flight.
+	constexpr uint32_t K = F32 ? 2 : 4;
+	struct alignas(16) V16 { RV v[K]; };
+	struct alignas(2 * K) I16 { uint16_t i[K]; };
+	const V16 *pv = reinterpret_cast<const V16 *>(rec_val + r0);
+	const I16 *pi = reinterpret_cast<const I16 *>(rec_idx + r0);
+	const uint32_t groups = count / K;
 	uint32_t r = threadIdx.x;
-	for (; r + 3 * 1024 < pairs; r += 4 * 1024) {
-		uint4 x[4];
+	for (; r + 3 * 1024 < groups; r += 4 * 1024) {
+		V16 x[4]; I16 k[4];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) x[u] = rec2[r + u * 1024];
+		for (int u = 0; u < 4; ++u) { x[u] = pv[r + u * 1024]; k[u] = pi[r + u * 1024]; }
 #pragma unroll
-		for (int u = 0; u < 4; ++u) { add(x[u].x, x[u].y); add(x[u].z, x[u].w); }
+		for (int u = 0; u < 4; ++u)
+#pragma unroll
+			for (uint32_t q = 0; q < K; ++q) add(k[u].i[q], x[u].v[q]);
 	}
-	for (; r < pairs; r += 1024) { const uint4 x = rec2[r]; add(x.x, x.y); add(x.z, x.w); }
-	if ((count & 1u) && threadIdx.x == 0) { const uint2 x = rec[count - 1]; add(x.x, x.y); }
-	__syncthreads();
-	const float inv = 1.0f / (vs * 16777216.0f);
-	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level] + (size_t)bin * BIN_ENTRIES;
-	GP oldv[BIN_ENTRIES / 1024];
+	for (; r < groups; r += 1024) {
+		const V16 x = pv[r]; const I16 k = pi[r];
 #pragma unroll
-	for (uint32_t k = 0; k < BIN_ENTRIES / 1024; ++k) oldv[k] = dst[threadIdx.x + k * 1024];      // all eight read-modify-write loads in flight
+		for (uint32_t q = 0; q < K; ++q) add(k.i[q], x.v[q]);
+	}
+	if (threadIdx.x < count - groups * K) { const uint32_t t = groups * K + threadIdx.x; add(rec_idx[r0 + t], rec_val[r0 + t]); }
+	if (raw > bp.cap) {                                                   // this bin overflowed: its surplus records are somewhere in the shared spill list
+		const uint32_t ns = min(*spill_count, bp.spill_cap), key_lo = (hl << 19) | (bin << BIN_BITS);
+		for (uint32_t t = threadIdx.x; t < ns; t += 1024) {
+			const SpillEntry se = spill[t];
+			if ((se.key & ~(BIN_ENTRIES - 1u)) == key_lo) { RV v; from_f2(v, make_float2(se.x, se.y)); add(se.key & (BIN_ENTRIES - 1u), v); }
+		}
+	}
+	__syncthreads();
+	GP oldv[BIN_ENTRIES / 1024];
+	if (!overwrite) {
+#pragma unroll
+		for (uint32_t k = 0; k < BIN_ENTRIES / 1024; ++k) oldv[k] = dst[threadIdx.x + k * 1024];      // all eight read-modify-write loads in flight
+	}
 #pragma unroll
 	for (uint32_t k = 0; k < BIN_ENTRIES / 1024; ++k) {
 		const uint32_t e = threadIdx.x + k * 1024;
 		const long long sx = (long long)iacc[2 * e], sy = (long long)iacc[2 * e + 1];
-		if (sx == 0 && sy == 0) continue;
-		const float2 old = to_f2(oldv[k]);
-		GP o; from_f2(o, make_float2(old.x + (float)sx * inv, old.y + (float)sy * inv));
+		float2 v = make_float2((float)sx * inv, (float)sy * inv);
+		if (!overwrite) { if (sx == 0 && sy == 0) continue; const float2 old = to_f2(oldv[k]); v.x += old.x; v.y += old.y; }
+		GP o; from_f2(o, v);
 		dst[e] = o;
 	}
 }
@@ -675,12 +738,24 @@ static uint64_t hash_bwd_workspace_bytes(const LevelTable &lt) {           // de
 	for (int l = 0; l < 16; ++l) if (!level_binned(lt, l)) entries += (uint64_t)32u * lt.v[4 * l + 1];
 	return (entries * sizeof(float2) + 255) & ~(uint64_t)255;
 }
-static uint32_t bin_capacity(uint32_t n) { uint32_t c = (n / 2 + 1u) & ~1u; return c < 4096u ? 4096u : c; }   // 4x the expected n*8/64 records per bin
-static uint64_t hash_bwd_workspace_bytes_binned(const LevelTable &lt, uint32_t n) {
-	uint32_t n_hashed = 0;
-	for (int l = 0; l < 16; ++l) if (level_binned(lt, l)) ++n_hashed;
-	return hash_bwd_workspace_bytes(lt) + 4096 /*cursors u32[16*64]*/ + 256 /*absmax u32[16]*/ + (uint64_t)n_hashed * BINS_PER_LEVEL * bin_capacity(n) * sizeof(uint2);
+static uint32_t bin_capacity(uint32_t n) { uint32_t c = (n / 2 + 7u) & ~7u; return c < 4096u ? 4096u : c; }   // 4x the expected n*8/64 records per bin; % 8: 16-byte aligned streams
+// workspace = dense-level slabs | cursors u32[16*64] | absmax u32[16], spill count u32 | record values | record indices | spill list
+struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, total; uint32_t cap, spill_cap, n_hashed; };
+static WsLayout ws_layout(const LevelTable &lt, uint32_t n) {
+	WsLayout w;
+	w.n_hashed = 0;
+	for (int l = 0; l < 16; ++l) if (level_binned(lt, l)) ++w.n_hashed;
+	w.cap = bin_capacity(n);
+	w.spill_cap = w.n_hashed * 8u * (n < (1u << 25) / (w.n_hashed ? w.n_hashed : 1u) ? n : (1u << 25) / (w.n_hashed ? w.n_hashed : 1u));   // worst case: every record of every hashed level overflows (12 B each)
+	w.cursors = hash_bwd_workspace_bytes(lt);
+	w.absmax = w.cursors + 4096;
+	w.rec_val = w.absmax + 256;
+	w.rec_idx = w.rec_val + (uint64_t)w.n_hashed * BINS_PER_LEVEL * w.cap * sizeof(float2);       // sized for fp32 contributions
+	w.spill = (w.rec_idx + (uint64_t)w.n_hashed * BINS_PER_LEVEL * w.cap * sizeof(uint16_t) + 255) & ~(uint64_t)255;
+	w.total = w.spill + (uint64_t)w.spill_cap * sizeof(SpillEntry);
+	return w;
 }
+static uint64_t hash_bwd_workspace_bytes_binned(const LevelTable &lt, uint32_t n) { return ws_layout(lt, n).total; }
 NGP_API uint64_t ngp_hash_bwd_workspace_bytes(const uint32_t *level_table_host, uint32_t n) { return hash_bwd_workspace_bytes_binned(load_table(level_table_host), n); }
 
 // helper stream for the dense-level kernels of the binned path (created once per process; the hash table gradient regions of the two paths are disjoint)
@@ -728,15 +803,18 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	OwnerPlan plan;
 	uint32_t slices[16], units = 0, k = 0;
 	const bool use_slabs = workspace && workspace_bytes >= hash_bwd_workspace_bytes(lt);
-	// binned path for the hashed levels: needs the full workspace, fp16 dL/dy (records carry fp16 contributions — the same precision class as their input;
-	// an fp32 table keeps the float scan), fp32 gradient (the overflow fallback adds floats) and no fixed-point request
-	const bool use_bins = use_slabs && !level_scratch && dtype == NGP_F16 && grad_dtype == NGP_F32 && workspace_bytes >= hash_bwd_workspace_bytes_binned(lt, n) && getenv("NGP_HASH_BWD_NO_BINS") == nullptr;
+	// binned path for the hashed levels: needs the full workspace and no fixed-point request; fp32 dL/dy keeps fp32 contributions and an fp32 gradient
+	const WsLayout wl = ws_layout(lt, n);
+	const bool use_bins = use_slabs && !level_scratch && (dtype == NGP_F16 || grad_dtype == NGP_F32) && workspace_bytes >= wl.total && getenv("NGP_HASH_BWD_NO_BINS") == nullptr;
 	uint64_t slab_cursor = 0;
 	bool any_binned = false;
 	for (int l = 0; l < 16; ++l) any_binned |= level_binned(lt, l);
-	const bool fx64 = use_bins && any_binned;                             // the abs-max pass runs -> dense levels can use the 64-bit integer sums
+	const bool fx64 = use_bins && any_binned;                             // the abs-max pass runs -> dense levels can use the integer sums
+	plan.half_slices = 0;
 	for (int l = 0; l < 16; ++l) {
-		slices[l] = div_up(lt.v[4 * l + 1], OWN_SLICE);
+		const bool wide = fx64 && dtype == NGP_F32 && !level_binned(lt, l);          // fp32 dense level with slabs: 64-bit sum per feature, 8192-entry slices
+		if (wide) plan.half_slices |= 1u << l;
+		slices[l] = div_up(lt.v[4 * l + 1], wide ? OWN_SLICE / 2 : OWN_SLICE);
 		plan.slab_off[l] = ~0u;
 		if (level_binned(lt, l)) { plan.chunks[l] = 1u; continue; }
 		if (use_slabs) { plan.chunks[l] = 32u; plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)32u * lt.v[4 * l + 1]; }   // 32 sample chunks per slice, partial slabs
@@ -750,17 +828,17 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 				++k;
 			}
 	plan.first_unit[16] = units;
-	BinPlan bp; bp.n_levels = 0; bp.cap = bin_capacity(n);
+	BinPlan bp; bp.n_levels = 0; bp.cap = wl.cap; bp.spill_cap = wl.spill_cap;
 	for (int l = 0; l < 16; ++l) if (plan.chunks[l] == 1) bp.level[bp.n_levels++] = (uint32_t)l;
 	char *ws = (char *)workspace;
-	uint32_t *cursors = use_bins ? (uint32_t *)(ws + hash_bwd_workspace_bytes(lt)) : nullptr;
-	uint32_t *absmax = use_bins ? cursors + 1024 : nullptr;
-	uint2 *records = use_bins ? (uint2 *)(ws + hash_bwd_workspace_bytes(lt) + 4096 + 256) : nullptr;
+	uint32_t *cursors = use_bins ? (uint32_t *)(ws + wl.cursors) : nullptr;
+	uint32_t *absmax = use_bins ? (uint32_t *)(ws + wl.absmax) : nullptr;
+	uint32_t *spill_count = use_bins ? absmax + 16 : nullptr;
+	void *rec_val = use_bins ? (void *)(ws + wl.rec_val) : nullptr;
+	uint16_t *rec_idx = use_bins ? (uint16_t *)(ws + wl.rec_idx) : nullptr;
+	SpillEntry *spill = use_bins ? (SpillEntry *)(ws + wl.spill) : nullptr;
 	if (use_bins) {
-		hipError_t e = hipMemsetAsync(cursors, 0, 4096 + 256, s);
-		if (e == hipSuccess && zero_first)                               // phase B accumulates into the gradient: clear the hashed levels first
-			for (uint32_t h = 0; h < bp.n_levels && e == hipSuccess; ++h)
-				e = hipMemsetAsync((char *)grad + (size_t)lt.v[4 * bp.level[h]] * 2 * gsz, 0, (size_t)lt.v[4 * bp.level[h] + 1] * 2 * gsz, s);
+		hipError_t e = hipMemsetAsync(cursors, 0, 4096 + 256, s);       // cursors, abs-max, spill count.  (zero_first needs no memset of the hashed levels: phase B overwrites them)
 		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; }
 	}
 	{ const char *e = getenv("NGP_PROBE_LEVEL_MASK"); plan.level_mask = e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffu; }
@@ -777,21 +855,22 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	const dim3 grid(units), block(1024);
 	const bool probe_skip_bins = getenv("NGP_PROBE_SKIP_BINS") != nullptr;      // tools/probe_scatter.py: time the dense-level kernel alone
 #define GO(T, G, L) do { \
+	using RV_ = typename RecVal<T>::type; \
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_hash_bwd_owner<T, G, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
 	if (level_scratch) NGP_LAUNCH((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
 	if (use_bins && bp.n_levels) { \
 		static bool attr2 = false; \
-		if (!attr2) { hipError_t e = hipFuncSetAttribute((const void *)k_bin_records<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIN_STAGE_BYTES); \
+		if (!attr2) { hipError_t e = hipFuncSetAttribute((const void *)k_bin_records<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_stage_bytes<T>()); \
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
-			e = hipFuncSetAttribute((const void *)k_bin_accumulate<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_ENTRIES * 16)); \
+			e = hipFuncSetAttribute((const void *)k_bin_accumulate<G, RV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_ENTRIES * 16)); \
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr2 = true; } \
 		NGP_LAUNCH((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
 		if (units && side.ok) hipEventRecord(side.fork, s);   /* fork point: the dense-level kernel needs the abs-max too */ \
 		if (!probe_skip_bins) { \
-		NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, 1024), bp.n_levels), dim3(1024), BIN_STAGE_BYTES, s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, records, (float *)grad, n_valid); \
-		NGP_LAUNCH((k_bin_accumulate<G>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const uint2 *)records, (G *)grad); } \
+		NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, 1024), bp.n_levels), dim3(1024), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, (RV_ *)rec_val, rec_idx, spill_count, spill, n_valid); \
+		NGP_LAUNCH((k_bin_accumulate<G, RV_>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const RV_ *)rec_val, (const uint16_t *)rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, zero_first ? 1 : 0); } \
 	} \
 	hipStream_t sd = s; \
 	if (use_bins && bp.n_levels && units && side.ok) { sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* dense levels run beside the binning kernels */ \

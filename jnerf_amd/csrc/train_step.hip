@@ -59,15 +59,28 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		if (g_boundary.first) { hipEventRecord(g_boundary.second, hs); g_pending.push_back(g_boundary); g_boundary = {nullptr, nullptr}; }
 	}
 #define STAGE(id, call) do { Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
-	STAGE(NGP_STAGE_PACK, ngp_field_pack_weights(stream, a->wd_f16, a->wc_f16, a->packed_weights));
-	STAGE(NGP_STAGE_HASH_FWD, ngp_hash_encode_fwd(stream, a->n, a->pos, 3, a->table_f16, a->level_table_host, a->feat, NGP_F16, NGP_LAYOUT_SOA, a->n_valid));
-	STAGE(NGP_STAGE_FIELD_FWD, ngp_field_fwd(stream, a->n, a->feat, lay, dirs, 7, a->packed_weights, nullptr, a->out, NGP_F16, a->n_valid));
-	STAGE(NGP_STAGE_COMPOSITE_FWD, ngp_composite_fwd_huber(stream, a->n_rays, a->out, NGP_F16, a->coords, a->numsteps, a->numsteps_compacted, a->bg, a->cascades, a->rgb,
+	NGP_REQUIRE(a->dtype == NGP_F16 || a->dtype == NGP_F32, NGP_E_DTYPE, "ngp_train_step: bad dtype %d", a->dtype);
+	const int T = a->dtype, ow = a->grad_overwrite != 0;
+	if (T == NGP_F16) {
+		STAGE(NGP_STAGE_PACK, ngp_field_pack_weights(stream, a->wd, a->wc, a->packed_weights));
+		STAGE(NGP_STAGE_HASH_FWD, ngp_hash_encode_fwd(stream, a->n, a->pos, 3, a->table, a->level_table_host, a->feat, NGP_F16, NGP_LAYOUT_SOA, a->n_valid));
+		STAGE(NGP_STAGE_FIELD_FWD, ngp_field_fwd(stream, a->n, a->feat, lay, dirs, 7, a->packed_weights, nullptr, a->out, NGP_F16, a->n_valid));
+	} else {
+		STAGE(NGP_STAGE_PACK, ngp_field32_pack_weights(stream, (const float *)a->wd, (const float *)a->wc, (float *)a->packed_weights));
+		STAGE(NGP_STAGE_HASH_FWD, ngp_hash_encode_fwd(stream, a->n, a->pos, 3, a->table, a->level_table_host, a->feat, NGP_F32, NGP_LAYOUT_SOA, a->n_valid));
+		STAGE(NGP_STAGE_FIELD_FWD, ngp_field32_fwd(stream, a->n, (const float *)a->feat, lay, dirs, 7, (const float *)a->packed_weights, nullptr, (float *)a->out, a->n_valid));
+	}
+	STAGE(NGP_STAGE_COMPOSITE_FWD, ngp_composite_fwd_huber(stream, a->n_rays, a->out, T, a->coords, a->numsteps, a->numsteps_compacted, a->bg, a->cascades, a->rgb,
 	                                                       a->target, a->huber_delta, a->loss, a->loss_grad));
-	STAGE(NGP_STAGE_COMPOSITE_BWD, ngp_composite_bwd(stream, a->n_rays, a->n, a->out, NGP_F16, a->coords, a->numsteps_compacted, a->loss_grad, a->rgb, a->density_grid_mean, a->cascades, a->dout, 0));
-	STAGE(NGP_STAGE_FIELD_BWD, ngp_field_bwd(stream, a->n, a->feat, lay, dirs, 7, a->packed_weights, nullptr, a->dout, NGP_F16, a->dfeat, a->wgrad_slabs, a->n_slabs, a->n_valid));
-	STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, 1));
-	STAGE(NGP_STAGE_HASH_BWD, ngp_hash_encode_bwd_ws(stream, a->n, a->pos, 3, a->dfeat, a->level_table_host, a->table_grad, a->n_params, NGP_F16, NGP_F32, NGP_LAYOUT_SOA, 0, a->n_valid,
+	STAGE(NGP_STAGE_COMPOSITE_BWD, ngp_composite_bwd(stream, a->n_rays, a->n, a->out, T, a->coords, a->numsteps_compacted, a->loss_grad, a->rgb, a->density_grid_mean, a->cascades, a->dout, 0));
+	if (T == NGP_F16) {
+		STAGE(NGP_STAGE_FIELD_BWD, ngp_field_bwd(stream, a->n, a->feat, lay, dirs, 7, a->packed_weights, nullptr, a->dout, NGP_F16, a->dfeat, a->wgrad_slabs, a->n_slabs, a->n_valid));
+	} else {
+		STAGE(NGP_STAGE_FIELD_BWD, ngp_field32_bwd(stream, a->n, (const float *)a->feat, lay, dirs, 7, (const float *)a->packed_weights, nullptr, (const float *)a->dout, (float *)a->dfeat,
+		                                            a->wgrad_slabs, a->n_slabs, a->n_valid));
+	}
+	STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, ow ? 0 : 1));
+	STAGE(NGP_STAGE_HASH_BWD, ngp_hash_encode_bwd_ws(stream, a->n, a->pos, 3, a->dfeat, a->level_table_host, a->table_grad, a->n_params, T, NGP_F32, NGP_LAYOUT_SOA, ow ? 1 : 0, a->n_valid,
 	                                                 nullptr, a->hash_workspace, a->hash_workspace_bytes));
 	if (a->run_optimizer) {
 		int largest = 0;
@@ -75,7 +88,7 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		for (int t = 0; t < a->n_opt; ++t) {
 			Bracket br(hs, a->timed_stage == NGP_STAGE_ADAM && t == largest);
 			if ((rc = ngp_adam_ema_step(stream, a->numel[t], a->p[t], a->g[t], NGP_F32, a->m[t], a->v[t], a->ema[t], a->p_half[t], a->lr, a->beta0, a->beta1, a->eps,
-			                            a->step, a->ema_decay, 1))) return rc;
+			                            a->step, a->ema_decay, ow ? 0 : 1))) return rc;
 		}
 	}
 #undef STAGE

@@ -25,13 +25,14 @@ class FusedTrainStep:
     def __init__(self, runner):
         self.r = runner
         m = runner.model
-        self.enc, self.dm, self.cm = m.pos_encoder, m.density_mlp, m.rgb_mlp
+        self.enc = m.pos_encoder
         self.s = runner.sampler
         dev = self.enc.m_grid.device
         n = self.s.target_batch_size
         self.n = n
-        self.out = torch.empty((n, 4), dtype=torch.float16, device=dev)
-        self.dout = torch.empty((n, 4), dtype=torch.float16, device=dev)
+        self.half = m.fused_dtype == torch.float16            # fp16 table shadow + fp16-MFMA network (ngp_fox.py) | fp32 table + fp32-MFMA network (ngp_base.py)
+        self.out = torch.empty((n, 4), dtype=m.fused_dtype, device=dev)
+        self.dout = torch.empty((n, 4), dtype=m.fused_dtype, device=dev)
         self._per_rays = {}
         # single-GPU runs issue the whole sequence with ONE call into the library (ngp_train_step); data-parallel runs keep the per-stage calls below
         # because the gradient all-reduce sits between backward and the sweep
@@ -63,20 +64,33 @@ class FusedTrainStep:
         if enc._bwd_ws is None or enc._bwd_ws.numel() < need:
             enc._bwd_ws = torch.empty(need, dtype=torch.uint8, device=dev)
         a.hash_workspace, a.hash_workspace_bytes = P(enc._bwd_ws), enc._bwd_ws.numel()
-        dfeat, slabs, _ = m._bwd_buffers(n)
+        dfeat, slabs = m._bwd_buffers(n)
         a.feat, a.dfeat, a.out, a.dout = P(m._feat_buffer(n)), P(dfeat), P(self.out), P(self.dout)
         a.wgrad_slabs, a.n_slabs, a.wgrad_flat = P(slabs), slabs.shape[0], P(m._flat_weight_grad())
+        a.dtype = L.F16 if self.half else L.F32
+        a.grad_overwrite = 1                          # single GPU: backward overwrites the gradient buffers, the sweep does not zero them
         if getattr(m, "_packed", None) is None:
-            m._packed = torch.empty(ops.PACKED_WEIGHT_HALVES, dtype=torch.float16, device=dev)
+            m.packed_weights(refresh=True)
         a.packed_weights = P(m._packed)
         a.huber_delta = r.loss_func.delta
         pg, eg = adam.param_groups[0], ema.param_groups[0]
-        a.n_opt = len(pg["params"])
-        assert a.n_opt <= 4
+        # parameter tensors the sweep visits: every parameter on its own, except those that are views of one flat pack (fp32 network) - the pack is ONE tensor
+        flat_ids = set(adam._flat[3]) if adam._flat else set()
+        ents = []
         for i, p in enumerate(pg["params"]):
+            if id(p) in flat_ids:
+                continue
             assert p.grad is not None and p.grad.dtype == torch.float32
-            a.p[i], a.g[i], a.m[i], a.v[i], a.ema[i] = P(p.data), P(p.grad), P(pg["m"][i]), P(pg["values"][i]), P(eg["values"][i])
-            a.p_half[i], a.numel[i] = P(adam._half.get(id(p))), p.numel()
+            ents.append((p.data, p.grad, pg["m"][i], pg["values"][i], eg["values"][i], adam._half.get(id(p)), p.numel()))
+        if adam._flat:
+            pack, fm, fv, _ = adam._flat
+            first = next(i for i, p in enumerate(pg["params"]) if id(p) in flat_ids)
+            assert eg["values"][first].data_ptr() == pg["params"][first].data_ptr(), "flat sweep needs the aliased EMA (EMA.attach)"
+            ents.append((pack, m._flat_weight_grad(), fm, fv, pack, None, pack.numel()))
+        a.n_opt = len(ents)
+        assert a.n_opt <= 4
+        for i, (p_, g_, m_, v_, e_, h_, cnt) in enumerate(ents):
+            a.p[i], a.g[i], a.m[i], a.v[i], a.ema[i], a.p_half[i], a.numel[i] = P(p_), P(g_), P(m_), P(v_), P(e_), P(h_), cnt
         a.beta0, a.beta1, a.eps, a.ema_decay = adam.betas[0], adam.betas[1], adam.eps, ema.decay
         self._keep = (dfeat, slabs)
         return a
@@ -86,7 +100,7 @@ class FusedTrainStep:
         coords, numsteps, numsteps_c = s._coords, s._rays_numsteps, s._rays_numsteps_compacted
         nr = numsteps.shape[0]
         rgb, loss, lgrad = self._ray_bufs(nr, coords.device)
-        wd, wc = self.dm.half_weights(), self.cm.half_weights()
+        wd, wc = m.weight_packs()
         table = enc.table_for_kernels()
         if self._args is None:
             self._args = self._native_args(coords.device)
@@ -98,7 +112,7 @@ class FusedTrainStep:
         a.timed_stage = -1 if self.timed_stage is None else L.STAGES[self.timed_stage]
         a.coords, a.pos, a.numsteps, a.numsteps_compacted, a.n_valid = coords.data_ptr(), s._pos_train.data_ptr(), numsteps.data_ptr(), numsteps_c.data_ptr(), s._n_valid.data_ptr()
         a.bg, a.target = b["bg"].data_ptr(), b["target"].data_ptr()
-        a.table_f16, a.wd_f16, a.wc_f16 = table.data_ptr(), wd.data_ptr(), wc.data_ptr()
+        a.table, a.wd, a.wc = table.data_ptr(), wd.data_ptr(), wc.data_ptr()
         a.rgb, a.loss, a.loss_grad = rgb.data_ptr(), loss.data_ptr(), lgrad.data_ptr()
         L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step")
         return loss
@@ -125,11 +139,17 @@ class FusedTrainStep:
         pos = s._pos_train                                                # compact [n,3] positions (the marcher writes them next to the 28-byte records)
         feat = m._feat_buffer(n)
         ops.hash_encode_fwd(pos, table, enc.level_table, out=feat, layout=ops.LAYOUT_SOA, n_valid=n_valid)
-        ops.field_fwd(feat, dirs, None, None, layout=ops.LAYOUT_SOA, out=self.out, n_valid=n_valid, packed=packed)
+        if self.half:
+            ops.field_fwd(feat, dirs, None, None, layout=ops.LAYOUT_SOA, out=self.out, n_valid=n_valid, packed=packed)
+        else:
+            ops.field32_fwd(feat, dirs, None, None, layout=ops.LAYOUT_SOA, out=self.out, n_valid=n_valid, packed=packed)
         ops.composite_fwd_huber(self.out, coords, numsteps, numsteps_c, b["bg"], b["target"], r.loss_func.delta, s.NERF_CASCADES, out=rgb, loss=loss, grad=lgrad)
         ops.composite_bwd(self.out, coords, numsteps_c, lgrad, rgb, s.density_grid_mean, s.NERF_CASCADES, dout=self.dout, zero_first=False)
-        dfeat, slabs, _ = m._bwd_buffers(n)
-        ops.field_bwd(feat, dirs, None, None, self.dout, layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid, packed=packed)
+        dfeat, slabs = m._bwd_buffers(n)
+        if self.half:
+            ops.field_bwd(feat, dirs, None, None, self.dout, layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid, packed=packed)
+        else:
+            ops.field32_bwd(feat, dirs, None, None, self.dout, layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid, packed=packed)
         ops.reduce_slabs(slabs, out=m._flat_weight_grad(), accumulate=True)
         enc.accumulate_grad(pos, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
         r.optimizer.step(None)            # ExpDecay lr schedule -> Adam.step without a loss: all-reduce (data parallel) + bookkeeping

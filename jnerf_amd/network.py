@@ -2,9 +2,12 @@
 
 cfg.fp16 (projects/ngp/configs/ngp_fox.py:73): both MLPs + SH + concats run in ONE fp16-MFMA kernel with weights in LDS
 (csrc/field_mlp.hip), fed level-major by the XCD-aware hash kernel; backward recomputes the forward in-kernel.
-fp32 (ngp_base.py): the reference itself falls back to plain nn.Linear chains (ngp_network.py:57-67) — so do we (rocBLAS GEMMs via torch),
-with the fp32 hash kernels."""
+fp32 (ngp_base.py, the lego headline): the reference falls back to plain nn.Linear chains (ngp_network.py:57-67).  Here the module structure is the
+reference's (nn.Sequential of bias-free nn.Linear: same parameter names and shapes in the state dict), but with `use_fully` the five weight matrices are
+VIEWS of one flat fp32[10240] pack in the fused kernels' layout and the network runs as ONE fp32-MFMA kernel (csrc/field32.hip, v_mfma_f32_16x16x4_f32);
+`use_fully = False` keeps the rocBLAS/autograd chain (the generic path the fused kernels are tested against)."""
 import math
+import sys
 import torch
 from torch import nn
 from . import ops
@@ -77,17 +80,20 @@ class FMLP(nn.Module):
 
 
 class _FusedField(torch.autograd.Function):
-    """hash encode (level-major) -> fused SH + density MLP + colour MLP;  backward: fused dgrad/wgrad -> atomic scatter."""
+    """hash encode (level-major) -> fused SH + density MLP + colour MLP;  backward: fused dgrad/wgrad -> scatter.  fp16 or fp32 kernels by net.fused_dtype."""
 
     @staticmethod
-    def forward(ctx, pos, dirs, grid, wd, wc, net, n_valid):
+    def forward(ctx, pos, dirs, net, n_valid, *params):
         enc = net.pos_encoder
         n = pos.shape[0]
         if pos.stride(0) != 3:
             pos = pos.contiguous()      # compact [n,3] copy (3 MB): the 16 level passes then stream 12 B/sample out of L2 instead of 28 B records
         feat = net._feat_buffer(n)
         ops.hash_encode_fwd(pos, enc.table_for_kernels(), enc.level_table, out=feat, layout=ops.LAYOUT_SOA, n_valid=n_valid)
-        out = ops.field_fwd(feat, dirs, None, None, layout=ops.LAYOUT_SOA, out_dtype=torch.float16, n_valid=n_valid, packed=net.packed_weights(refresh=True))
+        if net.fused_dtype == torch.float16:
+            out = ops.field_fwd(feat, dirs, None, None, layout=ops.LAYOUT_SOA, out_dtype=torch.float16, n_valid=n_valid, packed=net.packed_weights(refresh=True))
+        else:
+            out = ops.field32_fwd(feat, dirs, None, None, layout=ops.LAYOUT_SOA, n_valid=n_valid, packed=net.packed_weights(refresh=True))
         ctx.net, ctx.n_valid = net, n_valid
         ctx.save_for_backward(pos, dirs, feat)
         return out
@@ -98,12 +104,19 @@ class _FusedField(torch.autograd.Function):
         net, n_valid = ctx.net, ctx.n_valid
         enc = net.pos_encoder
         n = pos.shape[0]
-        dfeat, slabs, wsum = net._bwd_buffers(n)
-        ops.field_bwd(feat, dirs, None, None, dout.contiguous(), layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid,
-                      packed=net.packed_weights(refresh=False))      # the fragments the forward of this step built (the weights have not changed since)
-        ops.reduce_slabs(slabs, out=net._flat_weight_grad(), accumulate=True)     # both MLP packs' .grad are views of this one buffer
+        dfeat, slabs = net._bwd_buffers(n)
+        packed = net.packed_weights(refresh=False)      # the fragments the forward of this step built (the weights have not changed since)
+        if net.fused_dtype == torch.float16:
+            ops.field_bwd(feat, dirs, None, None, dout.contiguous(), layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid, packed=packed)
+        else:
+            ops.field32_bwd(feat, dirs, None, None, dout.contiguous().float(), layout=ops.LAYOUT_SOA, dfeat=dfeat, slabs=slabs, n_valid=n_valid, packed=packed)
+        ops.reduce_slabs(slabs, out=net._flat_weight_grad(), accumulate=True)     # every MLP parameter's .grad is a view of this one buffer
         enc.accumulate_grad(pos, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
-        return None, None, None, None, None, None, None
+        return (None,) * len(ctx.needs_input_grad)      # the gradients were accumulated into the parameters' .grad buffers above
+
+
+# offsets (floats) of the five weight matrices inside the flat pack the fused kernels read: wd = W0 [64,32] | W1 [16,64];  wc = V0 [64,32] | V1 [64,64] | V2 [16,64] (3 rows used)
+_PACK32 = ((0, 64, 32), (2048, 16, 64), (3072, 64, 32), (5120, 64, 64), (9216, 3, 64))
 
 
 @NETWORKS.register_module()
@@ -116,42 +129,65 @@ class NGPNetworks(nn.Module):
         dev = self.cfg.device or "cuda"
         self.pos_encoder = build_from_cfg(self.cfg.encoder.pos_encoder, ENCODERS)
         self.dir_encoder = build_from_cfg(self.cfg.encoder.dir_encoder, ENCODERS)
-        self.fused = bool(self.use_fully and self.using_fp16 and density_n_neurons == 64 and rgb_n_neurons == 64
-                          and self.pos_encoder.out_dim == 32 and self.dir_encoder.out_dim == 16 and hasattr(self.pos_encoder, "level_table"))
-        if self.fused:
+        shapes_ok = bool(density_n_neurons == 64 and rgb_n_neurons == 64 and self.pos_encoder.out_dim == 32 and self.dir_encoder.out_dim == 16
+                         and hasattr(self.pos_encoder, "level_table") and density_hidden_layer == 1 and rgb_hidden_layer == 2)
+        self.fused = bool(self.use_fully and shapes_ok and torch.device(dev).type == "cuda")
+        self.fused_dtype = torch.float16 if self.using_fp16 else torch.float32
+        self._pack32 = None
+        if self.fused and self.using_fp16:
             self.density_mlp = FMLP([self.pos_encoder.out_dim, density_n_neurons, 16], dev)
             self.rgb_mlp = FMLP([self.dir_encoder.out_dim + 16, rgb_n_neurons, rgb_n_neurons, 3], dev)
         else:
-            if self.use_fully and not self.using_fp16:
-                print("Warning: FFMLPs only support float16. Automatically use original MLPs instead.")       # ngp_network.py:58
+            if self.use_fully and not self.fused:
+                print("Warning: the fused field kernels need the standard 32->64->16 / 32->64->64->3 shapes on a GPU. Automatically use original MLPs instead.", file=sys.stderr)   # ngp_network.py:58
             self.density_mlp = nn.Sequential(nn.Linear(self.pos_encoder.out_dim, density_n_neurons, bias=False), nn.ReLU(),
                                              nn.Linear(density_n_neurons, 16, bias=False)).to(dev)
             self.rgb_mlp = nn.Sequential(nn.Linear(self.dir_encoder.out_dim + 16, rgb_n_neurons, bias=False), nn.ReLU(),
                                          nn.Linear(rgb_n_neurons, rgb_n_neurons, bias=False), nn.ReLU(), nn.Linear(rgb_n_neurons, 3, bias=False)).to(dev)
-            for m in list(self.density_mlp) + list(self.rgb_mlp):
-                if isinstance(m, nn.Linear):
-                    with torch.no_grad():
-                        m.weight.copy_(invariant_uniform(m.out_features, m.in_features, dev))
+            lins = self._linears()
+            if self.fused:      # fp32 fused path: the five nn.Linear weights become views of ONE flat buffer in the kernels' pack layout (padding rows of the last layer stay zero)
+                self._pack32 = torch.zeros(10240, dtype=torch.float32, device=dev)
+                for m, (off, o, i) in zip(lins, _PACK32):
+                    m.weight = nn.Parameter(self._pack32[off:off + o * i].view(o, i))
+            for m in lins:
+                with torch.no_grad():
+                    m.weight.copy_(invariant_uniform(m.out_features, m.in_features, dev))
         self._bufs = {}
+
+    def _linears(self):
+        return [m for m in list(self.density_mlp) + list(self.rgb_mlp) if isinstance(m, nn.Linear)]
+
+    def flat_param_views(self):
+        """(flat fp32 pack, [parameters that are views of it, in pack order]) for the optimiser, or None: Adam keeps ONE flat m / v buffer for them so the fused sweep
+        updates all five matrices (and the zero padding, which stays zero: g = m = v = 0) in one launch"""
+        if self._pack32 is None:
+            return None
+        return self._pack32, [m.weight for m in self._linears()]
 
     # ---- scratch owned by the module (no per-step allocation; SURVEY.md §8b "ops never allocate")
     def _feat_buffer(self, n):
         b = self._bufs.get("feat")
         if b is None or b.shape[1] != n:
-            b = self._bufs["feat"] = torch.empty((16, n, 2), dtype=torch.float16, device=self.pos_encoder.m_grid.device)
+            b = self._bufs["feat"] = torch.empty((16, n, 2), dtype=self.fused_dtype, device=self.pos_encoder.m_grid.device)
         return b
 
+    def mlp_params(self):
+        return [self.density_mlp.con_weights, self.rgb_mlp.con_weights] if self._pack32 is None else [m.weight for m in self._linears()]
+
     def _flat_weight_grad(self):
-        """density_mlp.con_weights.grad and rgb_mlp.con_weights.grad as two views of ONE fp32[10240] buffer (slab layout of ngp_field_bwd)"""
+        """every MLP parameter's .grad as a view of ONE fp32[10240] buffer (slab layout of ngp_field_bwd / ngp_field32_bwd)"""
         g = self._bufs.get("wgrad")
-        dg, cg = self.density_mlp.con_weights.grad, self.rgb_mlp.con_weights.grad
-        if g is None or dg is None or cg is None or dg.data_ptr() != g.data_ptr() or cg.data_ptr() != g[3072:].data_ptr():
+        if self._pack32 is None:
+            spans = [(self.density_mlp.con_weights, 0, 3072), (self.rgb_mlp.con_weights, 3072, 7168)]
+        else:
+            spans = [(m.weight, off, o * i) for m, (off, o, i) in zip(self._linears(), _PACK32)]
+        ok = g is not None and all(p.grad is not None and p.grad.data_ptr() == g[off:].data_ptr() for p, off, _ in spans)
+        if not ok:
             g = torch.zeros(10240, dtype=torch.float32, device=self.pos_encoder.m_grid.device)
-            if dg is not None:
-                g[:3072] += dg
-            if cg is not None:
-                g[3072:] += cg
-            self.density_mlp.con_weights.grad, self.rgb_mlp.con_weights.grad = g[:3072], g[3072:]
+            for p, off, cnt in spans:
+                if p.grad is not None:
+                    g[off:off + cnt] += p.grad.reshape(-1)
+                p.grad = g[off:off + cnt].view_as(p)
             self._bufs["wgrad"] = g
         return g
 
@@ -160,19 +196,31 @@ class NGPNetworks(nn.Module):
         if key not in self._bufs:
             dev = self.pos_encoder.m_grid.device
             self._bufs = {k: v for k, v in self._bufs.items() if not (isinstance(k, tuple) and k[0] == "bwd")}
-            self._bufs[key] = (torch.empty((16, n, 2), dtype=torch.float16, device=dev),
-                               torch.empty((ops.field_bwd_slabs(n), 10240), dtype=torch.float32, device=dev),
-                               torch.empty(10240, dtype=torch.float32, device=dev))
+            ns = ops.field_bwd_slabs(n) if self.fused_dtype == torch.float16 else ops.field32_bwd_slabs(n)
+            self._bufs[key] = (torch.empty((16, n, 2), dtype=self.fused_dtype, device=dev), torch.empty((ns, 10240), dtype=torch.float32, device=dev))
         return self._bufs[key]
 
+    def weight_packs(self):
+        """(wd, wc) in the dtype the fused kernels read (reading them completes a deferred all-reduce + sweep)"""
+        if self._pack32 is None:
+            return self.density_mlp.half_weights(), self.rgb_mlp.half_weights()
+        from .optim import flush_all
+        flush_all()
+        return self._pack32[:3072], self._pack32[3072:]
+
     def packed_weights(self, refresh=True):
-        """MFMA-ordered fragments of both weight packs (ngp_field_pack_weights); rebuilt from the current fp16 weights when `refresh`"""
+        """MFMA-ordered fragments of both weight packs (ngp_field_pack_weights / ngp_field32_pack_weights); rebuilt from the current weights when `refresh`"""
         buf = getattr(self, "_packed", None)
         if buf is None or refresh:
-            wd, wc = self.density_mlp.half_weights(), self.rgb_mlp.half_weights()
-            if buf is None:
-                buf = self._packed = torch.empty(ops.PACKED_WEIGHT_HALVES, dtype=torch.float16, device=wd.device)
-            ops.field_pack_weights(wd, wc, out=buf)
+            wd, wc = self.weight_packs()
+            if self.fused_dtype == torch.float16:
+                if buf is None:
+                    buf = self._packed = torch.empty(ops.PACKED_WEIGHT_HALVES, dtype=torch.float16, device=wd.device)
+                ops.field_pack_weights(wd, wc, out=buf)
+            else:
+                if buf is None:
+                    buf = self._packed = torch.empty(ops.PACKED32_WEIGHT_FLOATS, dtype=torch.float32, device=wd.device)
+                ops.field32_pack_weights(wd, wc, out=buf)
         return buf
 
     def forward(self, pos_input, dir_input):
@@ -180,10 +228,13 @@ class NGPNetworks(nn.Module):
             sampler = self.cfg.sampler_obj
             n_valid = sampler.n_valid_for(pos_input) if sampler is not None and hasattr(sampler, "n_valid_for") else None
             if torch.is_grad_enabled():
-                return _FusedField.apply(pos_input, dir_input, self.pos_encoder.m_grid, self.density_mlp.con_weights, self.rgb_mlp.con_weights, self, n_valid)
+                return _FusedField.apply(pos_input, dir_input, self, n_valid, self.pos_encoder.m_grid, *self.mlp_params())
             enc = self.pos_encoder
             feat = ops.hash_encode_fwd(pos_input, enc.table_for_kernels(), enc.level_table, layout=ops.LAYOUT_SOA, n_valid=n_valid)
-            return ops.field_fwd(feat, dir_input, self.density_mlp.half_weights(), self.rgb_mlp.half_weights(), layout=ops.LAYOUT_SOA, out_dtype=torch.float16, n_valid=n_valid)
+            wd, wc = self.weight_packs()
+            if self.fused_dtype == torch.float16:
+                return ops.field_fwd(feat, dir_input, wd, wc, layout=ops.LAYOUT_SOA, out_dtype=torch.float16, n_valid=n_valid)
+            return ops.field32_fwd(feat, dir_input, wd, wc, layout=ops.LAYOUT_SOA, n_valid=n_valid)
         # generic path == the reference's execute_ (ngp_network.py:77-84)
         d = self.dir_encoder(dir_input)
         p = self.pos_encoder(pos_input)
@@ -197,7 +248,10 @@ class NGPNetworks(nn.Module):
             enc = self.pos_encoder
             n = pos_input.shape[0]
             feat = ops.hash_encode_fwd(pos_input, enc.table_for_kernels(), enc.level_table, layout=ops.LAYOUT_SOA)
-            return ops.density_fwd(feat, self.density_mlp.half_weights(), n, layout=ops.LAYOUT_SOA, out_dtype=torch.float16).view(n, 1)
+            wd, _ = self.weight_packs()
+            if self.fused_dtype == torch.float16:
+                return ops.density_fwd(feat, wd, n, layout=ops.LAYOUT_SOA, out_dtype=torch.float16).view(n, 1)
+            return ops.density32_fwd(feat, wd, n, layout=ops.LAYOUT_SOA).view(n, 1)
         return self.density_mlp(self.pos_encoder(pos_input).float())[:, :1]
 
     def set_fp16(self):

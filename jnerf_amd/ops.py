@@ -193,6 +193,61 @@ def field_bwd(feat, d, wd, wc, dLdout, layout=LAYOUT_AOS, dfeat=None, slabs=None
     return dfeat, slabs
 
 
+# ---- fp32 field network (cfg.fp16 unset: ngp_base.py / lego) on v_mfma_f32_16x16x4_f32
+PACKED32_WEIGHT_FLOATS = 19456
+
+
+def field32_pack_weights(wd, wc, out=None):
+    assert wd.dtype == torch.float32 and wc.dtype == torch.float32 and wd.numel() == 3072 and wc.numel() == 7168 and wd.is_contiguous() and wc.is_contiguous()
+    if out is None:
+        out = torch.empty(PACKED32_WEIGHT_FLOATS, dtype=torch.float32, device=wd.device)
+    check(L.lib().ngp_field32_pack_weights(_stream(), _p(wd), _p(wc), _p(out)), "ngp_field32_pack_weights")
+    return out
+
+
+def field32_fwd(feat, d, wd, wc, layout=LAYOUT_AOS, out=None, n_valid=None, packed=None):
+    assert feat.dtype == torch.float32 and feat.is_contiguous()
+    if packed is not None:
+        wd, wc, layout = packed, None, layout | WEIGHTS_PACKED
+    else:
+        assert wd.dtype == torch.float32 and wc.dtype == torch.float32 and wd.numel() == 3072 and wc.numel() == 7168
+    d, stride = _rows(d, 3)
+    n = d.shape[0]
+    if out is None:
+        out = torch.empty((n, 4), dtype=torch.float32, device=d.device)
+    check(L.lib().ngp_field32_fwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(out), _p(n_valid)), "ngp_field32_fwd")
+    return out
+
+
+def density32_fwd(feat, wd, n, layout=LAYOUT_AOS, packed=None):
+    assert feat.dtype == torch.float32 and feat.is_contiguous()
+    if packed is not None:
+        wd, layout = packed, layout | WEIGHTS_PACKED
+    out = torch.empty((n,), dtype=torch.float32, device=feat.device)
+    check(L.lib().ngp_density32_fwd(_stream(), n, _p(feat), layout, _p(wd), _p(out)), "ngp_density32_fwd")
+    return out
+
+
+def field32_bwd_slabs(n):
+    return int(L.lib().ngp_field32_bwd_slabs(n))
+
+
+def field32_bwd(feat, d, wd, wc, dLdout, layout=LAYOUT_AOS, dfeat=None, slabs=None, n_valid=None, packed=None):
+    """-> (dLdfeat f32 in `layout`, slabs f32[n_slabs,10240]); sum the slabs with reduce_slabs."""
+    assert feat.dtype == torch.float32 and feat.is_contiguous() and dLdout.dtype == torch.float32 and dLdout.is_contiguous()
+    if packed is not None:
+        wd, wc, layout = packed, None, layout | WEIGHTS_PACKED
+    d, stride = _rows(d, 3)
+    n = d.shape[0]
+    ns = field32_bwd_slabs(n)
+    if dfeat is None:
+        dfeat = torch.zeros_like(feat)
+    if slabs is None:
+        slabs = torch.empty((ns, 10240), dtype=torch.float32, device=d.device)
+    check(L.lib().ngp_field32_bwd(_stream(), n, _p(feat), layout, _p(d), stride, _p(wd), _p(wc), _p(dLdout), _p(dfeat), _p(slabs), ns, _p(n_valid)), "ngp_field32_bwd")
+    return dfeat, slabs
+
+
 def reduce_slabs(slabs, out=None, accumulate=False):
     ns, width = slabs.shape
     if out is None:

@@ -37,6 +37,7 @@ class Adam:
         self._comm_half = {}            # id(param) -> fp16 communication buffer (large fp32 gradients travel as fp16, see allreduce_grads)
         self._eff_grad = {}             # id(param) -> the reduced fp16 buffer the next sweep reads instead of p.grad
         self._deferred_ema = None
+        self._flat = None               # (flat parameter pack, flat m, flat v, ids of the parameters that are views of it), see use_flat_state
         _LIVE.add(self)
 
     @property
@@ -50,6 +51,18 @@ class Adam:
                 self._half[id(m.m_grid)] = m.m_grid_half
             if getattr(m, "con_weights_half", None) is not None:
                 self._half[id(m.con_weights)] = m.con_weights_half
+
+    def use_flat_state(self, flat_pack, params):
+        """`params` are views into the contiguous fp32 buffer `flat_pack` (NGPNetworks' fp32 weight pack): their first / second moments become views of ONE flat
+        buffer each, so the native step sweeps the whole pack - padding included, which stays zero because g = m = v = 0 there - in a single launch"""
+        fm, fv = torch.zeros_like(flat_pack), torch.zeros_like(flat_pack)
+        pg, base = self.param_groups[0], flat_pack.data_ptr()
+        for p in params:
+            i = next(k for k, q in enumerate(pg["params"]) if q is p)
+            off = (p.data_ptr() - base) // p.element_size()
+            pg["m"][i] = fm[off:off + p.numel()].view_as(p)
+            pg["values"][i] = fv[off:off + p.numel()].view_as(p)
+        self._flat = (flat_pack, fm, fv, [id(p) for p in params])
 
     def zero_grad(self):
         for p in self.param_groups[0]["params"]:
@@ -91,7 +104,7 @@ class Adam:
         merged = []
         for group in by_base.values():
             base = group[0]._base
-            if base is not None and len(group) > 1 and base.is_contiguous() and sum(g.numel() for g in group) == base.numel():
+            if base is not None and len(group) > 1 and base.is_contiguous():        # (a pack's zero-gradient padding travels along: one collective instead of five)
                 merged.append(base)
             else:
                 merged.extend(group)

@@ -31,6 +31,9 @@ class Runner:
         self._sync_initial_parameters(params)
         self.optimizer = build_from_cfg(cfg.optim, OPTIMS, params=params)
         self.optimizer.attach_half_shadows(self.model)
+        flat = self.model.flat_param_views() if hasattr(self.model, "flat_param_views") else None
+        if flat is not None:
+            self.optimizer.use_flat_state(*flat)
         self.optimizer = build_from_cfg(cfg.expdecay, OPTIMS, nested_optimizer=self.optimizer)
         self.ema_optimizer = build_from_cfg(cfg.ema, OPTIMS, params=params)
         self.ema_optimizer.attach(self.optimizer)                       # Adam + EMA become one fused sweep

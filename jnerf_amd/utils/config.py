@@ -103,7 +103,8 @@ _cfg = Config()
 
 
 def init_cfg(filename):
-    print("Loading config from: ", filename)
+    import sys
+    print("Loading config from: ", filename, file=sys.stderr)
     _cfg.load_from_file(filename)
 
 

@@ -215,6 +215,46 @@ def test_reference_configs_train_on_real_fox(tmp_path):
         os.chdir(cwd)
 
 
+def test_fp32_fused_network_equals_linear_chain():
+    """cfg.fp16 unset (ngp_base.py): `use_fully` runs the five bias-free nn.Linear layers as ONE fp32-MFMA kernel whose weights are views of a flat pack; with
+    use_fully = False the same module runs torch's nn.Linear / autograd chain (what the reference does, ngp_network.py:59-67).  Same parameters => same
+    outputs and same parameter gradients (fp32 rounding apart), and the state dict has the reference's keys and shapes."""
+    from jnerf_amd.presets import ngp_cfg
+    from jnerf_amd.utils.registry import build_from_cfg, NETWORKS, DATASETS
+    from jnerf_amd.utils.config import get_cfg
+    torch.manual_seed(3)
+    outs = []
+    sd = None
+    for fully in (True, False):
+        cfg = ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=2, W=16, H=16)
+        cfg.model.use_fully = fully
+        cfg.dataset_obj = build_from_cfg(cfg.dataset.train, DATASETS)
+        net = build_from_cfg(cfg.model, NETWORKS)
+        assert net.fused == fully
+        if sd is None:
+            sd = {k: v.clone() for k, v in net.state_dict().items()}
+            assert {k: tuple(v.shape) for k, v in sd.items() if "mlp" in k} == {"density_mlp.0.weight": (64, 32), "density_mlp.2.weight": (16, 64), "rgb_mlp.0.weight": (64, 32),
+                                                                               "rgb_mlp.2.weight": (64, 64), "rgb_mlp.4.weight": (3, 64)}
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            net.pos_encoder.m_grid.mul_(1e3)                       # features of order 0.1 instead of 1e-4
+        x, d = torch.rand((3000, 3), device="cuda"), torch.rand((3000, 3), device="cuda")
+        torch.manual_seed(5)
+        x, d = torch.rand((3000, 3), device="cuda"), torch.rand((3000, 3), device="cuda")
+        out = net(x, d)
+        g = torch.randn((3000, 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+        out.backward(g)
+        outs.append((out.detach().clone(), [p.grad.detach().clone() for p in net.mlp_params()], net.pos_encoder.m_grid.grad.detach().clone(), net.density(x).detach().clone()))
+    (o1, w1, t1, d1), (o0, w0, t0, d0) = outs
+    sc = float(o0.abs().max())
+    assert (o1 - o0).abs().max() <= 1e-5 * max(sc, 1.0) and (d1 - d0).abs().max() <= 1e-5 * max(sc, 1.0)
+    # (a ReLU whose pre-activation is within fp32 rounding of zero may open on one side only: that moves one sample's gradient by a whole neuron's contribution,
+    # so gradients are compared in norm, not element by element)
+    for a, b in zip(w1, w0):
+        assert a.shape == b.shape and float((a - b).norm()) <= 1e-4 * float(b.norm()), (a.shape, float((a - b).norm()), float(b.norm()))
+    assert float((t1 - t0).norm()) <= 1e-4 * float(t0.norm())
+
+
 def test_nerf_dataset_on_disk(tmp_path):
     """NerfDataset (dataset.py:68-170 semantics): transforms JSON + PNGs, train includes val, missing files skipped, fl_x / camera_angle_x, aabb_scale"""
     import json
@@ -251,16 +291,18 @@ def test_nerf_dataset_on_disk(tmp_path):
     assert np.allclose(ro[0].cpu().numpy(), t[[1, 2, 0]], atol=1e-6)
 
 
-def test_fast_path_equals_module_path():
-    """fastpath.FusedTrainStep launches the same kernels as the autograd/module path: parameters after a few steps agree (the only difference
-    is the fp32 atomic order inside the dense-level scatter)"""
+@pytest.mark.parametrize("fp16", [True, False])
+def test_fast_path_equals_module_path(fp16):
+    """fastpath.FusedTrainStep (native ngp_train_step, gradients overwritten) launches the same kernels as the autograd/module path (gradients accumulated, zeroed by
+    the sweep): parameters after a few steps agree.  fp16 = the fused fp16-MFMA stack, fp32 = the fp32-MFMA stack ngp_base.py runs"""
     res = []
     for fast in (True, False):
-        r = _runner(fp16=True, aabb_scale=1, const_dt=True, fast_path=fast, pipeline_sampling=False)
+        r = _runner(fp16=fp16, aabb_scale=1, const_dt=True, fast_path=fast, pipeline_sampling=False)
         for i in range(3):
             l = r.train_step(i)
-        assert bool(r._fast) == fast
-        res.append((r.model.pos_encoder.m_grid.detach().clone(), r.model.rgb_mlp.con_weights.detach().clone(), float(l.sum().item())))
+        assert bool(r._fast) == fast and r.model.fused
+        w = torch.cat([p.detach().reshape(-1) for p in r.model.mlp_params()])
+        res.append((r.model.pos_encoder.m_grid.detach().clone(), w.clone(), float(l.sum().item())))
         r.drain()
     (g0, w0, l0), (g1, w1, l1) = res
     assert torch.allclose(w0, w1, rtol=2e-3, atol=2e-4), (w0 - w1).abs().max()
