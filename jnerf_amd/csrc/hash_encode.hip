@@ -562,10 +562,14 @@ __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__res
 template <typename T> struct RecVal;
 template <> struct RecVal<__half> { using type = __half2; };
 template <> struct RecVal<float> { using type = float2; };
-template <typename T> constexpr uint32_t bin_stage_bytes() { return 1024u * 8u * (uint32_t)(sizeof(typename RecVal<T>::type) + 4u) + 3u * BINS_PER_LEVEL * 4u; }
+// 512 samples per workgroup: 33 KiB (fp16) / 49 KiB (fp32) of LDS, so 3-4 workgroups share a CU and one workgroup's serial phases (loads -> LDS histogram -> the
+// wave-0 reservation with its global atomics -> staging -> copy-out, five barriers) hide behind the others'.  With 1024 samples (99 KiB for fp32: one workgroup
+// per CU) the fp32 pass took 185 us for 230 MB of records.
+#define BIN_WG 512u
+template <typename T> constexpr uint32_t bin_stage_bytes() { return BIN_WG * 8u * (uint32_t)(sizeof(typename RecVal<T>::type) + 4u) + 3u * BINS_PER_LEVEL * 4u; }
 
 template <typename T, int LAYOUT>
-__global__ __launch_bounds__(1024) void k_bin_records(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp,
+__global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp,
                                                       const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ cursors, typename RecVal<T>::type *__restrict__ rec_val,
                                                       uint16_t *__restrict__ rec_idx, uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill,
                                                       const uint32_t *__restrict__ n_valid) {
@@ -573,17 +577,17 @@ __global__ __launch_bounds__(1024) void k_bin_records(uint32_t n, const float *_
 	using RV = typename RecVal<T>::type;
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
 	RV *stage_val = reinterpret_cast<RV *>(bin_smem);                                   // [8192] contributions, grouped by bin
-	uint32_t *stage_idx = bin_smem + 1024u * 8u * (sizeof(RV) / 4u);                     // [8192] level-wide entry indices
-	uint32_t *cnt = stage_idx + 1024u * 8u, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL;
+	uint32_t *stage_idx = bin_smem + BIN_WG * 8u * (sizeof(RV) / 4u);                     // [8192] level-wide entry indices
+	uint32_t *cnt = stage_idx + BIN_WG * 8u, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL;
 	const uint32_t hl = blockIdx.y, level = bp.level[hl];
 	const uint32_t size = lt.v[4 * level + 1];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const float vs = sizeof(T) == 2 ? bin_scale(absmax_bits[level]) : (absmax_bits[level] ? 1.0f : 0.f);       // fp32 records are stored unscaled
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	if (vs == 0.f || blockIdx.x * 1024u >= lim) return;                // uniform exit
+	if (vs == 0.f || blockIdx.x * BIN_WG >= lim) return;                // uniform exit
 	if (threadIdx.x < BINS_PER_LEVEL) cnt[threadIdx.x] = 0;
 	__syncthreads();
-	const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+	const uint32_t i = blockIdx.x * BIN_WG + threadIdx.x;
 	const P *dy = reinterpret_cast<const P *>(dLdy);
 	uint32_t idx[8], rank[8]; RV val[8];
 	bool live = false;
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(1024) void k_bin_records(uint32_t n, const float *_
 	}
 	__syncthreads();
 	const uint32_t total = loff[BINS_PER_LEVEL - 1] + cnt[BINS_PER_LEVEL - 1];
-	for (uint32_t p = threadIdx.x; p < total; p += 1024u) {
+	for (uint32_t p = threadIdx.x; p < total; p += BIN_WG) {
 		const uint32_t e = stage_idx[p];
 		const RV v = stage_val[p];
 		const uint32_t bin = e >> BIN_BITS, slot = base[bin] + (p - loff[bin]);
@@ -869,7 +873,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		NGP_LAUNCH((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
 		if (units && side.ok) hipEventRecord(side.fork, s);   /* fork point: the dense-level kernel needs the abs-max too */ \
 		if (!probe_skip_bins) { \
-		NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, 1024), bp.n_levels), dim3(1024), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, (RV_ *)rec_val, rec_idx, spill_count, spill, n_valid); \
+		NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, BIN_WG), bp.n_levels), dim3(BIN_WG), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, (RV_ *)rec_val, rec_idx, spill_count, spill, n_valid); \
 		NGP_LAUNCH((k_bin_accumulate<G, RV_>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const RV_ *)rec_val, (const uint16_t *)rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, zero_first ? 1 : 0); } \
 	} \
 	hipStream_t sd = s; \

@@ -11,6 +11,7 @@
 // the training path, and march + compaction are one pass (ngp_march_rays_compacted).  Per-ray arithmetic is kept in the reference's
 // evaluation order with FMA contraction off, so sample counts and records are bit-identical to the reference's kernels.
 #include "ngp_common.h"
+#include <stdlib.h>
 #pragma clang fp contract(off)
 
 struct MarchParams {
@@ -50,7 +51,8 @@ __device__ __forceinline__ bool occupied_at(const float pos[3], const uint8_t *_
 	const uint32_t idx = morton3D(c[0], c[1], c[2]);
 	return bitfield[idx / 8 + (NGP_GRIDSIZE * NGP_GRIDSIZE * NGP_GRIDSIZE * mip) / 8] & (1 << (idx % 8));
 }
-__device__ __forceinline__ float advance_to_next_voxel(float t, const float pos[3], const float dir[3], const float idir[3], uint32_t res, const MarchParams &p) {   // :728-753
+// the parameter t_target the marcher skips to when the cell at `pos` is empty (:728-748); the stepping itself is `do t += calc_dt(t) while (t < t_target)`
+__device__ __forceinline__ float next_voxel_target(float t, const float pos[3], const float dir[3], const float idir[3], uint32_t res) {
 	float t3[3];
 #pragma unroll
 	for (int d = 0; d < 3; ++d) {
@@ -58,7 +60,10 @@ __device__ __forceinline__ float advance_to_next_voxel(float t, const float pos[
 		t3[d] = (floorf(q + 0.5f + 0.5f * copysignf(1.0f, dir[d])) - q) * idir[d];
 	}
 	float tt = fminf(fminf(t3[0], t3[1]), t3[2]);
-	float t_target = t + fmaxf(tt / res, 0.0f);
+	return t + fmaxf(tt / res, 0.0f);
+}
+__device__ __forceinline__ float advance_to_next_voxel(float t, const float pos[3], const float dir[3], const float idir[3], uint32_t res, const MarchParams &p) {   // :728-753
+	const float t_target = next_voxel_target(t, pos, dir, idir, res);
 	do { t += calc_dt(t, p); } while (t < t_target);
 	return t;
 }
@@ -133,7 +138,188 @@ __global__ __launch_bounds__(128) void k_march_count(uint32_t n_rays, MarchParam
 	steps[i] = march<false>(p, bitfield, o, d, startt, NGP_STEPS, nullptr, startts ? startts + (size_t)i * NGP_TCACHE : nullptr, 1);
 }
 
-// Single-workgroup exclusive scans in ray order (n_rays <= 2^18 in this path; 1024 threads x <=256 rays each).
+// ---------------------------------------------------------------------------------------------------------------- wave-cooperative count pass
+// One thread per ray (k_march_count above, kept for ngp_march_rays) is a chain of dependent loads per ray - hundreds of microseconds for the longest ray while
+// the chip idles (8 k rays = 124 waves on 1024 SIMDs).  The cooperative pass rests on one observation about the reference's loop (ray_sampler.h:52-69,
+// ray_sampler_header.h:728-753): whether a cell is occupied or not, t only ever advances by t += calc_dt(t).  The sequence t_0 = start, t_{k+1} = t_k + calc_dt(t_k)
+// is therefore FIXED per ray, independent of the occupancy grid; the marcher visits a subsequence of it (occupied: emit, go to k+1; empty: go to the first
+// m > k with !(t_m < t_target(k))).  So:
+//   chain phase : thread r of a workgroup produces the next 64 chain values of ray r with the reference's own serial fp32 recurrence (bit-identical t), into LDS;
+//   eval phase  : one WAVEFRONT per ray evaluates all 64 candidates at once (lane = candidate: position, box test, mip level, occupancy bit, skip target) -
+//                 one memory round trip per 64 candidates instead of one per visited candidate - and, by a lower-bound search in the LDS chain, the candidate
+//                 each visit would continue at;
+//   walk phase  : one THREAD per ray follows those links through its window (runs of "continue at the successor" are taken whole with mask arithmetic);
+//                 walking with wave-uniform scalar code instead cost ~800 SALU instructions per window and made the kernel scalar-issue-bound;
+//   emit phase  : wavefront per ray again: the emitting lanes store their t into the ray's t-cache at slot j + popcount(emitters below me) - the wavefront
+//                 ballot / prefix-sum compaction of north_star.
+// Sample counts and cached t are bit-identical to the serial traversal by construction (same expressions on the same t); a window that lies entirely before
+// a pending skip target costs one LDS read and one compare.
+#define MC_WIN 64u           // candidates per wavefront-wide window
+
+// MC_NW windows (MC_NW * 64 chain values) per ray per round: a ray that crosses the whole box takes 2048 candidates, i.e. 32 rounds of one window - and every round
+// is a chain of dependent latencies (serial chain -> barrier -> LDS -> global load -> LDS -> walk -> store -> barrier, ~15 k cycles measured), so the longest ray
+// alone held the kernel at ~200 us.  With several windows per round the evaluations of a ray's windows are independent of each other (only the walk is
+// serial): their occupancy loads are issued back to back and the per-round latency is paid once per MC_NW windows.
+template <uint32_t MC_RAYS /*rays per workgroup*/, uint32_t MC_WAVES, uint32_t MC_NW>
+__global__ __launch_bounds__(MC_WAVES * 64) void k_march_coop(uint32_t n_rays, MarchParams p, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                              const uint8_t *__restrict__ bitfield, uint32_t *__restrict__ steps, float *__restrict__ tcache) {
+	constexpr uint32_t NC = MC_NW * MC_WIN;                   // chain values per ray per round
+	__shared__ float tch[MC_RAYS][NC + 1];                    // +1: the chain threads write column k of every row in one instruction (odd stride: conflict-free)
+	__shared__ float ray_o[MC_RAYS][3], ray_d[MC_RAYS][3], ray_idir[MC_RAYS][3], ray_hs[MC_RAYS][3], pend[MC_RAYS];      // per-ray constants of the skip target: 1/d, 0.5*sign(d)
+	__shared__ uint32_t cnt[MC_RAYS], done[MC_RAYS], wstart[MC_RAYS], wemit[MC_RAYS], n_live;
+	__shared__ unsigned long long wmask[MC_RAYS][MC_NW][4];  // per window: inside / occupied / "continues at the next candidate" / emitters
+	__shared__ float wtarget[MC_RAYS][NC];                    // skip target of every candidate of the round
+	__shared__ uint16_t wnext[MC_RAYS][NC];                   // candidate the visit continues at (NC = beyond this round's chain)
+	__shared__ uint32_t mlut[NGP_GRIDSIZE];                   // expand_bits(i): three LDS reads per candidate instead of 24 VALU instructions
+	if (threadIdx.x < NGP_GRIDSIZE) mlut[threadIdx.x] = expand_bits(threadIdx.x);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, ray0 = blockIdx.x * MC_RAYS;
+	float t_next = 0.f;
+	if (threadIdx.x < MC_RAYS) {
+		const uint32_t r = threadIdx.x, i = ray0 + r;
+		cnt[r] = 0; pend[r] = -__builtin_inff(); wstart[r] = NC;
+		if (i < n_rays) {
+			float o[3], d[3];
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				o[k] = rays_o[3 * (size_t)i + k]; d[k] = rays_d[3 * (size_t)i + k]; ray_o[r][k] = o[k]; ray_d[r][k] = d[k];
+				ray_idir[r][k] = 1.0f / d[k]; ray_hs[r][k] = 0.5f * copysignf(1.0f, d[k]);
+			}
+			t_next = ray_start(p, i, o, d);
+			done[r] = 0;
+		} else done[r] = 1;
+		if (r == 0) n_live = min(MC_RAYS, n_rays - ray0);
+	}
+	__syncthreads();
+	const float big_neg = -__builtin_inff();
+	for (;;) {
+		// ---- chain phase: the next NC values of every live ray's fixed sequence (the reference's own recurrence)
+		if (threadIdx.x < MC_RAYS && !done[threadIdx.x]) {
+			float t = t_next;
+			if (p.const_dt) {                                             // (the branch is hoisted: per step it cost more than the add - 43 cycles per chain value measured)
+				const float dtc = calc_dt(t, p);
+#pragma unroll 8
+				for (uint32_t k = 0; k < NC; ++k) { tch[threadIdx.x][k] = t; t += dtc; }
+			} else {
+				const float lo = min_cone_stepsize(), hi = max_cone_stepsize(p.cascades);
+#pragma unroll 8
+				for (uint32_t k = 0; k < NC; ++k) { tch[threadIdx.x][k] = t; t += clampf(t * p.cone_angle, lo, hi); }
+			}
+			t_next = t;
+		}
+		__syncthreads();
+		// ---- eval phase: the (ray, window) pairs of the round are dealt to the wavefronts; one wavefront-wide evaluation each, results parked in LDS for the walk
+		for (uint32_t item = wave; item < MC_RAYS * MC_NW; item += MC_WAVES) {
+			const uint32_t r = item / MC_NW, w = item % MC_NW, self = w * MC_WIN + lane;
+			if (__builtin_amdgcn_readfirstlane((int)done[r])) continue;   // (wave-uniform: per-ray state is read into SGPRs)
+			const float pd = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pend[r])));
+			const float tl = tch[r][self];
+			if (pd != big_neg) {                                          // a skip from an earlier round is still running: it lands on the first t with !(t < target)
+				const unsigned long long m = __ballot(!(tl < pd));
+				if (m == 0ull) { if (lane == 0) { wmask[r][w][0] = 0ull; wmask[r][w][3] = 0ull; } continue; }      // the whole window lies before the target
+				if (lane == 0) atomicMin(&wstart[r], w * MC_WIN + (uint32_t)__builtin_ctzll(m));
+			} else if (w == 0 && lane == 0) wstart[r] = 0;
+			const float o[3] = {ray_o[r][0], ray_o[r][1], ray_o[r][2]}, d[3] = {ray_d[r][0], ray_d[r][1], ray_d[r][2]};
+			float pos[3];
+#pragma unroll
+			for (int k = 0; k < 3; ++k) pos[k] = o[k] + tl * d[k];
+			const bool inside = contains(p, pos);
+			bool occ = false;
+			float target = 0.f;
+			uint32_t nx = self + 1u;                                      // where the visit of this candidate continues (occupied: the next candidate)
+			if (inside) {
+				const float dt = calc_dt(tl, p);
+				const uint32_t mip = (uint32_t)mip_from_dt(dt, pos, p.cascades);
+				// occupied_at (ray_sampler_header.h:755-776), morton code from the LDS table
+				const float mip_scale = scalbnf(1.0f, -(int)mip);
+				uint32_t c[3];
+#pragma unroll
+				for (int k = 0; k < 3; ++k) {
+					float q = pos[k] - 0.5f; q *= mip_scale; q += 0.5f;
+					const int ci = (int)(q * NGP_GRIDSIZE);
+					c[k] = (uint32_t)min(max(ci, 0), (int)NGP_GRIDSIZE - 1);
+				}
+				const uint32_t idx = mlut[c[0]] | (mlut[c[1]] << 1) | (mlut[c[2]] << 2);
+				occ = bitfield[idx / 8 + (NGP_GRIDSIZE * NGP_GRIDSIZE * NGP_GRIDSIZE * mip) / 8] & (1 << (idx % 8));
+				if (!occ) {                                              // next_voxel_target with the per-ray constants (same expressions: x / 2^k == x * 2^-k exactly)
+					const uint32_t res = NGP_GRIDSIZE >> mip;
+					const float resf = (float)res, inv_res = 1.0f / resf;
+					float t3[3];
+#pragma unroll
+					for (int k = 0; k < 3; ++k) { const float q = resf * pos[k]; t3[k] = (floorf(q + 0.5f + ray_hs[r][k]) - q) * ray_idir[r][k]; }
+					const float tt = fminf(fminf(t3[0], t3[1]), t3[2]);
+					target = tl + fmaxf(tt * inv_res, 0.0f);
+					// the skip `do t += dt while (t < target)` lands on the first candidate m > self with !(t_m < target): t is increasing, so that is a
+					// lower-bound search in this round's chain (NC = beyond it)
+					uint32_t lo = self + 1u, hi = NC;
+					while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (tch[r][mid] < target) lo = mid + 1u; else hi = mid; }
+					nx = lo;
+				}
+			}
+			// (an empty candidate whose skip leaves the round is NOT a plain successor step: its target stays pending)
+			const unsigned long long IN = __ballot(inside), OCC = __ballot(occ), NX = __ballot(inside && nx == self + 1u && (occ || nx < NC));
+			wnext[r][self] = (uint16_t)nx; wtarget[r][self] = target;
+			if (lane == 0) { wmask[r][w][0] = IN; wmask[r][w][1] = OCC; wmask[r][w][2] = NX; wmask[r][w][3] = 0ull; }
+		}
+		__syncthreads();
+		// ---- walk phase: ONE THREAD per ray follows the visit chain through the round; candidates that continue at their successor are taken a run at a time
+		// with mask arithmetic, longer skips are one LDS read each
+		if (threadIdx.x < MC_RAYS) {
+			const uint32_t r = threadIdx.x;
+			uint32_t cur = done[r] ? NC : wstart[r];
+			uint32_t flag = 0;
+			if (cur < NC) {
+				const uint32_t j0 = cnt[r];
+				uint32_t emitted = 0, fin = 0;
+				float new_pend = big_neg;
+				while (cur < NC) {
+					const uint32_t w = cur / MC_WIN, c = cur % MC_WIN;
+					const unsigned long long IN = wmask[r][w][0], OCC = wmask[r][w][1], NX = wmask[r][w][2];
+					if (!((IN >> c) & 1ull) || j0 + emitted >= NGP_STEPS) { fin = 1; break; }      // the loop condition of ray_sampler.h:52: contains(pos) && j < NERF_STEPS
+					if ((NX >> c) & 1ull) {                                  // a run of candidates visited one after the other; its occupied members emit
+						const unsigned long long rest = ~(NX >> c);
+						uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+						if (run > MC_WIN - c) run = MC_WIN - c;             // (a run that reaches the window's end continues in the next window's masks)
+						const unsigned long long runmask = (run >= 64u ? ~0ull : ((1ull << run) - 1ull)) << c;
+						unsigned long long em = OCC & runmask;
+						const uint32_t n_em = (uint32_t)__builtin_popcountll(em), room = NGP_STEPS - (j0 + emitted);
+						if (n_em > room) {                                   // NERF_STEPS is reached inside the run: keep its first `room` emitters, the ray ends there
+							unsigned long long keep = 0ull;
+							for (uint32_t q = 0; q < room; ++q) { const unsigned long long low = em & (0ull - em); keep |= low; em ^= low; }
+							wmask[r][w][3] |= keep; emitted += room; fin = 1;
+							break;
+						}
+						wmask[r][w][3] |= em; emitted += n_em; cur += run;
+					} else {                                                // an empty cell whose skip goes further than the next candidate
+						const uint32_t nx = wnext[r][cur];
+						if (nx >= NC) { new_pend = wtarget[r][cur]; break; }          // lands in a later round
+						cur = nx;
+					}
+				}
+				cnt[r] = j0 + emitted;
+				pend[r] = new_pend;
+				if (fin) { done[r] = 1; steps[ray0 + r] = j0 + emitted; atomicSub(&n_live, 1u); }
+				flag = j0 | 0x80000000u;                                  // tells the emit phase that the emitter masks are valid, and the slot of the round's first emitter
+			}
+			wemit[r] = flag;
+			wstart[r] = NC;                                               // reset for the next round's atomicMin
+		}
+		__syncthreads();
+		// ---- emit phase (wavefront per window again): emitters store their t at slot j0 + (number of emitters before me): the wavefront ballot / prefix-sum compaction
+		for (uint32_t item = wave; item < MC_RAYS * MC_NW; item += MC_WAVES) {
+			const uint32_t r = item / MC_NW, w = item % MC_NW;
+			const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)wemit[r]);
+			if (!(ws & 0x80000000u)) continue;
+			uint32_t slot = ws & 0x7fffffffu;
+			for (uint32_t v = 0; v < w; ++v) slot += (uint32_t)__builtin_popcountll(wmask[r][v][3]);
+			const unsigned long long E = wmask[r][w][3];
+			if (tcache && ((E >> lane) & 1ull)) tcache[(size_t)(ray0 + r) * NGP_TCACHE + slot + (uint32_t)__builtin_popcountll(E & ((1ull << lane) - 1ull))] = tch[r][w * MC_WIN + lane];
+		}
+		__syncthreads();
+		if (n_live == 0) break;          // (read by every thread before the next barrier; the walkers change it only after that barrier)
+	}
+}
+
+// Exclusive scans in ray order (n_rays <= 2^18 in this path):
 //  base[i]  = sum_{k<i} steps[k]                       (what atomicAdd(numsteps_counter) yields under a serial launch, ray_sampler.h:73)
 //  ok[i]    = base[i] + steps[i] <= max_samples        (:74-80; overflowed rays keep their reservation but get numsteps 0)
 //  ridx[i]  = #ok rays before i                        (:84)
@@ -152,52 +338,73 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 	__syncthreads();
 	return res;
 }
-#define SCAN_TILE 8192u     // rays per tile: coalesced load -> LDS -> each thread scans 8 consecutive rays -> workgroup scan -> coalesced store
-__global__ __launch_bounds__(1024) void k_march_scan(uint32_t n_rays, uint32_t max_samples, uint32_t cap, const uint32_t *__restrict__ steps,
-                                                     uint32_t *__restrict__ numsteps, uint32_t *__restrict__ numsteps_c, int32_t *__restrict__ ray_indices,
-                                                     uint32_t *__restrict__ counters, int n_counters) {
+// The three scans, multi-block (round 1's single 1024-thread workgroup took 78-99 us for ~40 k rays on a 256-CU chip): tiles of 2048 rays, one workgroup
+// each, three short launches - tile totals of the step counts; tile totals of the (ok, ok-steps) pairs, which need the global bases; final values.
+// Every launch re-derives what it needs from `steps` and the <= 128 tile totals (integer sums: the result does not depend on the tiling).
+#define MS_TILE 2048u
+__device__ __forceinline__ uint32_t tiles_before(const uint32_t *__restrict__ tot, uint32_t b, uint32_t *sh) {      // sum of tot[0..b)
+	uint32_t total;
+	(void)block_exclusive_scan_1024(threadIdx.x < b ? tot[threadIdx.x] : 0u, sh, total);
+	return total;
+}
+__global__ __launch_bounds__(1024) void k_mscan_totals(uint32_t n_rays, const uint32_t *__restrict__ steps, uint32_t *__restrict__ tot1) {
 	__shared__ uint32_t sh[17];
-	__shared__ uint32_t tile[SCAN_TILE + SCAN_TILE / 8];      // +1 word per 8 to dodge the 8-stride bank conflict
-	uint32_t run_base = 0, run_ok = 0, run_sumok = 0;           // running totals of the three scans (wave-uniform, identical in every thread)
-	for (uint32_t t0 = 0; t0 < n_rays; t0 += SCAN_TILE) {
-		const uint32_t cnt = min(SCAN_TILE, n_rays - t0);
-		for (uint32_t e = threadIdx.x; e < SCAN_TILE; e += 1024) tile[e + (e >> 3)] = e < cnt ? steps[t0 + e] : 0u;
-		__syncthreads();
-		uint32_t v[8], sum = 0;
+	const uint32_t i = blockIdx.x * MS_TILE + threadIdx.x * 2u;
+	const uint32_t v = (i < n_rays ? steps[i] : 0u) + (i + 1 < n_rays ? steps[i + 1] : 0u);
+	uint32_t total;
+	(void)block_exclusive_scan_1024(v, sh, total);
+	if (threadIdx.x == 0) tot1[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_mscan_ok(uint32_t n_rays, uint32_t max_samples, const uint32_t *__restrict__ steps, const uint32_t *__restrict__ tot1,
+                                                   uint32_t *__restrict__ tot2, uint32_t *__restrict__ tot3) {
+	__shared__ uint32_t sh[17];
+	const uint32_t i = blockIdx.x * MS_TILE + threadIdx.x * 2u;
+	const uint32_t v0 = i < n_rays ? steps[i] : 0u, v1 = i + 1 < n_rays ? steps[i + 1] : 0u;
+	const uint32_t before = tiles_before(tot1, blockIdx.x, sh);
+	uint32_t total;
+	const uint32_t base = before + block_exclusive_scan_1024(v0 + v1, sh, total);
+	const bool ok0 = i < n_rays && base + v0 <= max_samples, ok1 = i + 1 < n_rays && base + v0 + v1 <= max_samples;
+	uint32_t t2, t3;
+	(void)block_exclusive_scan_1024((uint32_t)ok0 + (uint32_t)ok1, sh, t2);
+	(void)block_exclusive_scan_1024((ok0 ? v0 : 0u) + (ok1 ? v1 : 0u), sh, t3);
+	if (threadIdx.x == 0) { tot2[blockIdx.x] = t2; tot3[blockIdx.x] = t3; }
+}
+__global__ __launch_bounds__(1024) void k_mscan_final(uint32_t n_rays, uint32_t max_samples, uint32_t cap, const uint32_t *__restrict__ steps, const uint32_t *__restrict__ tot1,
+                                                      const uint32_t *__restrict__ tot2, const uint32_t *__restrict__ tot3, uint32_t *__restrict__ numsteps,
+                                                      uint32_t *__restrict__ numsteps_c, int32_t *__restrict__ ray_indices, uint32_t *__restrict__ counters, int n_counters) {
+	__shared__ uint32_t sh[17];
+	const uint32_t i = blockIdx.x * MS_TILE + threadIdx.x * 2u;
+	const uint32_t v[2] = {i < n_rays ? steps[i] : 0u, i + 1 < n_rays ? steps[i + 1] : 0u};
+	const uint32_t b1 = tiles_before(tot1, blockIdx.x, sh), b2 = tiles_before(tot2, blockIdx.x, sh), b3 = tiles_before(tot3, blockIdx.x, sh);
+	uint32_t total, t2, t3;
+	uint32_t base = b1 + block_exclusive_scan_1024(v[0] + v[1], sh, total);
+	const bool ok[2] = {i < n_rays && base + v[0] <= max_samples, i + 1 < n_rays && base + v[0] + v[1] <= max_samples};
+	uint32_t ridx = b2 + block_exclusive_scan_1024((uint32_t)ok[0] + (uint32_t)ok[1], sh, t2);
+	uint32_t cbase = b3 + block_exclusive_scan_1024((ok[0] ? v[0] : 0u) + (ok[1] ? v[1] : 0u), sh, t3);
 #pragma unroll
-		for (int k = 0; k < 8; ++k) { v[k] = tile[threadIdx.x * 9 + k]; sum += v[k]; }
-		uint32_t total;
-		uint32_t base = run_base + block_exclusive_scan_1024(sum, sh, total);
-		uint32_t nok = 0, sumok = 0, okmask = 0, bases[8];
-#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const bool ok = (t0 + threadIdx.x * 8 + k < n_rays) && base + v[k] <= max_samples;
-			bases[k] = base; okmask |= ok ? (1u << k) : 0u;
-			nok += ok; sumok += ok ? v[k] : 0u;
-			base += v[k];
+	for (int k = 0; k < 2; ++k) {
+		const uint32_t r = i + k;
+		const uint32_t sk = ok[k] ? v[k] : 0u;
+		if (r < n_rays) {
+			numsteps[2 * r] = sk; numsteps[2 * r + 1] = base;
+			if (ray_indices) ray_indices[r] = !ok[k] ? 0 /*left untouched by the reference*/ : (sk == 0 ? -1 : (int32_t)ridx);
+			if (numsteps_c) { numsteps_c[2 * r] = min(cap - min(cap, cbase), sk); numsteps_c[2 * r + 1] = cbase; }
 		}
-		uint32_t total_ok, total_sumok;
-		uint32_t ridx = run_ok + block_exclusive_scan_1024(nok, sh, total_ok);
-		uint32_t cbase = run_sumok + block_exclusive_scan_1024(sumok, sh, total_sumok);
-#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const uint32_t i = t0 + threadIdx.x * 8 + k;
-			const bool ok = (okmask >> k) & 1u;
-			const uint32_t sk = ok ? v[k] : 0u;
-			if (i < n_rays) {
-				numsteps[2 * i] = sk; numsteps[2 * i + 1] = bases[k];
-				if (ray_indices) ray_indices[i] = !ok ? 0 /*left untouched by the reference*/ : (sk == 0 ? -1 : (int32_t)ridx);
-				if (numsteps_c) { numsteps_c[2 * i] = min(cap - min(cap, cbase), sk); numsteps_c[2 * i + 1] = cbase; }
-			}
-			ridx += ok; cbase += sk;
-		}
-		run_base += total; run_ok += total_ok; run_sumok += total_sumok;
-		__syncthreads();
+		base += v[k]; ridx += ok[k]; cbase += sk;
 	}
-	if (threadIdx.x == 0) {
-		counters[0] = run_ok; counters[1] = run_base;
-		if (n_counters == 4) { counters[2] = run_sumok; counters[3] = min(run_sumok, cap); }
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+		counters[0] = b2 + t2; counters[1] = b1 + total;
+		if (n_counters == 4) { counters[2] = b3 + t3; counters[3] = min(b3 + t3, cap); }
 	}
+}
+// tot: 3 x 128 u32 of scratch
+static void launch_march_scan(hipStream_t s, uint32_t n_rays, uint32_t max_samples, uint32_t cap, const uint32_t *steps, uint32_t *tot, uint32_t *numsteps, uint32_t *numsteps_c,
+                              int32_t *ray_indices, uint32_t *counters, int n_counters) {
+	const uint32_t nb = div_up(n_rays, MS_TILE);
+	NGP_LAUNCH(k_mscan_totals, dim3(nb), dim3(1024), 0, s, n_rays, steps, tot);
+	NGP_LAUNCH(k_mscan_ok, dim3(nb), dim3(1024), 0, s, n_rays, max_samples, steps, (const uint32_t *)tot, tot + 128, tot + 256);
+	NGP_LAUNCH(k_mscan_final, dim3(nb), dim3(1024), 0, s, n_rays, max_samples, cap, steps, (const uint32_t *)tot, (const uint32_t *)(tot + 128), (const uint32_t *)(tot + 256), numsteps,
+	           numsteps_c, ray_indices, counters, n_counters);
 }
 
 template <bool COMPACTED>
@@ -267,7 +474,7 @@ NGP_API int ngp_march_rays(void *stream, uint32_t n_rays, const float *rays_o, c
 	if (zero_coords && coords) { hipError_t e = hipMemsetAsync(coords, 0, (size_t)max_samples * 28, s); if (e != hipSuccess) { ngp_set_error("ngp_march_rays memset: %s", hipGetErrorString(e)); return (int)e; } }
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 8, s); return 0; }
 	NGP_LAUNCH(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, (float *)nullptr);
-	NGP_LAUNCH(k_march_scan, dim3(1), dim3(1024), 0, s, n_rays, max_samples, 0u, (const uint32_t *)scratch, numsteps, (uint32_t *)nullptr, ray_indices, counters, 2);
+	launch_march_scan(s, n_rays, max_samples, 0u, (const uint32_t *)scratch, scratch + n_rays, numsteps, (uint32_t *)nullptr, ray_indices, counters, 2);
 	NGP_LAUNCH(k_march_write<false>, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, (const uint32_t *)numsteps, coords);
 	NGP_LAUNCH_CHECK("ngp_march_rays");
 	return 0;
@@ -276,6 +483,8 @@ NGP_API int ngp_march_rays(void *stream, uint32_t n_rays, const float *rays_o, c
 NGP_API int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
                                          float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                                          uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch, float *pos_out);
+static int g_march_count_mode = -1;                                      // 0 = by samples per ray, 1 = serial, 2 = cooperative
+NGP_API void ngp_x_march_count_mode(int mode) { g_march_count_mode = mode; }      // probe hook (not part of the ABI): tests run both count passes on the same rays
 NGP_API uint64_t ngp_march_scratch_elems(uint32_t n_rays) { return (uint64_t)((n_rays + 1023u) & ~1023u) + (uint64_t)NGP_TCACHE * n_rays + 1024u; }
 
 NGP_API int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
@@ -294,8 +503,17 @@ NGP_API int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const fl
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 16, s); return 0; }
 	// scratch = steps[n_rays] | pad to 1024 | t-cache[NGP_TCACHE][n_rays]  (ngp_march_scratch_elems(n_rays) u32 elements)
 	float *tcache = reinterpret_cast<float *>(scratch + ((n_rays + 1023u) & ~1023u));
-	NGP_LAUNCH(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
-	NGP_LAUNCH(k_march_scan, dim3(1), dim3(1024), 0, s, n_rays, max_samples, cap, (const uint32_t *)scratch, numsteps, numsteps_compacted, (int32_t *)nullptr, counters, 4);
+	// Which count pass?  The cooperative one evaluates EVERY candidate of the ray's fixed t sequence (64 per wavefront instruction), the serial one only the
+	// candidates the loop visits (one per empty cell + one per sample) but as a chain of dependent loads per ray.  Measured alone on the GPU, steady state
+	// (tools/bench_march.py): ngp_base.py sampling (7.8 k rays x 33 samples, constant step, 9 candidates per cell) serial 800 us / cooperative 190 us;
+	// ngp_fox.py sampling (34 k rays x 7 samples, cone stepping through 4 cascades, 2-4 candidates per cell) serial 370 us on a nearly idle chip /
+	// cooperative 380-540 us on a busy one.  So: cooperative when rays carry many samples (>= 16 on average: also the first few hundred iterations of any
+	// run and every inference chunk), serial when they are mostly empty space.  Both produce identical bits (tests/test_hip_parity.py runs both).
+	if (g_march_count_mode < 0) { const char *e = getenv("NGP_MARCH_COUNT"); g_march_count_mode = !e ? 0 : (e[0] == 's' ? 1 : 2); }      // NGP_MARCH_COUNT=serial|coop overrides the choice
+	const bool coop = g_march_count_mode ? g_march_count_mode == 2 : (uint64_t)cap >= (uint64_t)16 * n_rays;
+	if (coop) NGP_LAUNCH((k_march_coop<4u, 4u, 4u>), dim3(div_up(n_rays, 4u)), dim3(256), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
+	else NGP_LAUNCH(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
+	launch_march_scan(s, n_rays, max_samples, cap, (const uint32_t *)scratch, scratch + ((n_rays + 1023u) & ~1023u) + (size_t)NGP_TCACHE * n_rays, numsteps, numsteps_compacted, (int32_t *)nullptr, counters, 4);
 	NGP_LAUNCH(k_march_write_cached, dim3(div_up(cap, 256)), dim3(256), 0, s, n_rays, p, rays_o, rays_d, (const uint32_t *)numsteps_compacted,
 	                   (const uint32_t *)counters, 3u, (const float *)tcache, coords_out, pos_out);
 	NGP_LAUNCH_CHECK("ngp_march_rays_compacted");

@@ -172,7 +172,7 @@ class NGPNetworks(nn.Module):
         return b
 
     def mlp_params(self):
-        return [self.density_mlp.con_weights, self.rgb_mlp.con_weights] if self._pack32 is None else [m.weight for m in self._linears()]
+        return [self.density_mlp.con_weights, self.rgb_mlp.con_weights] if isinstance(self.density_mlp, FMLP) else [m.weight for m in self._linears()]
 
     def _flat_weight_grad(self):
         """every MLP parameter's .grad as a view of ONE fp32[10240] buffer (slab layout of ngp_field_bwd / ngp_field32_bwd)"""

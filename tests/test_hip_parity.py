@@ -30,6 +30,11 @@ def test_hip_matches_golden(H, case):
     getattr(GC, case)(H, GC.load(), exact=False)
 
 
+@pytest.mark.parametrize("case", [c for c in GC.CASES if "march" in c])
+def test_hip_marcher_matches_golden_with_either_count_pass(H, case, count_pass):
+    getattr(GC, case)(H, GC.load(), exact=False)
+
+
 @pytest.mark.parametrize("aabb_scale", [1, 4])
 def test_hash_fwd_fp32_bit_exact_vs_oracle(H, aabb_scale):
     from jnerf_amd import ops
@@ -258,8 +263,20 @@ def test_field32_bwd_vs_oracle(H, n):
         assert not dw[3072 + 6144 + 3 * 64:].any()       # padded rows of the last layer stay zero
 
 
+@pytest.fixture(params=["serial", "coop"])
+def count_pass(request):
+    """ngp_march_rays_compacted picks its count pass by samples per ray (thread-per-ray serial traversal | wave-cooperative evaluation of the ray's fixed t sequence);
+    both must give the reference's bits, so the marcher tests run under each"""
+    import ctypes
+    from jnerf_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.ngp_x_march_count_mode({"serial": 1, "coop": 2}[request.param])
+    yield request.param
+    lib.ngp_x_march_count_mode(0)
+
+
 @pytest.mark.parametrize("const_dt,aabb", [(True, (0.0, 1.0)), (False, (-1.5, 2.5))])
-def test_march_compacted_equals_march_then_compact(H, const_dt, aabb):
+def test_march_compacted_equals_march_then_compact(H, const_dt, aabb, count_pass):
     xf, focal, meta = synth.camera_ring(8, radius=1.3)
     img, o, d, _ = synth.rays_from_cameras(xf, focal, meta, 64, 48, 4096, seed=9)
     bits = synth.shell_bitfield()
