@@ -813,7 +813,8 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	uint64_t slab_cursor = 0;
 	bool any_binned = false;
 	for (int l = 0; l < 16; ++l) any_binned |= level_binned(lt, l);
-	const bool fx64 = use_bins && any_binned;                             // the abs-max pass runs -> dense levels can use the integer sums
+	static const bool dense_float = getenv("NGP_HASH_BWD_DENSE_FLOAT") != nullptr;     // experiment hook: fp32 dense levels on LDS float atomics instead of 64-bit integer sums
+	const bool fx64 = use_bins && any_binned && !(dense_float && dtype == NGP_F32);                             // the abs-max pass runs -> dense levels can use the integer sums
 	plan.half_slices = 0;
 	for (int l = 0; l < 16; ++l) {
 		const bool wide = fx64 && dtype == NGP_F32 && !level_binned(lt, l);          // fp32 dense level with slabs: 64-bit sum per feature, 8192-entry slices
@@ -821,8 +822,24 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		slices[l] = div_up(lt.v[4 * l + 1], wide ? OWN_SLICE / 2 : OWN_SLICE);
 		plan.slab_off[l] = ~0u;
 		if (level_binned(lt, l)) { plan.chunks[l] = 1u; continue; }
-		if (use_slabs) { plan.chunks[l] = 32u; plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)32u * lt.v[4 * l + 1]; }   // 32 sample chunks per slice, partial slabs
+		if (use_slabs) plan.chunks[l] = 32u;                                 // (re-balanced below)
 		else plan.chunks[l] = 32u / slices[l] ? 32u / slices[l] : 1u;
+	}
+	if (use_slabs) {
+		// Sample chunks per slice of the dense levels.  A unit (slice, chunk) pays a fixed price - clear and flush 128 KiB of LDS, one partial slab to write and
+		// later re-read - before it looks at a single sample, and holds a whole CU (128 KiB of LDS) while it runs.  32 chunks for every slice meant 544 (fox, fp16)
+		// to 1376 (lego, fp32) units, i.e. up to 5.4 rounds of workgroups each dominated by that fixed part (230 us for the lego batch).  Now the chunk count is
+		// chosen so that all units together fill the 256 CUs about once; the small, heavily contended coarse levels get twice the chunks of the large ones.
+		uint32_t weighted = 0;
+		for (int l = 0; l < 16; ++l) if (!level_binned(lt, l)) weighted += slices[l] * (slices[l] <= 2u ? 2u : 1u);
+		uint32_t base = weighted ? 256u / weighted : 32u;
+		if (base < 1u) base = 1u;
+		for (int l = 0; l < 16; ++l) {
+			if (level_binned(lt, l)) continue;
+			uint32_t c = base * (slices[l] <= 2u ? 2u : 1u);
+			plan.chunks[l] = c > 32u ? 32u : (c < 2u ? 2u : c);              // >= 2: the exclusive-owner (chunks == 1) branch belongs to the hashed levels
+			plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)plan.chunks[l] * lt.v[4 * l + 1];
+		}
 	}
 	for (int pass = 0; pass < 2; ++pass)                                  // chunked dense levels first (their hot slices are the long poles), largest level first
 		for (int l = 15; l >= 0; --l)

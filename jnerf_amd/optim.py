@@ -165,11 +165,12 @@ class Adam:
             if p.grad is None:
                 continue
             e = ema.param_groups[0]["values"][i] if ema is not None else None
-            if p.is_cuda:
+            # the fused kernel streams 16-byte vectors; a 1- or 3-element bias (OriginNeRFNetworks' alpha / rgb heads) takes the same update in plain torch ops
+            if p.is_cuda and p.numel() % 4 == 0 and p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 and p.is_contiguous():
                 g_eff = self._eff_grad.pop(id(p), None)            # reduced fp16 gradient of the data-parallel path (p.grad was zeroed by the conversion pass)
                 ops.adam_ema_step(p.data, g_eff.view_as(p.grad) if g_eff is not None else p.grad, pg["m"][i], pg["values"][i], e, self._half.get(id(p)), self.lr, self.n_step, self.betas[0], self.betas[1], self.eps,
                                   ema.decay if ema is not None else 0.0, zero_grad=True)
-            else:                                   # CPU tensors (gloo unit tests of the data-parallel logic): same math in torch
+            else:                                   # CPU tensors (gloo unit tests of the data-parallel logic) and tiny / unaligned tensors: same math in torch
                 b0, b1 = self.betas
                 g = p.grad
                 m, v = pg["m"][i], pg["values"][i]
@@ -181,6 +182,9 @@ class Adam:
                     d, k = ema.decay, self.n_step
                     p.data.copy_(((1 - d) * p.data + d * e * (1 - d ** (k - 1))) / (1 - d ** k))
                     e.copy_(p.data)
+                h = self._half.get(id(p))
+                if h is not None:
+                    h.copy_(p.data)
                 g.zero_()
         self._pending = False
 

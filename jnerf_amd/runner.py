@@ -6,7 +6,7 @@ import torch
 from .utils.config import get_cfg
 from .utils.registry import build_from_cfg, NETWORKS, DATASETS, OPTIMS, SAMPLERS, LOSSES
 from .losses import img2mse, mse2psnr
-from . import encoders, network, sampler, optim, losses, dataset  # noqa: F401  (register modules)
+from . import encoders, network, networks_ori, sampler, optim, losses, dataset  # noqa: F401  (register modules)
 
 
 class Runner:

@@ -403,3 +403,109 @@ def test_full_size_properties(H):
     assert torch.allclose(rgb, alpha.expand(-1, 3), atol=1e-5) and (alpha >= 0).all() and (alpha <= 1 + 1e-6).all()
     ns64 = ns.cpu().numpy().view(np.uint32).astype(np.int64)
     assert (np.diff(ns64[:, 1]) >= 0).all() and ns64[:, 0].max() <= 1024      # ray-ordered bases, MAX_STEP respected
+
+
+def _ray_coherent_batch(H, n_target=1 << 18, aabb=(0.0, 1.0), const_dt=True, n_rays=9000):
+    """a full-size (2^18-sample) batch with the statistics of a trained scene: rays from a camera ring marched through a shell occupancy grid (consecutive
+    samples of a ray are spatially adjacent; everything sits on a thin surface) - SURVEY.md §8d's "ray-coherent" input"""
+    xf, focal, meta = synth.camera_ring(16, radius=1.3)
+    _, o, d, _ = synth.rays_from_cameras(xf, focal, meta, 200, 150, n_rays, seed=21)
+    coords, ns, nsc, cnt = H.march_rays_compacted(o, d, synth.shell_bitfield(), aabb, O.PCG32(1337), 4096 * 1024, n_target, const_dt=const_dt)
+    k = int(cnt[3])
+    assert k > n_target // 2, k
+    return np.ascontiguousarray(coords[:k]), ns, nsc, k
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_full_size_hash_fwd_bwd_vs_oracle_on_ray_coherent_samples(H, dtype):
+    """HIP vs oracle at BASELINE's full batch size on training-distribution inputs (the single-core oracle needs ~3 s per pass),
+    through the workspace path the training step uses (binned hashed levels + chunked dense levels), both table precisions"""
+    from jnerf_amd import ops
+    coords, _, _, k = _ray_coherent_batch(H)
+    x = np.ascontiguousarray(coords[:, :3])
+    table, offsets, n_params = O.level_table(1)
+    grid = synth.table(n_params, dtype, amp=2.0)
+    ref = O.hash_encode_fwd(x, grid, table)
+    out = H.hash_encode_fwd(x, grid, table)
+    if dtype == np.float32:
+        assert np.array_equal(out, ref)
+    else:
+        GC.close(out, ref, atol=3e-3, what="full-size fp16 fwd")
+    rng = np.random.default_rng(5)
+    dy = (rng.normal(size=(k, 32)) * 1e-3 * np.exp(rng.normal(size=(k, 1)))).astype(dtype)          # per-sample magnitudes over a few decades, like dL/dfeatures
+    gref = O.hash_encode_bwd(x, dy.astype(np.float32), table, n_params)
+    dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, k), dtype=torch.uint8, device="cuda")
+    g = torch.full((n_params,), 5.0, dtype=torch.float32, device="cuda")
+    ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
+    got = H.N(g)
+    for l in range(16):
+        lo, hi = int(offsets[l]) * 2, int(offsets[l + 1]) * 2
+        scale = np.abs(gref[lo:hi]).max()
+        tol = 1e-5 if dtype == np.float32 else 2e-3             # fp16: every contribution is rounded to 2^-11 once, sums of thousands of them on the coarse levels
+        err = np.abs(got[lo:hi] - gref[lo:hi]).max()
+        assert err <= tol * scale, (l, err, scale)
+    g2 = torch.zeros_like(g)
+    ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g2, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
+    assert torch.equal(g, g2)                                  # integer accumulation everywhere on this path: bit-reproducible, dense levels included
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_hash_bwd_bin_overflow_spills_exactly(H, dtype):
+    """a clustered batch (every sample inside one cell of the finest level) drives a few bins far beyond their record capacity (n/2): the surplus goes to the
+    shared spill list and is folded in by the bins' owners - same result as the oracle, still bit-reproducible, no float atomics (hash_encode.hip k_bin_records / k_bin_accumulate)"""
+    from jnerf_amd import ops
+    table, offsets, n_params = O.level_table(1)
+    n = 20000
+    rng = np.random.default_rng(9)
+    x = (0.37 + rng.random((n, 3)) * 2e-4).astype(np.float32)           # 2e-4 < 1/2048: one cell on every level
+    dy = (rng.normal(size=(n, 32)) * 1e-2).astype(dtype)
+    ref = O.hash_encode_bwd(x, dy.astype(np.float32), table, n_params)
+    dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n), dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        g = torch.full((n_params,), -3.0, dtype=torch.float32, device="cuda")
+        ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
+        outs.append(H.N(g))
+    assert np.array_equal(outs[0], outs[1])
+    # 8 corners x 20000 samples land in <= 8 bins of a hashed level: >= 20000 records in a bin with capacity max(4096, n/2) = 10000 => the spill path ran
+    tol = dict(atol=1e-6, rtol=1e-5) if dtype == np.float32 else dict(atol=2e-3 * np.abs(ref).max(), rtol=2e-3)
+    GC.close(outs[0], ref, what="clustered batch", **tol)
+    g = torch.from_numpy(outs[0]).cuda()
+    ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=False, workspace=ws)           # accumulate mode through the same path
+    GC.close(H.N(g) / 2, ref, what="clustered batch, accumulate", **tol)
+
+
+def test_full_size_field_fwd_bwd_vs_oracle(H):
+    """fp16-MFMA and fp32-MFMA field kernels at 2^18 samples against the oracle's fp32 chain (weight gradients are sums over all samples: the slab reduction and
+    the persistent-workgroup loop are only exercised at this size)"""
+    from jnerf_amd import ops
+    n = 1 << 18
+    feat, d, wd, wc = _field32_inputs(n, seed=30)
+    feat *= 0.2
+    rng = np.random.default_rng(31)
+    dout = (rng.normal(size=(n, 4)) * 1e-3).astype(np.float32)
+    sh = O.sh_encode(d, np.float32)
+    ref = O.field_fwd(feat, sh, wd, wc)
+    rdf, rdwd, rdwc = O.field_bwd(feat, sh, wd, wc, dout)
+    T = H.T
+    fs = np.ascontiguousarray(feat.reshape(n, 16, 2).transpose(1, 0, 2))
+    scale = max(1.0, np.abs(ref).max())
+    out32 = H.N(ops.field32_fwd(T(fs), T(d), T(wd), T(wc), layout=ops.LAYOUT_SOA))
+    GC.close(out32, ref, atol=1e-5 * scale, what="field32 fwd 2^18")
+    df32, slabs = ops.field32_bwd(T(fs), T(d), T(wd), T(wc), T(dout), layout=ops.LAYOUT_SOA)
+    dw32 = H.N(ops.reduce_slabs(slabs))
+    GC.close(dw32[:3072], rdwd, atol=5e-5 * np.abs(rdwd).max(), what="field32 dW density 2^18")
+    GC.close(dw32[3072:], rdwc, atol=5e-5 * np.abs(rdwc).max(), what="field32 dW rgb 2^18")
+    df32 = H.N(df32).transpose(1, 0, 2).reshape(n, 32)
+    assert np.quantile(np.abs(df32 - rdf), 0.9999) <= 1e-5 * np.abs(rdf).max()
+    # fp16 kernels on the same (rounded) inputs: fp16 activations => 2 % of scale, gradients in L2
+    f16, w16d, w16c = fs.astype(np.float16), wd.astype(np.float16), wc.astype(np.float16)
+    out16 = H.N(ops.field_fwd(T(f16), T(d), T(w16d), T(w16c), layout=ops.LAYOUT_SOA, out_dtype=torch.float32))
+    GC.close(out16, ref, atol=2e-2 * scale, what="field fp16 fwd 2^18")
+    df16, slabs16 = ops.field_bwd(T(f16), T(d), T(w16d), T(w16c), T(dout.astype(np.float16)), layout=ops.LAYOUT_SOA)
+    dw16 = H.N(ops.reduce_slabs(slabs16))
+    assert np.linalg.norm(dw16[:3072] - rdwd) <= 3e-2 * np.linalg.norm(rdwd) and np.linalg.norm(dw16[3072:] - rdwc) <= 3e-2 * np.linalg.norm(rdwc)
+    df16 = H.N(df16).astype(np.float32).transpose(1, 0, 2).reshape(n, 32)
+    assert np.linalg.norm(df16 - rdf) <= 3e-2 * np.linalg.norm(rdf)

@@ -255,6 +255,27 @@ def test_fp32_fused_network_equals_linear_chain():
     assert float((t1 - t0).norm()) <= 1e-4 * float(t0.norm())
 
 
+def test_original_nerf_config_plumbing(tmp_path):
+    """BASELINE config [0]: projects/nerf/configs/nerf_base.py's stack (FrequencyEncoder 10 / 4 bands, OriginNeRFNetworks 8 x 256, fp16 autocast, DensityGridSampler, Huber,
+    Adam lr 1e-2 + EMA) on a small procedural scene through the module path: occupancy refresh, marching, HIP compositing and its backward, torch MLP, fused sweep."""
+    from jnerf_amd.utils.config import init_cfg, get_cfg
+    from jnerf_amd.runner import Runner
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    init_cfg(os.path.join(root, "projects", "nerf", "configs", "nerf_base.py"))
+    cfg = get_cfg()
+    ds = dict(type="SyntheticNerfDataset", batch_size=512, n_images=6, W=64, H=64, aabb_scale=1)
+    cfg.dataset = cfg.dfs(dict(train=dict(ds, mode="train"), test=dict(ds, mode="test", n_images=1)))
+    cfg.target_batch_size, cfg.log_dir = 1 << 14, str(tmp_path)
+    torch.manual_seed(0)
+    r = Runner()
+    assert type(r.model).__name__ == "OriginNeRFNetworks" and not r._fast
+    losses = [float(r.train_step(i).mean().item()) for i in range(96)]
+    assert np.isfinite(losses).all() and np.mean(losses[-8:]) < 0.8 * np.mean(losses[:8]), (losses[:8], losses[-8:])
+    assert r._fast is False                                        # generic module path, not the fused fast path
+    r.drain()
+
+
 def test_nerf_dataset_on_disk(tmp_path):
     """NerfDataset (dataset.py:68-170 semantics): transforms JSON + PNGs, train includes val, missing files skipped, fl_x / camera_angle_x, aabb_scale"""
     import json
