@@ -250,9 +250,15 @@ __global__ __launch_bounds__(MC_WAVES * 64) void k_march_coop(uint32_t n_rays, M
 					target = tl + fmaxf(tt * inv_res, 0.0f);
 					// the skip `do t += dt while (t < target)` lands on the first candidate m > self with !(t_m < target): t is increasing, so that is a
 					// lower-bound search in this round's chain (NC = beyond it)
-					uint32_t lo = self + 1u, hi = NC;
-					while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (tch[r][mid] < target) lo = mid + 1u; else hi = mid; }
-					nx = lo;
+					// search in this round's chain (NC = beyond it).  The chain is locally uniform (consecutive steps differ by at most 1/256), so the estimate
+					// self + (target - t) / dt is off by a step at most and two LDS probes usually settle it (a bisection costs eight dependent ones)
+					const float est = (target - tl) / dt;
+					uint32_t g = self + 1u;
+					if (est > 1.0f) g = est >= (float)NC ? NC : self + (uint32_t)est;
+					if (g > NC) g = NC;
+					while (g > self + 1u && !(tch[r][g - 1u] < target)) --g;
+					while (g < NC && tch[r][g] < target) ++g;
+					nx = g;
 				}
 			}
 			// (an empty candidate whose skip leaves the round is NOT a plain successor step: its target stays pending)

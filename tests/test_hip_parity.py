@@ -405,14 +405,14 @@ def test_full_size_properties(H):
     assert (np.diff(ns64[:, 1]) >= 0).all() and ns64[:, 0].max() <= 1024      # ray-ordered bases, MAX_STEP respected
 
 
-def _ray_coherent_batch(H, n_target=1 << 18, aabb=(0.0, 1.0), const_dt=True, n_rays=9000):
+def _ray_coherent_batch(H, n_target=1 << 18, aabb=(0.0, 1.0), const_dt=True, n_rays=24000):
     """a full-size (2^18-sample) batch with the statistics of a trained scene: rays from a camera ring marched through a shell occupancy grid (consecutive
     samples of a ray are spatially adjacent; everything sits on a thin surface) - SURVEY.md §8d's "ray-coherent" input"""
     xf, focal, meta = synth.camera_ring(16, radius=1.3)
     _, o, d, _ = synth.rays_from_cameras(xf, focal, meta, 200, 150, n_rays, seed=21)
     coords, ns, nsc, cnt = H.march_rays_compacted(o, d, synth.shell_bitfield(), aabb, O.PCG32(1337), 4096 * 1024, n_target, const_dt=const_dt)
     k = int(cnt[3])
-    assert k > n_target // 2, k
+    assert k > (n_target * 3) // 4, k
     return np.ascontiguousarray(coords[:k]), ns, nsc, k
 
 
