@@ -149,6 +149,10 @@ int ngp_grid_mark_untrained(void *stream, uint32_t n_elements, float *grid, uint
                             const float *xforms /*[n,4,3]*/, int W, int H);
 int ngp_grid_generate_samples(void *stream, uint32_t n, uint64_t *rng_state_host, const uint32_t *ema_step /*device*/, float aabb0, float aabb1,
                               const float *grid, float *positions /*[n,3]*/, uint32_t *indices, uint32_t n_cascades, float thresh);
+/* same samples (the same multiset of (position, cell) pairs); morton_order != 0 stores them so that consecutive slots hold consecutive Morton cells: the
+ * 16-level gather of the density query that follows then walks the tables coherently (the consumer, ngp_grid_splat_max, is order-independent) */
+int ngp_grid_generate_samples_ordered(void *stream, uint32_t n, uint64_t *rng_state_host, const uint32_t *ema_step /*device*/, float aabb0, float aabb1,
+                                      const float *grid, float *positions /*[n,3]*/, uint32_t *indices, uint32_t n_cascades, float thresh, int morton_order);
 int ngp_grid_splat_max(void *stream, uint32_t n, const uint32_t *indices, const void *density /*[n] T*/, int dtype, float *grid_tmp);
 int ngp_grid_ema(void *stream, uint32_t n_elements, float decay, float *grid, const float *grid_tmp);
 /* mean over cascade 0 -> mean[0]; grid_to_bitfield; 4x bitfield_max_pool (update_bitfield.py:15-37) */

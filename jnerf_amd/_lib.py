@@ -65,6 +65,7 @@ SIGNATURES = {
     "ngp_huber": (C.c_int, [_vp, _u32, _vp, _vp, _f32, _vp, _vp]),
     "ngp_grid_mark_untrained": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _i32, _i32]),
     "ngp_grid_generate_samples": (C.c_int, [_vp, _u32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _u32, _f32]),
+    "ngp_grid_generate_samples_ordered": (C.c_int, [_vp, _u32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _u32, _f32, _i32]),
     "ngp_grid_splat_max": (C.c_int, [_vp, _u32, _vp, _vp, _i32, _vp]),
     "ngp_grid_ema": (C.c_int, [_vp, _u32, _f32, _vp, _vp]),
     "ngp_grid_update_bitfield": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),

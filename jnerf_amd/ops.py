@@ -369,13 +369,14 @@ def grid_mark_untrained(n_elements, focal, xforms, W, H, grid=None):
     return grid
 
 
-def grid_generate_samples(n, rng_state, ema_step, aabb, grid, n_cascades, thresh, pos=None, idx=None):
+def grid_generate_samples(n, rng_state, ema_step, aabb, grid, n_cascades, thresh, pos=None, idx=None, morton_order=False):
+    """morton_order: same samples, stored so that consecutive slots are consecutive Morton cells (coherent gathers in the density query that follows)"""
     if pos is None:
         pos = torch.empty((n, 3), dtype=torch.float32, device=grid.device)
     if idx is None:
         idx = torch.empty(n, dtype=torch.int32, device=grid.device)
-    check(L.lib().ngp_grid_generate_samples(_stream(), n, rng_state.ctypes.data_as(C.c_void_p), _p(ema_step), aabb[0], aabb[1], _p(grid), _p(pos), _p(idx), n_cascades, thresh),
-          "ngp_grid_generate_samples")
+    check(L.lib().ngp_grid_generate_samples_ordered(_stream(), n, rng_state.ctypes.data_as(C.c_void_p), _p(ema_step), aabb[0], aabb[1], _p(grid), _p(pos), _p(idx), n_cascades, thresh,
+                                                    int(morton_order)), "ngp_grid_generate_samples")
     return pos, idx
 
 

@@ -212,11 +212,12 @@ class DensityGridSampler(nn.Module):
         n_total = n_uniform + n_nonuniform
         pos = torch.empty((n_total, 3), dtype=torch.float32, device=self.device)
         idx = torch.empty(n_total, dtype=torch.int32, device=self.device)
+        mo = self.cfg.grid_samples_morton_order is not False       # (ours) same samples, Morton-ordered in memory: the 16-level gather of model.density() walks the tables coherently
         ops.grid_generate_samples(n_uniform, self.rng_state, self.density_grid_ema_step, self.aabb_range, self.density_grid, self.max_cascade + 1, -0.01,
-                                  pos=pos[:n_uniform], idx=idx[:n_uniform])
+                                  pos=pos[:n_uniform], idx=idx[:n_uniform], morton_order=mo)
         if n_nonuniform:
             ops.grid_generate_samples(n_nonuniform, self.rng_state, self.density_grid_ema_step, self.aabb_range, self.density_grid, self.max_cascade + 1,
-                                      self.NERF_MIN_OPTICAL_THICKNESS, pos=pos[n_uniform:], idx=idx[n_uniform:])
+                                      self.NERF_MIN_OPTICAL_THICKNESS, pos=pos[n_uniform:], idx=idx[n_uniform:], morton_order=mo)
         else:   # the reference still advances the global rng for the empty second call (generate_grid_samples…py:44)
             from .rng import pcg32_advance
             pcg32_advance(self.rng_state, 1 << 32)

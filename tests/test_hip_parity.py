@@ -509,3 +509,25 @@ def test_full_size_field_fwd_bwd_vs_oracle(H):
     assert np.linalg.norm(dw16[:3072] - rdwd) <= 3e-2 * np.linalg.norm(rdwd) and np.linalg.norm(dw16[3072:] - rdwc) <= 3e-2 * np.linalg.norm(rdwc)
     df16 = H.N(df16).astype(np.float32).transpose(1, 0, 2).reshape(n, 32)
     assert np.linalg.norm(df16 - rdf) <= 3e-2 * np.linalg.norm(rdf)
+
+
+@pytest.mark.parametrize("n", [1 << 21, 5 << 19, 3 * 4096 + 64])
+def test_grid_samples_morton_order_is_a_permutation(H, n):
+    """ngp_grid_generate_samples_ordered(morton_order=1): exactly the reference's samples (bit-identical positions and cells), stored so that consecutive slots hold
+    consecutive Morton cells"""
+    from jnerf_amd import ops
+    rng = np.random.default_rng(4)
+    grid = H.T((rng.random(5 * 128 ** 3) * 0.03 - 0.005).astype(np.float32))
+    step = torch.tensor([7], dtype=torch.int32, device="cuda")
+    st = O.PCG32(1337).st
+    p0, i0 = ops.grid_generate_samples(n, st.copy(), step, (-1.5, 2.5), grid, 5, 0.01, morton_order=False)
+    p1, i1 = ops.grid_generate_samples(n, st.copy(), step, (-1.5, 2.5), grid, 5, 0.01, morton_order=True)
+    a = np.concatenate([H.N(p0).view(np.uint32), H.N(i0).view(np.uint32)[:, None]], 1)
+    b = np.concatenate([H.N(p1).view(np.uint32), H.N(i1).view(np.uint32)[:, None]], 1)
+    assert not np.array_equal(a, b)
+    order = lambda m: m[np.lexsort(m.T[::-1])]
+    assert np.array_equal(order(a), order(b))
+    # with a threshold every cell passes (first try), neighbours in memory are neighbours in Morton order except at the seams of the permutation blocks
+    _, i2 = ops.grid_generate_samples(n, st.copy(), step, (-1.5, 2.5), grid, 5, -1.0, morton_order=True)
+    cells = H.N(i2).view(np.uint32).astype(np.int64) % (128 ** 3)
+    assert ((np.diff(cells) % (128 ** 3)) == 1).mean() > 0.98
