@@ -608,11 +608,10 @@ __device__ __forceinline__ void huber3(const float *__restrict__ target, float d
 }
 struct HuberArgs { const float *target; float delta; float *loss, *grad; };     // target == nullptr: no loss stage
 
-template <typename T, bool INFERENCE>
+template <typename T, bool INFERENCE, uint32_t CG /*lanes per ray*/>
 __global__ __launch_bounds__(256) void k_composite_fwd(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps,
                                                        const uint32_t *__restrict__ numsteps_c, const float *__restrict__ bg, int cascades,
                                                        float *__restrict__ rgb_out, float *__restrict__ alpha_out, HuberArgs hub) {
-	constexpr uint32_t CG = INFERENCE ? CG_INFER : CG_TRAIN;
 	const uint32_t lane = threadIdx.x & (CG - 1u), i = blockIdx.x * (256u / CG) + threadIdx.x / CG;
 	if (i >= n_rays) return;
 	const uint32_t *nsrc = INFERENCE ? numsteps : numsteps_c;
@@ -664,11 +663,10 @@ __global__ __launch_bounds__(256) void k_composite_fwd(uint32_t n_rays, const T 
 	}
 }
 
-template <typename T>
+template <typename T, uint32_t CG /*lanes per ray*/>
 __global__ __launch_bounds__(256) void k_composite_bwd(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps_c,
                                                        const float *__restrict__ loss_grad, const float *__restrict__ rgb_ray, const float *__restrict__ density_grid_mean,
                                                        int cascades, T *__restrict__ dout) {
-	constexpr uint32_t CG = CG_TRAIN;
 	const uint32_t lane = threadIdx.x & (CG - 1u), i = blockIdx.x * (256u / CG) + threadIdx.x / CG;
 	if (i >= n_rays) return;
 	float loss_scale = 128; loss_scale /= n_rays;                                    // calc_rgb.h:100-101
@@ -732,10 +730,17 @@ static int composite_fwd_impl(void *stream, uint32_t n_rays, const void *net, in
 	NGP_REQUIRE(net && coords && numsteps && numsteps_c && bg && rgb_out, NGP_E_ARG, "ngp_composite_fwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_composite_fwd: bad dtype %d", dtype);
 	if (n_rays == 0) return 0;
-	const dim3 grid(div_up(n_rays, 256u / CG_TRAIN)), block(256);
 	hipStream_t s = (hipStream_t)stream;
-	if (dtype == NGP_F32) NGP_LAUNCH((k_composite_fwd<float, false>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
-	else NGP_LAUNCH((k_composite_fwd<__half, false>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub);
+	// lanes per ray: 16 when the adaptive ray count has settled at a handful of samples per ray (fox: ~7), a whole wavefront when rays are long (lego: ~33 samples,
+	// the first iterations of any run: hundreds) - one coalesced load round trip per 64 samples instead of four.  Same arithmetic order either way.  The
+	// training batch is 2^18 samples, so the ray count alone tells which regime this is.
+	const bool wide = (uint64_t)n_rays * 24u <= (1u << 18);
+	const uint32_t cg = wide ? CG_INFER : CG_TRAIN;
+	const dim3 grid(div_up(n_rays, 256u / cg)), block(256);
+#define CF_GO(T, W) NGP_LAUNCH((k_composite_fwd<T, false, W>), grid, block, 0, s, n_rays, (const T *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, (float *)nullptr, hub)
+	if (dtype == NGP_F32) { if (wide) CF_GO(float, CG_INFER); else CF_GO(float, CG_TRAIN); }
+	else { if (wide) CF_GO(__half, CG_INFER); else CF_GO(__half, CG_TRAIN); }
+#undef CF_GO
 	NGP_LAUNCH_CHECK("ngp_composite_fwd");
 	return 0;
 }
@@ -746,8 +751,8 @@ NGP_API int ngp_composite_inference(void *stream, uint32_t n_rays, const void *n
 	if (n_rays == 0) return 0;
 	const dim3 grid(div_up(n_rays, 256u / CG_INFER)), block(256);
 	hipStream_t s = (hipStream_t)stream;
-	if (dtype == NGP_F32) NGP_LAUNCH((k_composite_fwd<float, true>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
-	else NGP_LAUNCH((k_composite_fwd<__half, true>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
+	if (dtype == NGP_F32) NGP_LAUNCH((k_composite_fwd<float, true, CG_INFER>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
+	else NGP_LAUNCH((k_composite_fwd<__half, true, CG_INFER>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps, (const uint32_t *)nullptr, (const float *)nullptr, cascades, rgb_out, alpha_out, HuberArgs{nullptr, 0.f, nullptr, nullptr});
 	NGP_LAUNCH_CHECK("ngp_composite_inference");
 	return 0;
 }
@@ -758,9 +763,13 @@ NGP_API int ngp_composite_bwd(void *stream, uint32_t n_rays, uint32_t n_elems, c
 	hipStream_t s = (hipStream_t)stream;
 	if (zero_first) { hipError_t e = hipMemsetAsync(dout, 0, (size_t)n_elems * 4 * (dtype == NGP_F16 ? 2 : 4), s); if (e != hipSuccess) { ngp_set_error("ngp_composite_bwd memset: %s", hipGetErrorString(e)); return (int)e; } }
 	if (n_rays == 0) return 0;
-	const dim3 grid(div_up(n_rays, 256u / CG_TRAIN)), block(256);
-	if (dtype == NGP_F32) NGP_LAUNCH((k_composite_bwd<float>), grid, block, 0, s, n_rays, (const float *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (float *)dout);
-	else NGP_LAUNCH((k_composite_bwd<__half>), grid, block, 0, s, n_rays, (const __half *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (__half *)dout);
+	const bool wide = (uint64_t)n_rays * 24u <= (uint64_t)n_elems;          // >= 24 samples per ray on average: a wavefront per ray (see composite_fwd_impl)
+	const uint32_t cg = wide ? CG_INFER : CG_TRAIN;
+	const dim3 grid(div_up(n_rays, 256u / cg)), block(256);
+#define CB_GO(T, W) NGP_LAUNCH((k_composite_bwd<T, W>), grid, block, 0, s, n_rays, (const T *)net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades, (T *)dout)
+	if (dtype == NGP_F32) { if (wide) CB_GO(float, CG_INFER); else CB_GO(float, CG_TRAIN); }
+	else { if (wide) CB_GO(__half, CG_INFER); else CB_GO(__half, CG_TRAIN); }
+#undef CB_GO
 	NGP_LAUNCH_CHECK("ngp_composite_bwd");
 	return 0;
 }
