@@ -165,8 +165,14 @@ int ngp_grid_update_bitfield(void *stream, const float *grid, int cascades, floa
 /* data parallel: fp32 gradient -> fp16 buffer for the RCCL all-reduce (half the bytes over xGMI; the reference keeps fp16 gradients anyway), source optionally
  * zeroed in the same pass.  n % 8 == 0, 16-byte aligned.  Feed the reduced fp16 buffer to ngp_adam_ema_step with g_dtype = NGP_F16. */
 int ngp_grad_to_half(void *stream, uint64_t n, float *grad_f32, void *grad_f16, int zero_src);
+/* same with the values multiplied by `scale` (a power of two) before the conversion: gradients carry the 128 / n_rays loss scale and would otherwise sit in
+ * fp16's subnormal range; the sweep undoes it (ngp_adam_ema_step_scaled, grad_mul = 1 / scale) */
+int ngp_grad_to_half_scaled(void *stream, uint64_t n, float *grad_f32, void *grad_f16, int zero_src, float scale);
 int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
                       float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad);
+
+int ngp_adam_ema_step_scaled(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
+                             float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad, float grad_mul /* fp16 gradients are multiplied by this */);
 
 /* ---- ray generation (dataset/dataset.py:172-188) + target compositing (runner/runner.py:66-68) ------------------------------- */
 int ngp_generate_rays(void *stream, uint32_t n, const int64_t *pixel_index, int W, int H, const float *focal, const float *metadata /*[n_img,11]*/,

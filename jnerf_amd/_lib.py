@@ -72,6 +72,8 @@ SIGNATURES = {
     "ngp_train_step": (C.c_int, [_vp, C.POINTER(NgpTrainStep)]),
     "ngp_train_step_timings": (C.c_int, [_vp, _i32]),
     "ngp_grad_to_half": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _i32]),
+    "ngp_grad_to_half_scaled": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _i32, _f32]),
+    "ngp_adam_ema_step_scaled": (C.c_int, [_vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _f32, _i32, _f32]),
     "ngp_adam_ema_step": (C.c_int, [_vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _f32, _i32]),
     "ngp_prof_enable": (C.c_int, [C.c_char_p]),
     "ngp_prof_read": (C.c_int, [_i32, _vp, _i32, _vp, _i32]),

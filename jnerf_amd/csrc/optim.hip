@@ -8,7 +8,7 @@
 #include "ngp_common.h"
 #pragma clang fp contract(off)
 
-struct AdamConsts { float step_size, b0, b1, eps, ema_decay, debias_old, debias_new; };
+struct AdamConsts { float step_size, b0, b1, eps, ema_decay, debias_old, debias_new, g_mul /* gradient multiplier: undoes the scale a data-parallel fp16 gradient travelled with */; };
 
 template <typename G, int EMA /*0 none, 1 separate buffer, 2 the EMA state IS the parameter (v == p at every step boundary)*/, bool HALF, bool ZERO>
 __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restrict__ p, G *__restrict__ g, float4 *__restrict__ m, float4 *__restrict__ v, float4 *__restrict__ ema,
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restric
 		else {
 			uint2 t = reinterpret_cast<uint2 *>(g)[i];
 			float2 a = __half22float2(*reinterpret_cast<__half2 *>(&t.x)), b = __half22float2(*reinterpret_cast<__half2 *>(&t.y));
-			gi[0] = a.x; gi[1] = a.y; gi[2] = b.x; gi[3] = b.y;
+			gi[0] = a.x * c.g_mul; gi[1] = a.y * c.g_mul; gi[2] = b.x * c.g_mul; gi[3] = b.y * c.g_mul;
 			if (ZERO) reinterpret_cast<uint2 *>(g)[i] = make_uint2(0u, 0u);
 		}
 		float4 P = p[i], M = m[i], V = v[i], E;
@@ -46,29 +46,39 @@ __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restric
 
 // fp32 gradient -> fp16 communication buffer (data-parallel all-reduce at half the bytes; the reference's gradients are fp16 to begin with), optionally
 // zeroing the source for the next backward in the same sweep.  Streaming, 32 B in / 16 B out per thread.
-__global__ __launch_bounds__(256) void k_grad_to_half(uint64_t n8, float4 *__restrict__ src, uint4 *__restrict__ dst, int zero_src) {
+__global__ __launch_bounds__(256) void k_grad_to_half(uint64_t n8, float4 *__restrict__ src, uint4 *__restrict__ dst, int zero_src, float scale) {
 	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (uint64_t)gridDim.x * 256) {
-		const float4 a = src[2 * i], b = src[2 * i + 1];
+		float4 a = src[2 * i], b = src[2 * i + 1];
+		a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale; b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
 		const __half2 h0 = __floats2half2_rn(a.x, a.y), h1 = __floats2half2_rn(a.z, a.w), h2 = __floats2half2_rn(b.x, b.y), h3 = __floats2half2_rn(b.z, b.w);
 		dst[i] = make_uint4(*reinterpret_cast<const uint32_t *>(&h0), *reinterpret_cast<const uint32_t *>(&h1), *reinterpret_cast<const uint32_t *>(&h2), *reinterpret_cast<const uint32_t *>(&h3));
 		if (zero_src) { src[2 * i] = make_float4(0.f, 0.f, 0.f, 0.f); src[2 * i + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
 	}
 }
-NGP_API int ngp_grad_to_half(void *stream, uint64_t n, float *grad_f32, void *grad_f16, int zero_src) {
+NGP_API int ngp_grad_to_half_scaled(void *stream, uint64_t n, float *grad_f32, void *grad_f16, int zero_src, float scale);
+NGP_API int ngp_grad_to_half(void *stream, uint64_t n, float *grad_f32, void *grad_f16, int zero_src) { return ngp_grad_to_half_scaled(stream, n, grad_f32, grad_f16, zero_src, 1.0f); }
+NGP_API int ngp_grad_to_half_scaled(void *stream, uint64_t n, float *grad_f32, void *grad_f16, int zero_src, float scale) {
 	NGP_REQUIRE(n == 0 || (grad_f32 && grad_f16), NGP_E_ARG, "ngp_grad_to_half: null pointer");
 	NGP_REQUIRE(n % 8 == 0, NGP_E_ALIGN, "ngp_grad_to_half: n (%llu) must be a multiple of 8", (unsigned long long)n);
 	NGP_REQUIRE((((uintptr_t)grad_f32 | (uintptr_t)grad_f16) & 15) == 0, NGP_E_ALIGN, "ngp_grad_to_half: buffers must be 16-byte aligned");
 	if (n == 0) return 0;
 	const uint64_t n8 = n / 8;
 	uint32_t blocks = (uint32_t)((n8 + 255) / 256); if (blocks > 2048 * 4) blocks = 2048 * 4;
-	NGP_LAUNCH(k_grad_to_half, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n8, (float4 *)grad_f32, (uint4 *)grad_f16, zero_src);
+	NGP_LAUNCH(k_grad_to_half, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n8, (float4 *)grad_f32, (uint4 *)grad_f16, zero_src, scale);
 	NGP_LAUNCH_CHECK("ngp_grad_to_half");
 	return 0;
 }
 
+NGP_API int ngp_adam_ema_step_scaled(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
+                                     float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad, float grad_mul);
 NGP_API int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
                               float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad) {
+	return ngp_adam_ema_step_scaled(stream, n, p, g, g_dtype, m, v, ema, p_half, lr, beta0, beta1, eps, step, ema_decay, zero_grad, 1.0f);
+}
+NGP_API int ngp_adam_ema_step_scaled(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
+                                     float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad, float grad_mul) {
 	NGP_REQUIRE(p && g && m && v && step >= 1, NGP_E_ARG, "ngp_adam_ema_step: bad arguments");
+	NGP_REQUIRE(grad_mul == 1.0f || g_dtype == NGP_F16, NGP_E_ARG, "ngp_adam_ema_step: a gradient multiplier is only applied to fp16 (communication) gradients");
 	NGP_REQUIRE(g_dtype == NGP_F32 || g_dtype == NGP_F16, NGP_E_DTYPE, "ngp_adam_ema_step: bad gradient dtype %d", g_dtype);
 	NGP_REQUIRE(n % 4 == 0, NGP_E_ALIGN, "ngp_adam_ema_step: n (%llu) must be a multiple of 4", (unsigned long long)n);
 	NGP_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema | (uintptr_t)p_half) & 15) == 0, NGP_E_ALIGN, "ngp_adam_ema_step: buffers must be 16-byte aligned");
@@ -78,6 +88,7 @@ NGP_API int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g
 	c.step_size = (float)((double)lr * sqrt(bc1) / bc0); c.b0 = beta0; c.b1 = beta1; c.eps = eps; c.ema_decay = ema_decay;
 	c.debias_old = (float)(1.0 - pow((double)ema_decay, (double)step - 1.0));
 	c.debias_new = (float)(1.0 / (1.0 - pow((double)ema_decay, (double)step)));
+	c.g_mul = grad_mul;
 	const uint64_t n4 = n / 4;
 	uint32_t blocks = (uint32_t)((n4 + 255) / 256); if (blocks > 2048 * 4) blocks = 2048 * 4;
 	hipStream_t s = (hipStream_t)stream;

@@ -38,7 +38,7 @@ class FusedTrainStep:
         # because the gradient all-reduce sits between backward and the sweep
         self.timed_stage = None         # name from _lib.STAGES: the library brackets that stage of every native step with HIP events (bench.py)
         self.native = runner.cfg.native_step is not False and not runner.optimizer._nested_optimizer._dp_active()
-        self._args = None
+        self._args, self._grad_sig = None, None
 
     def _ray_bufs(self, nr, dev):
         b = self._per_rays.get(nr)
@@ -102,8 +102,10 @@ class FusedTrainStep:
         rgb, loss, lgrad = self._ray_bufs(nr, coords.device)
         wd, wc = m.weight_packs()
         table = enc.table_for_kernels()
-        if self._args is None:
+        sig = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in r.optimizer._nested_optimizer.param_groups[0]["params"])
+        if self._args is None or sig != self._grad_sig:           # (a .grad that was re-allocated behind our back - zero_grad(set_to_none), user code - invalidates the cached pointers)
             self._args = self._native_args(coords.device)
+            self._grad_sig = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in r.optimizer._nested_optimizer.param_groups[0]["params"])
         a = self._args
         ed, adam, ema = r.optimizer, r.optimizer._nested_optimizer, r.ema_optimizer
         ed.advance_schedule()                       # == ExpDecay.step / Adam.step / EMA.ema_step bookkeeping; the sweep itself is launched by the library

@@ -400,14 +400,15 @@ def grid_update_bitfield(grid, cascades=5, mean=None, bitfield=None):
 
 
 # ------------------------------------------------------------------ optimiser / rays
-def grad_to_half(g32, g16, zero_src=True):
+def grad_to_half(g32, g16, zero_src=True, scale=1.0):
     assert g32.dtype == torch.float32 and g16.dtype == torch.float16 and g32.numel() == g16.numel()
-    check(L.lib().ngp_grad_to_half(_stream(), g32.numel(), _p(g32), _p(g16), int(zero_src)), "ngp_grad_to_half")
+    check(L.lib().ngp_grad_to_half_scaled(_stream(), g32.numel(), _p(g32), _p(g16), int(zero_src), float(scale)), "ngp_grad_to_half")
     return g16
 
 
-def adam_ema_step(p, g, m, v, ema, p_half, lr, step, b0=0.9, b1=0.99, eps=1e-15, ema_decay=0.95, zero_grad=True):
-    check(L.lib().ngp_adam_ema_step(_stream(), p.numel(), _p(p), _p(g), _dt(g), _p(m), _p(v), _p(ema), _p(p_half), lr, b0, b1, eps, step, ema_decay, int(zero_grad)), "ngp_adam_ema_step")
+def adam_ema_step(p, g, m, v, ema, p_half, lr, step, b0=0.9, b1=0.99, eps=1e-15, ema_decay=0.95, zero_grad=True, grad_mul=1.0):
+    check(L.lib().ngp_adam_ema_step_scaled(_stream(), p.numel(), _p(p), _p(g), _dt(g), _p(m), _p(v), _p(ema), _p(p_half), lr, b0, b1, eps, step, ema_decay, int(zero_grad),
+                                           float(grad_mul)), "ngp_adam_ema_step")
 
 
 def generate_rays(pixel_index, W, H, focal, metadata, xforms, images=None, bg=None):

@@ -22,6 +22,10 @@ def flush_all():
 
 @OPTIMS.register_module()
 class Adam:
+    # data parallel, fp16 gradients on the wire: the fp32 gradient carries the compositor's 128 / n_rays loss scale (values of 1e-7 .. 1e-3), i.e. it sits in and below
+    # fp16's subnormal range; it travels multiplied by 2^14 (sums over <= 8 ranks stay far below 65504) and the sweep divides it out again
+    DP_HALF_SCALE = 16384.0
+
     def __init__(self, params, lr=1e-1, eps=1e-15, betas=(0.9, 0.99), **kwargs):
         if kwargs:      # jt.nn.Adam also takes weight_decay; the fused sweep does not implement it, and silently training without it would be worse than failing
             raise TypeError(f"Adam: unsupported arguments {sorted(kwargs)} (supported: lr, eps, betas)")
@@ -122,7 +126,7 @@ class Adam:
                     hb = self._comm_half.get(id(owner))
                     if hb is None or hb.numel() != g.numel():
                         hb = self._comm_half[id(owner)] = torch.empty(g.numel(), dtype=torch.float16, device=g.device)
-                    ops.grad_to_half(g.view(-1), hb, zero_src=True)
+                    ops.grad_to_half(g.view(-1), hb, zero_src=True, scale=self.DP_HALF_SCALE)
                     self._eff_grad[id(owner)] = hb
                     send.append(hb)
                 else:
@@ -169,7 +173,7 @@ class Adam:
             if p.is_cuda and p.numel() % 4 == 0 and p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 and p.is_contiguous():
                 g_eff = self._eff_grad.pop(id(p), None)            # reduced fp16 gradient of the data-parallel path (p.grad was zeroed by the conversion pass)
                 ops.adam_ema_step(p.data, g_eff.view_as(p.grad) if g_eff is not None else p.grad, pg["m"][i], pg["values"][i], e, self._half.get(id(p)), self.lr, self.n_step, self.betas[0], self.betas[1], self.eps,
-                                  ema.decay if ema is not None else 0.0, zero_grad=True)
+                                  ema.decay if ema is not None else 0.0, zero_grad=True, grad_mul=(1.0 / self.DP_HALF_SCALE) if g_eff is not None else 1.0)
             else:                                   # CPU tensors (gloo unit tests of the data-parallel logic) and tiny / unaligned tensors: same math in torch
                 b0, b1 = self.betas
                 g = p.grad

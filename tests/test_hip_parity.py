@@ -332,6 +332,11 @@ def test_grad_to_half(H):
     assert np.array_equal(t16.cpu().numpy(), g.astype(np.float16)) and np.array_equal(t32.cpu().numpy(), g)       # round-to-nearest-even, source untouched
     ops.grad_to_half(t32, t16, zero_src=True)
     assert np.array_equal(t16.cpu().numpy(), g.astype(np.float16)) and not t32.any()
+    tiny = (g * np.float32(1e-4)).astype(np.float32)             # what the data-parallel path sends: loss-scaled gradients, multiplied by a power of two on the way to fp16
+    t32 = torch.from_numpy(tiny.copy()).cuda()
+    ops.grad_to_half(t32, t16, zero_src=False, scale=16384.0)
+    assert np.array_equal(t16.cpu().numpy(), (tiny * np.float32(16384.0)).astype(np.float16))
+    assert (t16.cpu().numpy() != 0).mean() > (tiny.astype(np.float16) != 0).mean()              # values that would have been flushed survive
 
 
 def test_adam_ema_and_huber_and_rays(H):

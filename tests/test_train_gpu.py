@@ -117,19 +117,21 @@ def test_render_matches_cpu_fp32_oracle_on_identical_rays(tmp_path):
     assert float(np.mean(alpha_ref)) > 0.02           # the view actually shows the object
 
 
-def test_two_ranks_data_parallel_on_one_gpu():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_ranks_data_parallel_on_one_gpu(scaling):
     """the N>1 code path of bench.py (per-rank ray batches, gradient all-reduce on a side stream, deferred fused sweep, synchronised ray-count
     adaptation) with two ranks sharing cuda:0 over gloo — RCCL itself needs one GPU per rank and is exercised by the driver's scaling run"""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "8", "--burn-in", "32", "--config", "fox", "--images", "4", "--res", "64", "--no-psnr"]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "8", "--burn-in", "32", "--config", "fox", "--images", "4", "--res", "64", "--no-psnr", "--scaling", scaling]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and np.isfinite(d["loss"]) and d["config"]["parallelism"].startswith("ray-batch dp2")
+    assert d["n_gpus"] == 2 and d["value"] > 0 and np.isfinite(d["loss"]) and d["config"]["parallelism"].startswith("ray-batch dp2") and d["scaling"] == scaling
+    assert d["config"]["samples_per_iter_per_gpu"] == ((1 << 18) if scaling == "weak" else (1 << 17))       # strong: ONE 2^18-sample iteration split over the ranks (SURVEY.md §8e)
     assert d["extra"]["replicas_identical"] is True           # both ranks hold bit-identical parameters after 60 data-parallel steps
 
 
