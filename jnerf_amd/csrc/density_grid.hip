@@ -131,7 +131,7 @@ static int grid_generate_impl(void *stream, uint32_t n, uint64_t *rng_state_host
 	Pcg32 adv = rng; adv.advance(1ull << 32); rng_state_host[0] = adv.state;          // generate_grid_samples_nerf_nonuniform.py:44
 	if (n == 0) return 0;
 	uint32_t perm_mask = 0;
-	if (morton_order) { uint32_t P = n & (0u - n); if (P > G3) P = G3; perm_mask = P >= 64u ? P - 1u : 0u; }      // largest power of two dividing n (<= 128^3)
+	if (morton_order) { uint32_t P = n & (0u - n); if (P > G3) P = G3; perm_mask = P >= 65536u ? P - 1u : 0u; }      // largest power of two dividing n (<= 128^3); the refresh uses multiples of 2^19 - below 2^16 the order gains nothing
 	NGP_LAUNCH(k_grid_generate, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, rng, ema_step, aabb0, aabb1, grid, positions, indices, n_cascades, thresh, perm_mask);
 	NGP_LAUNCH_CHECK("ngp_grid_generate_samples");
 	return 0;

@@ -590,15 +590,32 @@ __device__ __forceinline__ float unwarp_dt(float dt, int cascades) {            
 	return dt * (max_stepsize - min_cone_stepsize()) + min_cone_stepsize();
 }
 
-// Sixteen lanes per ray (four rays per wavefront).  The reference walks a ray's samples serially in one thread (calc_rgb.h:20-60) - tens of thousands of threads,
-// each a chain of dependent, uncoalesced loads.  Here a ray's lanes load 16 consecutive samples coalesced and evaluate the transcendental part (exp, logistic)
-// in parallel; the transmittance / colour recurrences are then replayed in the reference's exact serial order (so results stay bit-identical) with the per-sample
-// terms broadcast inside the 16-lane group (ds_bpermute).  The replay is ~13 VALU instructions per sample with no memory access in it.  16 rather than 64 lanes
-// because the adaptive ray count settles at ~7 samples per ray: a 64-lane group would idle 90 % of its lanes.
-// Inference chunks hold only rays that hit something (dozens of samples each) and keep one wavefront per ray.
+// A group of lanes per ray (16 = four rays per wavefront when the adaptive ray count has settled at a handful of samples per ray, 64 = one wavefront per ray when
+// rays are long).  The reference walks a ray's samples serially in one thread (calc_rgb.h:20-60) - tens of thousands of threads, each a chain of dependent,
+// uncoalesced loads.  Here a ray's lanes load consecutive samples coalesced, evaluate the transcendental part (exp, logistic) in parallel, and obtain the
+// recurrences by SCANS over the lanes: transmittance = carried T x prefix product of (1 - alpha), colour so far = prefix sum of weight x colour (log2 lanes shuffle
+// steps per chunk of samples).  Round 1 replayed the recurrences in the reference's serial order to stay bit-identical; a ray with ~900 samples (through the object,
+// constant step) then cost ~90 k dependent cycles and set the kernel's duration (106 + 83 us per lego iteration).  The scans change only the order of fp32
+// products / sums: results agree with the serial order to ~1e-7 relative (tests: golden <= 2e-5).
 template <uint32_t CG> __device__ __forceinline__ float bcast(float v, uint32_t k) { return __shfl(v, (int)k, (int)CG); }
 template <> __device__ __forceinline__ float bcast<64>(float v, uint32_t k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)k)); }
 constexpr uint32_t CG_TRAIN = 16, CG_INFER = 64;                   // lanes per ray
+// inclusive scans / sum over the CG lanes of a ray (log2 CG shuffle steps)
+template <uint32_t CG> __device__ __forceinline__ float group_scan_mul(float v, uint32_t lane) {
+#pragma unroll
+	for (uint32_t d = 1; d < CG; d <<= 1) { const float u = __shfl_up(v, d, (int)CG); if (lane >= d) v *= u; }
+	return v;
+}
+template <uint32_t CG> __device__ __forceinline__ float group_scan_add(float v, uint32_t lane) {
+#pragma unroll
+	for (uint32_t d = 1; d < CG; d <<= 1) { const float u = __shfl_up(v, d, (int)CG); if (lane >= d) v += u; }
+	return v;
+}
+template <uint32_t CG> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+	for (uint32_t d = CG / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, (int)CG);
+	return v;
+}
 
 // Huber loss + its gradient of one ray's three channels (models/losses/huber_loss.py:6-14), the expressions of k_huber
 __device__ __forceinline__ void huber3(const float *__restrict__ target, float delta, float *__restrict__ loss, float *__restrict__ grad, uint32_t i, uint32_t c, float x) {
@@ -638,16 +655,16 @@ __global__ __launch_bounds__(256) void k_composite_fwd(uint32_t n_rays, const T 
 #pragma unroll
 			for (int c = 0; c < 3; ++c) rgb[c] = logistic(o[c]);
 		}
+		// transmittance in front of every sample of the chunk = carried T x exclusive product of (1 - alpha) over the lanes before it (inactive lanes hold 1)
+		const float P = group_scan_mul<CG>(1.f - alpha, lane);
+		float Pex = __shfl_up(P, 1, (int)CG); if (lane == 0) Pex = 1.f;
+		const float weight = alpha * (T_ * Pex);
 #pragma unroll
-		for (uint32_t k = 0; k < CG; ++k) {
-			if (k >= m) break;
-			const float a = bcast<CG>(alpha, k);
-			const float weight = a * T_;
-#pragma unroll
-			for (int c = 0; c < 3; ++c) ray[c] += weight * bcast<CG>(rgb[c], k);
-			T_ *= (1.f - a);
-		}
+		for (int c = 0; c < 3; ++c) ray[c] += weight * rgb[c];            // per-lane partial sums over the chunks, folded once at the end
+		T_ *= bcast<CG>(P, CG - 1u);
 	}
+#pragma unroll
+	for (int c = 0; c < 3; ++c) ray[c] = group_sum<CG>(ray[c]);
 	if (!INFERENCE && ns == numsteps[2 * i]) {
 #pragma unroll
 		for (int c = 0; c < 3; ++c) ray[c] += T_ * bg[3 * i + c];
@@ -687,17 +704,15 @@ __global__ __launch_bounds__(256) void k_composite_bwd(uint32_t n_rays, const T 
 			const float density = __expf(o[3]);
 			alpha = 1.f - __expf(-density * dt);
 		}
-		float my_w = 0.f, my_T = 0.f, my_r2[3] = {0.f, 0.f, 0.f};                      // the recurrence's state right after this lane's sample
+		// the recurrence's state right after this lane's sample, by scans over the ray's lanes: T after = carried T x inclusive product of (1 - alpha);
+		// colour so far = carried sum + inclusive sum of weight x colour
+		const float P = group_scan_mul<CG>(1.f - alpha, lane);
+		float Pex = __shfl_up(P, 1, (int)CG); if (lane == 0) Pex = 1.f;
+		const float my_w = alpha * (T_ * Pex), my_T = T_ * P;
+		float my_r2[3];
 #pragma unroll
-		for (uint32_t k = 0; k < CG; ++k) {
-			if (k >= m) break;
-			const float a = bcast<CG>(alpha, k);
-			const float weight = a * T_;
-#pragma unroll
-			for (int c = 0; c < 3; ++c) ray2[c] += weight * bcast<CG>(rgb[c], k);
-			T_ *= (1.f - a);
-			if (lane == k) { my_w = weight; my_T = T_; my_r2[0] = ray2[0]; my_r2[1] = ray2[1]; my_r2[2] = ray2[2]; }
-		}
+		for (int c = 0; c < 3; ++c) { const float S = group_scan_add<CG>(my_w * rgb[c], lane); my_r2[c] = ray2[c] + S; ray2[c] += bcast<CG>(S, CG - 1u); }
+		T_ *= bcast<CG>(P, CG - 1u);
 		if (lane < m) {
 			float dl[4], dv[3];
 #pragma unroll

@@ -529,6 +529,9 @@ def test_grid_samples_morton_order_is_a_permutation(H, n):
     p1, i1 = ops.grid_generate_samples(n, st.copy(), step, (-1.5, 2.5), grid, 5, 0.01, morton_order=True)
     a = np.concatenate([H.N(p0).view(np.uint32), H.N(i0).view(np.uint32)[:, None]], 1)
     b = np.concatenate([H.N(p1).view(np.uint32), H.N(i1).view(np.uint32)[:, None]], 1)
+    if (n & -n) < 65536:                                   # no large power of two divides n: the ordered variant keeps the reference order
+        assert np.array_equal(a, b)
+        return
     assert not np.array_equal(a, b)
     order = lambda m: m[np.lexsort(m.T[::-1])]
     assert np.array_equal(order(a), order(b))

@@ -3,7 +3,7 @@ import sqlite3, sys
 db = sys.argv[1]; nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 c = sqlite3.connect(db)
 rows = list(c.execute("select d.start, d.end, d.stream_id, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id order by d.start"))
-marks = [i for i, r in enumerate(rows) if "k_field_fwdI6__halfLi1ELb0" in r[3]]
+marks = [i for i, r in enumerate(rows) if "k_field_fwdI6__halfLi1ELb0" in r[3] or "k_field32_fwdILi1ELb0" in r[3]]      # one per training step (fp16 | fp32 network)
 a, b = marks[-nsteps - 1], marks[-1]
 seg = rows[a:b]
 main = seg[0][2]
@@ -12,10 +12,13 @@ ms = [r for r in seg if r[2] == main]
 busy = sum(r[1] - r[0] for r in ms)
 print(f"{nsteps} steps: {(t1 - t0) / nsteps / 1e3:.1f} us/step, main stream busy {busy / nsteps / 1e3:.1f} us/step ({100 * busy / (t1 - t0):.0f} %)")
 gaps = []
+allgap = 0
 for p, q in zip(ms, ms[1:]):
     g = q[0] - p[1]
+    allgap += max(g, 0)
     if g > 15000:
         gaps.append((g, p, q))
+print(f"all gaps between consecutive main-stream kernels: {allgap / nsteps / 1e3:.1f} us/step over {len(ms) / nsteps:.1f} launches/step")
 tot = sum(g for g, _, _ in gaps)
 print(f"gaps > 15 us: {len(gaps)} totalling {tot / nsteps / 1e3:.1f} us/step")
 for g, p, q in sorted(gaps, key=lambda x: -x[0])[:14]:
