@@ -682,29 +682,36 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		__hip_atomic_fetch_add(&iacc[2 * local + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	};
-	// one workgroup per CU (128 KiB of LDS) and ~32 records per thread: with one load per trip the loop is a chain of HBM round trips.
-	// Each thread takes K consecutive records per trip (one 16-byte load of values, one 4- or 8-byte load of indices), four trips in flight.
-	constexpr uint32_t K = F32 ? 2 : 4;
-	struct alignas(16) V16 { RV v[K]; };
-	struct alignas(2 * K) I16 { uint16_t i[K]; };
-	const V16 *pv = reinterpret_cast<const V16 *>(rec_val + r0);
-	const I16 *pi = reinterpret_cast<const I16 *>(rec_idx + r0);
+	// Consecutive records of a bin come from consecutive samples of a ray, and on the coarser hashed levels those sit in the SAME cell (a cell of level 5-8 is
+	// 8-14 constant-size steps long): a wavefront's 64 lanes would hit a handful of entries, and same-address ds_add_u64 serialise.  So every thread takes K = 8
+	// CONSECUTIVE records, sums runs of equal entries in registers (exact: the sums are integers) and issues one pair of LDS atomics per run; neighbouring lanes
+	// are then 8 records apart.  Two trips (64 / 32 + 16 bytes per thread each) are in flight.
+	constexpr uint32_t K = 8;
+	struct alignas(16) VK { RV v[K]; };
+	struct alignas(16) IK { uint16_t i[K]; };
+	const VK *pv = reinterpret_cast<const VK *>(rec_val + r0);
+	const IK *pi = reinterpret_cast<const IK *>(rec_idx + r0);
 	const uint32_t groups = count / K;
+	auto add_fixed = [&](uint32_t local, long long ix, long long iy) {
+		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add(&iacc[2 * local + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+	auto run_add = [&](const VK &x, const IK &k) {
+		uint32_t cur = k.i[0]; long long sx, sy; rec_to_fixed(x.v[0], s32, sx, sy);
+#pragma unroll
+		for (uint32_t q = 1; q < K; ++q) {
+			long long ix, iy; rec_to_fixed(x.v[q], s32, ix, iy);
+			if (k.i[q] == cur) { sx += ix; sy += iy; }
+			else { add_fixed(cur, sx, sy); cur = k.i[q]; sx = ix; sy = iy; }
+		}
+		add_fixed(cur, sx, sy);
+	};
 	uint32_t r = threadIdx.x;
-	for (; r + 3 * 1024 < groups; r += 4 * 1024) {
-		V16 x[4]; I16 k[4];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) { x[u] = pv[r + u * 1024]; k[u] = pi[r + u * 1024]; }
-#pragma unroll
-		for (int u = 0; u < 4; ++u)
-#pragma unroll
-			for (uint32_t q = 0; q < K; ++q) add(k[u].i[q], x[u].v[q]);
+	for (; r + 1024 < groups; r += 2 * 1024) {
+		const VK x0 = pv[r], x1 = pv[r + 1024]; const IK k0 = pi[r], k1 = pi[r + 1024];
+		run_add(x0, k0); run_add(x1, k1);
 	}
-	for (; r < groups; r += 1024) {
-		const V16 x = pv[r]; const I16 k = pi[r];
-#pragma unroll
-		for (uint32_t q = 0; q < K; ++q) add(k.i[q], x.v[q]);
-	}
+	for (; r < groups; r += 1024) { const VK x = pv[r]; const IK k = pi[r]; run_add(x, k); }
 	if (threadIdx.x < count - groups * K) { const uint32_t t = groups * K + threadIdx.x; add(rec_idx[r0 + t], rec_val[r0 + t]); }
 	if (raw > bp.cap) {                                                   // this bin overflowed: its surplus records are somewhere in the shared spill list
 		const uint32_t ns = min(*spill_count, bp.spill_cap), key_lo = (hl << 19) | (bin << BIN_BITS);
