@@ -7,9 +7,9 @@ import sys
 def main(db, out, title, last_steps=0):
     c = sqlite3.connect(db)
     cutoff = 0
-    if last_steps:      # restrict to the last N training steps: cut at the start of the N-th from last Adam sweep over the hash table (largest grid)
+    if last_steps:      # restrict to the last N training steps: cut at the start of the N-th from last batch launch of the field network
         marks = [r[0] for r in c.execute("""select d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
-                                            where s.kernel_name like '%k_march_count%' order by d.start""")]
+                                            where s.kernel_name like '%k_field32_fwdILi1ELb0%' or s.kernel_name like '%k_field_fwdI6__halfLi1ELb0%' order by d.start""")]      # one per training step
         if len(marks) > last_steps:
             cutoff = marks[-last_steps]
             title += f" — last {last_steps} training steps only"
