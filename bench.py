@@ -117,7 +117,7 @@ def alg_bytes_table(n, P, R, n_refresh, fp16):
         "k_hash_fwd": n * hf, "k_field_fwd": n * fio, "k_field_bwd": n * (fio + 32 * T),
         "k_field32_fwd": n * fio, "k_field32_bwd": n * (fio + 32 * T),
         "k_composite_fwd": n * (4 * T + 28), "k_composite_bwd": n * (4 * T + 28 + 4 * T),
-        "k_adam_ema": P * (34 if fp16 else 32),
+        "k_adam_ema": P * (30 if fp16 else 28),                # read p, g, m, v; write p, m, v (+ the fp16 shadow); the gradient is overwritten by the next backward, not zeroed here
         # hash backward: the stage's necessary traffic is pos 12 + dL/dy 32*T + 128 scattered fp32 updates (4 B each as one write); attributed to the kernels that do each part
         "k_level_absmax": n * 32 * T, "k_bin_records": n * (12 + 32 * T) * 12 / 16, "k_bin_accumulate": n * 12 * 8 * 2 * 4, "k_hash_bwd_owner": n * ((12 + 32 * T) * 4 / 16 + 4 * 8 * 2 * 4),
         "k_reduce_dense": 0, "k_reduce_slabs": 10240 * 4, "k_pack_frags": 21504 * 2 * 2,
