@@ -1,5 +1,6 @@
 """PSNR-vs-wall-time of the FULL reference schedule (40 000 iterations, ExpDecay at 20 k / 30 k) on the bench scene: BASELINE.json's second headline
-("PSNR@5min") restated for a scene that exists on the GPU box.  Writes a markdown table.  usage: train_curve.py out.md [steps]"""
+("PSNR@5min") restated for a scene that exists on the GPU box.  Writes a markdown table.  usage: train_curve.py out.md [steps] [lego|fox]
+lego = projects/ngp/configs/ngp_base.py hyper-parameters (fp32, aabb 1, constant step) on the 100 x 800 x 800 procedural scene; fox = ngp_fox.py's on 50 x 400 x 400."""
 import os
 import sys
 import time
@@ -12,8 +13,14 @@ from jnerf_amd.utils.registry import build_from_cfg, DATASETS
 
 out = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
+which = sys.argv[3] if len(sys.argv) > 3 else "lego"
 torch.manual_seed(1234)
-ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0", tot_train_steps=steps)
+if which == "lego":
+    ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=100, W=800, H=800, device="cuda:0", tot_train_steps=steps)
+    title = "procedural 100 x 800 x 800 RGBA, ngp_base.py (lego) hyper-parameters, fp32"
+else:
+    ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0", tot_train_steps=steps)
+    title = "procedural 50 x 400 x 400 RGBA, fox hyper-parameters, fp16"
 r = Runner()
 r.dataset["test"] = build_from_cfg(r.cfg.dataset.test, DATASETS)
 marks = [m for m in (100, 250, 500, 1000, 2000, 5000, 10000, 20000, 30000, 40000) if m <= steps]
@@ -40,8 +47,8 @@ for i in range(steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
 with open(out, "w") as f:
-    f.write("# Full training schedule on one MI355X (bench scene: procedural 50 x 400 x 400 RGBA, fox hyper-parameters, fp16)\n\n")
-    f.write(f"`python tools/train_curve.py` - {steps} iterations of 2^18 samples, ExpDecay x0.33 at 20 k and 30 k (ngp_base.py:31-37); PSNR = mean over the held-out test views;\n")
+    f.write(f"# Full training schedule on one MI355X (bench scene: {title})\n\n")
+    f.write(f"`python tools/train_curve.py out.md {steps} {which}` - {steps} iterations of 2^18 samples, ExpDecay x0.33 at 20 k and 30 k (ngp_base.py:31-37); PSNR = mean over the held-out test views;\n")
     f.write("training time excludes the evaluation renders.\n\n| iteration | training seconds | it/s so far | test PSNR (dB) | lr | rays / batch |\n|---|---|---|---|---|---|\n")
     for it, s, p, lr, nr in rows:
         f.write(f"| {it} | {s:.2f} | {it / s:.0f} | {p:.2f} | {lr:.4g} | {nr} |\n")
