@@ -834,16 +834,15 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	}
 	if (use_slabs) {
 		// Sample chunks per slice of the dense levels.  A unit (slice, chunk) pays a fixed price - clear and flush 128 KiB of LDS, one partial slab to write and
-		// later re-read - before it looks at a single sample, and holds a whole CU (128 KiB of LDS) while it runs.  32 chunks for every slice meant 544 (fox, fp16)
-		// to 1376 (lego, fp32) units, i.e. up to 5.4 rounds of workgroups each dominated by that fixed part (230 us for the lego batch).  Now the chunk count is
-		// chosen so that all units together fill the 256 CUs about once; the small, heavily contended coarse levels get twice the chunks of the large ones.
-		uint32_t weighted = 0;
-		for (int l = 0; l < 16; ++l) if (!level_binned(lt, l)) weighted += slices[l] * (slices[l] <= 2u ? 2u : 1u);
-		uint32_t base = weighted ? 256u / weighted : 32u;
-		if (base < 1u) base = 1u;
+		// later re-read - and holds a whole CU while it runs; a level's duration is its slowest unit.  32 chunks for every slice (round 1) meant 544 (fox, fp16) to
+		// 1376 (lego, fp32) units, several rounds of workgroups.  Swept on a lego-like batch (tools/probe_owner_levels.py, all dense levels together, incl. ~50 us of
+		// abs-max / launch / reduce): fp32 32,32,32,32,32: 170 us - 10,10,5,5,5: 168 - 32,32,16,10,8: 141; fp16 112 / 139 / 109.  Small, heavily contended coarse
+		// levels want many short units, large levels few long ones: chunks = 64 / slices (fp32: 8192-entry slices) or 144 / slices (fp16: 16384-entry slices), clamped to [8, 32].
 		for (int l = 0; l < 16; ++l) {
 			if (level_binned(lt, l)) continue;
-			uint32_t c = base * (slices[l] <= 2u ? 2u : 1u);
+			uint32_t c = ((plan.half_slices >> l) & 1u ? 64u : 144u) / slices[l];      // (fp16 units are cheaper - one packed atomic per corner, half the slices - and like shorter sample ranges: fox 26,26,13,13 measured best)
+			if (c < 8u) c = 8u;
+			{ const char *e = getenv("NGP_PROBE_DENSE_CHUNKS"); if (e) { int v[16]; int k = sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7); if (l < k) c = (uint32_t)v[l]; } }   // tools/probe_owner_levels.py
 			plan.chunks[l] = c > 32u ? 32u : (c < 2u ? 2u : c);              // >= 2: the exclusive-owner (chunks == 1) branch belongs to the hashed levels
 			plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)plan.chunks[l] * lt.v[4 * l + 1];
 		}

@@ -38,3 +38,9 @@ for l in range(16):
         print("  level %d (res %d, %d entries): %.1f us" % (l, table[l, 2], table[l, 1], timeit()))
 os.environ["NGP_PROBE_LEVEL_MASK"] = "0"
 print("  no level (launch + abs-max + reduce only): %.1f us" % timeit())
+
+os.environ.pop("NGP_PROBE_LEVEL_MASK", None)
+print("chunk sweeps (dense levels only, all levels together):")
+for spec in ("10,10,5,5,5", "32,32,32,32,32", "32,32,16,8,4", "32,32,32,8,4", "32,16,8,4,2", "16,16,8,6,6", "32,32,16,10,8", "20,20,10,8,6", "32,32,32,16,8"):
+    os.environ["NGP_PROBE_DENSE_CHUNKS"] = spec
+    print("  chunks %-16s %.1f us" % (spec, timeit()))
