@@ -122,7 +122,7 @@ def alg_bytes_table(n, P, R, n_refresh, fp16):
         "k_level_absmax": n * 32 * T, "k_bin_records": n * (12 + 32 * T) * 12 / 16, "k_bin_accumulate": n * 12 * 8 * 2 * 4, "k_hash_bwd_owner": n * ((12 + 32 * T) * 4 / 16 + 4 * 8 * 2 * 4),
         "k_reduce_dense": 0, "k_reduce_slabs": 10240 * 4, "k_pack_frags": 21504 * 2 * 2,
         # sampling: ray in (24 B) + one 28-byte record and one 12-byte position out per sample
-        "k_march_count": R * 24 + n * 4, "k_march_coop": R * 24 + n * 4, "k_mscan_totals": R * 4, "k_mscan_ok": R * 4, "k_mscan_final": R * 20, "k_march_write_cached": n * (4 + 40),
+        "k_march_count": R * 24 + n * 4, "k_march_wave": R * 24 + n * 4, "k_mscan_totals": R * 4, "k_mscan_ok": R * 4, "k_mscan_final": R * 20, "k_march_write_cached": n * (4 + 40),
         "k_generate_rays": R * (8 + 16 + 12 + 40),
         # occupancy refresh (one launch over all points)
         "k_grid_generate": n_refresh * (4 + 16), "k_grid_splat": n_refresh * (4 + T + 4), "k_grid_ema": 5 * 128 ** 3 * 12, "k_grid_mean": 128 ** 3 * 4, "k_grid_to_bitfield": 5 * 128 ** 3 * 4.125,

@@ -139,98 +139,126 @@ __global__ __launch_bounds__(128) void k_march_count(uint32_t n_rays, MarchParam
 }
 
 // ---------------------------------------------------------------------------------------------------------------- wave-cooperative count pass
-// One thread per ray (k_march_count above, kept for ngp_march_rays) is a chain of dependent loads per ray - hundreds of microseconds for the longest ray while
-// the chip idles (8 k rays = 124 waves on 1024 SIMDs).  The cooperative pass rests on one observation about the reference's loop (ray_sampler.h:52-69,
-// ray_sampler_header.h:728-753): whether a cell is occupied or not, t only ever advances by t += calc_dt(t).  The sequence t_0 = start, t_{k+1} = t_k + calc_dt(t_k)
-// is therefore FIXED per ray, independent of the occupancy grid; the marcher visits a subsequence of it (occupied: emit, go to k+1; empty: go to the first
-// m > k with !(t_m < t_target(k))).  So:
-//   chain phase : thread r of a workgroup produces the next 64 chain values of ray r with the reference's own serial fp32 recurrence (bit-identical t), into LDS;
-//   eval phase  : one WAVEFRONT per ray evaluates all 64 candidates at once (lane = candidate: position, box test, mip level, occupancy bit, skip target) -
-//                 one memory round trip per 64 candidates instead of one per visited candidate - and, by a lower-bound search in the LDS chain, the candidate
-//                 each visit would continue at;
-//   walk phase  : one THREAD per ray follows those links through its window (runs of "continue at the successor" are taken whole with mask arithmetic);
-//                 walking with wave-uniform scalar code instead cost ~800 SALU instructions per window and made the kernel scalar-issue-bound;
-//   emit phase  : wavefront per ray again: the emitting lanes store their t into the ray's t-cache at slot j + popcount(emitters below me) - the wavefront
-//                 ballot / prefix-sum compaction of north_star.
-// Sample counts and cached t are bit-identical to the serial traversal by construction (same expressions on the same t); a window that lies entirely before
-// a pending skip target costs one LDS read and one compare.
+// One thread per ray (k_march_count above, kept for ngp_march_rays and for mostly-empty rays) is a chain of dependent loads per ray - hundreds of microseconds for
+// the longest ray while the chip idles (8 k rays = 124 waves on 1024 SIMDs).  The cooperative pass rests on one observation about the reference's loop
+// (ray_sampler.h:52-69, ray_sampler_header.h:728-753): whether a cell is occupied or not, t only ever advances by t += calc_dt(t).  The sequence t_0 = start,
+// t_{k+1} = t_k + calc_dt(t_k) is therefore FIXED per ray, independent of the occupancy grid; the marcher visits a subsequence of it (occupied: emit, go to k+1;
+// empty: go to the first m > k with !(t_m < t_target(k))).  One WAVEFRONT per ray works through that sequence NC = 256 candidates at a time:
+//   chain : the next NC values of the sequence, in LDS.  With a CONSTANT step the recurrence t_{k+1} = fl(t_k + dt) has a closed form inside a binade: t = a*U
+//           (U the binade's ulp, a an integer in [2^23, 2^24)), and as long as the exact sum stays below the binade's end every step adds the same integer
+//           q = rint(dt/U) (the fractional part of dt/U is the same at every step, so every step rounds the same way; a tie disables the shortcut).  Lane i writes
+//           (a0 + i*q)*U - exact integer arithmetic, bit-identical to the serial sum - and only the 1-3 steps around a binade crossing are real fp32 adds.
+//           (Cone stepping has no closed form: lane 0 runs the recurrence.)
+//   eval  : lane = candidate (position, box test, mip level, occupancy bit, skip target and - by a lower-bound search in the LDS chain - the candidate nx the
+//           visit would continue at): one memory round trip per 64 candidates instead of one per visited candidate;
+//   walk  : the visited candidates are the orbit of the start under c -> nx[c].  G[c] = "no earlier candidate of this round skips past c" (prefix-max of nx,
+//           one wavefront scan per window) is a guess that is right unless float fuzz makes two candidates of one empty cell land differently; it is CHECKED
+//           exactly - every member of G must continue at the next member of G - and if the check holds G IS the orbit (induction from the start).  Otherwise
+//           lane 0 walks the links serially.  Either way the result is bit-identical to the serial traversal;
+//   emit  : the emitting lanes store their t into the ray's t-cache at slot j + popcount(emitters below me) - the wavefront ballot / prefix-sum compaction of
+//           north_star.
+// No workgroup-level synchronisation at all: a ray's rounds depend on nothing but the ray.  History (ngp_base.py sampling, 7.8 k rays x 33 samples, alone on the
+// GPU): serial 665 us; four rays per workgroup with one THREAD per ray for the chain and the walk and four barriers per round (round 2's first version) 169 us -
+// those single-thread phases of the eight workgroups resident on a CU queued up behind each other; this kernel 94 us.
 #define MC_WIN 64u           // candidates per wavefront-wide window
 
-// MC_NW windows (MC_NW * 64 chain values) per ray per round: a ray that crosses the whole box takes 2048 candidates, i.e. 32 rounds of one window - and every round
-// is a chain of dependent latencies (serial chain -> barrier -> LDS -> global load -> LDS -> walk -> store -> barrier, ~15 k cycles measured), so the longest ray
-// alone held the kernel at ~200 us.  With several windows per round the evaluations of a ray's windows are independent of each other (only the walk is
-// serial): their occupancy loads are issued back to back and the per-round latency is paid once per MC_NW windows.
-template <uint32_t MC_RAYS /*rays per workgroup*/, uint32_t MC_WAVES, uint32_t MC_NW>
-__global__ __launch_bounds__(MC_WAVES * 64) void k_march_coop(uint32_t n_rays, MarchParams p, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                              const uint8_t *__restrict__ bitfield, uint32_t *__restrict__ steps, float *__restrict__ tcache) {
-	constexpr uint32_t NC = MC_NW * MC_WIN;                   // chain values per ray per round
-	__shared__ float tch[MC_RAYS][NC + 1];                    // +1: the chain threads write column k of every row in one instruction (odd stride: conflict-free)
-	__shared__ float ray_o[MC_RAYS][3], ray_d[MC_RAYS][3], ray_idir[MC_RAYS][3], ray_hs[MC_RAYS][3], pend[MC_RAYS];      // per-ray constants of the skip target: 1/d, 0.5*sign(d)
-	__shared__ uint32_t cnt[MC_RAYS], done[MC_RAYS], wstart[MC_RAYS], wemit[MC_RAYS], n_live;
-	__shared__ unsigned long long wmask[MC_RAYS][MC_NW][4];  // per window: inside / occupied / "continues at the next candidate" / emitters
-	__shared__ float wtarget[MC_RAYS][NC];                    // skip target of every candidate of the round
-	__shared__ uint16_t wnext[MC_RAYS][NC];                   // candidate the visit continues at (NC = beyond this round's chain)
-	__shared__ uint32_t mlut[NGP_GRIDSIZE];                   // expand_bits(i): three LDS reads per candidate instead of 24 VALU instructions
-	if (threadIdx.x < NGP_GRIDSIZE) mlut[threadIdx.x] = expand_bits(threadIdx.x);
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, ray0 = blockIdx.x * MC_RAYS;
-	float t_next = 0.f;
-	if (threadIdx.x < MC_RAYS) {
-		const uint32_t r = threadIdx.x, i = ray0 + r;
-		cnt[r] = 0; pend[r] = -__builtin_inff(); wstart[r] = NC;
-		if (i < n_rays) {
-			float o[3], d[3];
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, uint32_t lane) {
 #pragma unroll
-			for (int k = 0; k < 3; ++k) {
-				o[k] = rays_o[3 * (size_t)i + k]; d[k] = rays_d[3 * (size_t)i + k]; ray_o[r][k] = o[k]; ray_d[r][k] = d[k];
-				ray_idir[r][k] = 1.0f / d[k]; ray_hs[r][k] = 0.5f * copysignf(1.0f, d[k]);
-			}
-			t_next = ray_start(p, i, o, d);
-			done[r] = 0;
-		} else done[r] = 1;
-		if (r == 0) n_live = min(MC_RAYS, n_rays - ray0);
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(v, off); if (lane >= (uint32_t)off) v = max(v, y); }
+	return v;
+}
+__device__ __forceinline__ unsigned long long bits_below(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+
+template <uint32_t NW, bool CONST_DT>
+__global__ __launch_bounds__(64) void k_march_wave(uint32_t n_rays, MarchParams p, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                   const uint8_t *__restrict__ bitfield, uint32_t *__restrict__ steps, float *__restrict__ tcache) {
+	constexpr uint32_t NC = NW * MC_WIN;                      // chain values per round
+	__shared__ float tch[NC + 1];
+	__shared__ uint32_t mlut[NGP_GRIDSIZE];
+	__shared__ uint16_t wnext[NC];                            // slow path only: links, skip targets, masks, results
+	__shared__ float wtarget[NC];
+	__shared__ unsigned long long wmask[NW][4];
+	__shared__ uint32_t wres[3];
+	const uint32_t lane = threadIdx.x, i = blockIdx.x;
+	if (i >= n_rays) return;
+	mlut[lane] = expand_bits(lane); mlut[lane + 64u] = expand_bits(lane + 64u);
+	float o[3], d[3], idir[3], hs[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) { o[k] = rays_o[3 * (size_t)i + k]; d[k] = rays_d[3 * (size_t)i + k]; idir[k] = 1.0f / d[k]; hs[k] = 0.5f * copysignf(1.0f, d[k]); }
+	float t_round = ray_start(p, i, o, d);
+	{
+		float pos[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) pos[k] = o[k] + t_round * d[k];
+		if (!contains(p, pos)) { if (lane == 0) steps[i] = 0; return; }     // the ray misses the box (or starts behind it): the reference's loop does not run
 	}
-	__syncthreads();
 	const float big_neg = -__builtin_inff();
+	uint32_t j0 = 0;
+	float pend = big_neg;
 	for (;;) {
-		// ---- chain phase: the next NC values of every live ray's fixed sequence (the reference's own recurrence)
-		if (threadIdx.x < MC_RAYS && !done[threadIdx.x]) {
-			float t = t_next;
-			if (p.const_dt) {                                             // (the branch is hoisted: per step it cost more than the add - 43 cycles per chain value measured)
-				const float dtc = calc_dt(t, p);
-#pragma unroll 8
-				for (uint32_t k = 0; k < NC; ++k) { tch[threadIdx.x][k] = t; t += dtc; }
-			} else {
-				const float lo = min_cone_stepsize(), hi = max_cone_stepsize(p.cascades);
-#pragma unroll 8
-				for (uint32_t k = 0; k < NC; ++k) { tch[threadIdx.x][k] = t; t += clampf(t * p.cone_angle, lo, hi); }
+		__syncthreads();                                      // (one wavefront: orders this round's LDS writes after the last round's reads; also publishes mlut)
+		// ---- chain: tch[0 .. NC] = the next NC + 1 values of the ray's fixed sequence
+		if (CONST_DT) {
+			const float dtc = calc_dt(t_round, p);
+			uint32_t k = 0; float t = t_round;
+			while (k <= NC) {
+				int e; (void)frexpf(t, &e);
+				const float sc = ldexpf(1.0f, 24 - e), a0f = t * sc;             // t = a0 * 2^(e-24), a0 in [2^23, 2^24) for a normal positive t
+				uint32_t m = 0, a0 = 0, q = 0;
+				if (e > -100 && e < 100 && a0f >= 8388608.0f && a0f < 16777216.0f) {
+					const float delta = dtc * sc;
+					if (delta < 16777216.0f) {
+						const float fl = floorf(delta);
+						a0 = (uint32_t)a0f; q = (uint32_t)rintf(delta);
+						const int X = (int)(16777215u - a0) - (int)(uint32_t)ceilf(delta);       // steps 0 .. X/q keep the exact sum below the binade's end
+						if (delta - fl != 0.5f && X >= 0 && q > 0u) m = (uint32_t)X / q + 1u;
+					}
+				}
+				if (m == 0u) { if (lane == 0) tch[k] = t; t += dtc; ++k; continue; }             // near a binade crossing (or a degenerate t): one real step
+				const uint32_t last = min(m, NC - k);
+				const float U = ldexpf(1.0f, e - 24);
+				for (uint32_t c = lane; c <= last; c += 64u) tch[k + c] = (float)(a0 + c * q) * U;
+				t = (float)(a0 + last * q) * U; k += last;
+				if (k == NC) break;
 			}
-			t_next = t;
+		} else if (lane == 0) {
+			const float lo = min_cone_stepsize(), hi = max_cone_stepsize(p.cascades);
+			float t = t_round;
+#pragma unroll 8
+			for (uint32_t k = 0; k <= NC; ++k) { tch[k] = t; t += clampf(t * p.cone_angle, lo, hi); }
 		}
 		__syncthreads();
-		// ---- eval phase: the (ray, window) pairs of the round are dealt to the wavefronts; one wavefront-wide evaluation each, results parked in LDS for the walk
-		for (uint32_t item = wave; item < MC_RAYS * MC_NW; item += MC_WAVES) {
-			const uint32_t r = item / MC_NW, w = item % MC_NW, self = w * MC_WIN + lane;
-			if (__builtin_amdgcn_readfirstlane((int)done[r])) continue;   // (wave-uniform: per-ray state is read into SGPRs)
-			const float pd = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pend[r])));
-			const float tl = tch[r][self];
-			if (pd != big_neg) {                                          // a skip from an earlier round is still running: it lands on the first t with !(t < target)
-				const unsigned long long m = __ballot(!(tl < pd));
-				if (m == 0ull) { if (lane == 0) { wmask[r][w][0] = 0ull; wmask[r][w][3] = 0ull; } continue; }      // the whole window lies before the target
-				if (lane == 0) atomicMin(&wstart[r], w * MC_WIN + (uint32_t)__builtin_ctzll(m));
-			} else if (w == 0 && lane == 0) wstart[r] = 0;
-			const float o[3] = {ray_o[r][0], ray_o[r][1], ray_o[r][2]}, d[3] = {ray_d[r][0], ray_d[r][1], ray_d[r][2]};
+		float tl[NW];
+#pragma unroll
+		for (uint32_t w = 0; w < NW; ++w) tl[w] = tch[w * MC_WIN + lane];
+		t_round = tch[NC];
+		// ---- where the round starts: candidate 0, or the landing of the skip that is still running
+		uint32_t s = 0;
+		if (pend != big_neg) {
+			s = NC;
+#pragma unroll
+			for (int w = (int)NW - 1; w >= 0; --w) { const unsigned long long m = __ballot(!(tl[w] < pend)); if (m) s = (uint32_t)w * MC_WIN + (uint32_t)__builtin_ctzll(m); }
+			if (s == NC) continue;                            // the whole round lies before the target
+		}
+		// ---- eval: lane = candidate, NW candidates per lane
+		unsigned long long INm[NW], OCCm[NW];
+		uint32_t nxw[NW]; float tgt[NW];
+#pragma unroll
+		for (uint32_t w = 0; w < NW; ++w) {
+			const uint32_t self = w * MC_WIN + lane;
+			nxw[w] = 0; tgt[w] = 0.f; INm[w] = 0ull; OCCm[w] = 0ull;
+			if ((w + 1u) * MC_WIN <= s) continue;             // (wave-uniform) window before the start
 			float pos[3];
 #pragma unroll
-			for (int k = 0; k < 3; ++k) pos[k] = o[k] + tl * d[k];
+			for (int k = 0; k < 3; ++k) pos[k] = o[k] + tl[w] * d[k];
 			const bool inside = contains(p, pos);
 			bool occ = false;
 			float target = 0.f;
-			uint32_t nx = self + 1u;                                      // where the visit of this candidate continues (occupied: the next candidate)
+			uint32_t nx = self + 1u;
 			if (inside) {
-				const float dt = calc_dt(tl, p);
+				const float dt = calc_dt(tl[w], p);
 				const uint32_t mip = (uint32_t)mip_from_dt(dt, pos, p.cascades);
-				// occupied_at (ray_sampler_header.h:755-776), morton code from the LDS table
-				const float mip_scale = scalbnf(1.0f, -(int)mip);
+				const float mip_scale = scalbnf(1.0f, -(int)mip);                 // occupied_at (ray_sampler_header.h:755-776), morton code from the LDS table
 				uint32_t c[3];
 #pragma unroll
 				for (int k = 0; k < 3; ++k) {
@@ -245,83 +273,141 @@ __global__ __launch_bounds__(MC_WAVES * 64) void k_march_coop(uint32_t n_rays, M
 					const float resf = (float)res, inv_res = 1.0f / resf;
 					float t3[3];
 #pragma unroll
-					for (int k = 0; k < 3; ++k) { const float q = resf * pos[k]; t3[k] = (floorf(q + 0.5f + ray_hs[r][k]) - q) * ray_idir[r][k]; }
+					for (int k = 0; k < 3; ++k) { const float q = resf * pos[k]; t3[k] = (floorf(q + 0.5f + hs[k]) - q) * idir[k]; }
 					const float tt = fminf(fminf(t3[0], t3[1]), t3[2]);
-					target = tl + fmaxf(tt * inv_res, 0.0f);
-					// the skip `do t += dt while (t < target)` lands on the first candidate m > self with !(t_m < target): t is increasing, so that is a
-					// lower-bound search in this round's chain (NC = beyond it)
-					// search in this round's chain (NC = beyond it).  The chain is locally uniform (consecutive steps differ by at most 1/256), so the estimate
-					// self + (target - t) / dt is off by a step at most and two LDS probes usually settle it (a bisection costs eight dependent ones)
-					const float est = (target - tl) / dt;
+					target = tl[w] + fmaxf(tt * inv_res, 0.0f);
+					// the skip lands on the first candidate m > self with !(t_m < target): estimate from the local step, settle with LDS probes (NC = beyond this round)
+					const float est = (target - tl[w]) / dt;
 					uint32_t g = self + 1u;
 					if (est > 1.0f) g = est >= (float)NC ? NC : self + (uint32_t)est;
 					if (g > NC) g = NC;
-					while (g > self + 1u && !(tch[r][g - 1u] < target)) --g;
-					while (g < NC && tch[r][g] < target) ++g;
+					while (g > self + 1u && !(tch[g - 1u] < target)) --g;
+					while (g < NC && tch[g] < target) ++g;
 					nx = g;
 				}
 			}
-			// (an empty candidate whose skip leaves the round is NOT a plain successor step: its target stays pending)
-			const unsigned long long IN = __ballot(inside), OCC = __ballot(occ), NX = __ballot(inside && nx == self + 1u && (occ || nx < NC));
-			wnext[r][self] = (uint16_t)nx; wtarget[r][self] = target;
-			if (lane == 0) { wmask[r][w][0] = IN; wmask[r][w][1] = OCC; wmask[r][w][2] = NX; wmask[r][w][3] = 0ull; }
+			INm[w] = __ballot(inside); OCCm[w] = __ballot(occ);
+			nxw[w] = nx; tgt[w] = target;
 		}
-		__syncthreads();
-		// ---- walk phase: ONE THREAD per ray follows the visit chain through the round; candidates that continue at their successor are taken a run at a time
-		// with mask arithmetic, longer skips are one LDS read each
-		if (threadIdx.x < MC_RAYS) {
-			const uint32_t r = threadIdx.x;
-			uint32_t cur = done[r] ? NC : wstart[r];
-			uint32_t flag = 0;
-			if (cur < NC) {
-				const uint32_t j0 = cnt[r];
-				uint32_t emitted = 0, fin = 0;
+		// ---- walk, in parallel: G = candidates no earlier candidate of the round skips past
+		unsigned long long G[NW];
+		{
+			uint32_t carry = 0;
+#pragma unroll
+			for (uint32_t w = 0; w < NW; ++w) {
+				const uint32_t self = w * MC_WIN + lane;
+				const uint32_t incl = wave_incl_max(self >= s ? nxw[w] : 0u, lane);
+				const uint32_t up = __shfl_up(incl, 1);
+				const uint32_t ex = max(carry, lane ? up : 0u);
+				G[w] = __ballot(self >= s && (self == s || ex == self));
+				carry = max(carry, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
+			}
+		}
+		uint32_t FO = NC;                                     // first visited candidate outside the box: the ray ends there
+#pragma unroll
+		for (int w = (int)NW - 1; w >= 0; --w) { const unsigned long long out = G[w] & ~INm[w]; if (out) FO = (uint32_t)w * MC_WIN + (uint32_t)__builtin_ctzll(out); }
+		unsigned long long E[NW];
+		bool bad = false;
+		{
+			uint32_t nfirst = NC;                             // first member of G in a later window
+#pragma unroll
+			for (int w = (int)NW - 1; w >= 0; --w) {
+				const uint32_t self = (uint32_t)w * MC_WIN + lane;
+				const unsigned long long V = G[w] & INm[w] & bits_below(FO > (uint32_t)w * MC_WIN ? FO - (uint32_t)w * MC_WIN : 0u);
+				const unsigned long long rest = lane == 63u ? 0ull : G[w] >> (lane + 1u);
+				const uint32_t ng = rest ? self + 1u + (uint32_t)__builtin_ctzll(rest) : nfirst;
+				if (__ballot(((V >> lane) & 1ull) && ng != nxw[w])) bad = true;
+				E[w] = V & OCCm[w];
+				if (G[w]) nfirst = (uint32_t)w * MC_WIN + (uint32_t)__builtin_ctzll(G[w]);
+			}
+		}
+		uint32_t emitted = 0, fin = 0;
+		if (!bad) {
+			uint32_t total = 0;
+#pragma unroll
+			for (uint32_t w = 0; w < NW; ++w) total += (uint32_t)__builtin_popcountll(E[w]);
+			const uint32_t room = NGP_STEPS - j0;
+			if (total >= room) {                              // NERF_STEPS is reached in this round: keep the first `room` emitters, the ray ends
+				uint32_t cum = 0;
+#pragma unroll
+				for (uint32_t w = 0; w < NW; ++w) {
+					const uint32_t c = (uint32_t)__builtin_popcountll(E[w]);
+					if (cum + c > room) {
+						const uint32_t pre = (uint32_t)__builtin_popcountll(E[w] & bits_below(lane));
+						E[w] = __ballot(((E[w] >> lane) & 1ull) && cum + pre < room);
+					}
+					cum += c;
+				}
+				emitted = room; fin = 1; pend = big_neg;
+			} else {
+				emitted = total; fin = FO < NC ? 1u : 0u; pend = big_neg;
+				if (!fin) {                                   // the last visited candidate: an empty cell there leaves its skip target pending
+#pragma unroll
+					for (int w = (int)NW - 1; w >= 0; --w) {
+						if (G[w]) {
+							const uint32_t ll = 63u - (uint32_t)__builtin_clzll(G[w]);
+							if (!((OCCm[w] >> ll) & 1ull)) pend = __shfl(tgt[w], (int)ll);
+							break;
+						}
+					}
+				}
+			}
+		} else {
+			// ---- slow path (float fuzz inside an empty cell): lane 0 follows the links
+#pragma unroll
+			for (uint32_t w = 0; w < NW; ++w) {
+				const uint32_t self = w * MC_WIN + lane;
+				const bool inside = (INm[w] >> lane) & 1ull, occ = (OCCm[w] >> lane) & 1ull;
+				const unsigned long long NX = __ballot(inside && nxw[w] == self + 1u && (occ || nxw[w] < NC));
+				wnext[self] = (uint16_t)nxw[w]; wtarget[self] = tgt[w];
+				if (lane == 0) { wmask[w][0] = INm[w]; wmask[w][1] = OCCm[w]; wmask[w][2] = NX; wmask[w][3] = 0ull; }
+			}
+			__syncthreads();
+			if (lane == 0) {
+				uint32_t cur = s, em = 0, fn = 0;
 				float new_pend = big_neg;
 				while (cur < NC) {
 					const uint32_t w = cur / MC_WIN, c = cur % MC_WIN;
-					const unsigned long long IN = wmask[r][w][0], OCC = wmask[r][w][1], NX = wmask[r][w][2];
-					if (!((IN >> c) & 1ull) || j0 + emitted >= NGP_STEPS) { fin = 1; break; }      // the loop condition of ray_sampler.h:52: contains(pos) && j < NERF_STEPS
-					if ((NX >> c) & 1ull) {                                  // a run of candidates visited one after the other; its occupied members emit
+					const unsigned long long IN = wmask[w][0], OCC = wmask[w][1], NX = wmask[w][2];
+					if (!((IN >> c) & 1ull) || j0 + em >= NGP_STEPS) { fn = 1; break; }
+					if ((NX >> c) & 1ull) {
 						const unsigned long long rest = ~(NX >> c);
 						uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
-						if (run > MC_WIN - c) run = MC_WIN - c;             // (a run that reaches the window's end continues in the next window's masks)
-						const unsigned long long runmask = (run >= 64u ? ~0ull : ((1ull << run) - 1ull)) << c;
-						unsigned long long em = OCC & runmask;
-						const uint32_t n_em = (uint32_t)__builtin_popcountll(em), room = NGP_STEPS - (j0 + emitted);
-						if (n_em > room) {                                   // NERF_STEPS is reached inside the run: keep its first `room` emitters, the ray ends there
+						if (run > MC_WIN - c) run = MC_WIN - c;
+						const unsigned long long runmask = bits_below(run) << c;
+						unsigned long long emm = OCC & runmask;
+						const uint32_t n_em = (uint32_t)__builtin_popcountll(emm), room = NGP_STEPS - (j0 + em);
+						if (n_em > room) {
 							unsigned long long keep = 0ull;
-							for (uint32_t q = 0; q < room; ++q) { const unsigned long long low = em & (0ull - em); keep |= low; em ^= low; }
-							wmask[r][w][3] |= keep; emitted += room; fin = 1;
+							for (uint32_t q = 0; q < room; ++q) { const unsigned long long low = emm & (0ull - emm); keep |= low; emm ^= low; }
+							wmask[w][3] |= keep; em += room; fn = 1;
 							break;
 						}
-						wmask[r][w][3] |= em; emitted += n_em; cur += run;
-					} else {                                                // an empty cell whose skip goes further than the next candidate
-						const uint32_t nx = wnext[r][cur];
-						if (nx >= NC) { new_pend = wtarget[r][cur]; break; }          // lands in a later round
+						wmask[w][3] |= emm; em += n_em; cur += run;
+					} else {
+						const uint32_t nx = wnext[cur];
+						if (nx >= NC) { new_pend = wtarget[cur]; break; }
 						cur = nx;
 					}
 				}
-				cnt[r] = j0 + emitted;
-				pend[r] = new_pend;
-				if (fin) { done[r] = 1; steps[ray0 + r] = j0 + emitted; atomicSub(&n_live, 1u); }
-				flag = j0 | 0x80000000u;                                  // tells the emit phase that the emitter masks are valid, and the slot of the round's first emitter
+				wres[0] = em; wres[1] = fn; wres[2] = __float_as_uint(new_pend);
 			}
-			wemit[r] = flag;
-			wstart[r] = NC;                                               // reset for the next round's atomicMin
+			__syncthreads();
+#pragma unroll
+			for (uint32_t w = 0; w < NW; ++w) E[w] = wmask[w][3];
+			emitted = wres[0]; fin = wres[1]; pend = __uint_as_float(wres[2]);
 		}
-		__syncthreads();
-		// ---- emit phase (wavefront per window again): emitters store their t at slot j0 + (number of emitters before me): the wavefront ballot / prefix-sum compaction
-		for (uint32_t item = wave; item < MC_RAYS * MC_NW; item += MC_WAVES) {
-			const uint32_t r = item / MC_NW, w = item % MC_NW;
-			const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)wemit[r]);
-			if (!(ws & 0x80000000u)) continue;
-			uint32_t slot = ws & 0x7fffffffu;
-			for (uint32_t v = 0; v < w; ++v) slot += (uint32_t)__builtin_popcountll(wmask[r][v][3]);
-			const unsigned long long E = wmask[r][w][3];
-			if (tcache && ((E >> lane) & 1ull)) tcache[(size_t)(ray0 + r) * NGP_TCACHE + slot + (uint32_t)__builtin_popcountll(E & ((1ull << lane) - 1ull))] = tch[r][w * MC_WIN + lane];
+		// ---- emit: emitters store their t at slot j0 + (number of emitters before me): wavefront ballot / popcount compaction
+		{
+			uint32_t cum = j0;
+#pragma unroll
+			for (uint32_t w = 0; w < NW; ++w) {
+				if (tcache && ((E[w] >> lane) & 1ull)) tcache[(size_t)i * NGP_TCACHE + cum + (uint32_t)__builtin_popcountll(E[w] & bits_below(lane))] = tl[w];
+				cum += (uint32_t)__builtin_popcountll(E[w]);
+			}
 		}
-		__syncthreads();
-		if (n_live == 0) break;          // (read by every thread before the next barrier; the walkers change it only after that barrier)
+		j0 += emitted;
+		if (fin) { if (lane == 0) steps[i] = j0; return; }
 	}
 }
 
@@ -517,7 +603,8 @@ NGP_API int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const fl
 	// run and every inference chunk), serial when they are mostly empty space.  Both produce identical bits (tests/test_hip_parity.py runs both).
 	if (g_march_count_mode < 0) { const char *e = getenv("NGP_MARCH_COUNT"); g_march_count_mode = !e ? 0 : (e[0] == 's' ? 1 : 2); }      // NGP_MARCH_COUNT=serial|coop overrides the choice
 	const bool coop = g_march_count_mode ? g_march_count_mode == 2 : (uint64_t)cap >= (uint64_t)16 * n_rays;
-	if (coop) NGP_LAUNCH((k_march_coop<4u, 4u, 4u>), dim3(div_up(n_rays, 4u)), dim3(256), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
+	if (coop && const_dt) NGP_LAUNCH((k_march_wave<4u, true>), dim3(n_rays), dim3(64), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
+	else if (coop) NGP_LAUNCH((k_march_wave<4u, false>), dim3(n_rays), dim3(64), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
 	else NGP_LAUNCH(k_march_count, dim3(div_up(n_rays, 128)), dim3(128), 0, s, n_rays, p, rays_o, rays_d, bitfield, scratch, tcache);
 	launch_march_scan(s, n_rays, max_samples, cap, (const uint32_t *)scratch, scratch + ((n_rays + 1023u) & ~1023u) + (size_t)NGP_TCACHE * n_rays, numsteps, numsteps_compacted, (int32_t *)nullptr, counters, 4);
 	NGP_LAUNCH(k_march_write_cached, dim3(div_up(cap, 256)), dim3(256), 0, s, n_rays, p, rays_o, rays_d, (const uint32_t *)numsteps_compacted,

@@ -303,6 +303,40 @@ def test_march_compacted_equals_march_then_compact(H, const_dt, aabb, count_pass
     assert e[1].shape == (0, 2) and not e[2].any()
 
 
+@pytest.mark.parametrize("const_dt,aabb,density", [(True, (0.0, 1.0), 0.05), (True, (0.0, 1.0), 0.5), (True, (-1.5, 2.5), 0.2), (False, (-1.5, 2.5), 0.2), (False, (0.0, 1.0), 0.95)])
+def test_count_passes_agree_on_a_noisy_grid(H, const_dt, aabb, density):
+    """A random occupancy grid (every cell independent: the hardest case for the cooperative pass - skips of every length, landing fuzz, rays that reach
+    NERF_STEPS = 1024 samples) marched by the serial thread-per-ray count pass and by the cooperative one: counts, records and counters must be the same bits.
+    Origins inside and outside the box, 12 k rays."""
+    import ctypes
+    from jnerf_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    rng = np.random.default_rng(41)
+    n = 12000
+    lo, hi = aabb
+    o = rng.uniform(lo - 0.8 * (hi - lo), hi + 0.8 * (hi - lo), (n, 3)).astype(np.float32)
+    o[: n // 4] = rng.uniform(lo, hi, (n // 4, 3)).astype(np.float32)                      # a quarter start inside
+    tgt = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    bits = np.packbits(rng.random(5 * 128 ** 3) < density, bitorder="little")
+    res = {}
+    try:
+        for name, mode in (("serial", 1), ("coop", 2)):
+            lib.ngp_x_march_count_mode(mode)
+            res[name] = H.march_rays_compacted(o, d, bits, aabb, O.PCG32(99), n * 1024, 1 << 21, const_dt=const_dt)
+    finally:
+        lib.ngp_x_march_count_mode(0)
+    c0, n0, nc0, cnt0 = res["serial"]
+    assert n0[:, 0].max() == 1024 or not (const_dt and density >= 0.5), "no ray reached NERF_STEPS"
+    k = int(cnt0[3])
+    assert k > 100000
+    c1, n1, nc1, cnt1 = res["coop"]
+    assert np.array_equal(n1, n0) and np.array_equal(nc1, nc0) and np.array_equal(cnt1, cnt0)
+    assert np.array_equal(c1[:k], c0[:k])
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
 def test_composite_fwd_huber_equals_the_two_calls(H, dtype):
     """the fused launch of the fast training path == ngp_composite_fwd then ngp_huber, bit for bit; both == oracle"""
