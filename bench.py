@@ -107,9 +107,10 @@ def cpu_baseline(aabb_scale, fp16, const_dt, n_samples=1 << 18, n_rays=4096, n_m
 
 
 # ---------------------------------------------------------------------------------------------------------------- roofline bookkeeping
-def alg_bytes_table(n, P, R, n_refresh, fp16):
+def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
     """ALGORITHMIC bytes (and flops) per launch of every hot-path kernel: per-unit figure x units one launch processes.
-    n = samples in the batch, P = hash-table parameters, R = rays in the batch, n_refresh = points of one occupancy-grid refresh launch, T/F = bytes per table / feature element."""
+    n = samples in the batch, P = hash-table parameters, R = rays in the batch, n_refresh = points of one occupancy-grid refresh launch, n_runs = levels with
+    res <= 300 (k_bin_records_runs; the other 16 - n_runs go through k_bin_records), T = bytes per table / feature element."""
     T = 2 if fp16 else 4
     hf = 12 + 16 * 8 * 2 * T + 32 * T                      # hash fwd per sample: pos + 128 corner values + 32 features out (588 | 1164)
     fio = 32 * T + 12 + 4 * T                              # field fwd per sample: features + direction + 4 outputs
@@ -119,8 +120,8 @@ def alg_bytes_table(n, P, R, n_refresh, fp16):
         "k_composite_fwd": n * (4 * T + 28), "k_composite_bwd": n * (4 * T + 28 + 4 * T),
         "k_adam_ema": P * (30 if fp16 else 28),                # read p, g, m, v; write p, m, v (+ the fp16 shadow); the gradient is overwritten by the next backward, not zeroed here
         # hash backward: the stage's necessary traffic is pos 12 + dL/dy 32*T + 128 scattered fp32 updates (4 B each as one write); attributed to the kernels that do each part
-        "k_level_absmax": n * 32 * T, "k_bin_records": n * (12 + 32 * T) * 12 / 16, "k_bin_accumulate": n * 12 * 8 * 2 * 4, "k_hash_bwd_owner": n * ((12 + 32 * T) * 4 / 16 + 4 * 8 * 2 * 4),
-        "k_reduce_dense": 0, "k_reduce_slabs": 10240 * 4, "k_pack_frags": 21504 * 2 * 2,
+        "k_level_absmax": n * 32 * T, "k_bin_records": n * (12 + 32 * T) * (16 - n_runs) / 16, "k_bin_records_runs": n * (12 + 32 * T) * n_runs / 16, "k_bin_accumulate": n * 16 * 8 * 2 * 4,
+        "k_reduce_slabs": 10240 * 4, "k_pack_frags": 21504 * 2 * 2,
         # sampling: ray in (24 B) + one 28-byte record and one 12-byte position out per sample
         "k_march_count": R * 24 + n * 4, "k_march_wave": R * 24 + n * 4, "k_mscan_totals": R * 4, "k_mscan_ok": R * 4, "k_mscan_final": R * 20, "k_march_write_cached": n * (4 + 40),
         "k_generate_rays": R * (8 + 16 + 12 + 40),
@@ -248,7 +249,8 @@ def main():
     # ---- roofline of the dominant kernel: live HIP-event durations over the timed region, algorithmic bytes per launch
     P = runner.model.pos_encoder.n_params
     n_refresh = 128 ** 3 * (runner.sampler.max_cascade + 1) // 2
-    alg, flops = alg_bytes_table(mean_valid, P, mean_rays, n_refresh, fp16)
+    n_runs = int((runner.model.pos_encoder.level_table.reshape(16, 4)[:, 2] <= 300).sum())
+    alg, flops = alg_bytes_table(mean_valid, P, mean_rays, n_refresh, fp16, n_runs)
     roof = None
     if dom is not None and dom_ms:
         cls = batch_class(dom_ms)

@@ -144,6 +144,8 @@ __global__ __launch_bounds__(256) void k_hash_bwd(uint32_t n, const float *__res
 
 
 // ---------------------------------------------------------------------------------------------------------------- owner-computes scatter
+// (Since round 2 this scan is the FALLBACK: calls without a workspace, the fixed-point request of ngp_hash_encode_bwd_fx, levels beyond 2^19 entries.  The training
+// path hands over a workspace and every level goes through the binned scatter further down.)
 // Measured on MI355X (tools/microbench_hash.py, profiles/): float atomics to global memory retire at ~20 G instructions/s chip-wide no
 // matter how local they are, i.e. >= 3.3 ms for the 2 x 33.5 M updates of one 2^18-sample batch (7.8 ms on real, spatially concentrated
 // samples).  This kernel removes them: every workgroup OWNS a contiguous slice of one level's table (16384 entries = 128 KiB of fp32
@@ -169,16 +171,9 @@ __device__ __forceinline__ float bin_scale(uint32_t absmax_bits) {     // power 
 // sum = (sum_y << 32) + sum_x in two's complement, decoded exactly at the flush.  The scale is the power of two with scale * L1(level) <= 2^30,
 // where L1(level) = sum over all samples of |dL/dy| bounds any entry's |sum| — overflow is impossible by construction, integer adds commute,
 // so the exclusive slices become bit-reproducible.
-// FX = 2 (fp32 gradients): each feature as its own 64-bit fixed-point sum (two ds_add_u64).  The scale is the power of two that puts the level's largest |dL/dy|
-// (k_level_absmax, shared with the binned path) in [2^37, 2^38): a contribution of that size keeps all 24 bits of its fp32 significand, one 2^-16 of it
-// still keeps 8, and a 64-bit sum of 2^21 register-combined runs of <= 8 samples cannot overflow.  Integer adds commute => bit-reproducible.
 template <int FX>
 __device__ __forceinline__ void acc_add(float *acc, uint32_t l, float vx, float vy, float fx_scale) {
-	if (FX == 2) {
-		unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + 2 * l;
-		__hip_atomic_fetch_add(a, (unsigned long long)__float2ll_rn(vx * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		__hip_atomic_fetch_add(a + 1, (unsigned long long)__float2ll_rn(vy * fx_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-	} else if (FX == 1) {
+	if (FX == 1) {
 		const int ix = __float2int_rn(vx * fx_scale), iy = __float2int_rn(vy * fx_scale);
 		const unsigned long long add = (unsigned long long)(long long)ix + ((unsigned long long)(uint32_t)iy << 32);
 		__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(acc) + l, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -189,10 +184,6 @@ __device__ __forceinline__ void acc_add(float *acc, uint32_t l, float vx, float 
 }
 template <int FX>
 __device__ __forceinline__ float2 acc_read(const float *acc, uint32_t e, float fx_inv) {
-	if (FX == 2) {
-		const long long *a = reinterpret_cast<const long long *>(acc) + 2 * e;
-		return make_float2((float)a[0] * fx_inv, (float)a[1] * fx_inv);
-	}
 	if (FX == 1) {
 		const unsigned long long t = reinterpret_cast<const unsigned long long *>(acc)[e];
 		const int lo = (int)(uint32_t)(t & 0xffffffffull);
@@ -202,7 +193,7 @@ __device__ __forceinline__ float2 acc_read(const float *acc, uint32_t e, float f
 	return make_float2(acc[2 * e], acc[2 * e + 1]);
 }
 
-struct OwnerPlan { uint32_t first_unit[17]; uint32_t chunks[16]; uint32_t order[16]; uint32_t slab_off[16]; uint32_t level_mask; uint32_t coarse_res; uint32_t half_slices /* bit l: level l uses 8192-entry slices (FX = 2, 16 B of LDS per entry) */; };   // slab_off: float2 offset of the level's [chunks][size] partial slabs, ~0u = none
+struct OwnerPlan { uint32_t first_unit[17]; uint32_t chunks[16]; uint32_t order[16]; uint32_t slab_off[16]; uint32_t level_mask; uint32_t coarse_res; };   // slab_off: float2 offset of the level's [chunks][size] partial slabs, ~0u = none
 
 template <typename T, typename G, int LAYOUT, bool HASHED, bool COMBINE, int FX>
 __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, const LevelTable &lt, uint32_t level,
@@ -211,10 +202,10 @@ __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const flo
 	using GP = typename Pair<G>::type;
 	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
-	constexpr uint32_t SLICE = FX == 2 ? OWN_SLICE / 2 : OWN_SLICE;      // 16 bytes per entry instead of 8
+	constexpr uint32_t SLICE = OWN_SLICE;
 	const uint32_t lo = slice * SLICE;
 	const uint32_t cnt = min(SLICE, size - lo);
-	for (uint32_t e = threadIdx.x; e < cnt * (FX == 2 ? 4 : 2); e += 1024) acc[e] = 0.f;
+	for (uint32_t e = threadIdx.x; e < cnt * 2; e += 1024) acc[e] = 0.f;
 	__syncthreads();
 	const uint32_t per = ((lim + n_chunks - 1) / n_chunks + 7u) & ~7u;
 	const uint32_t begin = min(chunk * per, lim), end = min(begin + per, lim);
@@ -373,7 +364,7 @@ __device__ __forceinline__ void owner_unit(float fx_scale, uint32_t n, const flo
 template <typename T, typename G, int LAYOUT>
 __global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt,
                                                          OwnerPlan plan, G *__restrict__ grad, int accumulate, const uint32_t *__restrict__ n_valid,
-                                                         const float *__restrict__ level_l1, float2 *__restrict__ slabs, const uint32_t *__restrict__ absmax_bits) {
+                                                         const float *__restrict__ level_l1, float2 *__restrict__ slabs) {
 	extern __shared__ __attribute__((aligned(16))) float acc[];          // [slice entries][2]
 	// block -> (level, slice, chunk); plan.order lists the chunked dense levels first, then the exclusive-owner (hashed) levels
 	uint32_t k = 0;
@@ -389,28 +380,7 @@ __global__ __launch_bounds__(1024) void k_hash_bwd_owner(uint32_t n, const float
 	const bool coarse = res <= plan.coarse_res;     // cells much longer than a marching step: consecutive samples of a ray share them
 	const bool dense = level_is_dense(size, res);
 #define OWNER_GO(H, C, F, SC) owner_unit<T, G, LAYOUT, H, C, F>(SC, n, pos, stride, dLdy, lt, level, slice, chunk, n_chunks, grad, accumulate, lim, acc, slab)
-	if (absmax_bits && slab && dense) {                          // dense level with partial slabs: integer sums
-		const bool wide = sizeof(T) == 4;                        // fp32 gradients: one 64-bit sum per feature (FX = 2); fp16: both features in ONE ds_add_u64 (two 32-bit fields)
-		float sc;
-		if (wide) {
-			const float m = __uint_as_float(absmax_bits[level]);
-			int ex = 0; if (m > 0.f && m < 3.0e38f) frexpf(m, &ex);
-			sc = (m > 0.f && m < 3.0e38f) ? ldexpf(1.0f, 38 - ex) : 0.f;
-		} else {
-			// scale: largest |dL/dy| of the level -> [2^13, 2^14) (k_level_absmax, shared with the binned path), times 2^k with k the largest value that keeps
-			// (samples of this chunk) * 2^14 * 2^k <= 2^31: an entry receives at most one corner (weight <= 1) per sample, so a field cannot overflow.
-			const uint32_t per = (lim + n_chunks - 1) / n_chunks + 8u;
-			int k = 17 - (32 - __builtin_clz(per));
-			sc = k < -13 ? 0.f : ldexpf(bin_scale(absmax_bits[level]), k);
-		}
-		if (sc == 0.f) {                                         // no gradient on this level: the slab part is zeros
-			const uint32_t SL = wide ? OWN_SLICE / 2 : OWN_SLICE;
-			const uint32_t lo = slice * SL, cnt = min(SL, size - lo);
-			for (uint32_t e = threadIdx.x; e < cnt; e += 1024) slab[(size_t)chunk * size + lo + e] = make_float2(0.f, 0.f);
-			return;
-		}
-		if (wide) OWNER_GO(false, true, 2, sc); else OWNER_GO(false, true, 1, sc);
-	} else if (level_l1) {
+	if (level_l1) {
 		const float l1 = level_l1[level];
 		if (!(l1 > 0.f)) {                                       // nothing to add on this level: write zeros / leave the accumulating buffer alone
 			if (n_chunks == 1 && !(accumulate & 1)) {
@@ -501,29 +471,49 @@ static int hash_bwd_method() {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------- binned scatter (hashed levels)
+// ---------------------------------------------------------------------------------------------------------------- binned scatter (every level of up to 2^19 entries)
 // The owner-computes scan above redoes every sample's index arithmetic once per slice owner (32x per level, ~220 instructions each) — it is
-// VALU-bound at ~0.45 ms per 2^18-sample batch.  With a workspace the hashed levels take this two-phase path instead:
-//   A  k_bin_records: one thread per (sample, level) computes the eight (entry, weight*gradient) contributions ONCE, and appends each
-//      to the record list of the 8192-entry bin the entry lives in (64 bins per level).  Slots are handed out by an LDS histogram per
-//      workgroup plus ONE global integer atomic per (workgroup, bin) — ~10^5 global atomics per batch instead of 3*10^7.
+// VALU-bound at ~0.45 ms per 2^18-sample batch.  With a workspace the levels take this two-phase path instead:
+//   A  records: the eight (entry, weight*gradient) contributions of a (sample, level) are computed ONCE and appended to the record list of the bin the
+//      entry lives in (64 bins per level).  Slots are handed out by an LDS histogram per workgroup plus ONE global integer atomic per
+//      (workgroup, bin) — ~10^5 global atomics per batch instead of 3*10^7.
+//        k_bin_records       (fine levels)   one thread per (sample, level);
+//        k_bin_records_runs  (coarse levels, **r2b**) one thread per EIGHT CONSECUTIVE samples: the samples of a ray are consecutive in the batch and a cell of a
+//                            level with res <= 300 is 3-40 marching steps long, so the thread sums the runs that share a cell in registers and emits one set of
+//                            eight records per run - 2.2 instead of 10 levels' worth of records on the ngp_base.py batch, and the dense levels (whose whole
+//                            table is a few thousand entries hit by 2 M contributions) fit the same machinery: no owner-computes scan, no partial slabs.
 //   B  k_bin_accumulate: one workgroup per bin streams its records (coalesced reads) into 64-bit INTEGER accumulators in LDS
-//      (ds_add_u64: 16.6 cycles per wave instruction vs 194 for ds_add_f32) and writes the bin's slice of the gradient with plain stores.
-// A record is a 16-bit entry index inside the bin plus the contribution, kept as two streams (structure of arrays: 2 + 4 bytes for fp16 gradients, 2 + 8 for
-// fp32 - the 8-byte {u32 index, half2} records of round 1 moved a third more bytes).
-//   fp16 dL/dy: the contribution is stored as fp16 after scaling by the power of two that maps the level's max |dL/dy| into [2^13, 2^14): every fp16 value is a
-//     multiple of 2^-24, so value * 2^24 is an exact integer < 2^39 and the sum of up to 2^21 records cannot overflow 63 bits.  Each contribution is rounded once
-//     (2^-11 relative, like the `(__half)(grad*weight)` of HashEncode.h:345).
-//   fp32 dL/dy (ngp_base.py): the contribution is stored as fp32 and converted to fixed point at 2^38 / max|dL/dy| (see acc_add<2>): fp32-exact for every
+//      (ds_add_u64: 16.6 cycles per wave instruction vs 194 for ds_add_f32) and writes the bin's entries of the gradient with plain stores.
+// A record is a 16-bit slot inside the bin plus the contribution, kept as two streams (structure of arrays: 2 + 4 bytes for fp16 gradients on the fine levels,
+// 2 + 8 for fp32 and for every run record - the 8-byte {u32 index, half2} records of round 1 moved a third more bytes).
+//   fp16 dL/dy, fine levels: the contribution is stored as fp16 after scaling by the power of two that maps the level's max |dL/dy| into [2^13, 2^14): every
+//     fp16 value is a multiple of 2^-24, so value * 2^24 is an exact integer < 2^39 and the sum of up to 2^21 records cannot overflow 63 bits.  Each contribution
+//     is rounded once (2^-11 relative, like the `(__half)(grad*weight)` of HashEncode.h:345).
+//   fp32 records (fp32 dL/dy - ngp_base.py - and all run records): converted to fixed point at 2^38 / max|dL/dy| (a 64-bit sum per feature): fp32-exact for every
 //     contribution within 2^-14 of the level's largest, and still 2^-10-relative 14 binades further down.
 // In both cases the accumulation itself is EXACT and order-independent => bit-reproducible gradients (the reference's atomics round after every add, in
-// random order).  A bin that overflows its record capacity (pathological clustering: all samples in a few cells) spills to one shared list that the bin's
-// owner scans before it writes - no float atomics anywhere, still deterministic, just slow in that corner.
+// random order; the run sums are fp32 sums in sample order inside one thread: deterministic too).  A bin that overflows its record capacity (pathological
+// clustering) spills to one shared list that the bin's owner scans before it writes - no float atomics anywhere, still deterministic, just slow in that corner.
 #define BIN_BITS 13u
 #define BIN_ENTRIES (1u << BIN_BITS)
 #define BINS_PER_LEVEL 64u
-struct BinPlan { uint32_t level[16]; uint32_t n_levels; uint32_t cap; uint32_t spill_cap; };   // hashed levels, records per bin, entries of the spill list
-struct SpillEntry { uint32_t key /* hashed-level ordinal << 19 | entry */; float x, y; };       // value in record units (fp16 path: scaled)
+#define BIN_LEVEL_MAX (BIN_ENTRIES * BINS_PER_LEVEL)                  // 2^19 entries: the largest level the bins cover
+#define RUN_RES_MAX 300u                                              // levels up to this resolution go through k_bin_records_runs
+struct BinPlan { uint32_t level[16]; uint32_t n_levels; uint32_t cap; uint32_t spill_cap; };   // binned levels, records per bin, entries of the spill list
+struct LevelSel { uint32_t hl[16]; };                                  // the binned-level ordinals one launch works on (blockIdx.y, or blockIdx.x / 64)
+struct SpillEntry { uint32_t key /* binned-level ordinal << 19 | entry */; float x, y; };       // value in record units (fp16 records: scaled)
+
+// entry -> (bin, slot inside the bin).  A full 2^19-entry hashed level: bin = the entry's 8192-entry slice (pseudo-random entries: balanced; contiguous write-out).
+// Any smaller level (the dense levels, small hashed tables): groups of 8 entries are dealt round-robin to the 64 bins, so the spatially coherent dense indices
+// (x + y*res + z*res^2: a batch lives in a few z-slabs) spread evenly as well.
+__device__ __forceinline__ uint32_t bin_of(uint32_t e, bool il) { return il ? (e >> 3) & 63u : e >> BIN_BITS; }
+__device__ __forceinline__ uint32_t local_of(uint32_t e, bool il) { return il ? ((e >> 9) << 3) | (e & 7u) : e & (BIN_ENTRIES - 1u); }
+__device__ __forceinline__ uint32_t entry_of(uint32_t bin, uint32_t local, bool il) { return il ? ((local >> 3) << 9) | (bin << 3) | (local & 7u) : (bin << BIN_BITS) | local; }
+// record streams of (binned level hl, bin): every level owns 64 * cap * 8 bytes of the value area whatever its record type
+template <typename RV> __device__ __forceinline__ RV *rec_val_at(void *base, uint32_t hl, uint32_t bin, uint32_t cap) {
+	return reinterpret_cast<RV *>(reinterpret_cast<char *>(base) + (size_t)hl * BINS_PER_LEVEL * cap * 8u) + (size_t)bin * cap;
+}
+__device__ __forceinline__ uint16_t *rec_idx_at(uint16_t *base, uint32_t hl, uint32_t bin, uint32_t cap) { return base + ((size_t)hl * BINS_PER_LEVEL + bin) * cap; }
 
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__restrict__ dLdy, uint32_t *__restrict__ absmax_bits, const uint32_t *__restrict__ n_valid) {
@@ -568,20 +558,38 @@ template <> struct RecVal<float> { using type = float2; };
 #define BIN_WG 512u
 template <typename T> constexpr uint32_t bin_stage_bytes() { return BIN_WG * 8u * (uint32_t)(sizeof(typename RecVal<T>::type) + 4u) + 3u * BINS_PER_LEVEL * 4u; }
 
+// the eight entries of the cell whose lowest corner is (gx, gy, gz): level-wide indices (HashEncode.h:68-94)
+__device__ __forceinline__ void cell_entries(uint32_t size, uint32_t res, bool dense, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t idx[8]) {
+	if (dense) {
+		const uint32_t y0 = gy * res, z0 = gz * res * res;
+#pragma unroll
+		for (uint32_t q = 0; q < 8; ++q) {
+			uint32_t e = (gx + (q & 1u)) + (y0 + ((q & 2u) ? res : 0u)) + (z0 + ((q & 4u) ? res * res : 0u));
+			if (e >= size) { e -= size; if (e >= size) e %= size; }              // wraps only at the +1 boundary corner
+			idx[q] = e;
+		}
+	} else {
+		const uint32_t ty0 = gy * 19349663u, tz0 = gz * 83492791u;
+#pragma unroll
+		for (uint32_t q = 0; q < 8; ++q) idx[q] = ((gx + (q & 1u)) ^ (ty0 + ((q & 2u) ? 19349663u : 0u)) ^ (tz0 + ((q & 4u) ? 83492791u : 0u))) & (size - 1u);
+	}
+}
+
 template <typename T, int LAYOUT>
-__global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp,
-                                                      const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ cursors, typename RecVal<T>::type *__restrict__ rec_val,
+__global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
+                                                      const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ cursors, void *__restrict__ rec_val,
                                                       uint16_t *__restrict__ rec_idx, uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill,
                                                       const uint32_t *__restrict__ n_valid) {
 	using P = typename Pair<T>::type;
 	using RV = typename RecVal<T>::type;
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
-	RV *stage_val = reinterpret_cast<RV *>(bin_smem);                                   // [8192] contributions, grouped by bin
-	uint32_t *stage_idx = bin_smem + BIN_WG * 8u * (sizeof(RV) / 4u);                     // [8192] level-wide entry indices
+	RV *stage_val = reinterpret_cast<RV *>(bin_smem);                                   // [4096] contributions, grouped by bin
+	uint32_t *stage_idx = bin_smem + BIN_WG * 8u * (sizeof(RV) / 4u);                     // [4096] level-wide entry indices
 	uint32_t *cnt = stage_idx + BIN_WG * 8u, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL;
-	const uint32_t hl = blockIdx.y, level = bp.level[hl];
-	const uint32_t size = lt.v[4 * level + 1];
+	const uint32_t hl = sel.hl[blockIdx.y], level = bp.level[hl];
+	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
+	const bool dense = level_is_dense(size, res), il = size < BIN_LEVEL_MAX;
 	const float vs = sizeof(T) == 2 ? bin_scale(absmax_bits[level]) : (absmax_bits[level] ? 1.0f : 0.f);       // fp32 records are stored unscaled
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
 	if (vs == 0.f || blockIdx.x * BIN_WG >= lim) return;                // uniform exit
@@ -596,15 +604,13 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float 
 		live = (g2.x != 0.f || g2.y != 0.f);
 		if (live) {
 			const Corner c = locate(pos, stride, i, scale);
-			const uint32_t ty0 = c.g[1] * 19349663u, tz0 = c.g[2] * 83492791u;
+			cell_entries(size, res, dense, c.g[0], c.g[1], c.g[2], idx);
 			const float gx = g2.x * vs, gy = g2.y * vs;
 #pragma unroll
 			for (uint32_t q = 0; q < 8; ++q) {
-				const uint32_t ex = c.g[0] + (q & 1u), ey = ty0 + ((q & 2u) ? 19349663u : 0u), ez = tz0 + ((q & 4u) ? 83492791u : 0u);
-				idx[q] = (ex ^ ey ^ ez) & (size - 1);
 				const float w = ((q & 1u) ? c.w[0] : 1 - c.w[0]) * ((q & 2u) ? c.w[1] : 1 - c.w[1]) * ((q & 4u) ? c.w[2] : 1 - c.w[2]);
 				from_f2(val[q], make_float2(gx * w, gy * w));
-				rank[q] = atomicAdd(&cnt[idx[q] >> BIN_BITS], 1u);
+				rank[q] = atomicAdd(&cnt[bin_of(idx[q], il)], 1u);
 			}
 		}
 	}
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float 
 	if (live) {
 #pragma unroll
 		for (uint32_t q = 0; q < 8; ++q) {
-			const uint32_t slot = loff[idx[q] >> BIN_BITS] + rank[q];
+			const uint32_t slot = loff[bin_of(idx[q], il)] + rank[q];
 			stage_val[slot] = val[q]; stage_idx[slot] = idx[q];
 		}
 	}
@@ -630,10 +636,9 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float 
 	for (uint32_t p = threadIdx.x; p < total; p += BIN_WG) {
 		const uint32_t e = stage_idx[p];
 		const RV v = stage_val[p];
-		const uint32_t bin = e >> BIN_BITS, slot = base[bin] + (p - loff[bin]);
+		const uint32_t bin = bin_of(e, il), slot = base[bin] + (p - loff[bin]);
 		if (slot < bp.cap) {
-			const size_t r = ((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap + slot;
-			rec_val[r] = v; rec_idx[r] = (uint16_t)(e & (BIN_ENTRIES - 1u));
+			rec_val_at<RV>(rec_val, hl, bin, bp.cap)[slot] = v; rec_idx_at(rec_idx, hl, bin, bp.cap)[slot] = (uint16_t)local_of(e, il);
 		} else {                                                        // bin full (pathological clustering): the shared spill list, scanned by the bin's owner
 			const uint32_t k = atomicAdd(spill_count, 1u);
 			if (k < bp.spill_cap) { const float2 f = to_f2(v); spill[k] = SpillEntry{(hl << 19) | e, f.x, f.y}; }
@@ -641,7 +646,124 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float 
 	}
 }
 
-// value of one record in the accumulator's integer unit.  fp16 records: multiples of 2^-24 (exact).  fp32 records: fixed point at `s32` (see acc_add<2>).
+// Coarse levels: one thread per RUN_K consecutive samples, runs of samples in one cell summed in registers, one set of eight fp32 records per run.  The number
+// of records a workgroup produces is data dependent (2048 samples: 2048 on the coarsest levels, 16384 for scattered positions), so the pass runs twice over
+// the registers: COUNT (LDS histogram of the bins) - reservation - PLACE.  Up to RUN_STAGE records are staged in LDS and leave as full lines; whatever exceeds
+// that (scattered positions only) is stored to its reserved slot directly.
+#define RUN_K 8u
+#define RUN_WG 256u
+#define RUN_STAGE 3072u
+static uint32_t run_stage_bytes(uint32_t stage) { return stage * 12u + 4u * BINS_PER_LEVEL * 4u; }
+
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(RUN_WG) void k_bin_records_runs(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
+                                                           const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ cursors, void *__restrict__ rec_val,
+                                                           uint16_t *__restrict__ rec_idx, uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill,
+                                                           const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */) {
+	using P = typename Pair<T>::type;
+	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
+	float2 *stage_val = reinterpret_cast<float2 *>(bin_smem);                             // [stage]
+	uint32_t *stage_idx = bin_smem + stage * 2u;                                          // [stage] level-wide entry indices
+	uint32_t *cnt = stage_idx + stage, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL, *cnt2 = loff + BINS_PER_LEVEL;
+	const uint32_t hl = sel.hl[blockIdx.y], level = bp.level[hl];
+	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
+	const float scale = __uint_as_float(lt.v[4 * level + 3]);
+	const bool dense = level_is_dense(size, res), il = size < BIN_LEVEL_MAX;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	if (absmax_bits[level] == 0u || blockIdx.x * RUN_WG * RUN_K >= lim) return;          // uniform exit
+	if (threadIdx.x < BINS_PER_LEVEL) { cnt[threadIdx.x] = 0; cnt2[threadIdx.x] = 0; }
+	__syncthreads();
+	const uint32_t first = (blockIdx.x * RUN_WG + threadIdx.x) * RUN_K;
+	const P *dy = reinterpret_cast<const P *>(dLdy);
+	uint32_t cell[RUN_K][3]; float frac[RUN_K][3]; float2 gk[RUN_K];
+	{
+		float px[RUN_K][3];
+		if (first + RUN_K <= lim && stride == 3) {
+			const float4 *p4 = reinterpret_cast<const float4 *>(pos + (size_t)first * 3);   // 24 floats, 16-byte aligned (first % 8 == 0)
+			float4 v[6];
+#pragma unroll
+			for (int r = 0; r < 6; ++r) v[r] = p4[r];
+			const float *f = reinterpret_cast<const float *>(v);
+#pragma unroll
+			for (uint32_t k = 0; k < RUN_K; ++k) { px[k][0] = f[3 * k]; px[k][1] = f[3 * k + 1]; px[k][2] = f[3 * k + 2]; }
+#pragma unroll
+			for (uint32_t k = 0; k < RUN_K; ++k) gk[k] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + first + k] : dy[(size_t)(first + k) * 16 + level]);
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < RUN_K; ++k) {
+				const uint32_t i = first + k;
+				if (i < lim) {
+					px[k][0] = pos[(size_t)i * stride]; px[k][1] = pos[(size_t)i * stride + 1]; px[k][2] = pos[(size_t)i * stride + 2];
+					gk[k] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level]);
+				} else { px[k][0] = px[k][1] = px[k][2] = 0.f; gk[k] = make_float2(0.f, 0.f); }
+			}
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < RUN_K; ++k)
+#pragma unroll
+			for (int d = 0; d < 3; ++d) { const float p = px[k][d] * scale + 0.5f; const float fl = floorf(p); cell[k][d] = (uint32_t)(int)fl; frac[k][d] = p - fl; }   // pos_fract, HashEncode.h:106-115
+	}
+	// one sweep over the thread's samples; emit(q, entry, x, y) is called for the eight corners of every finished run
+	auto sweep = [&](auto emit) {
+		bool open = false;
+		uint32_t key[3] = {0u, 0u, 0u};
+		float ax[8], ay[8];
+		auto flush = [&]() {
+			uint32_t idx[8];
+			cell_entries(size, res, dense, key[0], key[1], key[2], idx);
+#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q) emit(idx[q], ax[q], ay[q]);
+		};
+#pragma unroll
+		for (uint32_t k = 0; k < RUN_K; ++k) {
+			if (gk[k].x == 0.f && gk[k].y == 0.f) continue;        // zero rows (padding) add exact zeros in the reference: skipped, they do not end a run either
+			if (open && !(cell[k][0] == key[0] && cell[k][1] == key[1] && cell[k][2] == key[2])) { flush(); open = false; }
+			if (!open) {
+				open = true; key[0] = cell[k][0]; key[1] = cell[k][1]; key[2] = cell[k][2];
+#pragma unroll
+				for (uint32_t q = 0; q < 8; ++q) { ax[q] = 0.f; ay[q] = 0.f; }
+			}
+			const float x1 = frac[k][0], x0 = 1 - x1, y1 = frac[k][1], y0 = 1 - y1, z1 = frac[k][2], z0 = 1 - z1;
+#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q) {
+				const float w = ((q & 1u) ? x1 : x0) * ((q & 2u) ? y1 : y0) * ((q & 4u) ? z1 : z0);                 // the reference's x, y, z multiplication order
+				ax[q] += gk[k].x * w; ay[q] += gk[k].y * w;
+			}
+		}
+		if (open) flush();
+	};
+	sweep([&](uint32_t e, float, float) { atomicAdd(&cnt[bin_of(e, il)], 1u); });
+	__syncthreads();
+	if (threadIdx.x < BINS_PER_LEVEL) {                                    // wave 0: global reservation + exclusive prefix of the counts
+		const uint32_t c = cnt[threadIdx.x];
+		base[threadIdx.x] = c ? atomicAdd(&cursors[hl * BINS_PER_LEVEL + threadIdx.x], c) : 0u;
+		uint32_t x = c;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)threadIdx.x >= o) x += y; }
+		loff[threadIdx.x] = x - c;
+	}
+	__syncthreads();
+	const uint32_t cap = bp.cap;
+	auto store = [&](uint32_t e, uint32_t bin, uint32_t slot, float2 v) {
+		if (slot < cap) { rec_val_at<float2>(rec_val, hl, bin, cap)[slot] = v; rec_idx_at(rec_idx, hl, bin, cap)[slot] = (uint16_t)local_of(e, il); }
+		else { const uint32_t k = atomicAdd(spill_count, 1u); if (k < bp.spill_cap) spill[k] = SpillEntry{(hl << 19) | e, v.x, v.y}; }
+	};
+	sweep([&](uint32_t e, float x, float y) {
+		const uint32_t bin = bin_of(e, il), rank = atomicAdd(&cnt2[bin], 1u), p = loff[bin] + rank;
+		if (p < stage) { stage_val[p] = make_float2(x, y); stage_idx[p] = e; }
+		else store(e, bin, base[bin] + rank, make_float2(x, y));
+	});
+	__syncthreads();
+	const uint32_t total = min(loff[BINS_PER_LEVEL - 1] + cnt[BINS_PER_LEVEL - 1], stage);
+	for (uint32_t p = threadIdx.x; p < total; p += RUN_WG) {
+		const uint32_t e = stage_idx[p];
+		const uint32_t bin = bin_of(e, il);
+		store(e, bin, base[bin] + (p - loff[bin]), stage_val[p]);
+	}
+}
+
+// value of one record in the accumulator's integer unit.  fp16 records: multiples of 2^-24 (exact).  fp32 records: fixed point at `s32` = 2^38 / (binade of the level's largest |dL/dy|): a contribution of that size keeps all 24 bits of its
+// fp32 significand, one 2^-16 of it still keeps 8, and a 64-bit sum of 2^21 run records of <= 8 samples cannot overflow.
 __device__ __forceinline__ void rec_to_fixed(__half2 v, float, long long &ix, long long &iy) {
 	const float2 f = __half22float2(v);
 	ix = (long long)(f.x * 16777216.0f); iy = (long long)(f.y * 16777216.0f);
@@ -649,13 +771,18 @@ __device__ __forceinline__ void rec_to_fixed(__half2 v, float, long long &ix, lo
 __device__ __forceinline__ void rec_to_fixed(float2 v, float s32, long long &ix, long long &iy) { ix = __float2ll_rn(v.x * s32); iy = __float2ll_rn(v.y * s32); }
 
 template <typename G, typename RV>
-__global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan bp, const uint32_t *__restrict__ absmax_bits, const uint32_t *__restrict__ cursors,
-                                                         const RV *__restrict__ rec_val, const uint16_t *__restrict__ rec_idx, const uint32_t *__restrict__ spill_count,
+__global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan bp, LevelSel sel, const uint32_t *__restrict__ absmax_bits, const uint32_t *__restrict__ cursors,
+                                                         void *__restrict__ rec_val_base, uint16_t *__restrict__ rec_idx_base, const uint32_t *__restrict__ spill_count,
                                                          const SpillEntry *__restrict__ spill, G *__restrict__ grad, int overwrite) {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long iacc[];   // [BIN_ENTRIES][2] 64-bit fixed point
 	using GP = typename Pair<G>::type;
 	constexpr bool F32 = sizeof(RV) == 8;
-	const uint32_t hl = blockIdx.x / BINS_PER_LEVEL, bin = blockIdx.x % BINS_PER_LEVEL, level = bp.level[hl];
+	const uint32_t hl = sel.hl[blockIdx.x / BINS_PER_LEVEL], bin = blockIdx.x % BINS_PER_LEVEL, level = bp.level[hl];
+	const uint32_t size = lt.v[4 * level + 1];
+	const bool il = size < BIN_LEVEL_MAX;
+	// slots of this bin that are entries of the level (interleaved: groups bin, bin + 64, ... of the level's ceil(size / 8) groups)
+	const uint32_t groups_all = (size + 7u) >> 3;
+	const uint32_t n_local = il ? (groups_all > bin ? ((groups_all - bin + 63u) >> 6) << 3 : 0u) : BIN_ENTRIES;
 	const uint32_t amax = absmax_bits[level];
 	float s32 = 0.f, inv;
 	if (F32) {
@@ -669,28 +796,32 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	}
 	const uint32_t raw = cursors[hl * BINS_PER_LEVEL + bin];
 	const uint32_t count = min(raw, bp.cap);
-	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level] + (size_t)bin * BIN_ENTRIES;
+	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level];
 	if (s32 == 0.f || count == 0) {                                      // nothing to add: an accumulating destination is left alone, an overwritten one gets its zeros
-		if (overwrite) { GP zv; from_f2(zv, make_float2(0.f, 0.f)); for (uint32_t e = threadIdx.x; e < BIN_ENTRIES; e += 1024) dst[e] = zv; }
+		if (overwrite) {
+			GP zv; from_f2(zv, make_float2(0.f, 0.f));
+			for (uint32_t e = threadIdx.x; e < n_local; e += 1024) { const uint32_t t = entry_of(bin, e, il); if (t < size) dst[t] = zv; }
+		}
 		return;
 	}
-	for (uint32_t e = threadIdx.x; e < BIN_ENTRIES * 2; e += 1024) iacc[e] = 0ull;
+	for (uint32_t e = threadIdx.x; e < n_local * 2; e += 1024) iacc[e] = 0ull;
 	__syncthreads();
-	const size_t r0 = ((size_t)hl * BINS_PER_LEVEL + bin) * bp.cap;             // cap % 8 == 0: both streams of a bin start 16-byte aligned
+	const RV *rec_val = rec_val_at<RV>(rec_val_base, hl, bin, bp.cap);             // cap % 8 == 0: both streams of a bin start 16-byte aligned
+	const uint16_t *rec_idx = rec_idx_at(rec_idx_base, hl, bin, bp.cap);
 	auto add = [&](uint32_t local, RV v) {
 		long long ix, iy; rec_to_fixed(v, s32, ix, iy);
 		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		__hip_atomic_fetch_add(&iacc[2 * local + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	};
-	// Consecutive records of a bin come from consecutive samples of a ray, and on the coarser hashed levels those sit in the SAME cell (a cell of level 5-8 is
-	// 8-14 constant-size steps long): a wavefront's 64 lanes would hit a handful of entries, and same-address ds_add_u64 serialise.  So every thread takes K = 8
-	// CONSECUTIVE records, sums runs of equal entries in registers (exact: the sums are integers) and issues one pair of LDS atomics per run; neighbouring lanes
-	// are then 8 records apart.  Two trips (64 / 32 + 16 bytes per thread each) are in flight.
+	// Consecutive records of a bin come from neighbouring samples of a ray, which often still share a cell (a run that was split between two threads of the
+	// record pass; a fine level's cell that is two steps long): a wavefront's 64 lanes would hit a handful of entries, and same-address ds_add_u64 serialise.  So
+	// every thread takes K = 8 CONSECUTIVE records, sums runs of equal entries in registers (exact: the sums are integers) and issues one pair of LDS atomics per
+	// run; neighbouring lanes are then 8 records apart.  Two trips (64 / 32 + 16 bytes per thread each) are in flight.
 	constexpr uint32_t K = 8;
 	struct alignas(16) VK { RV v[K]; };
 	struct alignas(16) IK { uint16_t i[K]; };
-	const VK *pv = reinterpret_cast<const VK *>(rec_val + r0);
-	const IK *pi = reinterpret_cast<const IK *>(rec_idx + r0);
+	const VK *pv = reinterpret_cast<const VK *>(rec_val);
+	const IK *pi = reinterpret_cast<const IK *>(rec_idx);
 	const uint32_t groups = count / K;
 	auto add_fixed = [&](uint32_t local, long long ix, long long iy) {
 		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -712,64 +843,76 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 		run_add(x0, k0); run_add(x1, k1);
 	}
 	for (; r < groups; r += 1024) { const VK x = pv[r]; const IK k = pi[r]; run_add(x, k); }
-	if (threadIdx.x < count - groups * K) { const uint32_t t = groups * K + threadIdx.x; add(rec_idx[r0 + t], rec_val[r0 + t]); }
+	if (threadIdx.x < count - groups * K) { const uint32_t t = groups * K + threadIdx.x; add(rec_idx[t], rec_val[t]); }
 	if (raw > bp.cap) {                                                   // this bin overflowed: its surplus records are somewhere in the shared spill list
-		const uint32_t ns = min(*spill_count, bp.spill_cap), key_lo = (hl << 19) | (bin << BIN_BITS);
+		const uint32_t ns = min(*spill_count, bp.spill_cap);
 		for (uint32_t t = threadIdx.x; t < ns; t += 1024) {
 			const SpillEntry se = spill[t];
-			if ((se.key & ~(BIN_ENTRIES - 1u)) == key_lo) { RV v; from_f2(v, make_float2(se.x, se.y)); add(se.key & (BIN_ENTRIES - 1u), v); }
+			const uint32_t e = se.key & (BIN_LEVEL_MAX - 1u);
+			if ((se.key >> 19) == hl && bin_of(e, il) == bin) { RV v; from_f2(v, make_float2(se.x, se.y)); add(local_of(e, il), v); }
 		}
 	}
 	__syncthreads();
-	GP oldv[BIN_ENTRIES / 1024];
-	if (!overwrite) {
+	for (uint32_t e0 = 0; e0 < n_local; e0 += 8u * 1024u) {                // (a full bin: one trip, all eight read-modify-write loads in flight)
+		GP oldv[8]; uint32_t tgt[8];
 #pragma unroll
-		for (uint32_t k = 0; k < BIN_ENTRIES / 1024; ++k) oldv[k] = dst[threadIdx.x + k * 1024];      // all eight read-modify-write loads in flight
-	}
+		for (uint32_t k = 0; k < 8; ++k) {
+			const uint32_t e = e0 + threadIdx.x + k * 1024;
+			tgt[k] = e < n_local ? entry_of(bin, e, il) : ~0u;
+			if (tgt[k] >= size) tgt[k] = ~0u;
+			if (!overwrite && tgt[k] != ~0u) oldv[k] = dst[tgt[k]];
+		}
 #pragma unroll
-	for (uint32_t k = 0; k < BIN_ENTRIES / 1024; ++k) {
-		const uint32_t e = threadIdx.x + k * 1024;
-		const long long sx = (long long)iacc[2 * e], sy = (long long)iacc[2 * e + 1];
-		float2 v = make_float2((float)sx * inv, (float)sy * inv);
-		if (!overwrite) { if (sx == 0 && sy == 0) continue; const float2 old = to_f2(oldv[k]); v.x += old.x; v.y += old.y; }
-		GP o; from_f2(o, v);
-		dst[e] = o;
+		for (uint32_t k = 0; k < 8; ++k) {
+			if (tgt[k] == ~0u) continue;
+			const uint32_t e = e0 + threadIdx.x + k * 1024;
+			const long long sx = (long long)iacc[2 * e], sy = (long long)iacc[2 * e + 1];
+			float2 v = make_float2((float)sx * inv, (float)sy * inv);
+			if (!overwrite) { if (sx == 0 && sy == 0) continue; const float2 old = to_f2(oldv[k]); v.x += old.x; v.y += old.y; }
+			GP o; from_f2(o, v);
+			dst[tgt[k]] = o;
+		}
 	}
 }
 
-// A level takes the binned path only if it is REALLY hashed: k_bin_records indexes with (x ^ y*p1 ^ z*p2) & (size - 1).  A dense level whose table is large
-// enough for 32 slices (res 80: 512000 entries, reachable with non-power-of-two aabb scales) must stay on the owner-computes scan (chunked, with slabs).
+// Which levels can take the binned path: up to 2^19 entries, and indexed the way the record kernels index (dense, or the XOR hash masked by a power of two).
+// (aabb_scale 23.4 has a DENSE level with res 80 = 512000 entries - round 1 binned it with the XOR hash by looking at the size alone.)
 static bool level_dense_host(uint32_t size, uint32_t res) { uint32_t stride = 1; for (int d = 0; d < 3; ++d) if (stride <= size) stride *= res; return !(size < stride); }
 static bool level_binned(const LevelTable &lt, int l) {
 	const uint32_t size = lt.v[4 * l + 1], res = lt.v[4 * l + 2];
+	return size <= BIN_LEVEL_MAX && (level_dense_host(size, res) || (size & (size - 1)) == 0);
+}
+// the hashed 2^19-entry levels: the only ones that do not need partial slabs when the owner-computes scan runs (no bins: fixed-point request, small workspace)
+static bool level_exclusive(const LevelTable &lt, int l) {
+	const uint32_t size = lt.v[4 * l + 1], res = lt.v[4 * l + 2];
 	return div_up(size, OWN_SLICE) >= 32 && (size & (size - 1)) == 0 && !level_dense_host(size, res);
 }
-static uint64_t hash_bwd_workspace_bytes(const LevelTable &lt) {           // dense-level slabs only
+static uint64_t hash_bwd_workspace_bytes(const LevelTable &lt) {           // partial slabs of the owner-computes scan
 	uint64_t entries = 0;
-	for (int l = 0; l < 16; ++l) if (!level_binned(lt, l)) entries += (uint64_t)32u * lt.v[4 * l + 1];
+	for (int l = 0; l < 16; ++l) if (!level_exclusive(lt, l)) entries += (uint64_t)32u * lt.v[4 * l + 1];
 	return (entries * sizeof(float2) + 255) & ~(uint64_t)255;
 }
 static uint32_t bin_capacity(uint32_t n) { uint32_t c = (n / 2 + 7u) & ~7u; return c < 4096u ? 4096u : c; }   // 4x the expected n*8/64 records per bin; % 8: 16-byte aligned streams
-// workspace = dense-level slabs | cursors u32[16*64] | absmax u32[16], spill count u32 | record values | record indices | spill list
-struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, total; uint32_t cap, spill_cap, n_hashed; };
+// workspace = slabs | cursors u32[16*64] | absmax u32[16], spill count u32 | record values | record indices | spill list
+struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, total; uint32_t cap, spill_cap, n_binned; };
 static WsLayout ws_layout(const LevelTable &lt, uint32_t n) {
 	WsLayout w;
-	w.n_hashed = 0;
-	for (int l = 0; l < 16; ++l) if (level_binned(lt, l)) ++w.n_hashed;
+	w.n_binned = 0;
+	for (int l = 0; l < 16; ++l) if (level_binned(lt, l)) ++w.n_binned;
 	w.cap = bin_capacity(n);
-	w.spill_cap = w.n_hashed * 8u * (n < (1u << 25) / (w.n_hashed ? w.n_hashed : 1u) ? n : (1u << 25) / (w.n_hashed ? w.n_hashed : 1u));   // worst case: every record of every hashed level overflows (12 B each)
+	w.spill_cap = w.n_binned * 8u * (n < (1u << 25) / (w.n_binned ? w.n_binned : 1u) ? n : (1u << 25) / (w.n_binned ? w.n_binned : 1u));   // worst case: every record of every binned level overflows (12 B each)
 	w.cursors = hash_bwd_workspace_bytes(lt);
 	w.absmax = w.cursors + 4096;
 	w.rec_val = w.absmax + 256;
-	w.rec_idx = w.rec_val + (uint64_t)w.n_hashed * BINS_PER_LEVEL * w.cap * sizeof(float2);       // sized for fp32 contributions
-	w.spill = (w.rec_idx + (uint64_t)w.n_hashed * BINS_PER_LEVEL * w.cap * sizeof(uint16_t) + 255) & ~(uint64_t)255;
+	w.rec_idx = w.rec_val + (uint64_t)w.n_binned * BINS_PER_LEVEL * w.cap * sizeof(float2);       // every level owns 64 * cap * 8 bytes (rec_val_at)
+	w.spill = (w.rec_idx + (uint64_t)w.n_binned * BINS_PER_LEVEL * w.cap * sizeof(uint16_t) + 255) & ~(uint64_t)255;
 	w.total = w.spill + (uint64_t)w.spill_cap * sizeof(SpillEntry);
 	return w;
 }
 static uint64_t hash_bwd_workspace_bytes_binned(const LevelTable &lt, uint32_t n) { return ws_layout(lt, n).total; }
 NGP_API uint64_t ngp_hash_bwd_workspace_bytes(const uint32_t *level_table_host, uint32_t n) { return hash_bwd_workspace_bytes_binned(load_table(level_table_host), n); }
 
-// helper stream for the dense-level kernels of the binned path (created once per process; the hash table gradient regions of the two paths are disjoint)
+// helper stream for the owner-computes kernels when some levels are binned and others are not (tables beyond 2^19 entries per level); created once per process
 struct SideStream {
 	hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false;
 	SideStream() {
@@ -810,53 +953,50 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		NGP_LAUNCH_CHECK("ngp_hash_encode_bwd");
 		return 0;
 	}
-	// ---- owner-computes plan: slices of OWN_SLICE entries; levels with < 32 slices split the samples into chunks instead
+	// ---- which levels go where.  With the full workspace and no fixed-point request: every level of up to 2^19 entries through the bins (coarse ones with run
+	// combining).  Whatever is left - everything, without a workspace - takes the owner-computes scan: slices of OWN_SLICE entries, the 2^19-entry hashed levels
+	// with one exclusive owner per slice, the others split into sample chunks (partial slabs if the workspace holds them, an atomic flush otherwise).
 	OwnerPlan plan;
 	uint32_t slices[16], units = 0, k = 0;
 	const bool use_slabs = workspace && workspace_bytes >= hash_bwd_workspace_bytes(lt);
-	// binned path for the hashed levels: needs the full workspace and no fixed-point request; fp32 dL/dy keeps fp32 contributions and an fp32 gradient
 	const WsLayout wl = ws_layout(lt, n);
 	const bool use_bins = use_slabs && !level_scratch && (dtype == NGP_F16 || grad_dtype == NGP_F32) && workspace_bytes >= wl.total && getenv("NGP_HASH_BWD_NO_BINS") == nullptr;
+	bool in_bins[16];
+	BinPlan bp; bp.n_levels = 0; bp.cap = wl.cap; bp.spill_cap = wl.spill_cap;
+	LevelSel sel_fine, sel_runs, sel_all;
+	uint32_t n_fine = 0, n_runs = 0;
+	const uint32_t run_res_max = [] { const char *e = getenv("NGP_HASH_BWD_RUN_RES"); return e ? (uint32_t)strtoul(e, nullptr, 0) : RUN_RES_MAX; }();   // probe hook
+	const uint32_t run_stage = [] { const char *e = getenv("NGP_HASH_BWD_RUN_STAGE"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : RUN_STAGE; return v > 8192u ? 8192u : v; }();   // probe hook
+	for (int l = 0; l < 16; ++l) {                                       // (coarsest level first measured 1 % faster than finest first on both samplings)
+		in_bins[l] = use_bins && level_binned(lt, l);
+		if (!in_bins[l]) continue;
+		const uint32_t hl = bp.n_levels++;
+		bp.level[hl] = (uint32_t)l; sel_all.hl[hl] = hl;
+		if (lt.v[4 * l + 2] <= run_res_max) sel_runs.hl[n_runs++] = hl; else sel_fine.hl[n_fine++] = hl;
+	}
 	uint64_t slab_cursor = 0;
-	bool any_binned = false;
-	for (int l = 0; l < 16; ++l) any_binned |= level_binned(lt, l);
-	static const bool dense_float = getenv("NGP_HASH_BWD_DENSE_FLOAT") != nullptr;     // experiment hook: fp32 dense levels on LDS float atomics instead of 64-bit integer sums
-	const bool fx64 = use_bins && any_binned && !(dense_float && dtype == NGP_F32);                             // the abs-max pass runs -> dense levels can use the integer sums
-	plan.half_slices = 0;
 	for (int l = 0; l < 16; ++l) {
-		const bool wide = fx64 && dtype == NGP_F32 && !level_binned(lt, l);          // fp32 dense level with slabs: 64-bit sum per feature, 8192-entry slices
-		if (wide) plan.half_slices |= 1u << l;
-		slices[l] = div_up(lt.v[4 * l + 1], wide ? OWN_SLICE / 2 : OWN_SLICE);
+		slices[l] = div_up(lt.v[4 * l + 1], OWN_SLICE);
 		plan.slab_off[l] = ~0u;
-		if (level_binned(lt, l)) { plan.chunks[l] = 1u; continue; }
-		if (use_slabs) plan.chunks[l] = 32u;                                 // (re-balanced below)
-		else plan.chunks[l] = 32u / slices[l] ? 32u / slices[l] : 1u;
+		plan.chunks[l] = 1u;
+		if (in_bins[l] || level_exclusive(lt, l)) continue;
+		// Sample chunks per slice of a level without an exclusive owner.  A unit (slice, chunk) pays a fixed price - clear and flush 128 KiB of LDS, one partial
+		// slab to write and later re-read - and holds a whole CU while it runs.  Small, heavily contended coarse levels want many short units, large levels few
+		// long ones: with slabs 144 / slices clamped to [8, 32] (swept on fox- and lego-like batches, tools/probe_owner_levels.py).
+		uint32_t c = use_slabs ? 144u / slices[l] : (32u / slices[l] ? 32u / slices[l] : 1u);
+		if (use_slabs && c < 8u) c = 8u;
+		{ const char *e = getenv("NGP_PROBE_DENSE_CHUNKS"); if (e && use_slabs) { int v[16]; int kk = sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7); if (l < kk) c = (uint32_t)v[l]; } }   // tools/probe_owner_levels.py
+		plan.chunks[l] = c > 32u ? 32u : (use_slabs && c < 2u ? 2u : c);          // with slabs >= 2: the exclusive-owner (chunks == 1) branch does not write slabs
+		if (use_slabs) { plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)plan.chunks[l] * lt.v[4 * l + 1]; }
 	}
-	if (use_slabs) {
-		// Sample chunks per slice of the dense levels.  A unit (slice, chunk) pays a fixed price - clear and flush 128 KiB of LDS, one partial slab to write and
-		// later re-read - and holds a whole CU while it runs; a level's duration is its slowest unit.  32 chunks for every slice (round 1) meant 544 (fox, fp16) to
-		// 1376 (lego, fp32) units, several rounds of workgroups.  Swept on a lego-like batch (tools/probe_owner_levels.py, all dense levels together, incl. ~50 us of
-		// abs-max / launch / reduce): fp32 32,32,32,32,32: 170 us - 10,10,5,5,5: 168 - 32,32,16,10,8: 141; fp16 112 / 139 / 109.  Small, heavily contended coarse
-		// levels want many short units, large levels few long ones: chunks = 64 / slices (fp32: 8192-entry slices) or 144 / slices (fp16: 16384-entry slices), clamped to [8, 32].
-		for (int l = 0; l < 16; ++l) {
-			if (level_binned(lt, l)) continue;
-			uint32_t c = ((plan.half_slices >> l) & 1u ? 64u : 144u) / slices[l];      // (fp16 units are cheaper - one packed atomic per corner, half the slices - and like shorter sample ranges: fox 26,26,13,13 measured best)
-			if (c < 8u) c = 8u;
-			{ const char *e = getenv("NGP_PROBE_DENSE_CHUNKS"); if (e) { int v[16]; int k = sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7); if (l < k) c = (uint32_t)v[l]; } }   // tools/probe_owner_levels.py
-			plan.chunks[l] = c > 32u ? 32u : (c < 2u ? 2u : c);              // >= 2: the exclusive-owner (chunks == 1) branch belongs to the hashed levels
-			plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)plan.chunks[l] * lt.v[4 * l + 1];
-		}
-	}
-	for (int pass = 0; pass < 2; ++pass)                                  // chunked dense levels first (their hot slices are the long poles), largest level first
+	for (int pass = 0; pass < 2; ++pass)                                  // chunked levels first (their hot slices are the long poles), largest level first
 		for (int l = 15; l >= 0; --l)
 			if ((plan.chunks[l] > 1) == (pass == 0)) {
 				plan.order[k] = (uint32_t)l; plan.first_unit[k] = units;
-				if (!(use_bins && plan.chunks[l] == 1)) units += slices[l] * plan.chunks[l];       // binned levels get no scan units
+				if (!in_bins[l]) units += slices[l] * plan.chunks[l];              // binned levels get no scan units
 				++k;
 			}
 	plan.first_unit[16] = units;
-	BinPlan bp; bp.n_levels = 0; bp.cap = wl.cap; bp.spill_cap = wl.spill_cap;
-	for (int l = 0; l < 16; ++l) if (plan.chunks[l] == 1) bp.level[bp.n_levels++] = (uint32_t)l;
 	char *ws = (char *)workspace;
 	uint32_t *cursors = use_bins ? (uint32_t *)(ws + wl.cursors) : nullptr;
 	uint32_t *absmax = use_bins ? (uint32_t *)(ws + wl.absmax) : nullptr;
@@ -864,14 +1004,14 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	void *rec_val = use_bins ? (void *)(ws + wl.rec_val) : nullptr;
 	uint16_t *rec_idx = use_bins ? (uint16_t *)(ws + wl.rec_idx) : nullptr;
 	SpillEntry *spill = use_bins ? (SpillEntry *)(ws + wl.spill) : nullptr;
-	if (use_bins) {
-		hipError_t e = hipMemsetAsync(cursors, 0, 4096 + 256, s);       // cursors, abs-max, spill count.  (zero_first needs no memset of the hashed levels: phase B overwrites them)
+	if (use_bins && bp.n_levels) {
+		hipError_t e = hipMemsetAsync(cursors, 0, 4096 + 256, s);       // cursors, abs-max, spill count.  (zero_first needs no memset of the binned levels: phase B overwrites them)
 		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; }
 	}
 	{ const char *e = getenv("NGP_PROBE_LEVEL_MASK"); plan.level_mask = e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffu; }
 	{ const char *e = getenv("NGP_PROBE_COARSE_RES"); plan.coarse_res = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }
-	for (int l = 0; l < 16; ++l) {                                       // chunked levels are flushed with atomics -> need a zeroed destination
-		if (plan.chunks[l] > 1 && zero_first && !use_slabs) {
+	for (int l = 0; l < 16; ++l) {                                       // chunked levels without slabs are flushed with atomics -> need a zeroed destination
+		if (!in_bins[l] && plan.chunks[l] > 1 && zero_first && !use_slabs) {
 			hipError_t e = hipMemsetAsync((char *)grad + (size_t)lt.v[4 * l] * 2 * gsz, 0, (size_t)lt.v[4 * l + 1] * 2 * gsz, s);
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; }
 		}
@@ -880,34 +1020,41 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	const int accumulate = (zero_first ? 0 : 1) | ((getenv("NGP_PROBE_NO_LDS_ATOMICS") != nullptr) ? 2 : 0);
 	const size_t shmem = (size_t)OWN_SLICE * 2 * sizeof(float);
 	const dim3 grid(units), block(1024);
-	const bool probe_skip_bins = getenv("NGP_PROBE_SKIP_BINS") != nullptr;      // tools/probe_scatter.py: time the dense-level kernel alone
+	const bool probe_skip_bins = getenv("NGP_PROBE_SKIP_BINS") != nullptr;      // tools/probe_scatter.py: time the scan kernel alone
+	const int ow = zero_first ? 1 : 0;
+#define SET_LDS(K, BYTES) do { static bool done_ = false; if (!done_) { hipError_t e = hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
+	if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } done_ = true; } } while (0)
 #define GO(T, G, L) do { \
 	using RV_ = typename RecVal<T>::type; \
-	static bool attr_set = false; \
-	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_hash_bwd_owner<T, G, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
+	if (units) SET_LDS((k_hash_bwd_owner<T, G, L>), shmem); \
 	if (level_scratch) NGP_LAUNCH((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
-	if (use_bins && bp.n_levels) { \
-		static bool attr2 = false; \
-		if (!attr2) { hipError_t e = hipFuncSetAttribute((const void *)k_bin_records<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_stage_bytes<T>()); \
-			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
-			e = hipFuncSetAttribute((const void *)k_bin_accumulate<G, RV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_ENTRIES * 16)); \
-			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr2 = true; } \
-		NGP_LAUNCH((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
-		if (units && side.ok) hipEventRecord(side.fork, s);   /* fork point: the dense-level kernel needs the abs-max too */ \
-		if (!probe_skip_bins) { \
-		NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, BIN_WG), bp.n_levels), dim3(BIN_WG), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, (const uint32_t *)absmax, cursors, (RV_ *)rec_val, rec_idx, spill_count, spill, n_valid); \
-		NGP_LAUNCH((k_bin_accumulate<G, RV_>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, (const uint32_t *)absmax, (const uint32_t *)cursors, (const RV_ *)rec_val, (const uint16_t *)rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, zero_first ? 1 : 0); } \
-	} \
 	hipStream_t sd = s; \
-	if (use_bins && bp.n_levels && units && side.ok) { sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* dense levels run beside the binning kernels */ \
-	if (units) NGP_LAUNCH((k_hash_bwd_owner<T, G, L>), grid, block, shmem, sd, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr, fx64 ? (const uint32_t *)absmax : (const uint32_t *)nullptr); \
-	if (use_slabs) NGP_LAUNCH((k_reduce_dense<G>), dim3(1024, 16), dim3(256), 0, sd, lt, plan, (const float2 *)workspace, (G *)grad, accumulate & 1); \
+	if (use_bins && bp.n_levels) { \
+		NGP_LAUNCH((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
+		if (units && side.ok) { hipEventRecord(side.fork, s); sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* the scan of the remaining levels runs beside the binning kernels */ \
+		if (!probe_skip_bins) { \
+		if (n_runs) { SET_LDS((k_bin_records_runs<T, L>), run_stage_bytes(8192u)); \
+			NGP_LAUNCH((k_bin_records_runs<T, L>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(run_stage), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, run_stage); } \
+		if (n_fine) { SET_LDS((k_bin_records<T, L>), bin_stage_bytes<T>()); \
+			NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, BIN_WG), n_fine), dim3(BIN_WG), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_fine, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid); } \
+		if (sizeof(RV_) == 8) {                                  /* fp32: run records and fine records have the same type - one accumulate launch over all levels */ \
+			SET_LDS((k_bin_accumulate<G, float2>), BIN_ENTRIES * 16); \
+			NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
+		} else { \
+			if (n_runs) { SET_LDS((k_bin_accumulate<G, float2>), BIN_ENTRIES * 16); \
+				NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_runs * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_runs, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); } \
+			if (n_fine) { SET_LDS((k_bin_accumulate<G, RV_>), BIN_ENTRIES * 16); \
+				NGP_LAUNCH((k_bin_accumulate<G, RV_>), dim3(n_fine * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_fine, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); } \
+		} } \
+	} \
+	if (units) NGP_LAUNCH((k_hash_bwd_owner<T, G, L>), grid, block, shmem, sd, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr); \
+	if (units && use_slabs && slab_cursor) NGP_LAUNCH((k_reduce_dense<G>), dim3(1024, 16), dim3(256), 0, sd, lt, plan, (const float2 *)workspace, (G *)grad, accumulate & 1); \
 	if (sd != s) { hipEventRecord(side.join, sd); hipStreamWaitEvent(s, side.join, 0); } } while (0)
 	if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, float, NGP_LAYOUT_SOA); else GO(float, float, NGP_LAYOUT_AOS); }
 	else if (grad_dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(__half, float, NGP_LAYOUT_SOA); else GO(__half, float, NGP_LAYOUT_AOS); }
 	else { if (in_layout == NGP_LAYOUT_SOA) GO(__half, __half, NGP_LAYOUT_SOA); else GO(__half, __half, NGP_LAYOUT_AOS); }
 #undef GO
+#undef SET_LDS
 	NGP_LAUNCH_CHECK("ngp_hash_encode_bwd");
 	return 0;
 }

@@ -68,20 +68,18 @@ def test_hash_bwd_vs_oracle(H, dtype, grad_dtype):
     dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
     out2 = H.hash_encode_bwd(x, dys, table, n_params, grad_dtype=grad_dtype, layout=ops.LAYOUT_SOA)
     GC.close(out2, ref, what="hash bwd soa", **tol)
-    # workspace variant (atomic-free dense levels), overwrite and accumulate semantics
+    # workspace variant (every level through the binned scatter), overwrite and accumulate semantics
     ws = torch.empty(ops.hash_bwd_workspace_bytes(table, x.shape[0]), dtype=torch.uint8, device="cuda")
     gdt = grad_dtype or (torch.float16 if dtype == np.float16 else torch.float32)
     g = torch.full((n_params,), 7.0, dtype=gdt, device="cuda")
     ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
-    # binned hashed levels, fp16 dL/dy: every contribution (|v| up to ~4e-2 here) is rounded to scaled fp16 once => 2^-11 of the contribution, not of the (cancelling) sum;
+    # binned fine levels, fp16 dL/dy: every contribution (|v| up to ~4e-2 here) is rounded to scaled fp16 once => 2^-11 of the contribution, not of the (cancelling) sum;
     # fp32 dL/dy: fixed point at 2^-38 of the level's largest |dL/dy| => the fp32 tolerance holds
     wtol = dict(atol=2e-5, rtol=1.5e-3) if (dtype == np.float16 and gdt == torch.float32) else tol
     GC.close(H.N(g), ref, what="hash bwd workspace", **wtol)
-    if True:                                                   # exact integer accumulation (all three dtype combinations) => bit-reproducible on the hashed levels
-        g2 = torch.zeros_like(g)
-        ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g2, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
-        lo = int(offsets[4]) * 2
-        assert torch.equal(g[lo:], g2[lo:])
+    g2 = torch.zeros_like(g)                                   # exact integer accumulation (all three dtype combinations, every level) => bit-reproducible
+    ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g2, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
+    assert torch.equal(g, g2)
     tol = wtol
     ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=False, workspace=ws)
     GC.close(H.N(g).astype(np.float64) / 2, ref, what="hash bwd workspace accumulate", atol=tol["atol"] * 2, rtol=tol["rtol"] * 2)
@@ -89,8 +87,9 @@ def test_hash_bwd_vs_oracle(H, dtype, grad_dtype):
 
 @pytest.mark.parametrize("aabb_scale", [1, 2, 16, 23.4])
 def test_hash_bwd_workspace_other_level_tables(H, aabb_scale):
-    """levels are routed to the binned path only if they are really hashed.  aabb_scale 23.4 has a DENSE level with res 80 = 512000
-    entries (32 slices of 16384) that the size-only predicate used to bin with the XOR hash; 2 and 16 (colmap2nerf's usual value) have large dense levels."""
+    """the record kernels must index a level the way the level is laid out.  aabb_scale 23.4 has a DENSE level with res 80 = 512000 entries
+    that round 1's size-only predicate binned with the XOR hash; 2 and 16 (colmap2nerf's usual value) have large dense levels (dense levels are dealt to the
+    64 bins in interleaved groups of eight entries, hashed 2^19-entry levels in 8192-entry slices)."""
     from jnerf_amd import ops
     table, offsets, n_params = O.level_table(aabb_scale)
     rng = np.random.default_rng(11)
@@ -458,7 +457,7 @@ def _ray_coherent_batch(H, n_target=1 << 18, aabb=(0.0, 1.0), const_dt=True, n_r
 @pytest.mark.parametrize("dtype", [np.float16, np.float32])
 def test_full_size_hash_fwd_bwd_vs_oracle_on_ray_coherent_samples(H, dtype):
     """HIP vs oracle at BASELINE's full batch size on training-distribution inputs (the single-core oracle needs ~3 s per pass),
-    through the workspace path the training step uses (binned hashed levels + chunked dense levels), both table precisions"""
+    through the workspace path the training step uses (binned scatter; the levels up to res 300 with run combining - these samples ARE runs), both table precisions"""
     from jnerf_amd import ops
     coords, _, _, k = _ray_coherent_batch(H)
     x = np.ascontiguousarray(coords[:, :3])

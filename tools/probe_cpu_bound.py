@@ -1,5 +1,5 @@
-"""How fast can the host issue training steps?  Runs the bench configuration with a tiny sample budget (2^12 samples per step: the GPU work becomes
-negligible, the launch sequence stays the same) and prints steps/s = the CPU-side ceiling of the training loop."""
+"""How fast can the host issue training steps?  Runs the bench configuration (lego | fox) with a tiny sample budget (the GPU work becomes negligible, the launch
+sequence stays the same) and with the real one, and prints steps/s: the first is the CPU-side ceiling of the training loop.   python tools/probe_cpu_bound.py [lego|fox]"""
 import os
 import sys
 import time
@@ -8,11 +8,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jnerf_amd.presets import ngp_cfg
 from jnerf_amd.runner import Runner
 
-for tb in (1 << 16, 1 << 17, 1 << 18):
-    ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0", target_batch_size=tb, n_rays_per_batch=4096 * tb >> 18)
+lego = (sys.argv[1] if len(sys.argv) > 1 else "lego") == "lego"
+for tb in (1 << 13, 1 << 16, 1 << 18):
+    ngp_cfg(fp16=not lego, aabb_scale=1 if lego else 4, const_dt=lego, n_images=100 if lego else 50, W=800 if lego else 400, H=800 if lego else 400, device="cuda:0",
+            target_batch_size=tb, n_rays_per_batch=max(64, 4096 * tb >> 18))
     r = Runner()
     step = 0
-    for _ in range(200):
+    for _ in range(400):
         r.train_step(step); step += 1
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -41,14 +41,13 @@ def main():
         for k in env:
             os.environ.pop(k, None)
         print(f"{rows[-1][0]:60s} {rows[-1][1]:8.1f} us", flush=True)
-    run("full backward (production)")
-    run("no side stream", NGP_HASH_BWD_NO_SIDE_STREAM="1")
-    run("binning kernels only (dense levels masked off)", NGP_PROBE_LEVEL_MASK="0x0")
-    run("dense-level kernel + abs-max + reduce only", NGP_PROBE_SKIP_BINS="1")
-    for l in range(4):
-        run(f"  dense level {l} alone", NGP_PROBE_SKIP_BINS="1", NGP_PROBE_LEVEL_MASK=hex(1 << l))
-    run("dense kernel without the LDS atomics", NGP_PROBE_SKIP_BINS="1", NGP_PROBE_NO_LDS_ATOMICS="1")
-    run("float owner path for everything (no bins)", NGP_HASH_BWD_NO_BINS="1")
+    run("full backward (production: every level through the bins, res <= 300 with run combining)")
+    run("abs-max pass only", NGP_PROBE_SKIP_BINS="1")
+    for res in (0, 64, 128, 200, 450, 4096):
+        run(f"run combining for levels with res <= {res}", NGP_HASH_BWD_RUN_RES=str(res))
+    for st in (1024, 2048, 4096, 6144, 8192):
+        run(f"LDS staging of {st} run records per workgroup", NGP_HASH_BWD_RUN_STAGE=str(st))
+    run("owner-computes scan for everything (no bins)", NGP_HASH_BWD_NO_BINS="1")
 
 
 if __name__ == "__main__":
