@@ -52,6 +52,11 @@ class Runner:
         self.pipeline = cfg.pipeline_sampling is not False      # `pipeline_sampling = False` in the config restores the strictly sequential loop
         self._queue, self._sides, self._done_steps, self._fast, self._rays_event = {}, [], set(), None, None
         self.pipeline_depth = int(cfg.pipeline_depth or 2)          # batches marched ahead of the one being trained on
+        self.done_period = int(cfg.pipeline_done_period or 4)       # the training stream records a `done` checkpoint every this many steps (train_step)
+        n_sets = len(getattr(self.sampler, "_sets", ())) or 3
+        assert n_sets >= self.pipeline_depth + self.done_period - 1, (
+            f"pipeline_buffer_sets = {n_sets} is too small for pipeline_depth = {self.pipeline_depth} and pipeline_done_period = {self.done_period}")
+        self._train_stream = None
         self.render_chunk = int(cfg.render_chunk or 32768)       # rays per inference pass (the reference: n_rays_per_batch = 4096)
         self.W, self.H = self.dataset["train"].resolution
 
@@ -67,6 +72,26 @@ class Runner:
         for m in self.model.modules():
             if hasattr(m, "shadow_dirty"):
                 m.shadow_dirty = True                       # fp16 shadows are rebuilt from the synchronised masters at the next read
+
+    def training_stream(self):
+        """Context manager: run the training loop on a stream of its own.  The default (null) stream pays ~10 us more per iteration at the step boundary on
+        ROCm (tools/probe_boundary.py: 0.678 -> 0.667 ms per ngp_base.py iteration).  Exiting synchronises the stream, so results are visible to code on any
+        stream afterwards.  `train_on_default_stream = True` in the config turns it into a no-op."""
+        import contextlib
+        if not torch.cuda.is_available() or self.cfg.train_on_default_stream:
+            return contextlib.nullcontext()
+        if self._train_stream is None:
+            self._train_stream = torch.cuda.Stream()
+
+        @contextlib.contextmanager
+        def ctx():
+            self._train_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._train_stream):
+                try:
+                    yield
+                finally:
+                    self._train_stream.synchronize()
+        return ctx()
 
     def drain(self):
         """wait for a batch that was marched ahead on the side stream (call before dropping the Runner or touching its buffers from elsewhere)"""
@@ -141,17 +166,20 @@ class Runner:
             return loss
         # ---- batches i+1 .. i+depth on the side streams.  Issued AFTER step i's own launches: every 16th prefetch ends in update_batch_rays' host
         # read-back, and the main stream should have step i queued while the host waits for it.
-        n_sets = len(self.sampler._sets)
+        n_sets, P = len(self.sampler._sets), self.done_period
         if not self._sides:
             self._sides = [torch.cuda.Stream() for _ in range(2)]
             self._ready = [torch.cuda.Event() for _ in range(n_sets)]            # persistent events, re-recorded (no create/destroy per step)
-            self._done = [torch.cuda.Event() for _ in range(n_sets + 1)]
+            self._done = [torch.cuda.Event() for _ in range(n_sets // P + 2)]
             self._grid_event, self._grid_valid = torch.cuda.Event(), False
             if self.sampler.grid_updated_in_last_sample:
                 self._grid_event.record(main); self._grid_valid = True
-        self._done[i % (n_sets + 1)].record(main)        # done(i)
-        self._done_steps.add(i)
-        self._done_steps.discard(i - n_sets - 1)
+        # `done` checkpoint of the training stream, every P-th step only: an event record is a marker packet in the stream's queue and costs ~15 us of dead time
+        # on MI355X (rocprof timeline: 30 us between the sweep and the next step's first kernel with one record + one wait per step)
+        if i % P == P - 1:
+            self._done[(i // P) % len(self._done)].record(main)
+            self._done_steps.add(i)
+            self._done_steps = {c for c in self._done_steps if c > i - n_sets - 2 * P}
         cur_state = None
         for k in range(i + 1, i + 1 + self.pipeline_depth):
             if k >= self.tot_train_steps or k % self.sampler.update_den_freq == 0:
@@ -159,8 +187,10 @@ class Runner:
             if k in self._queue:
                 continue
             side = self._sides[k & 1]
-            if (k - n_sets) in self._done_steps:
-                side.wait_event(self._done[(k - n_sets) % (n_sets + 1)])         # the buffer set batch k writes was last read by step k - n_sets
+            if k - n_sets >= 0:                          # the buffer set batch k writes was last read by step k - n_sets: wait for the first checkpoint at or after it
+                c = (k - n_sets) // P * P + P - 1            # (<= i: n_sets >= pipeline_depth + P - 1, checked in __init__)
+                if c in self._done_steps:
+                    side.wait_event(self._done[(c // P) % len(self._done)])
             if self._grid_valid:
                 side.wait_event(self._grid_event)
             if cur_state is None:
@@ -181,12 +211,13 @@ class Runner:
     def train(self):
         os.makedirs(self.save_path, exist_ok=True)
         loss = None
-        for i in range(self.start, self.tot_train_steps):
-            loss = self.train_step(i)
-            if i > 0 and i % self.val_freq == 0:
-                psnr = mse2psnr(self.val_img(i))
-                print("STEP={} | LOSS={} | VAL PSNR={}".format(i, loss.mean().item(), psnr))
-        self.drain()
+        with self.training_stream():
+            for i in range(self.start, self.tot_train_steps):
+                loss = self.train_step(i)
+                if i > 0 and i % self.val_freq == 0:
+                    psnr = mse2psnr(self.val_img(i))
+                    print("STEP={} | LOSS={} | VAL PSNR={}".format(i, loss.mean().item(), psnr))
+            self.drain()
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if not multi or dist.get_rank() == 0:           # replicas are bit-identical: one writer (every rank writing the same files would race)

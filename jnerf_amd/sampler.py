@@ -86,10 +86,13 @@ class DensityGridSampler(nn.Module):
             pcg32_advance(self.rng_state, rank << 40)
         self.measured_batch_size = torch.zeros(1, dtype=torch.int32, device=dev)
         cap_r = 1 << 18
-        # three buffer sets: the Runner marches up to two batches ahead on side streams while batch i is still being trained on (software pipelining)
+        # buffer sets: the Runner marches up to two batches ahead on side streams while batch i is still being trained on (software pipelining), and lets a set be
+        # rewritten only after a `done` checkpoint of the training stream, recorded every 4th step (runner.py) - hence 8 sets (12 MB each)
+        n_sets = int(self.cfg.pipeline_buffer_sets or 8)
         self._sets = [dict(numsteps=torch.empty((cap_r, 2), dtype=torch.int32, device=dev), numsteps_c=torch.empty((cap_r, 2), dtype=torch.int32, device=dev),
                            counters=torch.zeros(4, dtype=torch.int32, device=dev), coords=torch.zeros((self.target_batch_size, 7), dtype=torch.float32, device=dev),
-                           pos=torch.zeros((self.target_batch_size, 3), dtype=torch.float32, device=dev), scratch=None) for _ in range(3)]
+                           pos=torch.zeros((self.target_batch_size, 3), dtype=torch.float32, device=dev)) for _ in range(n_sets)]
+        self._march_scratch = [None, None]                  # count-pass output + t-cache of one march call: one per stream parity (even / odd batches never share a stream)
         self._set_idx = 0
         self._numsteps_buf, self._numsteps_c_buf = self._sets[0]["numsteps"], self._sets[0]["numsteps_c"]
         self._counters = self._sets[0]["counters"]
@@ -156,12 +159,14 @@ class DensityGridSampler(nn.Module):
         self._coords_train, self._counters = bs["coords"], bs["counters"]
         numsteps, numsteps_c = bs["numsteps"][:n], bs["numsteps_c"][:n]
         need = ops.march_scratch_elems(n)
-        if bs["scratch"] is None or bs["scratch"].numel() < need:
-            # sized once for the largest ray count update_batch_rays can choose (<= target_batch_size): no re-allocation while two streams use the sets
-            bs["scratch"] = torch.empty(max(need, ops.march_scratch_elems(min(self.target_batch_size, 1 << 18))), dtype=torch.int32, device=self.device)
+        par = int(self.cfg.m_training_step or 0) & 1
+        if self._march_scratch[par] is None or self._march_scratch[par].numel() < need:
+            # sized once for the largest ray count update_batch_rays can choose (<= target_batch_size): no re-allocation while the streams use it
+            self._march_scratch[par] = torch.empty(max(need, ops.march_scratch_elems(min(self.target_batch_size, 1 << 18))), dtype=torch.int32, device=self.device)
+        scratch = self._march_scratch[par]
         ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.target_batch_size,
                                  self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
-                                 coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=bs["scratch"], pos_out=bs["pos"])
+                                 coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=scratch, pos_out=bs["pos"])
         self._pos_train = bs["pos"]                                    # compact [n,3] copy of coords[:, :3], written by the marcher's write pass
         # two side streams may be marching at once: their read-modify-writes of the running sample count are ordered by an event chain
         # (the wait sits AFTER this batch's march kernels in stream order, so the marches themselves still overlap)

@@ -26,17 +26,18 @@ s, ds = r.sampler, r.dataset["train"]
 res = {"config": a.config, "rays": s.n_rays_per_batch}
 ops.prof_enable("*"); ops.prof_read()
 tot = 0
+scratch = None
 for k in range(a.reps):
     img_ids, ro, rd, _ = next(ds)
     torch.cuda.synchronize()
     s.sample(img_ids, ro, rd, is_training=True) if False else None
     bs = s._sets[0]
     need = ops.march_scratch_elems(ro.shape[0])
-    if bs["scratch"] is None or bs["scratch"].numel() < need:
-        bs["scratch"] = torch.empty(need, dtype=torch.int32, device="cuda")
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(need, dtype=torch.int32, device="cuda")
     ops.march_rays_compacted(ro.contiguous(), rd.contiguous(), s.density_grid_bitfield, s.aabb_range, s.rng_state, s.max_samples, s.target_batch_size, s.cone_angle_constant,
                              s.near_distance, s.const_dt, s.NERF_CASCADES, coords_out=bs["coords"], numsteps=bs["numsteps"][:ro.shape[0]], numsteps_c=bs["numsteps_c"][:ro.shape[0]],
-                             counters=bs["counters"], scratch=bs["scratch"], pos_out=bs["pos"])
+                             counters=bs["counters"], scratch=scratch, pos_out=bs["pos"])
     torch.cuda.synchronize()
     tot += int(bs["counters"][2].item())
 ops.prof_enable("")
