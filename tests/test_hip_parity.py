@@ -488,15 +488,30 @@ def test_full_size_hash_fwd_bwd_vs_oracle_on_ray_coherent_samples(H, dtype):
     assert torch.equal(g, g2)                                  # integer accumulation everywhere on this path: bit-reproducible, dense levels included
 
 
+@pytest.mark.parametrize("cluster", ["one_cell", "one_bin_of_a_dense_level"])
 @pytest.mark.parametrize("dtype", [np.float16, np.float32])
-def test_hash_bwd_bin_overflow_spills_exactly(H, dtype):
-    """a clustered batch (every sample inside one cell of the finest level) drives a few bins far beyond their record capacity (n/2): the surplus goes to the
-    shared spill list and is folded in by the bins' owners - same result as the oracle, still bit-reproducible, no float atomics (hash_encode.hip k_bin_records / k_bin_accumulate)"""
+def test_hash_bwd_bin_overflow_spills_exactly(H, dtype, cluster):
+    """A clustered batch drives a few bins far beyond their record capacity (n/2): the surplus goes to the shared spill list and is folded in by the bins'
+    owners - same result as the oracle, still bit-reproducible, no float atomics (hash_encode.hip k_bin_records[_runs] / k_bin_accumulate).
+    one_cell: every sample inside one cell of the finest level (the fine, hashed levels overflow; on the coarse levels the runs collapse to a few records).
+    one_bin_of_a_dense_level: every sample in a DIFFERENT cell of dense level 4 whose lowest corner lives in bin 5 of the interleaved entry->bin map, in random
+    order (no runs to combine): >= 20000 records for a bin of capacity 10000, through the run-combining record kernel's direct / spill stores."""
     from jnerf_amd import ops
     table, offsets, n_params = O.level_table(1)
     n = 20000
     rng = np.random.default_rng(9)
-    x = (0.37 + rng.random((n, 3)) * 2e-4).astype(np.float32)           # 2e-4 < 1/2048: one cell on every level
+    if cluster == "one_cell":
+        x = (0.37 + rng.random((n, 3)) * 2e-4).astype(np.float32)           # 2e-4 < 1/2048: one cell on every level
+    else:
+        size, res = int(table[4, 1]), int(table[4, 2])
+        scale = float(np.array([table[4, 3]], dtype=np.uint32).view(np.float32)[0])
+        g = np.stack(np.meshgrid(np.arange(res - 1), np.arange(res - 1), np.arange(res - 1), indexing="ij"), -1).reshape(-1, 3)
+        idx = g[:, 0] + g[:, 1] * res + g[:, 2] * res * res
+        assert size < (1 << 19) and idx.max() < size                       # a dense level: interleaved bins
+        cells = g[((idx >> 3) & 63) == 5]
+        x = ((cells[rng.integers(0, len(cells), n)] + 0.25) / scale).astype(np.float32)
+        p = x * np.float32(scale) + np.float32(0.5)
+        assert (np.floor(p).astype(np.int64) == np.floor((x.astype(np.float64) * scale + 0.5)).astype(np.int64)).all() and x.max() < 1.0
     dy = (rng.normal(size=(n, 32)) * 1e-2).astype(dtype)
     ref = O.hash_encode_bwd(x, dy.astype(np.float32), table, n_params)
     dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
@@ -507,7 +522,7 @@ def test_hash_bwd_bin_overflow_spills_exactly(H, dtype):
         ops.hash_encode_bwd(H.T(x), H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws)
         outs.append(H.N(g))
     assert np.array_equal(outs[0], outs[1])
-    # 8 corners x 20000 samples land in <= 8 bins of a hashed level: >= 20000 records in a bin with capacity max(4096, n/2) = 10000 => the spill path ran
+    # 8 corners x 20000 samples land in <= 8 bins of a level: >= 20000 records in a bin with capacity max(4096, n/2) = 10000 => the spill path ran
     tol = dict(atol=1e-6, rtol=1e-5) if dtype == np.float32 else dict(atol=2e-3 * np.abs(ref).max(), rtol=2e-3)
     GC.close(outs[0], ref, what="clustered batch", **tol)
     g = torch.from_numpy(outs[0]).cuda()
