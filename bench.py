@@ -178,7 +178,8 @@ def main():
     res = args.res or (800 if lego else 400)
     share = world if args.scaling == "strong" else 1
     ngp_cfg(fp16=fp16, aabb_scale=aabb_scale, const_dt=const_dt, n_images=n_images, W=res, H=res, device=f"cuda:{local_rank}", rank=rank, world_size=world,
-            target_batch_size=(1 << 18) // share, n_rays_per_batch=4096 // share, dp_force_collectives=bool(args.force_dist))
+            target_batch_size=(1 << 18) // share, n_rays_per_batch=4096 // share, dp_force_collectives=bool(args.force_dist),
+            **json.loads(os.environ.get("BENCH_EXTRA_CFG", "{}")))       # probe hook: extra config keys as JSON, e.g. {"pipeline_sampling": false}
     runner = Runner()
     import contextlib
     on_stream = contextlib.ExitStack()
