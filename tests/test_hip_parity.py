@@ -488,6 +488,34 @@ def test_full_size_hash_fwd_bwd_vs_oracle_on_ray_coherent_samples(H, dtype):
     assert torch.equal(g, g2)                                  # integer accumulation everywhere on this path: bit-reproducible, dense levels included
 
 
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_hash_bwd_workspace_strided_positions_n_valid_and_zero_rows(H, dtype):
+    """the training step's call shape: positions as a stride-7 view of the sample records, only the first n_valid rows count (device-side count), zero gradient
+    rows inside runs of samples that share a cell (a zero row neither contributes nor ends a run) - through the binned scatter, against the oracle on the valid prefix"""
+    from jnerf_amd import ops
+    coords, _, _, k = _ray_coherent_batch(H)
+    n, nv = 40000, 33333                                                   # nv is not a multiple of 8: the last thread of the run kernel takes the scalar path
+    table, offsets, n_params = O.level_table(1)
+    rng = np.random.default_rng(17)
+    rec = np.ascontiguousarray(coords[:n]).astype(np.float32)
+    dy = (rng.normal(size=(n, 32)) * 1e-3).astype(dtype)
+    dy[rng.random(n) < 0.2] = 0                                            # zero rows scattered through the runs
+    dy[100:140] = 0                                                        # and a whole stretch of them
+    ref = O.hash_encode_bwd(np.ascontiguousarray(rec[:nv, :3]), dy[:nv].astype(np.float32), table, n_params)
+    dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n), dtype=torch.uint8, device="cuda")
+    trec = H.T(rec)
+    n_valid = torch.tensor([nv], dtype=torch.int32, device="cuda")
+    g = torch.full((n_params,), 9.0, dtype=torch.float32, device="cuda")
+    ops.hash_encode_bwd(trec[:, :3], H.T(dys), table, n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws, n_valid=n_valid)
+    got = H.N(g)
+    for l in range(16):
+        lo, hi = int(offsets[l]) * 2, int(offsets[l + 1]) * 2
+        scale = np.abs(ref[lo:hi]).max()
+        err = np.abs(got[lo:hi] - ref[lo:hi]).max()
+        assert err <= (1e-5 if dtype == np.float32 else 2e-3) * scale, (l, err, scale)
+
+
 @pytest.mark.parametrize("cluster", ["one_cell", "one_bin_of_a_dense_level"])
 @pytest.mark.parametrize("dtype", [np.float16, np.float32])
 def test_hash_bwd_bin_overflow_spills_exactly(H, dtype, cluster):
