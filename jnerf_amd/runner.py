@@ -1,6 +1,7 @@
 """Runner — the caller of the hot path (python/jnerf/runner/runner.py:14-264), re-hosted on torch: same construction order
 through the registries and the global cfg, same train/test/render_img/save_ckpt/load_ckpt methods and checkpoint keys."""
 import os
+import sys
 import numpy as np
 import torch
 from .utils.config import get_cfg
@@ -238,6 +239,39 @@ class Runner:
             tot = sum(mse2psnr(m) for m in mse_list)
             print("TOTAL TEST PSNR===={}".format(tot / len(mse_list)))
             return tot / len(mse_list)
+
+    def render(self, load_ckpt=True, save_path=None, nframe=80):
+        """runner.py:101-121: the demo video along camera_path.path_spherical().  The reference writes demo.mp4 through cv2; without cv2 (this image) the frames are
+        written as a PNG sequence into `<save_path minus .mp4>_frames/` instead.  Returns the path written."""
+        if load_ckpt:
+            assert os.path.exists(self.ckpt_path), "ckpt file does not exist: " + self.ckpt_path
+            self.load_ckpt(self.ckpt_path)
+        if save_path is None or save_path == "":
+            save_path = os.path.join(self.save_path, "demo.mp4")
+        else:
+            assert save_path.endswith(".mp4"), "suffix of save_path need to be .mp4"
+        from .camera_path import path_spherical
+        print("rendering video with specified camera path")
+        os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
+        try:
+            import cv2
+        except ImportError:
+            cv2 = None
+        poses = path_spherical(nframe=nframe)
+        if cv2 is not None:
+            W, H = int(self.W), int(self.H)
+            writer = cv2.VideoWriter(save_path, cv2.VideoWriter_fourcc(*"mp4v"), 28, (W, H))
+            for pose in poses:
+                img = (self.render_img_with_pose(pose) * 255 + 0.5).clip(0, 255).astype("uint8")
+                writer.write(cv2.cvtColor(img, cv2.COLOR_BGR2RGB))
+            writer.release()
+            return save_path
+        out = save_path[:-4] + "_frames"
+        os.makedirs(out, exist_ok=True)
+        print("cv2 is not installed: writing the frames to " + out, file=sys.stderr)
+        for k, pose in enumerate(poses):
+            self.save_img(os.path.join(out, f"{k:04d}.png"), self.render_img_with_pose(pose))
+        return out
 
     def save_ckpt(self, path):
         from .optim import flush_all

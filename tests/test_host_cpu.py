@@ -118,6 +118,14 @@ def test_jnerf_alias_package_resolves_to_this_build():
     assert all(r is not None for r in (SCHEDULERS, DATASETS, OPTIMS, SAMPLERS, LOSSES))
     with pytest.raises(NotImplementedError):
         NeuSRunner()
+    # the methods the reference's tools/run_net.py and tools/extract_mesh.py call on a Runner (runner.py:62-264), with the reference's leading arguments
+    import inspect
+    for name, args in (("train", []), ("test", ["load_ckpt"]), ("render", ["load_ckpt", "save_path"]), ("save_ckpt", ["path"]), ("load_ckpt", ["path"]), ("val_img", None),
+                       ("render_test", ["save_img", "save_path"]), ("save_img", ["path", "img", "alpha"]), ("render_img", ["dataset_mode", "img_id"]),
+                       ("render_img_with_pose", ["pose"])):
+        fn = getattr(Runner, name)
+        if args is not None:
+            assert list(inspect.signature(fn).parameters)[1:1 + len(args)] == args, name
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/projects/nerf/configs"), reason="reference checkout not present (GPU box)")

@@ -190,6 +190,27 @@ def test_render_survives_sample_capacity_overflow():
     assert abs(float(a_big[-1024:].mean()) - float(a_ref[-1024:].mean())) < 0.05
 
 
+def test_render_task_writes_the_camera_path(tmp_path):
+    """Runner.render (runner.py:101-121; what the reference's tools/run_net.py --task render calls): checkpoint -> frames along camera_path.path_spherical().
+    Without cv2 the frames are PNGs next to the requested .mp4."""
+    import os
+    from PIL import Image
+    r = _runner(fp16=True, aabb_scale=1, const_dt=True)
+    for i in range(48):
+        r.train_step(i)
+    r.drain()
+    r.ckpt_path = str(tmp_path / "params.pkl")
+    r.save_ckpt(r.ckpt_path)
+    out = r.render(True, str(tmp_path / "demo.mp4"), nframe=3)
+    if out.endswith(".mp4"):
+        assert os.path.getsize(out) > 0
+    else:
+        frames = sorted(os.listdir(out))
+        assert frames == ["0000.png", "0001.png", "0002.png"]
+        img = np.asarray(Image.open(os.path.join(out, frames[1])))
+        assert img.shape == (int(r.H), int(r.W), 3) and img.std() > 0
+
+
 def test_reference_configs_train_on_real_fox(tmp_path):
     """projects/ngp/configs/ngp_fox.py (same keys/values as the reference's file, checked key by key against /root/reference in tests/test_host_cpu.py) on the REAL
     fox photographs: 50 images 1080x1920 load through NerfDataset, 64 training steps run on the native fast path, the loss falls."""

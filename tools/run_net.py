@@ -31,14 +31,7 @@ def main():
     elif args.task == "test":
         runner.test(True)
     elif args.task == "render":
-        import numpy as np
-        from jnerf_amd.camera_path import path_spherical
-        out = args.save_dir or os.path.join(runner.save_path, "render")
-        os.makedirs(out, exist_ok=True)
-        runner.load_ckpt(runner.ckpt_path)
-        for k, pose in enumerate(path_spherical()):          # PNG sequence (cv2's mp4 writer is not available here)
-            runner.save_img(os.path.join(out, f"{k:04d}.png"), runner.render_img_with_pose(pose))
-
+        runner.render(True, args.save_dir)                   # demo.mp4 with cv2, a PNG sequence next to it without (jnerf_amd/runner.py)
 
 if __name__ == "__main__":
     main()
