@@ -35,17 +35,18 @@ def psnr_now():
 
 
 rows, train_s = [], 0.0
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(steps):
-    r.train_step(i)
-    if i + 1 in marks:
-        r.drain(); torch.cuda.synchronize()
-        train_s += time.perf_counter() - t0
-        rows.append((i + 1, train_s, psnr_now(), r.optimizer._nested_optimizer.lr, r.sampler.n_rays_per_batch))
-        print(rows[-1], flush=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+with r.training_stream():                                   # as Runner.train does
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        r.train_step(i)
+        if i + 1 in marks:
+            r.drain(); torch.cuda.synchronize()
+            train_s += time.perf_counter() - t0
+            rows.append((i + 1, train_s, psnr_now(), r.optimizer._nested_optimizer.lr, r.sampler.n_rays_per_batch))
+            print(rows[-1], flush=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
 with open(out, "w") as f:
     f.write(f"# Full training schedule on one MI355X (bench scene: {title})\n\n")
     f.write(f"`python tools/train_curve.py out.md {steps} {which}` - {steps} iterations of 2^18 samples, ExpDecay x0.33 at 20 k and 30 k (ngp_base.py:31-37); PSNR = mean over the held-out test views;\n")
