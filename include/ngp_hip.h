@@ -219,6 +219,32 @@ enum { NGP_STAGE_PACK = 0, NGP_STAGE_HASH_FWD, NGP_STAGE_FIELD_FWD, NGP_STAGE_CO
        NGP_STAGE_HASH_BWD, NGP_STAGE_ADAM /* the largest parameter tensor's sweep */,
        NGP_STAGE_BOUNDARY /* not a stage: from the end of one call's last launch to the start of the next call's first launch (main-stream idle + waits) */ };
 int ngp_train_step(void *stream, const NgpTrainStep *args_host);
+
+/* ---- one inference chunk from native code --------------------------------------------------------------------------------------------------------------
+ * The loop body of Runner.render_img (runner/runner.py:211-226: sampler.sample -> model -> rays2rgb(inference)) for `n_rays` rays: march + compaction
+ * (ngp_march_rays_compacted_pos with cap = sample capacity of the buffers), hash encode, fused field network (weights pre-packed by the caller), inference
+ * compositing straight into the image buffers.  No host read-back: `totals` (device u64[2]) accumulates {samples rendered, chunks whose requested samples
+ * exceeded max_samples - the caller re-renders those images in smaller chunks}.  The Python loop around it spent as long on tensor plumbing as the kernels ran. */
+typedef struct NgpRenderChunk {
+	uint32_t n_rays, cap /* samples the buffers below hold */, max_samples;
+	int32_t const_dt, cascades, dtype /* NGP_F16 | NGP_F32: table + fused network precision */;
+	float aabb0, aabb1, near_distance, cone_angle;
+	const float *rays_o, *rays_d;            /* [n_rays,3] */
+	const uint8_t *bitfield;
+	uint64_t *rng_state_host;                /* pcg32 {state, inc}; advanced like ray_sampler.py:61 */
+	float *coords;                           /* [cap,7] */
+	float *pos;                              /* [cap,3] */
+	uint32_t *numsteps, *numsteps_compacted; /* [n_rays,2] */
+	uint32_t *counters;                      /* u32[4] */
+	uint32_t *scratch;                       /* ngp_march_scratch_elems(n_rays) */
+	const void *table; const uint32_t *level_table_host;
+	const void *packed_weights;              /* ngp_field_pack_weights / ngp_field32_pack_weights output */
+	void *feat;                              /* T[16][cap][2] */
+	void *out;                               /* T[cap,4] */
+	float *rgb_out, *alpha_out;              /* [n_rays,3], [n_rays,1]: this chunk's rows of the image */
+	uint64_t *totals;                        /* device u64[2], accumulated */
+} NgpRenderChunk;
+int ngp_render_chunk(void *stream, const NgpRenderChunk *args_host);
 /* waits for the bracketed launches of earlier ngp_train_step calls (this thread's device) and writes up to `max` durations in milliseconds, oldest first;
  * returns how many were written (<0 on error) and forgets them */
 int ngp_train_step_timings(float *ms_out_host, int max);

@@ -30,6 +30,15 @@ class NgpTrainStep(C.Structure):
                 ("timed_stage", _i32), ("grad_overwrite", _i32)]
 
 
+class NgpRenderChunk(C.Structure):
+    """mirror of `struct NgpRenderChunk` in include/ngp_hip.h (argument block of ngp_render_chunk)"""
+    _fields_ = [("n_rays", _u32), ("cap", _u32), ("max_samples", _u32), ("const_dt", _i32), ("cascades", _i32), ("dtype", _i32),
+                ("aabb0", _f32), ("aabb1", _f32), ("near_distance", _f32), ("cone_angle", _f32),
+                ("rays_o", _vp), ("rays_d", _vp), ("bitfield", _vp), ("rng_state_host", _vp), ("coords", _vp), ("pos", _vp), ("numsteps", _vp), ("numsteps_compacted", _vp),
+                ("counters", _vp), ("scratch", _vp), ("table", _vp), ("level_table_host", _vp), ("packed_weights", _vp), ("feat", _vp), ("out", _vp),
+                ("rgb_out", _vp), ("alpha_out", _vp), ("totals", _vp)]
+
+
 SIGNATURES = {
     "ngp_abi_version": (C.c_int, []),
     "ngp_last_error": (C.c_char_p, []),
@@ -70,6 +79,7 @@ SIGNATURES = {
     "ngp_grid_ema": (C.c_int, [_vp, _u32, _f32, _vp, _vp]),
     "ngp_grid_update_bitfield": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "ngp_train_step": (C.c_int, [_vp, C.POINTER(NgpTrainStep)]),
+    "ngp_render_chunk": (C.c_int, [_vp, C.POINTER(NgpRenderChunk)]),
     "ngp_train_step_timings": (C.c_int, [_vp, _i32]),
     "ngp_grad_to_half": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _i32]),
     "ngp_grad_to_half_scaled": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _i32, _f32]),

@@ -69,14 +69,15 @@ __global__ __launch_bounds__(256) void k_hash_fwd(uint32_t n, const float *__res
                                                   T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid) {
 	using P = typename Pair<T>::type;
 	uint32_t level, chunk; block_to_level_chunk(nblk, level, chunk);
-	const uint32_t i = chunk * 256u + threadIdx.x;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	if (i >= lim) return;
 	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const bool dense = level_is_dense(size, res);
-	const Corner c = locate(pos, stride, i, scale);
 	const P *tab = reinterpret_cast<const P *>(table) + off;
+	// nblk is capped by the host: a block takes chunks chunk, chunk + nblk, ... of its level (one trip for a training batch; the fixed-capacity inference buffers
+	// - 4 M rows of which a device-side count says how many are valid - used to launch 260 k blocks of which 87 % found nothing to do)
+	for (uint32_t i = chunk * 256u + threadIdx.x; i < lim; i += nblk * 256u) {
+	const Corner c = locate(pos, stride, i, scale);
 	P v[8]; float w[8];
 	// The kernel is bound by the L2 request rate (one gather = one request), so the two x-neighbours of a cell edge are fetched with ONE double-width load
 	// whenever they are adjacent in memory: always on dense levels (index x + ...; not across the wrap), and on hashed levels when x is even
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void k_hash_fwd(uint32_t n, const float *__res
 	P *o = reinterpret_cast<P *>(out);
 	if (LAYOUT == NGP_LAYOUT_SOA) o[(size_t)level * n + i] = r;
 	else o[(size_t)i * 16 + level] = r;
+	}
 }
 
 __device__ __forceinline__ void atomic_add_pair(float *p, float2 v) {
@@ -451,7 +453,7 @@ NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_fwd: bad dtype %d", dtype);
 	if (n == 0) return 0;
 	NGP_REQUIRE(pos_stride >= 3, NGP_E_ARG, "ngp_hash_encode_fwd: pos stride %u < 3", pos_stride);
-	const uint32_t nblk = div_up(n, 256);
+	const uint32_t nblk = min(div_up(n, 256), 2048u);         // chunks per level in flight (k_hash_fwd strides over the rest)
 	const dim3 grid(16 * nblk), block(256);
 	const LevelTable lt = load_table(level_table_host);
 	hipStream_t s = (hipStream_t)stream;

@@ -100,3 +100,33 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	}
 	return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------- one inference chunk (Runner.render_img's loop body)
+__global__ void k_render_totals(const uint32_t *__restrict__ counters, uint32_t max_samples, unsigned long long *__restrict__ totals) {
+	if (threadIdx.x == 0 && blockIdx.x == 0) {                // counters: {-, requested samples, -, samples written}; atomics: chunks may run on two streams at once
+		atomicAdd(&totals[0], (unsigned long long)counters[3]);
+		if (counters[1] > max_samples) atomicAdd(&totals[1], 1ull);
+	}
+}
+
+NGP_API int ngp_render_chunk(void *stream, const NgpRenderChunk *a) {
+	NGP_REQUIRE(a, NGP_E_ARG, "ngp_render_chunk: null argument block");
+	NGP_REQUIRE(a->dtype == NGP_F16 || a->dtype == NGP_F32, NGP_E_DTYPE, "ngp_render_chunk: bad dtype %d", a->dtype);
+	NGP_REQUIRE(a->rays_o && a->rays_d && a->bitfield && a->rng_state_host && a->coords && a->pos && a->numsteps && a->numsteps_compacted && a->counters && a->scratch &&
+	            a->table && a->level_table_host && a->packed_weights && a->feat && a->out && a->rgb_out && a->alpha_out && a->totals, NGP_E_ARG, "ngp_render_chunk: null pointer");
+	if (a->n_rays == 0) return 0;
+	int rc;
+	const int lay = NGP_LAYOUT_SOA | NGP_WEIGHTS_PACKED;
+	if ((rc = ngp_march_rays_compacted_pos(stream, a->n_rays, a->rays_o, a->rays_d, a->bitfield, a->aabb0, a->aabb1, a->near_distance, a->cone_angle, a->const_dt, a->cascades,
+	                                       a->rng_state_host, a->max_samples, a->cap, a->coords, a->numsteps, a->numsteps_compacted, a->counters, a->scratch, a->pos))) return rc;
+	const uint32_t *n_valid = a->counters + 3;
+	if ((rc = ngp_hash_encode_fwd(stream, a->cap, a->pos, 3, a->table, a->level_table_host, a->feat, a->dtype, NGP_LAYOUT_SOA, n_valid))) return rc;
+	if (a->dtype == NGP_F16) rc = ngp_field_fwd(stream, a->cap, a->feat, lay, a->coords + 4, 7, a->packed_weights, nullptr, a->out, NGP_F16, n_valid);
+	else rc = ngp_field32_fwd(stream, a->cap, (const float *)a->feat, lay, a->coords + 4, 7, (const float *)a->packed_weights, nullptr, (float *)a->out, n_valid);
+	if (rc) return rc;
+	if ((rc = ngp_composite_inference(stream, a->n_rays, a->out, a->dtype, a->coords, a->numsteps_compacted, a->cascades, a->rgb_out, a->alpha_out))) return rc;
+	NGP_LAUNCH(k_render_totals, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint32_t *)a->counters, a->max_samples, (unsigned long long *)a->totals);
+	NGP_LAUNCH_CHECK("ngp_render_chunk");
+	return 0;
+}

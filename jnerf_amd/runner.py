@@ -58,7 +58,9 @@ class Runner:
         assert n_sets >= self.pipeline_depth + self.done_period - 1, (
             f"pipeline_buffer_sets = {n_sets} is too small for pipeline_depth = {self.pipeline_depth} and pipeline_done_period = {self.done_period}")
         self._train_stream = None
-        self.render_chunk = int(cfg.render_chunk or 32768)       # rays per inference pass (the reference: n_rays_per_batch = 4096)
+        # rays per inference pass (the reference: n_rays_per_batch = 4096).  16384: a pass that asks for more than the sampler's fixed 4096*1024-sample capacity has to be
+        # redone in 4096-ray passes, and 32768-ray passes did that on the rows through the object of an 800 x 800 view (27 ms per view instead of 18)
+        self.render_chunk = int(cfg.render_chunk or 16384)
         self.W, self.H = self.dataset["train"].resolution
 
     def _sync_initial_parameters(self, params):
@@ -336,6 +338,13 @@ class Runner:
         imgs = torch.empty((n, 3), device=dev)
         alphas = torch.empty((n, 1), device=dev)
         counts = torch.zeros(2, dtype=torch.int64, device=dev)      # [samples rendered, chunks whose requested samples exceeded the capacity]
+        if self._native_render_ok():
+            self._render_rays_native(rays_o_total, rays_d_total, chunk, imgs, alphas, counts)
+            host = counts.tolist()
+            self.n_samples_rendered = int(host[0])
+            if host[1] and chunk > self.sampler.max_samples // self.sampler.MAX_STEP:
+                return self._render_rays(img_ids, rays_o_total, rays_d_total, self.sampler.max_samples // self.sampler.MAX_STEP)
+            return imgs, alphas
         self.sampler.sync_free_inference = True
         try:
             for pixel in range(0, n, chunk):
@@ -357,6 +366,68 @@ class Runner:
             # the reference's chunk size (capacity / MAX_STEP = 4096 rays can never overflow) instead of returning black pixels.
             return self._render_rays(img_ids, rays_o_total, rays_d_total, self.sampler.max_samples // self.sampler.MAX_STEP)
         return imgs, alphas
+
+    def _native_render_ok(self):
+        """the standard stack on the GPU (hash encoder + SH + fused field network in either precision + occupancy-grid sampler): one ngp_render_chunk call per chunk"""
+        m, s = self.model, self.sampler
+        return bool(torch.cuda.is_available() and getattr(m, "fused", False) and hasattr(s, "density_grid_bitfield") and s.density_grid_bitfield.is_cuda
+                    and self.cfg.native_render is not False)
+
+    def _render_rays_native(self, rays_o_total, rays_d_total, chunk, imgs, alphas, counts):
+        """the chunk loop of _render_rays through ngp_render_chunk (csrc/train_step.hip): the same kernels in the same order as sampler.sample -> model ->
+        rays2rgb(inference), but one FFI crossing per chunk and no tensor plumbing in between (the Python loop took 34 ms per 800 x 800 view for 17 ms of kernels)"""
+        import ctypes as C
+        from . import _lib as L, ops
+        from .optim import flush_all
+        flush_all()
+        m, s, enc = self.model, self.sampler, self.model.pos_encoder
+        dev = rays_o_total.device
+        cap = int(s.max_samples)
+        # several buffer sets on as many streams: chunk i+1 is marched (a latency-bound traversal) while chunk i is in the gather / MLP kernels
+        n_sets = max(1, min(4, int(self.cfg.render_streams or 3)))           # (800 x 800 lego-like view: 1 stream 1222, 2: 1397, 3: 1488, 4: 1504 Msamples/s)
+        bufs = getattr(self, "_render_bufs", None)
+        if bufs is None or len(bufs) != n_sets or bufs[0]["chunk"] < chunk or bufs[0]["dtype"] != m.fused_dtype:
+            bufs = self._render_bufs = [dict(chunk=chunk, dtype=m.fused_dtype, coords=s._inference_coords() if k == 0 else torch.empty((cap, 7), dtype=torch.float32, device=dev),
+                                             pos=torch.empty((cap, 3), dtype=torch.float32, device=dev),
+                                             numsteps=torch.empty((chunk, 2), dtype=torch.int32, device=dev), numsteps_c=torch.empty((chunk, 2), dtype=torch.int32, device=dev),
+                                             counters=torch.zeros(4, dtype=torch.int32, device=dev), scratch=torch.empty(ops.march_scratch_elems(chunk), dtype=torch.int32, device=dev),
+                                             feat=torch.empty((16, cap, 2), dtype=m.fused_dtype, device=dev), out=torch.empty((cap, 4), dtype=m.fused_dtype, device=dev),
+                                             stream=torch.cuda.Stream() if n_sets > 1 else None) for k in range(n_sets)]
+        packed = m.packed_weights(refresh=True)
+        table = enc.table_for_kernels()
+        rays_o_total, rays_d_total = rays_o_total.contiguous(), rays_d_total.contiguous()
+        args = []
+        for b in bufs:
+            a = L.NgpRenderChunk()
+            a.cap, a.max_samples, a.const_dt, a.cascades = cap, cap, int(bool(s.const_dt)), int(s.NERF_CASCADES)
+            a.dtype = L.F16 if m.fused_dtype == torch.float16 else L.F32
+            a.aabb0, a.aabb1, a.near_distance, a.cone_angle = float(s.aabb_range[0]), float(s.aabb_range[1]), float(s.near_distance), float(s.cone_angle_constant)
+            a.bitfield, a.rng_state_host = s.density_grid_bitfield.data_ptr(), s.rng_state.ctypes.data
+            a.coords, a.pos, a.numsteps, a.numsteps_compacted = b["coords"].data_ptr(), b["pos"].data_ptr(), b["numsteps"].data_ptr(), b["numsteps_c"].data_ptr()
+            a.counters, a.scratch = b["counters"].data_ptr(), b["scratch"].data_ptr()
+            a.table, a.level_table_host, a.packed_weights = table.data_ptr(), enc.level_table.ctypes.data, packed.data_ptr()
+            a.feat, a.out, a.totals = b["feat"].data_ptr(), b["out"].data_ptr(), counts.data_ptr()
+            args.append(a)
+        n = rays_o_total.shape[0]
+        main = torch.cuda.current_stream()
+        for b in bufs:
+            if b["stream"] is not None:
+                b["stream"].wait_stream(main)               # rays, weights, image buffers are ready on the caller's stream
+        for j, pixel in enumerate(range(0, n, chunk)):
+            a, b = args[j % n_sets], bufs[j % n_sets]
+            k = min(chunk, n - pixel)
+            a.n_rays = k
+            a.rays_o, a.rays_d = rays_o_total.data_ptr() + pixel * 12, rays_d_total.data_ptr() + pixel * 12
+            a.rgb_out, a.alpha_out = imgs.data_ptr() + pixel * 12, alphas.data_ptr() + pixel * 4
+            stream = C.c_void_p(b["stream"].cuda_stream) if b["stream"] is not None else ops._stream()
+            L.check(L.lib().ngp_render_chunk(stream, C.byref(a)), "ngp_render_chunk")
+        for b in bufs:
+            if b["stream"] is not None:
+                main.wait_stream(b["stream"])
+        for t in (rays_o_total, rays_d_total, imgs, alphas, counts):
+            for b in bufs:
+                if b["stream"] is not None:
+                    t.record_stream(b["stream"])
 
     @torch.no_grad()
     def render_img(self, dataset_mode="train", img_id=None):

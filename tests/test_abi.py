@@ -4,6 +4,7 @@ import os
 import re
 import subprocess
 import numpy as np
+import pytest
 from jnerf_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,19 +28,21 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == syms
 
 
-def test_train_step_argument_block_layout(tmp_path):
-    """the ctypes mirror of `struct NgpTrainStep` must have the C compiler's size and field offsets (the header is plain C: gcc compiles it)"""
-    fields = [name for name, _ in _lib.NgpTrainStep._fields_]
-    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "ngp_hip.h"', 'int main(void) {', '  printf("%zu\\n", sizeof(NgpTrainStep));']
-    prog += [f'  printf("%zu\\n", offsetof(NgpTrainStep, {f}));' for f in fields]
+@pytest.mark.parametrize("struct", ["NgpTrainStep", "NgpRenderChunk"])
+def test_train_step_argument_block_layout(tmp_path, struct):
+    """the ctypes mirrors of `struct NgpTrainStep` / `struct NgpRenderChunk` must have the C compiler's size and field offsets (the header is plain C: gcc compiles it)"""
+    mirror = getattr(_lib, struct)
+    fields = [name for name, _ in mirror._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "ngp_hip.h"', 'int main(void) {', f'  printf("%zu\\n", sizeof({struct}));']
+    prog += [f'  printf("%zu\\n", offsetof({struct}, {f}));' for f in fields]
     prog += ['  return 0;', '}']
     src, exe = tmp_path / "layout.c", tmp_path / "layout"
     src.write_text("\n".join(prog))
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
     import ctypes as C
-    assert out[0] == C.sizeof(_lib.NgpTrainStep)
-    assert out[1:] == [getattr(_lib.NgpTrainStep, f).offset for f in fields]
+    assert out[0] == C.sizeof(mirror)
+    assert out[1:] == [getattr(mirror, f).offset for f in fields]
 
 
 def test_argument_errors_are_reported_before_any_launch():
@@ -60,6 +63,9 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.ngp_adam_ema_step(None, 6, one, one, 0, one, one, None, None, 0.1, 0.9, 0.99, 1e-15, 1, 0.95, 1) == -3 and b"multiple of 4" in lib.ngp_last_error()
     assert lib.ngp_adam_ema_step(None, 8, one, one, 0, one, one, None, None, 0.1, 0.9, 0.99, 1e-15, 0, 0.95, 1) == -1            # step is 1-based
     assert lib.ngp_train_step(None, None) == -1
+    assert lib.ngp_render_chunk(None, None) == -1
+    blk = _lib.NgpRenderChunk(); blk.dtype = 7
+    assert lib.ngp_render_chunk(None, C.byref(blk)) == -2 and b"dtype" in lib.ngp_last_error()
     assert lib.ngp_grad_to_half(None, 12, one, one, 1) == -3
 
 
