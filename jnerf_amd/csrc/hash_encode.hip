@@ -13,7 +13,10 @@
 //  * no extract_position / transpose kernels: positions are read strided from the caller's buffer and features are written
 //    either as the [n,32] rows HashEncoder returns or as a level-major [16][n] stream of pairs that the fused MLP consumes with
 //    fully coalesced 256-B wave accesses (no 4-byte-per-64-byte-line partial writes from sixteen different XCDs).
-//  * backward uses hardware float atomics (global_atomic_add_f32 / global_atomic_pk_add_f16), gradient zeroing is a fused memset.
+//  * backward: three implementations, chosen by what the caller hands over (hash_bwd_impl).  With a workspace (the training path): a binned scatter without any float
+//    atomic - every contribution computed once, written as a record into the list of the bin its entry lives in, summed per bin in 64-bit integer LDS accumulators,
+//    coarse levels with per-thread run combining; bit-reproducible.  Without one: an owner-computes scan (a workgroup owns a slice of a level in LDS and filters the
+//    sample stream).  NGP_HASH_BWD_ATOMICS=1 or a non-power-of-two hashed table: the reference's scheme, one global float atomic per corner.
 #include "ngp_common.h"
 #include <stdlib.h>
 #pragma clang fp contract(off)

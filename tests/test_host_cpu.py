@@ -153,3 +153,49 @@ def test_origin_nerf_network_on_cpu():
     assert out.shape == (50, 4) and out.dtype == torch.float32 and net.density(x).shape == (50, 1)
     out.sum().backward()
     assert all(p.grad is not None for p in net.parameters())
+
+
+def test_constant_step_chain_closed_form_is_bit_identical_to_the_serial_sum():
+    """The claim k_march_wave's chain phase rests on (csrc/sampler.hip): inside a binade, t_{k+1} = fl(t_k + dt) with a constant dt adds the same integer
+    q = rint(dt / ulp) at every step as long as the exact sum stays below the binade's end (no tie), so lane i can write (a0 + i*q) * ulp directly; the 1-3 steps
+    around a binade crossing are real fp32 adds.  Restated in numpy (same decisions as the kernel) and compared bit for bit with the serial recurrence."""
+    import math
+    f32 = np.float32
+
+    def closed(t0, nc, dt):
+        tch = np.full(nc + 1, np.nan, dtype=np.float32)
+        k, t = 0, f32(t0)
+        while k <= nc:
+            _, e = math.frexp(float(t))
+            m = 0
+            if -100 < e < 100:
+                sc = f32(math.ldexp(1.0, 24 - e))
+                a0f = f32(t * sc)
+                if f32(8388608.0) <= a0f < f32(16777216.0):
+                    delta = f32(dt * sc)
+                    if delta < f32(16777216.0):
+                        a0, q = int(a0f), int(np.rint(delta))
+                        x = 16777215 - a0 - int(np.ceil(delta))
+                        if f32(delta - np.floor(delta)) != f32(0.5) and x >= 0 and q > 0:
+                            m = x // q + 1
+            if m == 0:
+                tch[k] = t; t = f32(t + dt); k += 1
+                continue
+            last = min(m, nc - k)
+            u = f32(math.ldexp(1.0, e - 24))
+            tch[k:k + last + 1] = (np.arange(last + 1, dtype=np.int64) * q + a0).astype(np.float32) * u
+            t = tch[k + last]; k += last
+            if k == nc:
+                break
+        return tch
+
+    rng = np.random.default_rng(0)
+    steps = [f32(f32(math.sqrt(3.0) / 1024.0) * f32(0.5)), f32(0.001953125), f32(0.0009765625 * 1.5), f32(1e-3), f32(3e-8)]     # the marcher's constant step, ties, tiny steps
+    for dt in steps:
+        for trial in range(200):
+            t0 = f32(rng.uniform(*[(3.9, 4.0), (0.05, 0.3), (1.7, 2.0), (0.1, 8.0)][trial % 4]))      # around binade ends and anywhere
+            serial = np.empty(257, dtype=np.float32)
+            t = t0
+            for k in range(257):
+                serial[k] = t; t = f32(t + dt)
+            assert np.array_equal(closed(t0, 256, dt), serial), (float(dt), float(t0))

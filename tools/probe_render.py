@@ -18,7 +18,7 @@ with r.training_stream():
         r.train_step(i)
     r.drain()
 r.dataset["test"] = build_from_cfg(r.cfg.dataset.test, DATASETS)
-for chunk in (16384, 32768):
+for chunk in [int(c) for c in os.environ.get("RENDER_CHUNKS", "16384,32768").split(",")]:
     r.render_chunk = chunk
     r.render_img("test", 0)
     torch.cuda.synchronize()
