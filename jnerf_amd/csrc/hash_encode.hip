@@ -520,10 +520,26 @@ template <typename RV> __device__ __forceinline__ RV *rec_val_at(void *base, uin
 }
 __device__ __forceinline__ uint16_t *rec_idx_at(uint16_t *base, uint32_t hl, uint32_t bin, uint32_t cap) { return base + ((size_t)hl * BINS_PER_LEVEL + bin) * cap; }
 
+// Largest |dL/dy| of every level (the scale of the fixed-point accumulation).  Every workgroup writes the maximum of its share of the samples to ABSMAX_PARTS
+// partial slots per level - no atomics (same-address global atomics retire one at a time at the L2: 8192 of them on 16 addresses took ~90 us), nothing to zero
+// beforehand; the consumers take the maximum of a level's partials with scalar loads (level_absmax).  The pass also zeroes the record cursors and the spill
+// count for the kernels behind it in the stream (that was a separate 5 us memset launch).
+#define ABSMAX_PARTS 64u
+__device__ __forceinline__ uint32_t level_absmax(const uint32_t *__restrict__ parts, uint32_t level) {      // positive floats order like their bit patterns
+	uint32_t m = parts[level * ABSMAX_PARTS + (threadIdx.x & 63u)];          // one load per lane + a wavefront reduction (called by full wavefronts, at kernel entry)
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+	return m;
+}
 template <typename T, int LAYOUT>
-__global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__restrict__ dLdy, uint32_t *__restrict__ absmax_bits, const uint32_t *__restrict__ n_valid) {
+__global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__restrict__ dLdy, uint32_t *__restrict__ parts, const uint32_t *__restrict__ n_valid,
+                                                      uint32_t *__restrict__ cursors, uint32_t *__restrict__ spill_count) {
 	using P = typename Pair<T>::type;
 	const uint32_t level = blockIdx.y;
+	if (blockIdx.x == 0) {                                               // cursors u32[16][BINS_PER_LEVEL], spill count
+		if (threadIdx.x < BINS_PER_LEVEL) cursors[level * BINS_PER_LEVEL + threadIdx.x] = 0u;
+		if (level == 0 && threadIdx.x == BINS_PER_LEVEL) *spill_count = 0u;
+	}
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
 	const P *dy = reinterpret_cast<const P *>(dLdy);
 	float m = 0.f;
@@ -542,13 +558,12 @@ __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__res
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-	// one atomic per workgroup: same-address global atomics retire one at a time at the L2 (8192 of them on 16 addresses took ~90 us)
 	__shared__ float wave_max[4];
 	if ((threadIdx.x & 63u) == 0) wave_max[threadIdx.x >> 6] = m;
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-		if (m > 0.f) atomicMax(&absmax_bits[level], __float_as_uint(m));                      // positive floats order like their bit patterns
+		parts[level * ABSMAX_PARTS + blockIdx.x] = (m > 0.f) ? __float_as_uint(m) : 0u;     // (NaN -> 0: a level without a usable gradient is skipped, as before)
 	}
 }
 
@@ -595,7 +610,8 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float 
 	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const bool dense = level_is_dense(size, res), il = size < BIN_LEVEL_MAX;
-	const float vs = sizeof(T) == 2 ? bin_scale(absmax_bits[level]) : (absmax_bits[level] ? 1.0f : 0.f);       // fp32 records are stored unscaled
+	const uint32_t amax = level_absmax(absmax_bits, level);
+	const float vs = sizeof(T) == 2 ? bin_scale(amax) : (amax ? 1.0f : 0.f);       // fp32 records are stored unscaled
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
 	if (vs == 0.f || blockIdx.x * BIN_WG >= lim) return;                // uniform exit
 	if (threadIdx.x < BINS_PER_LEVEL) cnt[threadIdx.x] = 0;
@@ -675,7 +691,7 @@ __global__ __launch_bounds__(RUN_WG) void k_bin_records_runs(uint32_t n, const f
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const bool dense = level_is_dense(size, res), il = size < BIN_LEVEL_MAX;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	if (absmax_bits[level] == 0u || blockIdx.x * RUN_WG * RUN_K >= lim) return;          // uniform exit
+	if (level_absmax(absmax_bits, level) == 0u || blockIdx.x * RUN_WG * RUN_K >= lim) return;          // uniform exit
 	if (threadIdx.x < BINS_PER_LEVEL) { cnt[threadIdx.x] = 0; cnt2[threadIdx.x] = 0; }
 	__syncthreads();
 	const uint32_t first = (blockIdx.x * RUN_WG + threadIdx.x) * RUN_K;
@@ -788,7 +804,7 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	// slots of this bin that are entries of the level (interleaved: groups bin, bin + 64, ... of the level's ceil(size / 8) groups)
 	const uint32_t groups_all = (size + 7u) >> 3;
 	const uint32_t n_local = il ? (groups_all > bin ? ((groups_all - bin + 63u) >> 6) << 3 : 0u) : BIN_ENTRIES;
-	const uint32_t amax = absmax_bits[level];
+	const uint32_t amax = level_absmax(absmax_bits, level);
 	float s32 = 0.f, inv;
 	if (F32) {
 		const float m = __uint_as_float(amax);
@@ -898,7 +914,7 @@ static uint64_t hash_bwd_workspace_bytes(const LevelTable &lt) {           // pa
 	return (entries * sizeof(float2) + 255) & ~(uint64_t)255;
 }
 static uint32_t bin_capacity(uint32_t n) { uint32_t c = (n / 2 + 7u) & ~7u; return c < 4096u ? 4096u : c; }   // 4x the expected n*8/64 records per bin; % 8: 16-byte aligned streams
-// workspace = slabs | cursors u32[16*64] | absmax u32[16], spill count u32 | record values | record indices | spill list
+// workspace = slabs | cursors u32[16*64] | absmax partials u32[16*64], spill count u32 | record values | record indices | spill list
 struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, total; uint32_t cap, spill_cap, n_binned; };
 static WsLayout ws_layout(const LevelTable &lt, uint32_t n) {
 	WsLayout w;
@@ -908,7 +924,7 @@ static WsLayout ws_layout(const LevelTable &lt, uint32_t n) {
 	w.spill_cap = w.n_binned * 8u * (n < (1u << 25) / (w.n_binned ? w.n_binned : 1u) ? n : (1u << 25) / (w.n_binned ? w.n_binned : 1u));   // worst case: every record of every binned level overflows (12 B each)
 	w.cursors = hash_bwd_workspace_bytes(lt);
 	w.absmax = w.cursors + 4096;
-	w.rec_val = w.absmax + 256;
+	w.rec_val = w.absmax + 16u * ABSMAX_PARTS * 4u + 256;
 	w.rec_idx = w.rec_val + (uint64_t)w.n_binned * BINS_PER_LEVEL * w.cap * sizeof(float2);       // every level owns 64 * cap * 8 bytes (rec_val_at)
 	w.spill = (w.rec_idx + (uint64_t)w.n_binned * BINS_PER_LEVEL * w.cap * sizeof(uint16_t) + 255) & ~(uint64_t)255;
 	w.total = w.spill + (uint64_t)w.spill_cap * sizeof(SpillEntry);
@@ -1005,14 +1021,10 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	char *ws = (char *)workspace;
 	uint32_t *cursors = use_bins ? (uint32_t *)(ws + wl.cursors) : nullptr;
 	uint32_t *absmax = use_bins ? (uint32_t *)(ws + wl.absmax) : nullptr;
-	uint32_t *spill_count = use_bins ? absmax + 16 : nullptr;
+	uint32_t *spill_count = use_bins ? absmax + 16u * ABSMAX_PARTS : nullptr;
 	void *rec_val = use_bins ? (void *)(ws + wl.rec_val) : nullptr;
 	uint16_t *rec_idx = use_bins ? (uint16_t *)(ws + wl.rec_idx) : nullptr;
 	SpillEntry *spill = use_bins ? (SpillEntry *)(ws + wl.spill) : nullptr;
-	if (use_bins && bp.n_levels) {
-		hipError_t e = hipMemsetAsync(cursors, 0, 4096 + 256, s);       // cursors, abs-max, spill count.  (zero_first needs no memset of the binned levels: phase B overwrites them)
-		if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; }
-	}
 	{ const char *e = getenv("NGP_PROBE_LEVEL_MASK"); plan.level_mask = e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffu; }
 	{ const char *e = getenv("NGP_PROBE_COARSE_RES"); plan.coarse_res = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }
 	for (int l = 0; l < 16; ++l) {                                       // chunked levels without slabs are flushed with atomics -> need a zeroed destination
@@ -1035,7 +1047,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	if (level_scratch) NGP_LAUNCH((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
 	hipStream_t sd = s; \
 	if (use_bins && bp.n_levels) { \
-		NGP_LAUNCH((k_level_absmax<T, L>), dim3(32, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid); \
+		NGP_LAUNCH((k_level_absmax<T, L>), dim3(ABSMAX_PARTS, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid, cursors, spill_count);   /* also zeroes the cursors and the spill count */ \
 		if (units && side.ok) { hipEventRecord(side.fork, s); sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* the scan of the remaining levels runs beside the binning kernels */ \
 		if (!probe_skip_bins) { \
 		if (n_runs) { SET_LDS((k_bin_records_runs<T, L>), run_stage_bytes(8192u)); \
