@@ -1003,10 +1003,9 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		if (in_bins[l] || level_exclusive(lt, l)) continue;
 		// Sample chunks per slice of a level without an exclusive owner.  A unit (slice, chunk) pays a fixed price - clear and flush 128 KiB of LDS, one partial
 		// slab to write and later re-read - and holds a whole CU while it runs.  Small, heavily contended coarse levels want many short units, large levels few
-		// long ones: with slabs 144 / slices clamped to [8, 32] (swept on fox- and lego-like batches, tools/probe_owner_levels.py).
+		// long ones: with slabs 144 / slices clamped to [8, 32] (swept on fox- and lego-like batches when this scan still carried the dense levels of the training path).
 		uint32_t c = use_slabs ? 144u / slices[l] : (32u / slices[l] ? 32u / slices[l] : 1u);
 		if (use_slabs && c < 8u) c = 8u;
-		{ const char *e = getenv("NGP_PROBE_DENSE_CHUNKS"); if (e && use_slabs) { int v[16]; int kk = sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7); if (l < kk) c = (uint32_t)v[l]; } }   // tools/probe_owner_levels.py
 		plan.chunks[l] = c > 32u ? 32u : (use_slabs && c < 2u ? 2u : c);          // with slabs >= 2: the exclusive-owner (chunks == 1) branch does not write slabs
 		if (use_slabs) { plan.slab_off[l] = (uint32_t)slab_cursor; slab_cursor += (uint64_t)plan.chunks[l] * lt.v[4 * l + 1]; }
 	}
