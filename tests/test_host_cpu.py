@@ -199,3 +199,55 @@ def test_constant_step_chain_closed_form_is_bit_identical_to_the_serial_sum():
             for k in range(257):
                 serial[k] = t; t = f32(t + dt)
             assert np.array_equal(closed(t0, 256, dt), serial), (float(dt), float(t0))
+
+
+def test_parallel_walk_guess_is_accepted_only_when_it_is_the_orbit():
+    """The claim k_march_wave's walk rests on (csrc/sampler.hip): candidates c of a round continue at nx[c] > c; the visited ones are the orbit of the start s.
+    G[c] = (c == s) or (c > s and max(nx[s..c-1]) == c) is computed with a prefix maximum; it is ACCEPTED only if every member of G before the first member
+    outside the box continues at the next member of G.  Property checked on random link arrays (runs of equal targets with fuzz, like candidates of one empty
+    cell): whenever the check accepts, G (up to that first outside member) equals the serial orbit; and a plain successor chain is always accepted."""
+    rng = np.random.default_rng(7)
+    NC = 256
+    accepted = rejected = 0
+    for trial in range(3000):
+        # links: blocks of candidates that jump to (about) the block's end, or step to their successor
+        nx = np.arange(1, NC + 1)
+        c = 0
+        while c < NC:
+            ln = int(rng.integers(1, 14))
+            if rng.random() < 0.6:                                     # an "empty cell": everyone lands just past it, with occasional one-off fuzz
+                land = min(NC, c + ln)
+                for p in range(c, min(NC, c + ln)):
+                    nx[p] = min(NC, max(p + 1, land + (int(rng.integers(-1, 2)) if rng.random() < 0.004 else 0)))
+            c += ln
+        inside = np.ones(NC, bool)
+        first_out = int(rng.integers(NC // 2, NC + 40))
+        inside[first_out:] = False
+        nx[~inside] = np.arange(1, NC + 1)[~inside]
+        s = int(rng.integers(0, 20))
+        orbit, v = [], s
+        while v < NC:
+            orbit.append(v)
+            if not inside[v]:
+                break
+            v = int(nx[v])
+        pm = np.maximum.accumulate(np.where(np.arange(NC) >= s, nx, 0))
+        G = [c for c in range(s, NC) if c == s or pm[c - 1] == c]
+        fo = next((c for c in G if not inside[c]), NC)
+        ok = True
+        for k, c in enumerate(G):
+            if c >= fo or not inside[c]:
+                break
+            ng = G[k + 1] if k + 1 < len(G) else NC
+            if ng != nx[c]:
+                ok = False
+                break
+        if ok:
+            accepted += 1
+            assert [c for c in G if c <= fo] == orbit, (trial, s)
+        else:
+            rejected += 1
+    assert accepted > 500 and rejected > 100, (accepted, rejected)       # both branches were exercised
+    nx = np.arange(1, NC + 1)                                           # every candidate occupied: G is everything, accepted
+    pm = np.maximum.accumulate(nx)
+    assert all(pm[c - 1] == c for c in range(1, NC))
