@@ -72,6 +72,42 @@ def _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar, fp16, cons
     timed("adam_ema", lambda: O.adam_ema_step(p, g[:npar].astype(np.float32), m, v, e, 0.1, 1))
 
 
+def _ref_stage_times(O, table, offsets, n_params, grid, bits, aabb, aabb_scale, fp16, const_dt, n=1 << 15, n_rays=512):
+    """The reference's OWN kernels (oracle/_ref: its op_header/*.h compiled for the host by oracle/ref_shim, serial launcher) timed on one core for the stages that exist
+    as compilable source - marcher, hash encode forward / backward, compositing forward / backward - on a bounded sample, with the port (oracle/ngp_oracle.c) timed on
+    the SAME inputs beside it.  The fused MLP (binary-only in the reference) and Adam (Jittor's) have no reference build: the whole-iteration `value` stays the port's."""
+    import numpy as np
+    try:
+        from oracle import ref as R
+        if not R.available():
+            return {"skipped": "oracle/_ref is not built on this host (it is built where /root/reference exists and travels with the snapshot)"}
+    except Exception as e:                     # pragma: no cover
+        return {"skipped": repr(e)}
+    import synth
+    inp = _cpu_inputs(n, n_rays, n_rays, seed=11, aabb=aabb)
+    x, coords, ns, bg = inp["x"], inp["coords"], inp["ns"], inp["bg"]
+    T = np.float16 if fp16 else np.float32
+    dy = (np.random.default_rng(5).standard_normal((n, 32)) * 1e-3).astype(T)
+    out = np.random.default_rng(6).standard_normal((n, 4)).astype(T)
+    meta = np.zeros((1, 11), np.float32); ids = np.zeros(n_rays, np.uint32); xf = np.zeros((1, 4, 3), np.float32)
+    ref_ms, port_ms = {}, {}
+
+    def t(d, name, fn):
+        ts = time.perf_counter(); r = fn(); d[name] = round((time.perf_counter() - ts) * 1e3, 2); return r
+    t(ref_ms, "march", lambda: R.march(inp["ro"], inp["rd"], bits, aabb, R.PCG32(1337).st, 4096 * 1024, meta, ids, xf, const_dt=const_dt))
+    t(port_ms, "march", lambda: O.march_rays(inp["ro"], inp["rd"], bits, aabb, O.PCG32(1337), 4096 * 1024, const_dt=const_dt))
+    t(ref_ms, "hash_fwd", lambda: R.hash_fwd(x, grid, offsets, aabb_scale))
+    t(port_ms, "hash_fwd", lambda: O.hash_encode_fwd(x, grid, table))
+    t(ref_ms, "hash_bwd", lambda: R.hash_bwd(x, dy, offsets, aabb_scale, n_params))
+    t(port_ms, "hash_bwd", lambda: O.hash_encode_bwd(x, dy, table, n_params))
+    rgb = t(ref_ms, "composite_fwd", lambda: R.rgb_fwd(out, coords, ns, ns, bg, aabb))
+    t(port_ms, "composite_fwd", lambda: O.composite_fwd(out, coords, ns, ns, bg))
+    t(ref_ms, "composite_bwd", lambda: R.rgb_bwd(out, coords, ns, (rgb - bg).astype(np.float32), rgb, 0.001, aabb))
+    t(port_ms, "composite_bwd", lambda: O.composite_bwd(out, coords, ns, (rgb - bg).astype(np.float32), rgb, 0.001))
+    return {"kind": "reference", "cores": 1, "sample": f"{n_rays} rays marched through the shell bitfield; {n} samples ({n_rays} rays x {n // n_rays}) through hash encode fwd/bwd and compositing fwd/bwd",
+            "stage_ms": ref_ms, "port_stage_ms_same_inputs": port_ms}
+
+
 def cpu_baseline(aabb_scale, fp16, const_dt, n_samples=1 << 18, n_rays=4096, n_march_rays=4096):
     """The oracle (plain-C port of the reference's kernels) on ONE training iteration of the bench workload's shape, on this host's cores: the iteration is split
     into `cores` independent ray/sample slices that run concurrently (one thread each; the hash-table gradient and the parameter sweep are sliced the same
@@ -101,6 +137,7 @@ def cpu_baseline(aabb_scale, fp16, const_dt, n_samples=1 << 18, n_rays=4096, n_m
     _cpu_iteration(O, whole, table, n_params, grid, wd, wc, bits, npar, fp16, const_dt, stages)
     t_one = time.perf_counter() - t0
     return {"value": round(frac / t_par, 4), "unit": "iters/s", "cores": cores, "kind": "port", "single_core_value": round(frac / t_one, 4), "single_core_stage_ms": stages,
+            "reference_kernels": _ref_stage_times(O, table, offsets, n_params, grid, bits, aabb, aabb_scale, fp16, const_dt),
             "sample": f"one training iteration of the bench workload's shape ({'fp16' if fp16 else 'fp32'} table, aabb_scale {aabb_scale}, const_dt {const_dt}): {m_rays} rays marched through a "
                       f"shell bitfield, {n_samples} samples through hash fwd/bwd, SH, both MLPs fwd/bwd, compositing fwd/bwd, Huber; Adam+EMA on {npar} of {n_params} parameters "
                       f"(occupancy-grid refresh not included); {t_par:.1f} s on {cores} cores ({cores} concurrent slices), {t_one:.1f} s on 1 core"}
@@ -129,8 +166,14 @@ def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
         "k_grid_generate": n_refresh * (4 + 16), "k_grid_splat": n_refresh * (4 + T + 4), "k_grid_ema": 5 * 128 ** 3 * 12, "k_grid_mean": 128 ** 3 * 4, "k_grid_to_bitfield": 5 * 128 ** 3 * 4.125,
         "k_bitfield_max_pool": 128 ** 3 / 8 * 1.125, "k_refresh_fused": n_refresh * (4 + 16 * 8 * 2 * T + 4),
     }
-    flops = {"k_field_fwd": 20480.0 * n, "k_field_bwd": 61440.0 * n, "k_field32_fwd": 20480.0 * n, "k_field32_bwd": 61440.0 * n}
+    # 20 480 FLOP / sample forward, 40 960 backward.  (The backward kernels also RECOMPUTE the forward - 61 440 executed - which is the kernel's own
+    # choice, not algorithmic work: `roofline.frac` is on the §8(d) figure, the executed figure is reported next to it.)
+    flops = {"k_field_fwd": 20480.0 * n, "k_field_bwd": 40960.0 * n, "k_field32_fwd": 20480.0 * n, "k_field32_bwd": 40960.0 * n}
     return d, flops
+
+
+EXECUTED_FLOPS_PER_SAMPLE = {"k_field_fwd": 20480.0, "k_field_bwd": 61440.0, "k_field32_fwd": 20480.0, "k_field32_bwd": 61440.0}
+HASH_BWD_STAGE = ("k_level_absmax", "k_bin_records_runs", "k_bin_records", "k_bin_accumulate")
 
 
 def main():
@@ -148,15 +191,25 @@ def main():
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event brackets (then no roofline object)")
     ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: still create the process group and run the data-parallel sequence (RCCL all-reduce at world size 1)")
+    ap.add_argument("--dp-overlap", action="store_true", help="data parallel: two gradient buckets, the coarse levels' reduce-scatter on the library's communication stream under the fine levels' accumulate")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched the way the driver launches N = 1 (`python bench.py --gpus N ...`, no torchrun): spawn the N ranks ourselves, one process per GPU, and hand their
+        # output through (rank 0 prints the JSON line)
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus})"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {args.gpus}, or without WORLD_SIZE in the environment)"
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
@@ -178,7 +231,7 @@ def main():
     res = args.res or (800 if lego else 400)
     share = world if args.scaling == "strong" else 1
     ngp_cfg(fp16=fp16, aabb_scale=aabb_scale, const_dt=const_dt, n_images=n_images, W=res, H=res, device=f"cuda:{local_rank}", rank=rank, world_size=world,
-            target_batch_size=(1 << 18) // share, n_rays_per_batch=4096 // share, dp_force_collectives=bool(args.force_dist),
+            target_batch_size=(1 << 18) // share, n_rays_per_batch=4096 // share, dp_force_collectives=bool(args.force_dist), dp_overlap=bool(args.dp_overlap),
             **json.loads(os.environ.get("BENCH_EXTRA_CFG", "{}")))       # probe hook: extra config keys as JSON, e.g. {"pipeline_sampling": false}
     runner = Runner()
     import contextlib
@@ -226,7 +279,7 @@ def main():
             else:
                 cur.append(x)
         classes.append(cur)
-        return max(classes, key=sum)                    # the size class that carries most of the kernel's time
+        return max(classes, key=lambda c: (len(c), sum(c)))     # the size class with the most launches (ties: the one that carries more time) - a few slow outliers must not win
     dom = max(per_step, key=lambda k: per_step[k]) if per_step else None
     # ---- warm-up + timed region: only the dominant kernel keeps its bracket
     for _ in range(args.warmup):
@@ -263,26 +316,49 @@ def main():
         avg_ms = max(avg_raw - ev_overhead, 1e-6)
         nbytes = float(alg.get(dom, 0.0))
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
-        traffic = None      # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside this process): profiles/r02_pmc.json
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-            traffic = pm.get(args.config, {}).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+        # HBM bytes per launch: rocprofv3 cannot run inside this process, so this is a LOOK-UP in the committed --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+        # command (tools/collect_profiles.sh), newest round first; `traffic_source` says which file (null = no such pass committed)
+        traffic, traffic_source, counters = None, None, {}
+        for tag in ("r03", "r02"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
+                ent = pm.get(args.config, {}).get(dom, {})
+                if ent.get("hbm_bytes_per_launch") is not None:
+                    traffic, traffic_source, counters = ent["hbm_bytes_per_launch"], f"profiles/{tag}_pmc.json (rocprofv3 --pmc passes of this command; not measured in this run)", ent
+                    break
+            except Exception:
+                pass
         hbm = {"achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4)}
         if dom in flops:    # the fused field kernels are MFMA work (fp16 16x16x32: dense peak 2.5 PFLOP/s; fp32 16x16x4: 157.3 TFLOP/s); their HBM side is reported next to it
             peak = 2500.0 if fp16 else 157.3
             tf = flops[dom] / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "hbm": hbm}
+            tf_exec = EXECUTED_FLOPS_PER_SAMPLE[dom] * mean_valid / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "hbm": hbm,
+                    "alg_flop_per_sample": flops[dom] / mean_valid, "executed_flop_per_sample": EXECUTED_FLOPS_PER_SAMPLE[dom],
+                    "executed_frac": round(tf_exec / peak, 4),                      # counts the in-kernel forward recompute of the backward as work
+                    "issued_frac": counters.get("mfma_issued_frac"), "pipe_util": counters.get("mfma_pipe_util")}   # from the committed MFMA-counter pass (same source file as `traffic`), null if absent
         else:
             roof = dict(bound="hbm", **hbm)
-        roof.update({"kernel": dom, "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_raw": round(avg_raw, 4), "event_pair_overhead_ms": round(ev_overhead, 4),
+        # the hash-backward STAGE is four launches under four kernel names (abs-max, two record passes, accumulate): one roofline for the stage, from the probe steps
+        stage = None
+        if all(k in probe_ms for k in HASH_BWD_STAGE):
+            st_ms = sum(max(sum(batch_class(probe_ms[k])) / len(batch_class(probe_ms[k])) - ev_overhead, 0.0) for k in HASH_BWD_STAGE)
+            T_ = 2 if fp16 else 4
+            st_bytes = mean_valid * (12 + 32 * T_ + 16 * 8 * 2 * 4)                 # §8(d): pos + dL/dy + 128 scattered fp32 updates per sample
+            stage = {"name": "hash_backward", "kernels": list(HASH_BWD_STAGE), "ms": round(st_ms, 4), "alg_bytes": int(st_bytes), "achieved": round(st_bytes / (st_ms * 1e-3) / 1e9, 1),
+                     "peak": 8000.0, "unit": "GB/s", "frac": round(st_bytes / (st_ms * 1e-3) / 8e12, 4)}
+        roof.update({"kernel": dom, "traffic": traffic, "traffic_source": traffic_source, "stage": stage, "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_raw": round(avg_raw, 4), "event_pair_overhead_ms": round(ev_overhead, 4),
                      "launches_timed": len(cls), "launches_other_size_class": len(dom_ms) - len(cls), "alg_bytes_per_launch": int(nbytes),
                      "share_of_kernel_time": round(per_step[dom] / max(sum(per_step.values()), 1e-9), 4),
                      "ms_per_step_by_kernel": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}})
 
     extra = {"mean_samples_per_batch": round(mean_valid, 1), "rays_per_batch": runner.sampler.n_rays_per_batch, "burn_in_steps": args.burn_in, "probe_steps": probe,
              "native_step": bool(getattr(runner, "_fast", None) and runner._fast.native), "fast_path": bool(getattr(runner, "_fast", None))}
+    # fingerprint of the trained parameters (double-precision sums): equal between a non-distributed run and the world-size-1 data-parallel run of the same seed in
+    # fp32 mode - the exchange step adds no arithmetic (tests/test_train_gpu.py)
+    from jnerf_amd import optim as _optim0
+    _optim0.flush_all(); _optim0.sync_all_sharded()
+    extra["param_signature"] = [float(p.detach().double().sum().item()) for p in runner.model.parameters()] + [float(p.detach().double().abs().sum().item()) for p in runner.model.parameters()]
     if probe_ms:        # every kernel against its roofline, from the probe steps (training-batch size class)
         pk = {}
         for k, v in probe_ms.items():
@@ -313,11 +389,14 @@ def main():
         # data-parallel invariant: every rank must hold bit-identical parameters (identical summed gradients + a deterministic sweep)
         from jnerf_amd import optim as _optim
         _optim.flush_all()
+        _optim.sync_all_sharded()            # the sharded sweep keeps Adam moments (fp16 mode: the fp32 masters too) on their owner's shard: collect them before comparing
         sig = torch.stack([p.detach().double().sum() for p in runner.model.parameters()] + [p.detach().double().abs().sum() for p in runner.model.parameters()])
         sigs = [torch.empty_like(sig) for _ in range(world)]
         dist.all_gather(sigs, sig)
         extra["replicas_identical"] = bool(all(torch.equal(sigs[0], x) for x in sigs))
         dist.barrier()
+        extra["dp"] = {"exchange": "rccl in-library: reduce-scatter -> sharded sweep -> all-gather" if (dist.get_backend() == "nccl") else "host all-reduce between the two phases of the native step",
+                       "overlap": bool(args.dp_overlap)}
     if rank == 0 and not use_dist and not args.no_fox:
         del runner
         torch.cuda.empty_cache()
@@ -333,6 +412,8 @@ def main():
                 "roofline": roof, "cpu_baseline": None if (args.no_cpu_baseline or use_dist) else cpu_baseline(aabb_scale, fp16, const_dt), "extra": extra}
         print(json.dumps(line), flush=True)
     if use_dist:
+        from jnerf_amd import dp as _dp
+        _dp.destroy()
         dist.destroy_process_group()
 
 

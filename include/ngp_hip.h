@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NGP_ABI_VERSION 1
+#define NGP_ABI_VERSION 2
 enum { NGP_F32 = 0, NGP_F16 = 1 };
 enum { NGP_E_ARG = -1, NGP_E_DTYPE = -2, NGP_E_ALIGN = -3, NGP_E_CAPACITY = -4 };
 /* feature-tensor layouts between the encoder and the MLP */
@@ -179,13 +179,39 @@ int ngp_generate_rays(void *stream, uint32_t n, const int64_t *pixel_index, int 
                       const float *xforms, const float *images /*[n_img*H*W,4] or NULL*/, const float *bg /*[n,3] or NULL*/,
                       int32_t *img_id, float *rays_o, float *rays_d, float *target /*[n,3] or NULL*/);
 
+/* ---- data parallelism: ray batches shard over the GPUs of one node, gradients are summed over RCCL / xGMI (north_star).  The reference has no
+ * collective call sites (its only multi-process hook is utils/general.py:39-40), so these have no jt.code counterpart; a Jittor host would call them from the same
+ * place this repo's optimiser does (optims/adam.py: between backward and the parameter update).  RCCL is bound with dlopen at the first call (librccl.so.1 - the
+ * copy the host framework already mapped - or $NGP_RCCL_PATH); the library has no link-time dependency on it.  Return codes: 1000 + ncclResult_t for RCCL errors. */
+#define NGP_COMM_ID_BYTES 128
+#define NGP_DP_COARSE_RES_MAX 300           /* levels up to this resolution form the first bucket (== the scatter's run-combined levels) */
+/* rank 0: ncclGetUniqueId into id_out_host[NGP_COMM_ID_BYTES]; the host distributes it (this repo: a broadcast over the host framework's process group) */
+int ngp_comm_unique_id(void *id_out_host);
+/* every rank, with its device current: ncclCommInitRank.  *comm_out is an opaque handle for the calls below */
+int ngp_comm_init(void **comm_out, int rank, int world, const void *id_host);
+int ngp_comm_destroy(void *comm);
+int ngp_comm_rank_world(void *comm, int *rank_out, int *world_out);
+/* SUM all-reduce, in place, of n_bufs gradient buffers (device pointers in a HOST array; counts in elements; dtypes NGP_F32 | NGP_F16) as one RCCL group on `stream` */
+int ngp_allreduce_grads(void *comm, void *stream, int n_bufs, void *const *bufs_host, const uint64_t *counts_host, const int *dtypes_host);
+/* How a table of n_params elements is dealt to `world` ranks: up to two buckets [cut[b], cut[b+1]) whose boundaries are multiples of 8*world elements, each
+ * split into `world` equal shards (rank r owns [cut[b] + r*shard_count[b], +shard_count[b])), and a replicated tail [tail_begin, n_params) of < 8*world elements.
+ * With n_buckets == 2 the boundary is the first element of the first level finer than NGP_DP_COARSE_RES_MAX, rounded down (cut_level = that level).  Pure host code. */
+typedef struct NgpDpPlan {
+	uint64_t cut[3]; uint64_t shard_begin[2], shard_count[2]; uint64_t tail_begin, tail_count;
+	uint32_t n_buckets; int32_t cut_level; int32_t world, rank;
+} NgpDpPlan;
+int ngp_dp_plan(const uint32_t *level_table_host, uint64_t n_params, int world, int rank, int n_buckets, NgpDpPlan *out_host);
+/* all-gather, in place, of every rank's shards of n_bufs buffers laid out like the table (parameters every step; masters and Adam moments before a checkpoint) */
+int ngp_dp_allgather(void *comm, void *stream, const NgpDpPlan *plan_host, int n_bufs, void *const *bufs_host, const int *dtypes_host);
+
 /* ---- one training iteration's launch sequence, issued from native code -------------------------------------------------------------------
  * The body of Runner.train for one already-sampled batch (runner/runner.py:71-76: model(pos, dir) -> sampler.rays2rgb -> HuberLoss ->
  * optimizer.step -> ema_optimizer.ema_step), i.e. exactly these calls in this order on `stream`:
  *   ngp_field_pack_weights, ngp_hash_encode_fwd, ngp_field_fwd, ngp_composite_fwd_huber, ngp_composite_bwd, ngp_field_bwd, ngp_reduce_slabs,
  *   ngp_hash_encode_bwd_ws, then (run_optimizer != 0) ngp_adam_ema_step for each of the n_opt parameter tensors.
  * It exists because eleven separate FFI crossings per iteration cost the host more than the GPU needs for the work; it adds no arithmetic
- * of its own.  fp16 network, level-major features.  Data-parallel callers pass run_optimizer = 0, all-reduce the gradients, and sweep afterwards. */
+ * of its own.  Level-major features.  Data-parallel callers hand over a communicator (the exchange step then runs inside, see `comm` below) or split the call in phases. */
+struct NgpDpPlan;
 typedef struct NgpTrainStep {
 	uint32_t n;                 /* sample capacity of the batch buffers (2^18) */
 	uint32_t n_rays;
@@ -214,7 +240,20 @@ typedef struct NgpTrainStep {
 	/* != 0: the gradient buffers are OVERWRITTEN by this step's backward (hash scatter with zero_first, slab reduction without accumulation) and the sweep does
 	 * not zero them afterwards - 4 B/parameter less traffic than accumulate-then-zero.  0: gradients are accumulated into and zeroed by the sweep. */
 	int32_t grad_overwrite;
+	/* ---- (ABI 2) phases and data parallelism.  phase: NGP_PHASE_ALL = the whole iteration; NGP_PHASE_BACKWARD = everything up to and including the hash
+	 * scatter (gradients complete in table_grad / wgrad_flat, no sweep); NGP_PHASE_SWEEP = only the Adam+EMA sweeps.  A host that owns its own collective (gloo
+	 * in the two-ranks-on-one-GPU tests, Jittor's MPI hooks) calls BACKWARD, reduces the two gradient buffers, calls SWEEP.
+	 * comm != NULL (ngp_comm_init; phase must be NGP_PHASE_ALL): the exchange step runs inside the call on `stream` through RCCL - reduce-scatter of the table
+	 * gradient per `dp` (ngp_dp_plan), all-reduce of its tail and of wgrad_flat, sweep of this rank's shard (+ tail + every other tensor, replicated), all-gather
+	 * of the updated shard of p[dp_table] (dp_gather_master != 0) and of p_half[dp_table] (when present).  With dp_gather_master == 0 (fp16 mode: the kernels read
+	 * the shadow) the fp32 master, m and v are valid on their owner's shard only until ngp_dp_allgather collects them (checkpoint time).
+	 * grad_wire != NULL: the table gradient travels as fp16 multiplied by wire_scale (a power of two; ngp_grad_to_half_scaled into grad_wire, f16[n_params]);
+	 * the sweep divides it out.  dp_overlap != 0: two buckets - the coarse levels' reduce-scatter is issued on the library's communication stream as soon as
+	 * their accumulate launch has finished, under the fine levels' accumulate (costs four event packets per iteration; off by default). */
+	int32_t phase, dp_overlap, dp_table /* index into p[]/g[] of the hash table */, dp_gather_master;
+	void *comm; const struct NgpDpPlan *dp; void *grad_wire; float wire_scale; float pad3;
 } NgpTrainStep;
+enum { NGP_PHASE_ALL = 0, NGP_PHASE_BACKWARD = 1, NGP_PHASE_SWEEP = 2 };
 enum { NGP_STAGE_PACK = 0, NGP_STAGE_HASH_FWD, NGP_STAGE_FIELD_FWD, NGP_STAGE_COMPOSITE_FWD, NGP_STAGE_COMPOSITE_BWD, NGP_STAGE_FIELD_BWD, NGP_STAGE_REDUCE_SLABS,
        NGP_STAGE_HASH_BWD, NGP_STAGE_ADAM /* the largest parameter tensor's sweep */,
        NGP_STAGE_BOUNDARY /* not a stage: from the end of one call's last launch to the start of the next call's first launch (main-stream idle + waits) */ };

@@ -27,7 +27,18 @@ class NgpTrainStep(C.Structure):
                 ("huber_delta", _f32), ("pad1", _f32), ("rgb", _vp), ("loss", _vp), ("loss_grad", _vp),
                 ("n_opt", _i32), ("step", _u32), ("lr", _f32), ("beta0", _f32), ("beta1", _f32), ("eps", _f32), ("ema_decay", _f32), ("pad2", _f32),
                 ("p", _vp * 4), ("g", _vp * 4), ("m", _vp * 4), ("v", _vp * 4), ("ema", _vp * 4), ("p_half", _vp * 4), ("numel", _u64 * 4),
-                ("timed_stage", _i32), ("grad_overwrite", _i32)]
+                ("timed_stage", _i32), ("grad_overwrite", _i32),
+                ("phase", _i32), ("dp_overlap", _i32), ("dp_table", _i32), ("dp_gather_master", _i32), ("comm", _vp), ("dp", _vp), ("grad_wire", _vp), ("wire_scale", _f32), ("pad3", _f32)]
+
+
+PHASE_ALL, PHASE_BACKWARD, PHASE_SWEEP = 0, 1, 2      # NGP_PHASE_*
+COMM_ID_BYTES = 128
+
+
+class NgpDpPlan(C.Structure):
+    """mirror of `struct NgpDpPlan` (ngp_dp_plan): how the hash table is dealt to the ranks of a data-parallel run"""
+    _fields_ = [("cut", _u64 * 3), ("shard_begin", _u64 * 2), ("shard_count", _u64 * 2), ("tail_begin", _u64), ("tail_count", _u64),
+                ("n_buckets", _u32), ("cut_level", _i32), ("world", _i32), ("rank", _i32)]
 
 
 class NgpRenderChunk(C.Structure):
@@ -87,6 +98,13 @@ SIGNATURES = {
     "ngp_adam_ema_step": (C.c_int, [_vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _f32, _i32]),
     "ngp_prof_enable": (C.c_int, [C.c_char_p]),
     "ngp_prof_read": (C.c_int, [_i32, _vp, _i32, _vp, _i32]),
+    "ngp_comm_unique_id": (C.c_int, [_vp]),
+    "ngp_comm_init": (C.c_int, [C.POINTER(_vp), _i32, _i32, _vp]),
+    "ngp_comm_destroy": (C.c_int, [_vp]),
+    "ngp_comm_rank_world": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ngp_allreduce_grads": (C.c_int, [_vp, _vp, _i32, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_i32)]),
+    "ngp_dp_plan": (C.c_int, [_vp, _u64, _i32, _i32, _i32, C.POINTER(NgpDpPlan)]),
+    "ngp_dp_allgather": (C.c_int, [_vp, _vp, C.POINTER(NgpDpPlan), _i32, C.POINTER(_vp), C.POINTER(_i32)]),
     "ngp_generate_rays": (C.c_int, [_vp, _u32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -105,7 +123,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_lib, name)       # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
-        if _lib.ngp_abi_version() != 1:
+        if _lib.ngp_abi_version() != 2:
             raise RuntimeError("libngp_hip.so ABI version mismatch")
     return _lib
 

@@ -504,6 +504,7 @@ static int hash_bwd_method() {
 #define BINS_PER_LEVEL 64u
 #define BIN_LEVEL_MAX (BIN_ENTRIES * BINS_PER_LEVEL)                  // 2^19 entries: the largest level the bins cover
 #define RUN_RES_MAX 300u                                              // levels up to this resolution go through k_bin_records_runs
+static_assert(RUN_RES_MAX == NGP_DP_COARSE_RES_MAX, "the data-parallel bucket boundary (ngp_dp_plan) is the boundary between the run-combined and the fine levels");
 struct BinPlan { uint32_t level[16]; uint32_t n_levels; uint32_t cap; uint32_t spill_cap; };   // binned levels, records per bin, entries of the spill list
 struct LevelSel { uint32_t hl[16]; };                                  // the binned-level ordinals one launch works on (blockIdx.y, or blockIdx.x / 64)
 struct SpillEntry { uint32_t key /* binned-level ordinal << 19 | entry */; float x, y; };       // value in record units (fp16 records: scaled)
@@ -944,7 +945,8 @@ struct SideStream {
 };
 
 static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
-                         void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, float *level_scratch, void *workspace, uint64_t workspace_bytes) {
+                         void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, float *level_scratch, void *workspace, uint64_t workspace_bytes,
+                         hipEvent_t after_coarse = nullptr /* data parallel, overlapped exchange: recorded behind the accumulate launch of the run-combined (coarse) levels, which then is a launch of its own */) {
 	NGP_REQUIRE(grad && level_table_host && (n == 0 || (pos && dLdy)), NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_bwd: bad dtype %d", dtype);
 	NGP_REQUIRE(grad_dtype == NGP_F32 || (grad_dtype == NGP_F16 && dtype == NGP_F16), NGP_E_DTYPE, "ngp_hash_encode_bwd: bad grad dtype %d for dtype %d", grad_dtype, dtype);
@@ -963,7 +965,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 			hipError_t e = hipMemsetAsync(grad, 0, n_params * gsz, s);
 			if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd memset: %s", hipGetErrorString(e)); return (int)e; }
 		}
-		if (n == 0) return 0;
+		if (n == 0) { if (after_coarse) hipEventRecord(after_coarse, s); return 0; }
 		const uint32_t nblk = div_up(n, 256);
 		const dim3 grid(16 * nblk), block(256);
 #define GO(T, G, L) NGP_LAUNCH((k_hash_bwd<T, G, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)dLdy, lt, (G *)grad, nblk, n_valid)
@@ -972,6 +974,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		else { if (in_layout == NGP_LAYOUT_SOA) GO(__half, __half, NGP_LAYOUT_SOA); else GO(__half, __half, NGP_LAYOUT_AOS); }
 #undef GO
 		NGP_LAUNCH_CHECK("ngp_hash_encode_bwd");
+		if (after_coarse) hipEventRecord(after_coarse, s);
 		return 0;
 	}
 	// ---- which levels go where.  With the full workspace and no fixed-point request: every level of up to 2^19 entries through the bins (coarse ones with run
@@ -1038,6 +1041,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	const dim3 grid(units), block(1024);
 	const bool probe_skip_bins = getenv("NGP_PROBE_SKIP_BINS") != nullptr;      // tools/probe_scatter.py: time the scan kernel alone
 	const int ow = zero_first ? 1 : 0;
+	bool coarse_marked = false;
 #define SET_LDS(K, BYTES) do { static bool done_ = false; if (!done_) { hipError_t e = hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
 	if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } done_ = true; } } while (0)
 #define GO(T, G, L) do { \
@@ -1053,12 +1057,13 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 			NGP_LAUNCH((k_bin_records_runs<T, L>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(run_stage), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, run_stage); } \
 		if (n_fine) { SET_LDS((k_bin_records<T, L>), bin_stage_bytes<T>()); \
 			NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, BIN_WG), n_fine), dim3(BIN_WG), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_fine, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid); } \
-		if (sizeof(RV_) == 8) {                                  /* fp32: run records and fine records have the same type - one accumulate launch over all levels */ \
+		if (sizeof(RV_) == 8 && !(after_coarse && n_runs && n_fine)) {   /* fp32: run records and fine records have the same type - one accumulate launch over all levels */ \
 			SET_LDS((k_bin_accumulate<G, float2>), BIN_ENTRIES * 16); \
 			NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
 		} else { \
 			if (n_runs) { SET_LDS((k_bin_accumulate<G, float2>), BIN_ENTRIES * 16); \
-				NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_runs * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_runs, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); } \
+				NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_runs * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_runs, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
+				if (after_coarse && n_fine) { hipEventRecord(after_coarse, s); coarse_marked = true; } } \
 			if (n_fine) { SET_LDS((k_bin_accumulate<G, RV_>), BIN_ENTRIES * 16); \
 				NGP_LAUNCH((k_bin_accumulate<G, RV_>), dim3(n_fine * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_fine, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); } \
 		} } \
@@ -1072,7 +1077,14 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 #undef GO
 #undef SET_LDS
 	NGP_LAUNCH_CHECK("ngp_hash_encode_bwd");
+	if (after_coarse && !coarse_marked) hipEventRecord(after_coarse, s);      // no separate coarse launch on this path: the marker follows the whole scatter
 	return 0;
+}
+
+// the workspace path with the data-parallel marker (csrc/train_step.hip); not part of the public ABI
+int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host, void *grad, uint64_t n_params, int dtype,
+                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse) {
+	return hash_bwd_impl(stream, n, pos, pos_stride, dLdy, level_table_host, grad, n_params, dtype, grad_dtype, in_layout, zero_first, n_valid, nullptr, workspace, workspace_bytes, after_coarse);
 }
 
 NGP_API int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,

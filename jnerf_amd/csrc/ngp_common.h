@@ -24,6 +24,11 @@ struct NgpProfScope { int id; hipStream_t s; hipEvent_t a, b; NgpProfScope(int i
 	NgpProfScope ngp_ps_(ngp_kid_, (hipStream_t)(stream)); \
 	hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
 
+// internal cross-file entry points (not exported)
+int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host, void *grad, uint64_t n_params, int dtype,
+                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse);
+int ngp_dp_reduce(void *comm, hipStream_t s, const NgpDpPlan *plan, void *grad, int dtype, uint32_t first_bucket, uint32_t last_bucket, float *tail_f32, float *extra_f32, uint64_t extra_count);
+
 struct LevelTable { uint32_t v[64]; };   // [16][4] = offset, size, res, scale bits — passed by value (256 B of kernarg)
 
 // ------------------------------------------------------------------ pcg32 (ops/op_include/pcg32/pcg32.h semantics)

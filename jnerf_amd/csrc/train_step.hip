@@ -46,21 +46,56 @@ NGP_API int ngp_train_step_timings(float *ms_out, int max) {
 	return n;
 }
 
+// ---- data parallel, overlapped variant: the library's communication stream and the two markers of one iteration (created on first use, per process)
+namespace {
+struct DpSide {
+	hipStream_t stream = nullptr; hipEvent_t coarse = nullptr, reduced = nullptr; bool ok = false;
+	DpSide() {
+		ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&coarse, hipEventDisableTiming) == hipSuccess &&
+		     hipEventCreateWithFlags(&reduced, hipEventDisableTiming) == hipSuccess;
+	}
+};
+}  // namespace
+
+// one Adam+EMA sweep over elements [off, off + cnt) of optimiser tensor t (gradient: the fp32 buffer, or the fp16 wire buffer with its scale divided out)
+static int sweep_range(void *stream, const NgpTrainStep *a, int t, uint64_t off, uint64_t cnt, bool wire, int zero_grad) {
+	if (!cnt) return 0;
+	void *g = wire ? (void *)((__half *)a->grad_wire + off) : (void *)(a->g[t] + off);
+	return ngp_adam_ema_step_scaled(stream, cnt, a->p[t] + off, g, wire ? NGP_F16 : NGP_F32, a->m[t] + off, a->v[t] + off, a->ema[t] ? a->ema[t] + off : nullptr,
+	                                a->p_half[t] ? (void *)((__half *)a->p_half[t] + off) : nullptr, a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, zero_grad,
+	                                wire ? 1.0f / a->wire_scale : 1.0f);
+}
+
 NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	NGP_REQUIRE(a, NGP_E_ARG, "ngp_train_step: null argument block");
 	NGP_REQUIRE(a->n_opt >= 0 && a->n_opt <= 4, NGP_E_ARG, "ngp_train_step: n_opt %d out of range", a->n_opt);
-	NGP_REQUIRE(a->coords && a->pos && a->numsteps && a->numsteps_compacted && a->bg && a->target && a->rgb && a->loss_grad, NGP_E_ARG, "ngp_train_step: null batch pointer");
+	NGP_REQUIRE(a->phase == NGP_PHASE_ALL || a->phase == NGP_PHASE_BACKWARD || a->phase == NGP_PHASE_SWEEP, NGP_E_ARG, "ngp_train_step: bad phase %d", a->phase);
+	NGP_REQUIRE(a->dtype == NGP_F16 || a->dtype == NGP_F32, NGP_E_DTYPE, "ngp_train_step: bad dtype %d", a->dtype);
+	const bool do_bwd = a->phase != NGP_PHASE_SWEEP, do_sweep = a->phase != NGP_PHASE_BACKWARD && a->run_optimizer;
+	const bool dp = a->comm != nullptr;
+	if (dp) {
+		NGP_REQUIRE(a->phase == NGP_PHASE_ALL && a->run_optimizer, NGP_E_ARG, "ngp_train_step: a communicator needs phase NGP_PHASE_ALL with run_optimizer");
+		NGP_REQUIRE(a->dp && a->dp_table >= 0 && a->dp_table < a->n_opt && a->g[a->dp_table] == a->table_grad, NGP_E_ARG, "ngp_train_step: data parallel needs a plan and dp_table naming the hash table among the optimiser tensors");
+		NGP_REQUIRE(a->grad_overwrite, NGP_E_ARG, "ngp_train_step: data parallel needs grad_overwrite (the reduce-scatter leaves partial sums outside the rank's shard)");
+		NGP_REQUIRE(a->dp->tail_begin + a->dp->tail_count == a->n_params, NGP_E_ARG, "ngp_train_step: plan covers %llu elements, table has %llu", (unsigned long long)(a->dp->tail_begin + a->dp->tail_count), (unsigned long long)a->n_params);
+		NGP_REQUIRE(!a->grad_wire || (a->wire_scale > 0.f), NGP_E_ARG, "ngp_train_step: wire_scale must be positive");
+	}
+	if (do_bwd) NGP_REQUIRE(a->coords && a->pos && a->numsteps && a->numsteps_compacted && a->bg && a->target && a->rgb && a->loss_grad, NGP_E_ARG, "ngp_train_step: null batch pointer");
 	const int lay = NGP_LAYOUT_SOA | NGP_WEIGHTS_PACKED;
 	const float *dirs = a->coords + 4;                       // NerfCoordinate = {pos[3], dt, dir[3]}: directions at stride 7
 	int rc;
 	hipStream_t hs = (hipStream_t)stream;
-	if (a->timed_stage == NGP_STAGE_BOUNDARY) {              // close the bracket opened at the end of the previous call
+	static DpSide *side = nullptr;
+	const bool overlap = dp && a->dp_overlap && a->dp->n_buckets == 2;
+	if (overlap && !side) { side = new DpSide(); }
+	NGP_REQUIRE(!overlap || side->ok, NGP_E_ARG, "ngp_train_step: cannot create the communication stream");
+	if (a->timed_stage == NGP_STAGE_BOUNDARY && do_bwd) {    // close the bracket opened at the end of the previous call
 		std::lock_guard<std::mutex> lk(g_mu);
 		if (g_boundary.first) { hipEventRecord(g_boundary.second, hs); g_pending.push_back(g_boundary); g_boundary = {nullptr, nullptr}; }
 	}
 #define STAGE(id, call) do { Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
-	NGP_REQUIRE(a->dtype == NGP_F16 || a->dtype == NGP_F32, NGP_E_DTYPE, "ngp_train_step: bad dtype %d", a->dtype);
 	const int T = a->dtype, ow = a->grad_overwrite != 0;
+	if (do_bwd) {
 	if (T == NGP_F16) {
 		STAGE(NGP_STAGE_PACK, ngp_field_pack_weights(stream, a->wd, a->wc, a->packed_weights));
 		STAGE(NGP_STAGE_HASH_FWD, ngp_hash_encode_fwd(stream, a->n, a->pos, 3, a->table, a->level_table_host, a->feat, NGP_F16, NGP_LAYOUT_SOA, a->n_valid));
@@ -80,19 +115,55 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		                                            a->wgrad_slabs, a->n_slabs, a->n_valid));
 	}
 	STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, ow ? 0 : 1));
-	STAGE(NGP_STAGE_HASH_BWD, ngp_hash_encode_bwd_ws(stream, a->n, a->pos, 3, a->dfeat, a->level_table_host, a->table_grad, a->n_params, T, NGP_F32, NGP_LAYOUT_SOA, ow ? 1 : 0, a->n_valid,
-	                                                 nullptr, a->hash_workspace, a->hash_workspace_bytes));
-	if (a->run_optimizer) {
+	STAGE(NGP_STAGE_HASH_BWD, ngp_hash_encode_bwd_ws_marked(stream, a->n, a->pos, 3, a->dfeat, a->level_table_host, a->table_grad, a->n_params, T, NGP_F32, NGP_LAYOUT_SOA, ow ? 1 : 0, a->n_valid,
+	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr));
+	}
+	// ---- exchange step (data parallel): every rank ends up with the summed gradient of its shard of the table, of the tail and of the MLP pack
+	const bool wire = dp && a->grad_wire != nullptr;
+	if (dp) {
+		const NgpDpPlan *pl = a->dp;
+		void *gbuf = wire ? a->grad_wire : (void *)a->table_grad;
+		const int gdt = wire ? NGP_F16 : NGP_F32;
+		auto to_wire = [&](hipStream_t st, uint32_t b) -> int {      // fp32 -> scaled fp16, bucket b only
+			const uint64_t off = pl->cut[b], cnt = pl->cut[b + 1] - pl->cut[b];
+			return ngp_grad_to_half_scaled(st, cnt, a->table_grad + off, (__half *)a->grad_wire + off, 0, a->wire_scale);
+		};
+		if (overlap) {
+			// bucket 0 (coarse levels) + the MLP gradients on the communication stream, as soon as the coarse accumulate launch has finished - under the fine levels' accumulate
+			hipStreamWaitEvent(side->stream, side->coarse, 0);
+			if (wire && (rc = to_wire(side->stream, 0))) return rc;
+			if ((rc = ngp_dp_reduce(a->comm, side->stream, pl, gbuf, gdt, 0, 0, nullptr, a->wgrad_flat, 10240))) return rc;
+			hipEventRecord(side->reduced, side->stream);
+			if (wire && (rc = to_wire(hs, 1))) return rc;
+			if ((rc = ngp_dp_reduce(a->comm, hs, pl, gbuf, gdt, 1, 1, a->table_grad, nullptr, 0))) return rc;
+			hipStreamWaitEvent(hs, side->reduced, 0);
+		} else {
+			if (wire) for (uint32_t b = 0; b < pl->n_buckets; ++b) if ((rc = to_wire(hs, b))) return rc;
+			if ((rc = ngp_dp_reduce(a->comm, hs, pl, gbuf, gdt, 0, pl->n_buckets - 1, a->table_grad, a->wgrad_flat, 10240))) return rc;
+		}
+	}
+	if (do_sweep) {
 		int largest = 0;
 		for (int t = 1; t < a->n_opt; ++t) if (a->numel[t] > a->numel[largest]) largest = t;
 		for (int t = 0; t < a->n_opt; ++t) {
 			Bracket br(hs, a->timed_stage == NGP_STAGE_ADAM && t == largest);
-			if ((rc = ngp_adam_ema_step(stream, a->numel[t], a->p[t], a->g[t], NGP_F32, a->m[t], a->v[t], a->ema[t], a->p_half[t], a->lr, a->beta0, a->beta1, a->eps,
-			                            a->step, a->ema_decay, ow ? 0 : 1))) return rc;
+			if (dp && t == a->dp_table) {                    // this rank's shards (1/N of the 28 B/parameter stream) + the replicated tail
+				const NgpDpPlan *pl = a->dp;
+				for (uint32_t b = 0; b < pl->n_buckets; ++b) if ((rc = sweep_range(stream, a, t, pl->shard_begin[b], pl->shard_count[b], wire, 0))) return rc;
+				if ((rc = sweep_range(stream, a, t, pl->tail_begin, pl->tail_count, false, 0))) return rc;
+			} else if ((rc = ngp_adam_ema_step(stream, a->numel[t], a->p[t], a->g[t], NGP_F32, a->m[t], a->v[t], a->ema[t], a->p_half[t], a->lr, a->beta0, a->beta1, a->eps,
+			                                   a->step, a->ema_decay, ow ? 0 : 1))) return rc;
 		}
 	}
+	if (dp) {                                                    // everyone gets everyone's updated shard of what the kernels read
+		const int t = a->dp_table;
+		void *bufs[2]; int dts[2]; int nb = 0;
+		if (a->dp_gather_master || !a->p_half[t]) { bufs[nb] = a->p[t]; dts[nb++] = NGP_F32; }
+		if (a->p_half[t]) { bufs[nb] = a->p_half[t]; dts[nb++] = NGP_F16; }
+		if ((rc = ngp_dp_allgather(a->comm, stream, a->dp, nb, bufs, dts))) return rc;
+	}
 #undef STAGE
-	if (a->timed_stage == NGP_STAGE_BOUNDARY) {
+	if (a->timed_stage == NGP_STAGE_BOUNDARY && a->phase != NGP_PHASE_BACKWARD) {
 		std::lock_guard<std::mutex> lk(g_mu);
 		if (!g_free.empty()) { g_boundary = g_free.back(); g_free.pop_back(); }
 		else if (hipEventCreate(&g_boundary.first) != hipSuccess || hipEventCreate(&g_boundary.second) != hipSuccess) g_boundary = {nullptr, nullptr};

@@ -1,0 +1,86 @@
+"""Ray-batch data parallelism: the host side of csrc/dp_comm.hip (the reference itself has no collective call sites).
+
+One process per GPU.  `torch.distributed` is the control plane (rendezvous, the initial parameter broadcast, the scalar of update_batch_rays, barriers); the
+per-iteration exchange step runs INSIDE libngp_hip.so through RCCL on the training stream (reduce-scatter of the hash-table gradient -> sweep of this rank's shard
+-> all-gather of the updated shard), so that a data-parallel iteration is still ONE call into the library (fastpath.py).  The library's communicator is created
+here from the process group: rank 0 draws the RCCL unique id, torch.distributed broadcasts it.  Backends without RCCL (gloo: the two-ranks-on-one-GPU tests, CPU
+unit tests) return None and the callers fall back to the phase-split step with torch.distributed collectives in between."""
+import ctypes as C
+import torch
+import torch.distributed as dist
+from . import _lib as L
+
+_comm = None          # (handle, rank, world)
+
+
+def active():
+    """gradients go through collectives: more than one rank, or `dp_force_collectives = True` in the config (a single-rank process group then runs the complete
+    data-parallel sequence - that is how the RCCL path is exercised on a one-GPU box)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    from .utils.config import get_cfg
+    return dist.get_world_size() > 1 or get_cfg().dp_force_collectives is True
+
+
+def library_comm():
+    """handle of the library's RCCL communicator over the default process group, created on first use; None when the group's backend is not nccl (= RCCL)"""
+    global _comm
+    if not active() or dist.get_backend() != "nccl" or not torch.cuda.is_available():
+        return None
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if _comm is not None and _comm[1:] == (rank, world):
+        return _comm[0]
+    lib = L.lib()
+    uid = (C.c_char * L.COMM_ID_BYTES)()
+    if rank == 0:
+        L.check(lib.ngp_comm_unique_id(uid), "ngp_comm_unique_id")
+    box = [bytes(uid.raw)]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", torch.cuda.current_device()))
+    handle = C.c_void_p()
+    L.check(lib.ngp_comm_init(C.byref(handle), rank, world, C.create_string_buffer(box[0], L.COMM_ID_BYTES)), "ngp_comm_init")
+    _comm = (handle, rank, world)
+    return handle
+
+
+def destroy():
+    global _comm
+    if _comm is not None:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        L.lib().ngp_comm_destroy(_comm[0])
+        _comm = None
+
+
+def plan(level_table, n_params, n_buckets=1, rank=None, world=None):
+    """NgpDpPlan of a table (pure host arithmetic; works without a GPU or a process group when rank / world are given)"""
+    if rank is None:
+        rank, world = dist.get_rank(), dist.get_world_size()
+    import numpy as np
+    tbl = np.ascontiguousarray(level_table, dtype=np.uint32)
+    p = L.NgpDpPlan()
+    L.check(L.lib().ngp_dp_plan(tbl.ctypes.data_as(C.c_void_p), int(n_params), int(world), int(rank), int(n_buckets), C.byref(p)), "ngp_dp_plan")
+    return p
+
+
+def allreduce_grads(tensors, stream=None):
+    """SUM all-reduce, in place, of a list of CUDA gradient tensors as ONE RCCL group on the current stream (ngp_allreduce_grads)"""
+    comm = library_comm()
+    assert comm is not None
+    from . import ops
+    n = len(tensors)
+    bufs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    counts = (C.c_uint64 * n)(*[t.numel() for t in tensors])
+    dts = (C.c_int * n)(*[ops._dt(t) for t in tensors])
+    L.check(L.lib().ngp_allreduce_grads(comm, stream if stream is not None else ops._stream(), n, bufs, counts, dts), "ngp_allreduce_grads")
+
+
+def allgather_shards(plan_, tensors):
+    """in-place all-gather of every rank's shards of tensors laid out like the table (ngp_dp_allgather) on the current stream"""
+    comm = library_comm()
+    assert comm is not None
+    from . import ops
+    n = len(tensors)
+    bufs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    dts = (C.c_int * n)(*[ops._dt(t) for t in tensors])
+    L.check(L.lib().ngp_dp_allgather(comm, ops._stream(), C.byref(plan_), n, bufs, dts), "ngp_dp_allgather")

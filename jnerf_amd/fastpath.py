@@ -34,11 +34,13 @@ class FusedTrainStep:
         self.out = torch.empty((n, 4), dtype=m.fused_dtype, device=dev)
         self.dout = torch.empty((n, 4), dtype=m.fused_dtype, device=dev)
         self._per_rays = {}
-        # single-GPU runs issue the whole sequence with ONE call into the library (ngp_train_step); data-parallel runs keep the per-stage calls below
-        # because the gradient all-reduce sits between backward and the sweep
+        # the whole sequence is ONE call into the library (ngp_train_step) - also under data parallelism: with an RCCL process group the exchange step
+        # (reduce-scatter -> sharded sweep -> all-gather, csrc/dp_comm.hip) runs inside that call; with any other backend (gloo in the tests) the call is split
+        # in two phases around torch.distributed's all-reduce.  `native_step = False` keeps the per-stage calls of __call__ below.
         self.timed_stage = None         # name from _lib.STAGES: the library brackets that stage of every native step with HIP events (bench.py)
-        self.native = runner.cfg.native_step is not False and not runner.optimizer._nested_optimizer._dp_active()
+        self.native = runner.cfg.native_step is not False
         self._args, self._grad_sig = None, None
+        self._dp_plan, self._grad_wire = None, None
 
     def _ray_bufs(self, nr, dev):
         b = self._per_rays.get(nr)
@@ -81,6 +83,8 @@ class FusedTrainStep:
             if id(p) in flat_ids:
                 continue
             assert p.grad is not None and p.grad.dtype == torch.float32
+            if p is enc.m_grid:
+                self._table_index = i
             ents.append((p.data, p.grad, pg["m"][i], pg["values"][i], eg["values"][i], adam._half.get(id(p)), p.numel()))
         if adam._flat:
             pack, fm, fv, _ = adam._flat
@@ -93,6 +97,30 @@ class FusedTrainStep:
             a.p[i], a.g[i], a.m[i], a.v[i], a.ema[i], a.p_half[i], a.numel[i] = P(p_), P(g_), P(m_), P(v_), P(e_), P(h_), cnt
         a.beta0, a.beta1, a.eps, a.ema_decay = adam.betas[0], adam.betas[1], adam.eps, ema.decay
         self._keep = (dfeat, slabs)
+        # ---- data parallel: the exchange step inside the call (RCCL), or the two-phase split around the host's own collective
+        from . import dp
+        a.phase, a.comm, a.dp = L.PHASE_ALL, None, None
+        self._dp_host_collective = False
+        if dp.active():
+            comm = dp.library_comm()
+            if comm is None:
+                self._dp_host_collective = True           # gloo (tests): BACKWARD -> dist.all_reduce -> SWEEP, see _call_native
+            else:
+                cfg = r.cfg
+                table_g = enc.grad_buffer().data_ptr()
+                a.dp_table = next(i for i in range(a.n_opt) if a.g[i] == table_g)
+                a.dp_overlap = 1 if cfg.dp_overlap else 0
+                self._dp_plan = dp.plan(enc.level_table, enc.n_params, n_buckets=2 if cfg.dp_overlap else 1)
+                a.comm, a.dp = comm, C.addressof(self._dp_plan)
+                if self.half and cfg.dp_grad_dtype != "fp32":      # fp16 mode: the table gradient travels as scaled fp16 (the reference's gradients are fp16 to begin with)
+                    if self._grad_wire is None:
+                        self._grad_wire = torch.empty(enc.n_params, dtype=torch.float16, device=dev)
+                    a.grad_wire, a.wire_scale = self._grad_wire.data_ptr(), adam.DP_HALF_SCALE
+                # fp32 mode: the kernels read the master itself -> gathered every step.  fp16 mode: they read the shadow; the fp32 master (and, in both modes, the
+                # Adam moments) stay valid on their owner's shard only, until Adam.sync_sharded_state() collects them (checkpoints, state_dict, tests)
+                a.dp_gather_master = 0 if self.half else 1
+                sharded = [pg["m"][self._table_index], pg["values"][self._table_index]] + ([] if a.dp_gather_master else [pg["params"][self._table_index].data])
+                adam.register_sharded(self._dp_plan, sharded)
         return a
 
     def _call_native(self, b):
@@ -116,7 +144,18 @@ class FusedTrainStep:
         a.bg, a.target = b["bg"].data_ptr(), b["target"].data_ptr()
         a.table, a.wd, a.wc = table.data_ptr(), wd.data_ptr(), wc.data_ptr()
         a.rgb, a.loss, a.loss_grad = rgb.data_ptr(), loss.data_ptr(), lgrad.data_ptr()
+        if self._dp_host_collective:
+            # a process group without RCCL (gloo): the library runs the iteration in two phases and the host sums the two gradient buffers in between
+            a.phase = L.PHASE_BACKWARD
+            L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step(backward)")
+            for g in (enc.grad_buffer(), m._flat_weight_grad()):
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            a.phase = L.PHASE_SWEEP
+            L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step(sweep)")
+            return loss
         L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step")
+        if a.comm:
+            adam.mark_sharded_dirty()
         return loss
 
     def stage_timings(self, max_n=1 << 16):

@@ -153,6 +153,7 @@ class NGPNetworks(nn.Module):
                 with torch.no_grad():
                     m.weight.copy_(invariant_uniform(m.out_features, m.in_features, dev))
         self._bufs = {}
+        self.grad_pack_listeners = []       # called with the flat weight-gradient buffer whenever _flat_weight_grad (re)creates it (Runner: Adam.register_grad_pack)
 
     def _linears(self):
         return [m for m in list(self.density_mlp) + list(self.rgb_mlp) if isinstance(m, nn.Linear)]
@@ -189,6 +190,8 @@ class NGPNetworks(nn.Module):
                     g[off:off + cnt] += p.grad.reshape(-1)
                 p.grad = g[off:off + cnt].view_as(p)
             self._bufs["wgrad"] = g
+            for fn in self.grad_pack_listeners:
+                fn(g)
         return g
 
     def _bwd_buffers(self, n):

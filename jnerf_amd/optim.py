@@ -20,6 +20,13 @@ def flush_all():
         o.flush()
 
 
+def sync_all_sharded():
+    """data parallel with the sharded sweep (fastpath.py): collect the state that lives on its owner's shard only - Adam moments, in fp16 mode also the fp32
+    master of the hash table - on every rank.  Called before anything reads that state as a whole: checkpoints, state_dict(), replica comparisons."""
+    for o in list(_LIVE):
+        o.sync_sharded_state()
+
+
 @OPTIMS.register_module()
 class Adam:
     # data parallel, fp16 gradients on the wire: the fp32 gradient carries the compositor's 128 / n_rays loss scale (values of 1e-7 .. 1e-3), i.e. it sits in and below
@@ -42,6 +49,9 @@ class Adam:
         self._eff_grad = {}             # id(param) -> the reduced fp16 buffer the next sweep reads instead of p.grad
         self._deferred_ema = None
         self._flat = None               # (flat parameter pack, flat m, flat v, ids of the parameters that are views of it), see use_flat_state
+        self._grad_packs = set()        # data_ptr of flat gradient buffers whose views tile them (plus zero padding): safe to all-reduce as ONE collective
+        self._sharded = None            # (NgpDpPlan, [tensors valid on the owner's shard only]) while the native data-parallel step runs the sharded sweep
+        self._sharded_dirty = False
         _LIVE.add(self)
 
     @property
@@ -68,6 +78,26 @@ class Adam:
             pg["values"][i] = fv[off:off + p.numel()].view_as(p)
         self._flat = (flat_pack, fm, fv, [id(p) for p in params])
 
+    def register_grad_pack(self, flat_grad):
+        """`flat_grad` is a contiguous buffer every element of which is either the gradient of one of this optimiser's parameters or zero padding (NGPNetworks'
+        fp32[10240] weight-gradient pack): allreduce_grads then sends it as one collective instead of one per view"""
+        self._grad_packs.add(flat_grad.data_ptr())
+
+    def register_sharded(self, plan, tensors):
+        """the native data-parallel step (csrc/train_step.hip) sweeps only this rank's shard of the hash table: `tensors` (Adam moments; in fp16 mode the fp32
+        master too) are valid on the owner's shard only until sync_sharded_state() all-gathers them"""
+        self._sharded = (plan, list(tensors))
+
+    def mark_sharded_dirty(self):
+        self._sharded_dirty = self._sharded is not None
+
+    def sync_sharded_state(self):
+        if self._sharded is None or not self._sharded_dirty:
+            return
+        from . import dp
+        dp.allgather_shards(*self._sharded)
+        self._sharded_dirty = False
+
     def zero_grad(self):
         for p in self.param_groups[0]["params"]:
             if p.grad is not None:
@@ -88,10 +118,8 @@ class Adam:
     def _dp_active():
         """gradients go through the collectives: more than one rank, or `dp_force_collectives = True` in the config (a single-rank process group then runs the
         complete data-parallel sequence - fp16 conversion, RCCL all-reduce on the comm stream, deferred sweep - which is how the RCCL path is tested on a 1-GPU box)"""
-        if not (dist.is_available() and dist.is_initialized()):
-            return False
-        from .utils.config import get_cfg
-        return dist.get_world_size() > 1 or get_cfg().dp_force_collectives is True
+        from . import dp
+        return dp.active()
 
     def allreduce_grads(self):
         """Ray-batch data parallelism: SUM the hash-table gradient (49.9 MB fp32) and the two MLP gradients over ranks — RCCL over xGMI on
@@ -108,7 +136,7 @@ class Adam:
         merged = []
         for group in by_base.values():
             base = group[0]._base
-            if base is not None and len(group) > 1 and base.is_contiguous():        # (a pack's zero-gradient padding travels along: one collective instead of five)
+            if base is not None and len(group) > 1 and base.is_contiguous() and base.data_ptr() in self._grad_packs:   # a REGISTERED pack only: its zero padding travels along, one collective instead of five
                 merged.append(base)
             else:
                 merged.extend(group)
@@ -134,9 +162,13 @@ class Adam:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
             self._comm_stream.wait_stream(main)
+            from . import dp
             with torch.cuda.stream(self._comm_stream):
-                for g in send:
-                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                if dp.library_comm() is not None:       # RCCL from inside the library: one group = one launch (ngp_allreduce_grads)
+                    dp.allreduce_grads(send)
+                else:
+                    for g in send:
+                        dist.all_reduce(g, op=dist.ReduceOp.SUM)
             self._comm_pending = True
         else:
             for g in grads:
@@ -181,10 +213,13 @@ class Adam:
                 m.mul_(b0).add_(g, alpha=1 - b0)
                 v.mul_(b1).addcmul_(g, g, value=1 - b1)
                 step_size = self.lr * (1 - b1 ** self.n_step) ** 0.5 / (1 - b0 ** self.n_step)
+                # fused-EMA mode stores the EMA IN the parameter (EMA.attach aliases values[i] = p.data): the blend must read the value from BEFORE the Adam
+                # update, exactly like the kernel's `E = P` (without the snapshot the EMA of these tensors was a silent no-op)
+                e_old = p.data.clone() if (ema is not None and e.data_ptr() == p.data_ptr()) else e
                 p.data.sub_(m * step_size / (v.sqrt() + self.eps))
                 if ema is not None:
                     d, k = ema.decay, self.n_step
-                    p.data.copy_(((1 - d) * p.data + d * e * (1 - d ** (k - 1))) / (1 - d ** k))
+                    p.data.copy_(((1 - d) * p.data + d * e_old * (1 - d ** (k - 1))) / (1 - d ** k))
                     e.copy_(p.data)
                 h = self._half.get(id(p))
                 if h is not None:
@@ -194,6 +229,7 @@ class Adam:
 
     def state_dict(self):
         self.flush()
+        self.sync_sharded_state()
         return {"defaults": {"lr": self.lr, "eps": self.eps, "betas": self.betas, "n_step": self.n_step,
                              "param_groups": [{"values": [t.detach().cpu() for t in self.param_groups[0]["values"]], "m": [t.detach().cpu() for t in self.param_groups[0]["m"]]}]}}
 

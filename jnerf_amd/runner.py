@@ -35,6 +35,10 @@ class Runner:
         flat = self.model.flat_param_views() if hasattr(self.model, "flat_param_views") else None
         if flat is not None:
             self.optimizer.use_flat_state(*flat)
+        if getattr(self.model, "fused", False) and hasattr(self.model, "grad_pack_listeners"):
+            # the MLP gradients are views tiling one flat buffer: a data-parallel all-reduce may send that buffer as one collective (and only such registered packs)
+            self.model.grad_pack_listeners.append(self.optimizer.register_grad_pack)
+            self.optimizer.register_grad_pack(self.model._flat_weight_grad())
         self.optimizer = build_from_cfg(cfg.expdecay, OPTIMS, nested_optimizer=self.optimizer)
         self.ema_optimizer = build_from_cfg(cfg.ema, OPTIMS, params=params)
         self.ema_optimizer.attach(self.optimizer)                       # Adam + EMA become one fused sweep
@@ -223,11 +227,14 @@ class Runner:
             self.drain()
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        from .optim import sync_all_sharded
+        sync_all_sharded()                               # (collective: every rank) state that lives on its owner's shard under the sharded sweep
         if not multi or dist.get_rank() == 0:           # replicas are bit-identical: one writer (every rank writing the same files would race)
             self.save_ckpt(os.path.join(self.save_path, "params.pkl"))
-            self.test()
         if multi:
-            dist.barrier()
+            dist.barrier()                               # only the checkpoint write sits inside the collective window ...
+        if not multi or dist.get_rank() == 0:
+            self.test()                                  # ... the full test render (minutes with OriginNeRFNetworks) runs outside it: no rank waits in a barrier that can time out
 
     def test(self, load_ckpt=False):
         if load_ckpt:
@@ -278,6 +285,10 @@ class Runner:
     def save_ckpt(self, path):
         from .optim import flush_all
         flush_all()
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            from .optim import sync_all_sharded
+            sync_all_sharded()      # (multi-rank runs: train() has done it on every rank - it is a collective, and save_ckpt runs on rank 0 only)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         torch.save({"global_step": self.cfg.m_training_step, "model": self.model.state_dict(), "sampler": self.sampler.state_dict(),
                     "optimizer": self.optimizer.state_dict(), "nested_optimizer": self.optimizer._nested_optimizer.state_dict(),
@@ -306,10 +317,13 @@ class Runner:
             self.dataset["train"].batch_size = self.sampler.n_rays_per_batch
 
     def val_img(self, it):
+        import torch.distributed as dist
+        writer = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
         with torch.no_grad():
             img, _, img_tar = self.render_img(dataset_mode="val")
-            self.save_img(self.save_path + f"/img{it}.png", img)
-            self.save_img(self.save_path + f"/target{it}.png", img_tar)
+            if writer:                                   # every rank renders (replicas are identical), one writes the files
+                self.save_img(self.save_path + f"/img{it}.png", img)
+                self.save_img(self.save_path + f"/target{it}.png", img_tar)
             return float(np.mean((img - img_tar) ** 2))
 
     def render_test(self, save_img=True, save_path=None):

@@ -92,7 +92,8 @@ class DensityGridSampler(nn.Module):
         self._sets = [dict(numsteps=torch.empty((cap_r, 2), dtype=torch.int32, device=dev), numsteps_c=torch.empty((cap_r, 2), dtype=torch.int32, device=dev),
                            counters=torch.zeros(4, dtype=torch.int32, device=dev), coords=torch.zeros((self.target_batch_size, 7), dtype=torch.float32, device=dev),
                            pos=torch.zeros((self.target_batch_size, 3), dtype=torch.float32, device=dev)) for _ in range(n_sets)]
-        self._march_scratch = [None, None]                  # count-pass output + t-cache of one march call: one per stream parity (even / odd batches never share a stream)
+        self._march_scratch = {}                            # count-pass output + t-cache of one march call: one per STREAM (main / side 0 / side 1): calls on one stream are ordered, and
+                                                            # a main-stream march (first step, refresh steps, resume) no longer shares a buffer with the side stream of its parity
         self._set_idx = 0
         self._numsteps_buf, self._numsteps_c_buf = self._sets[0]["numsteps"], self._sets[0]["numsteps_c"]
         self._counters = self._sets[0]["counters"]
@@ -159,11 +160,11 @@ class DensityGridSampler(nn.Module):
         self._coords_train, self._counters = bs["coords"], bs["counters"]
         numsteps, numsteps_c = bs["numsteps"][:n], bs["numsteps_c"][:n]
         need = ops.march_scratch_elems(n)
-        par = int(self.cfg.m_training_step or 0) & 1
-        if self._march_scratch[par] is None or self._march_scratch[par].numel() < need:
+        key = torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
+        if key not in self._march_scratch or self._march_scratch[key].numel() < need:
             # sized once for the largest ray count update_batch_rays can choose (<= target_batch_size): no re-allocation while the streams use it
-            self._march_scratch[par] = torch.empty(max(need, ops.march_scratch_elems(min(self.target_batch_size, 1 << 18))), dtype=torch.int32, device=self.device)
-        scratch = self._march_scratch[par]
+            self._march_scratch[key] = torch.empty(max(need, ops.march_scratch_elems(min(self.target_batch_size, 1 << 18))), dtype=torch.int32, device=self.device)
+        scratch = self._march_scratch[key]
         ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.target_batch_size,
                                  self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
                                  coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=scratch, pos_out=bs["pos"])

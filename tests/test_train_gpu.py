@@ -133,6 +133,7 @@ def test_two_ranks_data_parallel_on_one_gpu(scaling):
     assert d["n_gpus"] == 2 and d["value"] > 0 and np.isfinite(d["loss"]) and d["config"]["parallelism"].startswith("ray-batch dp2") and d["scaling"] == scaling
     assert d["config"]["samples_per_iter_per_gpu"] == ((1 << 18) if scaling == "weak" else (1 << 17))       # strong: ONE 2^18-sample iteration split over the ranks
     assert d["extra"]["replicas_identical"] is True           # both ranks hold bit-identical parameters after 60 data-parallel steps
+    assert d["extra"]["native_step"] is True                  # data parallel keeps the one-call native step (here: two phases around gloo's all-reduce)
 
 
 def _run_bench(extra_args, timeout=900, env=None):
@@ -147,15 +148,32 @@ def _run_bench(extra_args, timeout=900, env=None):
 @pytest.mark.parametrize("config", ["fox", "lego"])
 def test_rccl_world_size_one(config):
     """RCCL on the one GPU this box has: bench.py --force-dist creates the nccl (= RCCL) process group with world size 1 and runs the COMPLETE data-parallel
-    sequence every step - fp32 -> fp16 gradient conversion (fox), all-reduce on the communication stream, deferred fused Adam+EMA sweep at the next parameter
-    read, all-reduced ray-count adaptation.  (N > 1 needs one GPU per rank: the driver's scaling run; gloo covers two ranks in test_two_ranks_...)"""
+    sequence every step inside the ONE native call - fp32 -> scaled fp16 gradient conversion (fox), reduce-scatter + tail / MLP all-reduce as one RCCL group, sweep of the
+    rank's shard, all-gather of the updated parameters - plus the all-reduced ray-count adaptation.  (N > 1 needs one GPU per rank: the driver's scaling run; gloo covers two ranks in test_two_ranks_...)"""
     import os, socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     d = _run_bench(["--gpus", "1", "--force-dist", "--config", config, "--steps", "48", "--warmup", "8", "--burn-in", "64", "--images", "8", "--res", "96", "--no-psnr", "--no-fox",
                     "--no-cpu-baseline"], env=env)
     assert d["n_gpus"] == 1 and d["value"] > 0 and np.isfinite(d["loss"]) and d["loss"] < 0.2
-    assert d["extra"]["dist_backend"] == "nccl" and d["extra"]["replicas_identical"] is True and d["extra"]["native_step"] is False
+    assert d["extra"]["dist_backend"] == "nccl" and d["extra"]["replicas_identical"] is True and d["extra"]["native_step"] is True
+    assert d["extra"]["dp"]["exchange"].startswith("rccl in-library")
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_rccl_exchange_step_adds_no_arithmetic(overlap):
+    """fp32 mode (ngp_base.py): the world-size-1 data-parallel run - in-library RCCL reduce-scatter, sharded sweep (shard + tail + MLP pack), all-gather, with and
+    without the overlapped two-bucket variant - must leave bit-identical parameters to the plain single-GPU run of the same seed: the exchange step only moves data"""
+    import os, socket
+    common = ["--gpus", "1", "--config", "lego", "--steps", "24", "--warmup", "4", "--burn-in", "36", "--images", "8", "--res", "96", "--no-psnr", "--no-fox", "--no-cpu-baseline",
+              "--no-kernel-events"]
+    a = _run_bench(common)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    b = _run_bench(common + ["--force-dist"] + (["--dp-overlap"] if overlap else []), env=env)
+    assert b["extra"]["native_step"] is True and b["extra"]["dp"]["overlap"] is overlap
+    assert a["extra"]["param_signature"] == b["extra"]["param_signature"], (a["extra"]["param_signature"], b["extra"]["param_signature"])
+    assert a["loss"] == b["loss"]
 
 
 def test_bench_contract_small():
