@@ -251,7 +251,10 @@ typedef struct NgpTrainStep {
 	 * the sweep divides it out.  dp_overlap != 0: two buckets - the coarse levels' reduce-scatter is issued on the library's communication stream as soon as
 	 * their accumulate launch has finished, under the fine levels' accumulate (costs four event packets per iteration; off by default). */
 	int32_t phase, dp_overlap, dp_table /* index into p[]/g[] of the hash table */, dp_gather_master;
-	void *comm; const struct NgpDpPlan *dp; void *grad_wire; float wire_scale; float pad3;
+	void *comm; const struct NgpDpPlan *dp; void *grad_wire; float wire_scale;
+	/* != 0: packed_weights already holds the fragments of the CURRENT weights - the previous ngp_train_step's sweep wrote them (fp32 network with the flat 10240-float pack
+	 * among the optimiser tensors: its Adam+EMA sweep and the fragment packing are one launch) and nothing has changed the weights since - so this call skips its packing launch */
+	int32_t frags_fresh;
 } NgpTrainStep;
 enum { NGP_PHASE_ALL = 0, NGP_PHASE_BACKWARD = 1, NGP_PHASE_SWEEP = 2 };
 enum { NGP_STAGE_PACK = 0, NGP_STAGE_HASH_FWD, NGP_STAGE_FIELD_FWD, NGP_STAGE_COMPOSITE_FWD, NGP_STAGE_COMPOSITE_BWD, NGP_STAGE_FIELD_BWD, NGP_STAGE_REDUCE_SLABS,

@@ -28,7 +28,7 @@ class NgpTrainStep(C.Structure):
                 ("n_opt", _i32), ("step", _u32), ("lr", _f32), ("beta0", _f32), ("beta1", _f32), ("eps", _f32), ("ema_decay", _f32), ("pad2", _f32),
                 ("p", _vp * 4), ("g", _vp * 4), ("m", _vp * 4), ("v", _vp * 4), ("ema", _vp * 4), ("p_half", _vp * 4), ("numel", _u64 * 4),
                 ("timed_stage", _i32), ("grad_overwrite", _i32),
-                ("phase", _i32), ("dp_overlap", _i32), ("dp_table", _i32), ("dp_gather_master", _i32), ("comm", _vp), ("dp", _vp), ("grad_wire", _vp), ("wire_scale", _f32), ("pad3", _f32)]
+                ("phase", _i32), ("dp_overlap", _i32), ("dp_table", _i32), ("dp_gather_master", _i32), ("comm", _vp), ("dp", _vp), ("grad_wire", _vp), ("wire_scale", _f32), ("frags_fresh", _i32)]
 
 
 PHASE_ALL, PHASE_BACKWARD, PHASE_SWEEP = 0, 1, 2      # NGP_PHASE_*

@@ -223,8 +223,9 @@ __device__ __forceinline__ floatx4 wgrad_tile(const float *stage, int row_a, int
 template <int LAYOUT>
 __global__ __launch_bounds__(512, 1) void k_field32_bwd(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                         const float *__restrict__ packed, const float *__restrict__ dout,
-                                                        float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid) {
+                                                        float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
 	extern __shared__ __attribute__((aligned(16))) float smem32[];
+	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // running max |dL/dfeature| of levels 8u + 2g + pr over this lane's samples (absmax_epilogue)
 	float *wl = smem32;                                   // 76 fragments
 	float *stage = smem32 + NF32_ALL * 256;               // [N_ROWS32][RS32]
 	stage_weights32(wl, packed, NF32_ALL);
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd(uint32_t n, const float 
 				for (int pr = 0; pr < 2; ++pr) {
 					const float2 v = make_float2(dF[u][2 * pr], dF[u][2 * pr + 1]);
 					const uint32_t level = 8 * u + 2 * g + pr;
+					lmax[u][pr] = fmaxf(lmax[u][pr], fmaxf(fabsf(v.x), fabsf(v.y)));
 					if (LAYOUT == NGP_LAYOUT_SOA) reinterpret_cast<float2 *>(dfeat)[(size_t)level * n + i] = v;
 					else *reinterpret_cast<float2 *>(dfeat + (size_t)i * 32 + 2 * level) = v;
 				}
@@ -387,6 +389,32 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd(uint32_t n, const float 
 			slab[3072 + 6144 + ro * 64 + 16 * tx + ci] = aV2[r] + xch[((tx * 2 + 1) * 64 + lane) * 4 + r];
 		}
 	}
+	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, stage, 8); }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- fused tail of the fp32 step (r3)
+// Adam+EMA sweep of the flat weight pack (10240 floats, EMA aliasing the parameter like k_adam_ema<float, 2>) and the MFMA fragments of the UPDATED weights for the
+// next iteration, one single-workgroup launch instead of k_adam_ema (pack) + next step's k_pack_frags32: two launches and their boundaries less per iteration.
+__global__ __launch_bounds__(1024) void k_mlp32_sweep_pack(float *__restrict__ pack, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, AdamConsts c,
+                                                           float *__restrict__ packed_out) {
+	__shared__ float w[10240];
+	for (int i = threadIdx.x; i < 10240; i += 1024) {
+		float P = pack[i], M = m[i], V = v[i], E = P;
+		adam_ema_update<true>(P, M, V, E, grad[i], c);
+		pack[i] = P; m[i] = M; v[i] = V; w[i] = P;
+	}
+	__syncthreads();
+	for (int idx = threadIdx.x; idx < NF32_ALL * 256; idx += 1024) {
+		const int f = idx >> 8, lane = (idx >> 2) & 63, j = idx & 3;
+		packed_out[idx] = frag_value32(w, w + 3072, f, lane & 15, lane >> 4, j);
+	}
+}
+int ngp_mlp32_sweep_pack(void *stream, float *pack, const float *grad, float *m, float *v, float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, float *packed_out) {
+	NGP_REQUIRE(pack && grad && m && v && packed_out && step >= 1, NGP_E_ARG, "ngp_mlp32_sweep_pack: bad arguments");
+	const AdamConsts c = adam_consts(lr, beta0, beta1, eps, step, ema_decay, 1.0f);
+	NGP_LAUNCH(k_mlp32_sweep_pack, dim3(1), dim3(1024), 0, (hipStream_t)stream, pack, grad, m, v, c, packed_out);
+	NGP_LAUNCH_CHECK("ngp_mlp32_sweep_pack");
+	return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- C ABI
@@ -454,6 +482,11 @@ NGP_API int ngp_density32_fwd(void *stream, uint32_t n, const float *feat, int l
 NGP_API int ngp_field32_bwd_slabs(uint32_t n) { uint32_t b = div_up(n, BT32); return (int)(b < 256 ? (b ? b : 1) : 256); }
 NGP_API int ngp_field32_bwd(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const float *wd, const float *wc,
                             const float *dLdout, float *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid) {
+	return ngp_field32_bwd_am(stream, n, feat, layout, dir, dir_stride, wd, wc, dLdout, dLdfeat, wgrad_slabs, n_slabs, n_valid, nullptr);
+}
+int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const float *wd, const float *wc,
+                       const float *dLdout, float *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am_in) {
+	const AbsmaxOut am = am_in ? *am_in : AbsmaxOut{nullptr, nullptr, 0u, nullptr};
 	int rc = check_field32("ngp_field32_bwd", feat, wd, wc, layout); if (rc) return rc;
 	const int layout_flags = layout; layout &= ~NGP_WEIGHTS_PACKED;
 	NGP_REQUIRE(dir && dLdout && dLdfeat && wgrad_slabs && dir_stride >= 3, NGP_E_ARG, "ngp_field32_bwd: null pointer");
@@ -467,7 +500,7 @@ NGP_API int ngp_field32_bwd(void *stream, uint32_t n, const float *feat, int lay
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	NGP_LAUNCH((k_field32_bwd<L>), grid, block, shmem, s, n, feat, dir, dir_stride, packed, dLdout, dLdfeat, wgrad_slabs, n_valid); } while (0)
+	NGP_LAUNCH((k_field32_bwd<L>), grid, block, shmem, s, n, feat, dir, dir_stride, packed, dLdout, dLdfeat, wgrad_slabs, n_valid, am); } while (0)
 	if (layout == NGP_LAYOUT_SOA) GO(NGP_LAYOUT_SOA); else GO(NGP_LAYOUT_AOS);
 #undef GO
 	NGP_LAUNCH_CHECK("ngp_field32_bwd");

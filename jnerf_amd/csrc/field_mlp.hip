@@ -216,7 +216,8 @@ template <> __device__ __forceinline__ void load_dout<__half>(const __half *p, f
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                       const _Float16 *__restrict__ packed, const T *__restrict__ dout,
-                                                      _Float16 *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid) {
+                                                      _Float16 *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
+	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // running max |dL/dfeature| (of the fp16 values as stored) of levels 8t + 2g + pr over this lane's samples (absmax_epilogue)
 	extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
 	_Float16 *wl = smem;                                         // 42 fragments
 	_Float16 *stage = smem + (N_FWD_FRAGS + N_BWD_FRAGS) * 512;  // [N_ROWS][RS]
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 				for (int pr = 0; pr < 2; ++pr) {
 					half2v v = {(_Float16)dF[t][2 * pr], (_Float16)dF[t][2 * pr + 1]};
 					const uint32_t level = 8 * t + 2 * g + pr;
+					lmax[t][pr] = fmaxf(lmax[t][pr], fmaxf(fabsf((float)v[0]), fabsf((float)v[1])));
 					if (LAYOUT == NGP_LAYOUT_SOA) *reinterpret_cast<half2v *>(dfeat + ((size_t)level * n + i) * 2) = v;
 					else *reinterpret_cast<half2v *>(dfeat + (size_t)i * 32 + 2 * level) = v;
 				}
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 		if (w < 4) slab[2048 + ro * 64 + 16 * w + ci] = aX[r];
 		else slab[3072 + 6144 + ro * 64 + 16 * (w - 4) + ci] = aX[r];
 	}
+	if (am.parts) absmax_epilogue(am, lmax, reinterpret_cast<float *>(stage), 8);      // (the trip loop ends with a barrier: the staging region is free)
 }
 
 __global__ __launch_bounds__(1024) void k_reduce_slabs(const float *__restrict__ slabs, uint32_t n_slabs, uint32_t width, float *__restrict__ out, int accumulate) {
@@ -466,6 +469,11 @@ NGP_API int ngp_field_pack_weights(void *stream, const void *wd, const void *wc,
 NGP_API int ngp_field_bwd_slabs(uint32_t n) { uint32_t b = div_up(n, BT); return (int)(b < 256 ? (b ? b : 1) : 256); }
 NGP_API int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,
                           const void *dLdout, int out_dtype, void *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid) {
+	return ngp_field_bwd_am(stream, n, feat, layout, dir, dir_stride, wd, wc, dLdout, out_dtype, dLdfeat, wgrad_slabs, n_slabs, n_valid, nullptr);
+}
+int ngp_field_bwd_am(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,
+                     const void *dLdout, int out_dtype, void *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am_in) {
+	const AbsmaxOut am = am_in ? *am_in : AbsmaxOut{nullptr, nullptr, 0u, nullptr};
 	int rc = check_field("ngp_field_bwd", feat, wd, wc, layout, out_dtype); if (rc) return rc;
 	const int layout_flags = layout; layout &= ~NGP_WEIGHTS_PACKED;
 	NGP_REQUIRE(dir && dLdout && dLdfeat && wgrad_slabs && dir_stride >= 3, NGP_E_ARG, "ngp_field_bwd: null pointer");
@@ -479,7 +487,7 @@ NGP_API int ngp_field_bwd(void *stream, uint32_t n, const void *feat, int layout
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field_bwd<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	NGP_LAUNCH((k_field_bwd<T, L>), grid, block, shmem, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid); } while (0)
+	NGP_LAUNCH((k_field_bwd<T, L>), grid, block, shmem, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid, am); } while (0)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO

@@ -19,6 +19,7 @@
 //    sample stream).  NGP_HASH_BWD_ATOMICS=1 or a non-power-of-two hashed table: the reference's scheme, one global float atomic per corner.
 #include "ngp_common.h"
 #include <stdlib.h>
+#include <string.h>
 #pragma clang fp contract(off)
 
 template <typename T> struct Pair;
@@ -54,6 +55,54 @@ __device__ __forceinline__ void block_to_level_chunk(uint32_t nblk, uint32_t &le
 
 static LevelTable load_table(const uint32_t *host) { LevelTable lt; for (int i = 0; i < 64; ++i) lt.v[i] = host[i]; return lt; }
 
+// Balanced variant of the map above (r3).  With "level 15-x, then level x" the XCDs whose first level is fine - samples in different cells, every gather a line of its
+// own - work ~60 us on it while the XCDs that drew two coherent levels are done after ~10 us and idle (lego: six fine levels on XCDs 0..5, XCDs 6 and 7 wait).
+// FwdMap hands every XCD a list of (level, chunk range) segments of equal estimated COST instead: fine levels (resolution above the run-combining limit, where
+// consecutive samples of a ray stop sharing cells) weigh 1 per chunk, the others `light`; the levels are laid end to end, finest first, and cut into eight equal
+// shares, so an XCD still works on at most two fine levels (their slices stay in its L2) but none waits for the others.  Speed only, results unchanged.
+#define FWD_MAP_SEGS 17
+#define FWD_MAP_LIGHT_SPAN 8u       // a block of a coherent level takes this many consecutive chunks (they cost ~1/8 of a fine level's: equal work per block, no swarm of tiny blocks)
+struct FwdMap { uint32_t level[8][FWD_MAP_SEGS], begin[8][FWD_MAP_SEGS], count[8][FWD_MAP_SEGS] /* chunks */; uint32_t slots; };     // slots = blocks per XCD in the launch (the longest list)
+__host__ __device__ static inline uint32_t fwd_map_span(const LevelTable &lt, uint32_t level) { return lt.v[4 * level + 2] > 300u ? 1u : FWD_MAP_LIGHT_SPAN; }
+static FwdMap fwd_map_balanced(const LevelTable &lt, uint32_t nblk, float light) {
+	FwdMap m; memset(&m, 0, sizeof(m));
+	float w[16], total = 0.f;
+	for (int l = 0; l < 16; ++l) { w[l] = lt.v[4 * l + 2] > 300u ? 1.0f : light; total += w[l] * (float)nblk; }
+	const float share = total / 8.0f;
+	uint32_t xcd = 0, seg = 0; float used = 0.f;
+	for (int l = 15; l >= 0; --l) {
+		uint32_t done = 0;
+		while (done < nblk) {
+			const float room = share - used;
+			uint32_t take = xcd == 7u ? nblk - done : (uint32_t)(room / w[l] + 0.5f);
+			if (take > nblk - done) take = nblk - done;
+			if (take == 0 && xcd < 7u) { ++xcd; seg = 0; used = 0.f; continue; }
+			if (seg == FWD_MAP_SEGS) { if (xcd < 7u) { ++xcd; seg = 0; used = 0.f; continue; } --seg; m.count[xcd][seg] += take; done += take; ++seg; continue; }   // (cannot happen with 16 levels / 8 shares; keeps the map total anyway)
+			m.level[xcd][seg] = (uint32_t)l; m.begin[xcd][seg] = done; m.count[xcd][seg] = take; ++seg;
+			done += take; used += (float)take * w[l];
+			if (used >= share - 0.5f * w[l] && xcd < 7u) { ++xcd; seg = 0; used = 0.f; }
+		}
+	}
+	for (int x = 0; x < 8; ++x) {
+		uint32_t c = 0;
+		for (int g = 0; g < FWD_MAP_SEGS; ++g) if (m.count[x][g]) c += div_up(m.count[x][g], fwd_map_span(lt, m.level[x][g]));
+		if (c > m.slots) m.slots = c;
+	}
+	return m;
+}
+__device__ __forceinline__ bool block_to_level_chunk_map(const FwdMap &m, const LevelTable &lt, uint32_t &level, uint32_t &chunk, uint32_t &chunk_end) {
+	const uint32_t b = blockIdx.x, xcd = b & 7u;
+	uint32_t slot = b >> 3;
+	for (int g = 0; g < FWD_MAP_SEGS; ++g) {
+		const uint32_t c = m.count[xcd][g];
+		if (!c) continue;
+		const uint32_t span = fwd_map_span(lt, m.level[xcd][g]), blocks = (c + span - 1u) / span;
+		if (slot < blocks) { level = m.level[xcd][g]; chunk = m.begin[xcd][g] + slot * span; chunk_end = min(chunk + span, m.begin[xcd][g] + c); return true; }
+		slot -= blocks;
+	}
+	return false;
+}
+
 struct Corner { uint32_t g[3]; float w[3]; };
 __device__ __forceinline__ Corner locate(const float *pos, uint32_t stride, uint32_t i, float scale) {
 	Corner c;
@@ -67,11 +116,26 @@ __device__ __forceinline__ Corner locate(const float *pos, uint32_t stride, uint
 	return c;
 }
 
+template <typename T, int LAYOUT, bool MAPPED>
+__device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, const LevelTable &lt,
+                                              T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid, uint32_t level, uint32_t chunk);
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void k_hash_fwd(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, LevelTable lt,
                                                   T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid) {
-	using P = typename Pair<T>::type;
 	uint32_t level, chunk; block_to_level_chunk(nblk, level, chunk);
+	hash_fwd_body<T, LAYOUT, false>(n, pos, stride, table, lt, out, nblk, n_valid, level, chunk);
+}
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void k_hash_fwd_bal(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, LevelTable lt,
+                                                      T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid, FwdMap map) {
+	uint32_t level, chunk, chunk_end;
+	if (!block_to_level_chunk_map(map, lt, level, chunk, chunk_end)) return;
+	for (; chunk < chunk_end; ++chunk) hash_fwd_body<T, LAYOUT, true>(n, pos, stride, table, lt, out, nblk, n_valid, level, chunk);
+}
+template <typename T, int LAYOUT, bool MAPPED>
+__device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, const LevelTable &lt,
+                                              T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid, uint32_t level, uint32_t chunk) {
+	using P = typename Pair<T>::type;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
 	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
@@ -457,9 +521,23 @@ NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint
 	if (n == 0) return 0;
 	NGP_REQUIRE(pos_stride >= 3, NGP_E_ARG, "ngp_hash_encode_fwd: pos stride %u < 3", pos_stride);
 	const uint32_t nblk = min(div_up(n, 256), 2048u);         // chunks per level in flight (k_hash_fwd strides over the rest)
-	const dim3 grid(16 * nblk), block(256);
+	const dim3 block(256);
 	const LevelTable lt = load_table(level_table_host);
 	hipStream_t s = (hipStream_t)stream;
+	// NGP_HASH_FWD_BALANCE=0 selects the round-1 map (probe hook); NGP_HASH_FWD_LIGHT = relative cost of a chunk of a coherent level
+	static const int balance = [] { const char *e = getenv("NGP_HASH_FWD_BALANCE"); return e ? atoi(e) : 1; }();
+	static const float light = [] { const char *e = getenv("NGP_HASH_FWD_LIGHT"); return e ? (float)atof(e) : 0.12f; }();
+	if (balance) {
+		const FwdMap map = fwd_map_balanced(lt, nblk, light);
+		const dim3 grid(8 * map.slots);
+#define GO(T, L) NGP_LAUNCH((k_hash_fwd_bal<T, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)table, lt, (T *)out, nblk, n_valid, map)
+		if (dtype == NGP_F32) { if (out_layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
+		else { if (out_layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
+#undef GO
+		NGP_LAUNCH_CHECK("ngp_hash_encode_fwd");
+		return 0;
+	}
+	const dim3 grid(16 * nblk);
 #define GO(T, L) NGP_LAUNCH((k_hash_fwd<T, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)table, lt, (T *)out, nblk, n_valid)
 	if (dtype == NGP_F32) { if (out_layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (out_layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
@@ -525,9 +603,11 @@ __device__ __forceinline__ uint16_t *rec_idx_at(uint16_t *base, uint32_t hl, uin
 // partial slots per level - no atomics (same-address global atomics retire one at a time at the L2: 8192 of them on 16 addresses took ~90 us), nothing to zero
 // beforehand; the consumers take the maximum of a level's partials with scalar loads (level_absmax).  The pass also zeroes the record cursors and the spill
 // count for the kernels behind it in the stream (that was a separate 5 us memset launch).
-#define ABSMAX_PARTS 64u
+#define ABSMAX_PARTS NGP_ABSMAX_PARTS
+#define ABSMAX_OWN_PARTS 64u                                                    // partials the scatter's own pass writes (its grid); the remaining slots are zeroed by it
 __device__ __forceinline__ uint32_t level_absmax(const uint32_t *__restrict__ parts, uint32_t level) {      // positive floats order like their bit patterns
-	uint32_t m = parts[level * ABSMAX_PARTS + (threadIdx.x & 63u)];          // one load per lane + a wavefront reduction (called by full wavefronts, at kernel entry)
+	const uint4 q = reinterpret_cast<const uint4 *>(parts + level * ABSMAX_PARTS)[threadIdx.x & 63u];         // four partials per lane + a wavefront reduction (called by full wavefronts, at kernel entry)
+	uint32_t m = max(max(q.x, q.y), max(q.z, q.w));
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
 	return m;
@@ -566,6 +646,7 @@ __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__res
 		m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
 		parts[level * ABSMAX_PARTS + blockIdx.x] = (m > 0.f) ? __float_as_uint(m) : 0u;     // (NaN -> 0: a level without a usable gradient is skipped, as before)
 	}
+	if (threadIdx.x >= 1 && threadIdx.x < ABSMAX_PARTS / ABSMAX_OWN_PARTS) parts[level * ABSMAX_PARTS + blockIdx.x + threadIdx.x * ABSMAX_OWN_PARTS] = 0u;   // the slots of the (larger) fused producer's grid
 }
 
 // Records are staged in LDS grouped by bin and written out run by run: a wave then stores 64 consecutive records (full lines) instead of 64
@@ -946,7 +1027,8 @@ struct SideStream {
 
 static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
                          void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, float *level_scratch, void *workspace, uint64_t workspace_bytes,
-                         hipEvent_t after_coarse = nullptr /* data parallel, overlapped exchange: recorded behind the accumulate launch of the run-combined (coarse) levels, which then is a launch of its own */) {
+                         hipEvent_t after_coarse = nullptr /* data parallel, overlapped exchange: recorded behind the accumulate launch of the run-combined (coarse) levels, which then is a launch of its own */,
+                         bool absmax_done = false /* the abs-max partials, zeroed cursors and spill count are already in the workspace (written by the field backward kernel, ngp_hash_bwd_absmax_slots) */) {
 	NGP_REQUIRE(grad && level_table_host && (n == 0 || (pos && dLdy)), NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_bwd: bad dtype %d", dtype);
 	NGP_REQUIRE(grad_dtype == NGP_F32 || (grad_dtype == NGP_F16 && dtype == NGP_F16), NGP_E_DTYPE, "ngp_hash_encode_bwd: bad grad dtype %d for dtype %d", grad_dtype, dtype);
@@ -1050,7 +1132,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	if (level_scratch) NGP_LAUNCH((k_level_l1<T, L>), dim3(64, 16), dim3(256), 0, s, n, (const T *)dLdy, level_scratch, n_valid); \
 	hipStream_t sd = s; \
 	if (use_bins && bp.n_levels) { \
-		NGP_LAUNCH((k_level_absmax<T, L>), dim3(ABSMAX_PARTS, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid, cursors, spill_count);   /* also zeroes the cursors and the spill count */ \
+		if (!absmax_done) NGP_LAUNCH((k_level_absmax<T, L>), dim3(ABSMAX_OWN_PARTS, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid, cursors, spill_count);   /* also zeroes the cursors and the spill count */ \
 		if (units && side.ok) { hipEventRecord(side.fork, s); sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* the scan of the remaining levels runs beside the binning kernels */ \
 		if (!probe_skip_bins) { \
 		if (n_runs) { SET_LDS((k_bin_records_runs<T, L>), run_stage_bytes(8192u)); \
@@ -1081,10 +1163,26 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	return 0;
 }
 
-// the workspace path with the data-parallel marker (csrc/train_step.hip); not part of the public ABI
+// the workspace path with the data-parallel marker and the fused abs-max (csrc/train_step.hip); not part of the public ABI
 int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host, void *grad, uint64_t n_params, int dtype,
-                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse) {
-	return hash_bwd_impl(stream, n, pos, pos_stride, dLdy, level_table_host, grad, n_params, dtype, grad_dtype, in_layout, zero_first, n_valid, nullptr, workspace, workspace_bytes, after_coarse);
+                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse, int absmax_done) {
+	return hash_bwd_impl(stream, n, pos, pos_stride, dLdy, level_table_host, grad, n_params, dtype, grad_dtype, in_layout, zero_first, n_valid, nullptr, workspace, workspace_bytes, after_coarse, absmax_done != 0);
+}
+// mirrors the routing decisions of hash_bwd_impl: the slots are handed out only when that call will read them
+AbsmaxOut ngp_hash_bwd_absmax_slots(const uint32_t *level_table_host, uint32_t n, int dtype, int grad_dtype, void *workspace, uint64_t workspace_bytes) {
+	AbsmaxOut am{nullptr, nullptr, 0u, nullptr};
+	if (!workspace || !level_table_host || n == 0 || hash_bwd_method() == 1 || getenv("NGP_HASH_BWD_NO_BINS") || getenv("NGP_NO_FUSED_ABSMAX")) return am;
+	const LevelTable lt = load_table(level_table_host);
+	for (int l = 0; l < 16; ++l) {
+		const uint32_t size = lt.v[4 * l + 1], res = lt.v[4 * l + 2];
+		if (!level_dense_host(size, res) && (size & (size - 1)) != 0) return am;            // (non-power-of-two hashed table: the atomic path)
+		if (!level_binned(lt, l)) return am;                                                 // a level outside the bins would still need the owner-computes scan: keep the plain sequence
+	}
+	const WsLayout wl = ws_layout(lt, n);
+	if (!(dtype == NGP_F16 || grad_dtype == NGP_F32) || workspace_bytes < wl.total) return am;
+	char *ws = (char *)workspace;
+	am.parts = (uint32_t *)(ws + wl.absmax); am.cursors = (uint32_t *)(ws + wl.cursors); am.n_cursors = 16u * BINS_PER_LEVEL; am.spill_count = am.parts + 16u * ABSMAX_PARTS;
+	return am;
 }
 
 NGP_API int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
@@ -1101,6 +1199,13 @@ NGP_API int ngp_hash_encode_bwd_ws(void *stream, uint32_t n, const float *pos, u
                                    void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid,
                                    float *level_scratch, void *workspace, uint64_t workspace_bytes) {
 	return hash_bwd_impl(stream, n, pos, pos_stride, dLdy, level_table_host, grad, n_params, dtype, grad_dtype, in_layout, zero_first, n_valid, level_scratch, workspace, workspace_bytes);
+}
+
+// test hook (tests/test_host_cpu.py): the balanced forward map as host arrays, u32[8][FWD_MAP_SEGS][3] = (level, first chunk, chunks); returns blocks per XCD
+NGP_API uint32_t ngp_x_fwd_map(const uint32_t *level_table_host, uint32_t nblk, float light, uint32_t *out_host) {
+	const FwdMap m = fwd_map_balanced(load_table(level_table_host), nblk, light);
+	for (int x = 0; x < 8; ++x) for (int g = 0; g < FWD_MAP_SEGS; ++g) { out_host[(x * FWD_MAP_SEGS + g) * 3] = m.level[x][g]; out_host[(x * FWD_MAP_SEGS + g) * 3 + 1] = m.begin[x][g]; out_host[(x * FWD_MAP_SEGS + g) * 3 + 2] = m.count[x][g]; }
+	return m.slots;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- probes (tools/microbench_hash.py only)

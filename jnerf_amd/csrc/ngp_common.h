@@ -26,7 +26,21 @@ struct NgpProfScope { int id; hipStream_t s; hipEvent_t a, b; NgpProfScope(int i
 
 // internal cross-file entry points (not exported)
 int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host, void *grad, uint64_t n_params, int dtype,
-                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse);
+                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse, int absmax_done);
+// Largest |dL/dfeature| per level, the scale of the hash scatter's fixed-point accumulation.  NGP_ABSMAX_PARTS partial maxima per level (bit patterns of
+// non-negative floats, 0 = none); the consumers take the maximum.  Written either by the scatter's own abs-max pass or - training path, r3 - by the field backward
+// kernel's epilogue (one partial per workgroup: no extra pass over the 33 MB of feature gradients, one launch less); that kernel then also zeroes the scatter's
+// record cursors and spill count.
+#define NGP_ABSMAX_PARTS 256u
+struct AbsmaxOut { uint32_t *parts; uint32_t *cursors; uint32_t n_cursors; uint32_t *spill_count; };
+// where the abs-max partials / cursors of a hash-backward workspace live, or parts == nullptr when that call would not take the binned path
+AbsmaxOut ngp_hash_bwd_absmax_slots(const uint32_t *level_table_host, uint32_t n, int dtype, int grad_dtype, void *workspace, uint64_t workspace_bytes);
+int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const float *wd, const float *wc,
+                       const float *dLdout, float *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am);
+int ngp_field_bwd_am(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,
+                     const void *dLdout, int out_dtype, void *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am);
+// fused tail of the fp32 step: Adam+EMA of the flat 10240-float weight pack (EMA aliasing the parameter) AND the MFMA fragments of the updated weights, one launch
+int ngp_mlp32_sweep_pack(void *stream, float *pack, const float *grad, float *m, float *v, float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, float *packed_out);
 int ngp_dp_reduce(void *comm, hipStream_t s, const NgpDpPlan *plan, void *grad, int dtype, uint32_t first_bucket, uint32_t last_bucket, float *tail_f32, float *extra_f32, uint64_t extra_count);
 
 struct LevelTable { uint32_t v[64]; };   // [16][4] = offset, size, res, scale bits — passed by value (256 B of kernarg)
@@ -72,6 +86,54 @@ __host__ __device__ static inline uint32_t morton3D(uint32_t x, uint32_t y, uint
 __host__ __device__ static inline uint32_t morton3D_invert(uint32_t x) {
 	x = x & 0x49249249; x = (x | (x >> 2)) & 0xc30c30c3; x = (x | (x >> 4)) & 0x0f00f00f;
 	x = (x | (x >> 8)) & 0xff0000ff; x = (x | (x >> 16)) & 0x0000ffff; return x;
+}
+
+// Epilogue of the field backward kernels: per-lane running maxima lmax[t][pr] (level 8t + 2g + pr of the samples the lane handled; lane = 16g + s) -> one partial per
+// level per workgroup.  `scratch`: >= n_waves * 16 floats of LDS nobody uses any more; all threads of the workgroup call it.
+__device__ __forceinline__ void absmax_epilogue(const AbsmaxOut &am, float lmax[2][2], float *scratch, int n_waves) {
+	const int lane = threadIdx.x & 63, g = lane >> 4, w = threadIdx.x >> 6;
+#pragma unroll
+	for (int t = 0; t < 2; ++t)
+#pragma unroll
+		for (int pr = 0; pr < 2; ++pr) {
+			float m = lmax[t][pr];
+#pragma unroll
+			for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+			if ((lane & 15) == 0) scratch[w * 16 + 8 * t + 2 * g + pr] = m;
+		}
+	__syncthreads();
+	if (threadIdx.x < 16) {
+		float m = 0.f;
+		for (int k = 0; k < n_waves; ++k) m = fmaxf(m, scratch[k * 16 + threadIdx.x]);
+		am.parts[threadIdx.x * NGP_ABSMAX_PARTS + blockIdx.x] = (m > 0.f) ? __float_as_uint(m) : 0u;      // (NaN -> 0: a level without a usable gradient is skipped)
+	}
+	if (blockIdx.x == 0) {                                     // partial slots no workgroup owns, and the scatter's cursors
+		for (uint32_t j = gridDim.x * 16u + threadIdx.x; j < NGP_ABSMAX_PARTS * 16u; j += blockDim.x) am.parts[(j & 15u) * NGP_ABSMAX_PARTS + (j >> 4)] = 0u;
+		for (uint32_t j = threadIdx.x; j < am.n_cursors; j += blockDim.x) am.cursors[j] = 0u;
+		if (threadIdx.x == 0) *am.spill_count = 0u;
+	}
+}
+
+// ------------------------------------------------------------------ Adam (Jittor nn.Adam, bias-corrected) + EMA.ema_step (optims/ema.py:26-37): one element
+struct AdamConsts { float step_size, b0, b1, eps, ema_decay, debias_old, debias_new, g_mul /* gradient multiplier: undoes the scale a data-parallel fp16 gradient travelled with */; };
+#include <math.h>
+static inline AdamConsts adam_consts(float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, float grad_mul) {
+	const double bc0 = 1.0 - pow((double)beta0, (double)step), bc1 = 1.0 - pow((double)beta1, (double)step);
+	AdamConsts c;
+	c.step_size = (float)((double)lr * sqrt(bc1) / bc0); c.b0 = beta0; c.b1 = beta1; c.eps = eps; c.ema_decay = ema_decay;
+	c.debias_old = (float)(1.0 - pow((double)ema_decay, (double)step - 1.0));
+	c.debias_new = (float)(1.0 / (1.0 - pow((double)ema_decay, (double)step)));
+	c.g_mul = grad_mul;
+	return c;
+}
+template <bool EMA>
+__device__ __forceinline__ void adam_ema_update(float &p, float &m, float &v, float &e, float g, const AdamConsts &c) {
+	const float mi = c.b0 * m + (1 - c.b0) * g;
+	const float vi = c.b1 * v + (1 - c.b1) * g * g;
+	m = mi; v = vi;
+	float pi = p - mi * c.step_size / (sqrtf(vi) + c.eps);
+	if (EMA) { pi = ((1 - c.ema_decay) * pi + c.ema_decay * e * c.debias_old) * c.debias_new; e = pi; }
+	p = pi;
 }
 
 // sampler constants (density_grid_sampler.py:35-39, 96-116)

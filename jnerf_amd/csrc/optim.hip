@@ -8,7 +8,6 @@
 #include "ngp_common.h"
 #pragma clang fp contract(off)
 
-struct AdamConsts { float step_size, b0, b1, eps, ema_decay, debias_old, debias_new, g_mul /* gradient multiplier: undoes the scale a data-parallel fp16 gradient travelled with */; };
 
 template <typename G, int EMA /*0 none, 1 separate buffer, 2 the EMA state IS the parameter (v == p at every step boundary)*/, bool HALF, bool ZERO>
 __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restrict__ p, G *__restrict__ g, float4 *__restrict__ m, float4 *__restrict__ v, float4 *__restrict__ ema,
@@ -27,14 +26,7 @@ __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restric
 		if (EMA == 2) E = P;                       // ema.py:26-37 ends with v <- p, so the stored EMA equals the parameter it is about to blend with
 		float *pp = &P.x, *mm = &M.x, *vv = &V.x, *ee = &E.x;
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const float mi = c.b0 * mm[k] + (1 - c.b0) * gi[k];
-			const float vi = c.b1 * vv[k] + (1 - c.b1) * gi[k] * gi[k];
-			mm[k] = mi; vv[k] = vi;
-			float pi = pp[k] - mi * c.step_size / (sqrtf(vi) + c.eps);
-			if (EMA) { pi = ((1 - c.ema_decay) * pi + c.ema_decay * ee[k] * c.debias_old) * c.debias_new; ee[k] = pi; }
-			pp[k] = pi;
-		}
+		for (int k = 0; k < 4; ++k) adam_ema_update<EMA != 0>(pp[k], mm[k], vv[k], ee[k], gi[k], c);
 		p[i] = P; m[i] = M; v[i] = V;
 		if (EMA == 1) ema[i] = E;
 		if (HALF) {
@@ -83,12 +75,7 @@ NGP_API int ngp_adam_ema_step_scaled(void *stream, uint64_t n, float *p, void *g
 	NGP_REQUIRE(n % 4 == 0, NGP_E_ALIGN, "ngp_adam_ema_step: n (%llu) must be a multiple of 4", (unsigned long long)n);
 	NGP_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema | (uintptr_t)p_half) & 15) == 0, NGP_E_ALIGN, "ngp_adam_ema_step: buffers must be 16-byte aligned");
 	if (n == 0) return 0;
-	const double bc0 = 1.0 - pow((double)beta0, (double)step), bc1 = 1.0 - pow((double)beta1, (double)step);
-	AdamConsts c;
-	c.step_size = (float)((double)lr * sqrt(bc1) / bc0); c.b0 = beta0; c.b1 = beta1; c.eps = eps; c.ema_decay = ema_decay;
-	c.debias_old = (float)(1.0 - pow((double)ema_decay, (double)step - 1.0));
-	c.debias_new = (float)(1.0 / (1.0 - pow((double)ema_decay, (double)step)));
-	c.g_mul = grad_mul;
+	const AdamConsts c = adam_consts(lr, beta0, beta1, eps, step, ema_decay, grad_mul);
 	const uint64_t n4 = n / 4;
 	uint32_t blocks = (uint32_t)((n4 + 255) / 256); if (blocks > 2048 * 4) blocks = 2048 * 4;
 	hipStream_t s = (hipStream_t)stream;

@@ -2,6 +2,7 @@
 // No kernels here - every stage is one of the library's own entry points, called in the order jnerf_amd/fastpath.py calls them; the point is to
 // cross the Python/ctypes boundary once per iteration instead of eleven times (the host had become the pacing side at ~0.45 ms per iteration).
 #include "ngp_common.h"
+#include <stdlib.h>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -95,13 +96,22 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	}
 #define STAGE(id, call) do { Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
 	const int T = a->dtype, ow = a->grad_overwrite != 0;
+	// the flat fp32 weight pack among the optimiser tensors (fp32 network): its sweep also writes the next iteration's MFMA fragments (ngp_mlp32_sweep_pack)
+	int t_pack = -1;
+	if (T == NGP_F32) for (int t = 0; t < a->n_opt; ++t)
+		if (a->p[t] == (float *)a->wd && a->numel[t] == 10240 && (const float *)a->wc == (const float *)a->wd + 3072 && a->ema[t] == a->p[t] && !a->p_half[t] && a->g[t] == a->wgrad_flat && ow) t_pack = t;
+	if (getenv("NGP_NO_FUSED_MLP_TAIL")) t_pack = -1;           // probe hook
 	if (do_bwd) {
+	// largest |dL/dfeature| per level: written by the field backward kernel's epilogue when the scatter takes the binned path (one pass and one launch less)
+	AbsmaxOut am = ngp_hash_bwd_absmax_slots(a->level_table_host, a->n, T, NGP_F32, a->hash_workspace, a->hash_workspace_bytes);
 	if (T == NGP_F16) {
 		STAGE(NGP_STAGE_PACK, ngp_field_pack_weights(stream, a->wd, a->wc, a->packed_weights));
 		STAGE(NGP_STAGE_HASH_FWD, ngp_hash_encode_fwd(stream, a->n, a->pos, 3, a->table, a->level_table_host, a->feat, NGP_F16, NGP_LAYOUT_SOA, a->n_valid));
 		STAGE(NGP_STAGE_FIELD_FWD, ngp_field_fwd(stream, a->n, a->feat, lay, dirs, 7, a->packed_weights, nullptr, a->out, NGP_F16, a->n_valid));
 	} else {
-		STAGE(NGP_STAGE_PACK, ngp_field32_pack_weights(stream, (const float *)a->wd, (const float *)a->wc, (float *)a->packed_weights));
+		if (!(a->frags_fresh && t_pack >= 0)) {                  // (else: the previous call's fused tail left the fragments of the current weights in packed_weights)
+			STAGE(NGP_STAGE_PACK, ngp_field32_pack_weights(stream, (const float *)a->wd, (const float *)a->wc, (float *)a->packed_weights));
+		}
 		STAGE(NGP_STAGE_HASH_FWD, ngp_hash_encode_fwd(stream, a->n, a->pos, 3, a->table, a->level_table_host, a->feat, NGP_F32, NGP_LAYOUT_SOA, a->n_valid));
 		STAGE(NGP_STAGE_FIELD_FWD, ngp_field32_fwd(stream, a->n, (const float *)a->feat, lay, dirs, 7, (const float *)a->packed_weights, nullptr, (float *)a->out, a->n_valid));
 	}
@@ -109,14 +119,14 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	                                                       a->target, a->huber_delta, a->loss, a->loss_grad));
 	STAGE(NGP_STAGE_COMPOSITE_BWD, ngp_composite_bwd(stream, a->n_rays, a->n, a->out, T, a->coords, a->numsteps_compacted, a->loss_grad, a->rgb, a->density_grid_mean, a->cascades, a->dout, 0));
 	if (T == NGP_F16) {
-		STAGE(NGP_STAGE_FIELD_BWD, ngp_field_bwd(stream, a->n, a->feat, lay, dirs, 7, a->packed_weights, nullptr, a->dout, NGP_F16, a->dfeat, a->wgrad_slabs, a->n_slabs, a->n_valid));
+		STAGE(NGP_STAGE_FIELD_BWD, ngp_field_bwd_am(stream, a->n, a->feat, lay, dirs, 7, a->packed_weights, nullptr, a->dout, NGP_F16, a->dfeat, a->wgrad_slabs, a->n_slabs, a->n_valid, &am));
 	} else {
-		STAGE(NGP_STAGE_FIELD_BWD, ngp_field32_bwd(stream, a->n, (const float *)a->feat, lay, dirs, 7, (const float *)a->packed_weights, nullptr, (const float *)a->dout, (float *)a->dfeat,
-		                                            a->wgrad_slabs, a->n_slabs, a->n_valid));
+		STAGE(NGP_STAGE_FIELD_BWD, ngp_field32_bwd_am(stream, a->n, (const float *)a->feat, lay, dirs, 7, (const float *)a->packed_weights, nullptr, (const float *)a->dout, (float *)a->dfeat,
+		                                               a->wgrad_slabs, a->n_slabs, a->n_valid, &am));
 	}
 	STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, ow ? 0 : 1));
 	STAGE(NGP_STAGE_HASH_BWD, ngp_hash_encode_bwd_ws_marked(stream, a->n, a->pos, 3, a->dfeat, a->level_table_host, a->table_grad, a->n_params, T, NGP_F32, NGP_LAYOUT_SOA, ow ? 1 : 0, a->n_valid,
-	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr));
+	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr, am.parts != nullptr));
 	}
 	// ---- exchange step (data parallel): every rank ends up with the summed gradient of its shard of the table, of the tail and of the MLP pack
 	const bool wire = dp && a->grad_wire != nullptr;
@@ -151,6 +161,8 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 				const NgpDpPlan *pl = a->dp;
 				for (uint32_t b = 0; b < pl->n_buckets; ++b) if ((rc = sweep_range(stream, a, t, pl->shard_begin[b], pl->shard_count[b], wire, 0))) return rc;
 				if ((rc = sweep_range(stream, a, t, pl->tail_begin, pl->tail_count, false, 0))) return rc;
+			} else if (t == t_pack) {
+				if ((rc = ngp_mlp32_sweep_pack(stream, a->p[t], a->g[t], a->m[t], a->v[t], a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, (float *)a->packed_weights))) return rc;
 			} else if ((rc = ngp_adam_ema_step(stream, a->numel[t], a->p[t], a->g[t], NGP_F32, a->m[t], a->v[t], a->ema[t], a->p_half[t], a->lr, a->beta0, a->beta1, a->eps,
 			                                   a->step, a->ema_decay, ow ? 0 : 1))) return rc;
 		}

@@ -41,6 +41,7 @@ class FusedTrainStep:
         self.native = runner.cfg.native_step is not False
         self._args, self._grad_sig = None, None
         self._dp_plan, self._grad_wire = None, None
+        self._frags_token = None        # (optimiser step, model weights version) for which the library's fused sweep left fresh MFMA fragments in m._packed
 
     def _ray_bufs(self, nr, dev):
         b = self._per_rays.get(nr)
@@ -136,6 +137,7 @@ class FusedTrainStep:
             self._grad_sig = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in r.optimizer._nested_optimizer.param_groups[0]["params"])
         a = self._args
         ed, adam, ema = r.optimizer, r.optimizer._nested_optimizer, r.ema_optimizer
+        a.frags_fresh = 1 if self._frags_token == (adam.n_step, getattr(m, "_weights_version", 0), m._packed.data_ptr()) else 0
         ed.advance_schedule()                       # == ExpDecay.step / Adam.step / EMA.ema_step bookkeeping; the sweep itself is launched by the library
         adam.n_step += 1; ed.steps += 1; ema.steps += 1
         a.n_rays, a.step, a.lr = nr, adam.n_step, adam.lr
@@ -152,8 +154,10 @@ class FusedTrainStep:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
             a.phase = L.PHASE_SWEEP
             L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step(sweep)")
+            self._frags_token = (adam.n_step, getattr(m, "_weights_version", 0), m._packed.data_ptr())
             return loss
         L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step")
+        self._frags_token = (adam.n_step, getattr(m, "_weights_version", 0), m._packed.data_ptr())
         if a.comm:
             adam.mark_sharded_dirty()
         return loss

@@ -158,6 +158,10 @@ class NGPNetworks(nn.Module):
     def _linears(self):
         return [m for m in list(self.density_mlp) + list(self.rgb_mlp) if isinstance(m, nn.Linear)]
 
+    def load_state_dict(self, *a, **k):
+        self._weights_version = getattr(self, "_weights_version", 0) + 1        # weights changed outside the optimiser: cached MFMA fragments (fastpath.py) are stale
+        return super().load_state_dict(*a, **k)
+
     def flat_param_views(self):
         """(flat fp32 pack, [parameters that are views of it, in pack order]) for the optimiser, or None: Adam keeps ONE flat m / v buffer for them so the fused sweep
         updates all five matrices (and the zero padding, which stays zero: g = m = v = 0) in one launch"""

@@ -251,3 +251,33 @@ def test_parallel_walk_guess_is_accepted_only_when_it_is_the_orbit():
     nx = np.arange(1, NC + 1)                                           # every candidate occupied: G is everything, accepted
     pm = np.maximum.accumulate(nx)
     assert all(pm[c - 1] == c for c in range(1, NC))
+
+
+def test_balanced_forward_map_covers_every_chunk_once():
+    """csrc/hash_encode.hip: the XCD-balanced blockIdx -> (level, chunk range) map of the forward gather (r3) is a partition of all (level, chunk) pairs for every
+    table / launch size, and its eight cost shares are equal to within one chunk (host arithmetic, probed through ngp_x_fwd_map)"""
+    import ctypes as C
+    from jnerf_amd import _lib, ops
+    lib = _lib.lib()
+    lib.ngp_x_fwd_map.restype = C.c_uint32
+    S = 17
+    for aabb in (1, 2, 4, 16):
+        t, _, _ = ops.level_table(aabb)
+        for light in (0.12, 0.5, 1.0):
+            for nblk in (1, 3, 64, 1016, 2048):
+                out = np.zeros((8, S, 3), np.uint32)
+                slots = lib.ngp_x_fwd_map(np.ascontiguousarray(t).ctypes.data_as(C.c_void_p), nblk, C.c_float(light), out.ctypes.data_as(C.c_void_p))
+                cov = np.zeros((16, nblk), int)
+                cost = np.zeros(8)
+                for x in range(8):
+                    blocks = 0
+                    for g in range(S):
+                        l, b, n = (int(v) for v in out[x, g])
+                        cov[l, b:b + n] += 1
+                        heavy = t[l, 2] > 300
+                        cost[x] += n * (1.0 if heavy else light)
+                        blocks += n if heavy else -(-n // 8)
+                    assert blocks <= slots
+                assert (cov == 1).all(), (aabb, light, nblk)
+                if nblk >= 64:
+                    assert cost.max() - cost.min() <= 0.05 * cost.mean() + 2.0, (aabb, light, nblk, cost)
