@@ -44,6 +44,14 @@ uint32_t ngp_level_table(double aabb_scale, uint32_t *level_table_host);
 /* replaces GridEncode.execute (grid_encode.py:71-125: extract_position + kernel_grid + transpose_encoded_position) */
 int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *table,
                         const uint32_t *level_table_host, void *out, int dtype, int out_layout, const uint32_t *n_valid /*device u32 or NULL*/);
+/* The same forward with d(encoding)/d(position): the `dy_dx` output of the reference's kernel_grid (op_header/HashEncode.h:205-251), which grid_encode.py:96 leaves
+ * disabled (`float*dy_dx=nullptr`).  dy_dx: f32[n][3][32], dy_dx[i][d][2*level+f] = d out[i][2*level+f] / d pos[i][d] (the reference's layout, :249).  This is what a
+ * hash-grid SDF network (BASELINE configs[4]) needs from the encoder. */
+int ngp_hash_encode_fwd_dydx(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *table, const uint32_t *level_table_host,
+                             void *out, int dtype, int out_layout, const uint32_t *n_valid, float *dy_dx);
+/* dL/dpos[i][d] = sum_k dLdy[i][k] * dy_dx[i][d][k] -> f32[n,3].  GridEncode.grad returns None for the positions (grid_encode.py:190) and the reference has no kernel
+ * for this contraction: it is what that `None` would have to become. */
+int ngp_hash_encode_bwd_input(void *stream, uint32_t n, const void *dLdy, int dtype, int in_layout, const float *dy_dx, float *dLdpos, const uint32_t *n_valid);
 /* replaces GridEncode.grad (grid_encode.py:137-184: memset + transpose_gradients + kernel_grid_backward).
  * grad_dtype may be NGP_F32 with dtype NGP_F16 (fp32 accumulation of fp16 gradients). zero_first!=0 clears `grad` (n_params elements). */
 int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, const uint32_t *level_table_host,

@@ -90,6 +90,32 @@ static FwdMap fwd_map_balanced(const LevelTable &lt, uint32_t nblk, float light)
 	}
 	return m;
 }
+// Variant 2 (measured after variant 1 lost: 75 -> 114 us - an XCD that works on TWO fine levels thrashes its 4 MiB L2 between two 4 MiB tables): the round-1 map
+// (XCD x: level 15-x, then level x) stays, so a fine level's table lives in ONE XCD's L2, but the XCDs whose two levels are both coherent ("helpers": 6 and 7 for the
+// ngp_base.py table) additionally take the last `help` fraction of the chunks of every fine level, dealt round-robin - they thrash, but only on a small share.
+static FwdMap fwd_map_helpers(const LevelTable &lt, uint32_t nblk, float help) {
+	FwdMap m; memset(&m, 0, sizeof(m));
+	bool heavy[16]; for (int l = 0; l < 16; ++l) heavy[l] = lt.v[4 * l + 2] > 300u;
+	int helpers[8], n_help = 0;
+	for (int x = 0; x < 8; ++x) if (!heavy[15 - x] && !heavy[x]) helpers[n_help++] = x;
+	uint32_t seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	auto add = [&](int x, uint32_t level, uint32_t begin, uint32_t count) { if (count && seg[x] < FWD_MAP_SEGS) { m.level[x][seg[x]] = level; m.begin[x][seg[x]] = begin; m.count[x][seg[x]] = count; ++seg[x]; } };
+	uint32_t given = (n_help && nblk >= 16u) ? (uint32_t)((float)nblk * help) : 0u;
+	int rr = 0;
+	for (int phase = 0; phase < 2; ++phase)
+		for (int x = 0; x < 8; ++x) {
+			const uint32_t l = phase == 0 ? 15u - x : (uint32_t)x;
+			const uint32_t keep = heavy[l] ? nblk - given : nblk;
+			add(x, l, 0u, keep);
+		}
+	if (given) for (int l = 15; l >= 0; --l) if (heavy[l]) { add(helpers[rr % n_help], (uint32_t)l, nblk - given, given); ++rr; }
+	for (int x = 0; x < 8; ++x) {
+		uint32_t c = 0;
+		for (int g = 0; g < FWD_MAP_SEGS; ++g) if (m.count[x][g]) c += div_up(m.count[x][g], fwd_map_span(lt, m.level[x][g]));
+		if (c > m.slots) m.slots = c;
+	}
+	return m;
+}
 __device__ __forceinline__ bool block_to_level_chunk_map(const FwdMap &m, const LevelTable &lt, uint32_t &level, uint32_t &chunk, uint32_t &chunk_end) {
 	const uint32_t b = blockIdx.x, xcd = b & 7u;
 	uint32_t slot = b >> 3;
@@ -118,7 +144,14 @@ __device__ __forceinline__ Corner locate(const float *pos, uint32_t stride, uint
 
 template <typename T, int LAYOUT, bool MAPPED>
 __device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, const LevelTable &lt,
-                                              T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid, uint32_t level, uint32_t chunk);
+                                              T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid, uint32_t level, uint32_t chunk, float *__restrict__ dy_dx = nullptr);
+// forward with d(encoding)/d(position) - the dy_dx branch of the reference's kernel_grid (HashEncode.h:205-251): same gathers, three more outputs per (sample, level)
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void k_hash_fwd_dydx(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, LevelTable lt,
+                                                       T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid, float *__restrict__ dy_dx) {
+	uint32_t level, chunk; block_to_level_chunk(nblk, level, chunk);
+	hash_fwd_body<T, LAYOUT, false>(n, pos, stride, table, lt, out, nblk, n_valid, level, chunk, dy_dx);
+}
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void k_hash_fwd(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, LevelTable lt,
                                                   T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid) {
@@ -134,7 +167,7 @@ __global__ __launch_bounds__(256) void k_hash_fwd_bal(uint32_t n, const float *_
 }
 template <typename T, int LAYOUT, bool MAPPED>
 __device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, const LevelTable &lt,
-                                              T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid, uint32_t level, uint32_t chunk) {
+                                              T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid, uint32_t level, uint32_t chunk, float *__restrict__ dy_dx) {
 	using P = typename Pair<T>::type;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
 	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
@@ -169,7 +202,50 @@ __device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restric
 	P *o = reinterpret_cast<P *>(out);
 	if (LAYOUT == NGP_LAYOUT_SOA) o[(size_t)level * n + i] = r;
 	else o[(size_t)i * 16 + level] = r;
+	if (dy_dx) {
+		// HashEncode.h:205-251: per derivative dimension the four (left, right) pairs along it, weight = scale * w(first other dim) * w(second other dim) in that order,
+		// summed in the reference's idx order (bit 0 = first other dim).  v[k]: corner k = x + 2 y + 4 z, already in registers - no extra gathers.
+		float2 f[8];
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k) f[k] = to_f2(v[k]);
+#pragma unroll
+		for (uint32_t gd = 0; gd < 3; ++gd) {
+			const uint32_t d0 = gd == 0 ? 1u : 0u, d1 = gd == 2 ? 1u : 2u;           // the two non-derivative dimensions, ascending
+			float2 a = make_float2(0.f, 0.f);
+#pragma unroll
+			for (uint32_t idx = 0; idx < 4; ++idx) {
+				const uint32_t b0 = idx & 1u, b1 = idx >> 1;
+				float weight = scale;
+				weight *= b0 ? c.w[d0] : 1 - c.w[d0];
+				weight *= b1 ? c.w[d1] : 1 - c.w[d1];
+				const uint32_t left = (b0 << d0) | (b1 << d1), right = left | (1u << gd);
+				a.x += weight * (f[right].x - f[left].x) * 1.0f;
+				a.y += weight * (f[right].y - f[left].y) * 1.0f;
+			}
+			*reinterpret_cast<float2 *>(dy_dx + (size_t)i * 96 + gd * 32 + 2 * level) = a;
+		}
 	}
+	}
+}
+
+// dL/dx[i][d] = sum_k dL/dy[i][k] * dy_dx[i][d][k] (fp32, k ascending): the contraction GridEncode.grad needs to return a position gradient.  The reference returns
+// None there (grid_encode.py:190) and has no kernel for it - restated from the chain rule (tiny-cuda-nn's kernel_grid_backward_input computes the same sum).
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void k_hash_bwd_input(uint32_t n, const T *__restrict__ dLdy, const float *__restrict__ dy_dx, float *__restrict__ dLdx, const uint32_t *__restrict__ n_valid) {
+	using P = typename Pair<T>::type;
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x, i = t / 3u, d = t - 3u * i;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	if (i >= lim) return;
+	const P *dy = reinterpret_cast<const P *>(dLdy);
+	const float2 *row = reinterpret_cast<const float2 *>(dy_dx + (size_t)i * 96 + d * 32);
+	float a = 0.f;
+#pragma unroll
+	for (uint32_t l = 0; l < 16; ++l) {
+		const float2 g = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)l * n + i] : dy[(size_t)i * 16 + l]);
+		const float2 r = row[l];
+		a += g.x * r.x; a += g.y * r.y;
+	}
+	dLdx[(size_t)i * 3 + d] = a;
 }
 
 __device__ __forceinline__ void atomic_add_pair(float *p, float2 v) {
@@ -525,10 +601,12 @@ NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint
 	const LevelTable lt = load_table(level_table_host);
 	hipStream_t s = (hipStream_t)stream;
 	// NGP_HASH_FWD_BALANCE=0 selects the round-1 map (probe hook); NGP_HASH_FWD_LIGHT = relative cost of a chunk of a coherent level
-	static const int balance = [] { const char *e = getenv("NGP_HASH_FWD_BALANCE"); return e ? atoi(e) : 1; }();
+	// (measured, gpurun_out/r3a_*: 0 = 75 us per training launch, 1 = 114 us at light 0.12 - see fwd_map_helpers)
+	static const int balance = [] { const char *e = getenv("NGP_HASH_FWD_BALANCE"); return e ? atoi(e) : 0; }();
 	static const float light = [] { const char *e = getenv("NGP_HASH_FWD_LIGHT"); return e ? (float)atof(e) : 0.12f; }();
+	static const float help = [] { const char *e = getenv("NGP_HASH_FWD_HELP"); return e ? (float)atof(e) : 0.15f; }();
 	if (balance) {
-		const FwdMap map = fwd_map_balanced(lt, nblk, light);
+		const FwdMap map = balance == 2 ? fwd_map_helpers(lt, nblk, help) : fwd_map_balanced(lt, nblk, light);
 		const dim3 grid(8 * map.slots);
 #define GO(T, L) NGP_LAUNCH((k_hash_fwd_bal<T, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)table, lt, (T *)out, nblk, n_valid, map)
 		if (dtype == NGP_F32) { if (out_layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
@@ -543,6 +621,39 @@ NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint
 	else { if (out_layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO
 	NGP_LAUNCH_CHECK("ngp_hash_encode_fwd");
+	return 0;
+}
+
+NGP_API int ngp_hash_encode_fwd_dydx(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *table, const uint32_t *level_table_host,
+                                     void *out, int dtype, int out_layout, const uint32_t *n_valid, float *dy_dx) {
+	NGP_REQUIRE(n == 0 || (pos && table && level_table_host && out && dy_dx), NGP_E_ARG, "ngp_hash_encode_fwd_dydx: null pointer");
+	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_fwd_dydx: bad dtype %d", dtype);
+	NGP_REQUIRE(((uintptr_t)dy_dx & 7) == 0, NGP_E_ALIGN, "ngp_hash_encode_fwd_dydx: dy_dx must be 8-byte aligned");
+	if (n == 0) return 0;
+	NGP_REQUIRE(pos_stride >= 3, NGP_E_ARG, "ngp_hash_encode_fwd_dydx: pos stride %u < 3", pos_stride);
+	const uint32_t nblk = min(div_up(n, 256), 2048u);
+	const dim3 grid(16 * nblk), block(256);
+	const LevelTable lt = load_table(level_table_host);
+	hipStream_t s = (hipStream_t)stream;
+#define GO(T, L) NGP_LAUNCH((k_hash_fwd_dydx<T, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)table, lt, (T *)out, nblk, n_valid, dy_dx)
+	if (dtype == NGP_F32) { if (out_layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
+	else { if (out_layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
+#undef GO
+	NGP_LAUNCH_CHECK("ngp_hash_encode_fwd_dydx");
+	return 0;
+}
+NGP_API int ngp_hash_encode_bwd_input(void *stream, uint32_t n, const void *dLdy, int dtype, int in_layout, const float *dy_dx, float *dLdx, const uint32_t *n_valid) {
+	NGP_REQUIRE(n == 0 || (dLdy && dy_dx && dLdx), NGP_E_ARG, "ngp_hash_encode_bwd_input: null pointer");
+	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_bwd_input: bad dtype %d", dtype);
+	NGP_REQUIRE(((uintptr_t)dy_dx & 7) == 0, NGP_E_ALIGN, "ngp_hash_encode_bwd_input: dy_dx must be 8-byte aligned");
+	if (n == 0) return 0;
+	const dim3 grid(div_up(n * 3u, 256)), block(256);
+	hipStream_t s = (hipStream_t)stream;
+#define GO(T, L) NGP_LAUNCH((k_hash_bwd_input<T, L>), grid, block, 0, s, n, (const T *)dLdy, dy_dx, dLdx, n_valid)
+	if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
+	else { if (in_layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
+#undef GO
+	NGP_LAUNCH_CHECK("ngp_hash_encode_bwd_input");
 	return 0;
 }
 
@@ -1203,7 +1314,7 @@ NGP_API int ngp_hash_encode_bwd_ws(void *stream, uint32_t n, const float *pos, u
 
 // test hook (tests/test_host_cpu.py): the balanced forward map as host arrays, u32[8][FWD_MAP_SEGS][3] = (level, first chunk, chunks); returns blocks per XCD
 NGP_API uint32_t ngp_x_fwd_map(const uint32_t *level_table_host, uint32_t nblk, float light, uint32_t *out_host) {
-	const FwdMap m = fwd_map_balanced(load_table(level_table_host), nblk, light);
+	const FwdMap m = light < 0.f ? fwd_map_helpers(load_table(level_table_host), nblk, -light) : fwd_map_balanced(load_table(level_table_host), nblk, light);
 	for (int x = 0; x < 8; ++x) for (int g = 0; g < FWD_MAP_SEGS; ++g) { out_host[(x * FWD_MAP_SEGS + g) * 3] = m.level[x][g]; out_host[(x * FWD_MAP_SEGS + g) * 3 + 1] = m.begin[x][g]; out_host[(x * FWD_MAP_SEGS + g) * 3 + 2] = m.count[x][g]; }
 	return m.slots;
 }

@@ -19,15 +19,25 @@ class _HashEncode(torch.autograd.Function):
     def forward(ctx, x, grid, enc):
         table = enc.table_for_kernels()
         ctx.enc = enc
+        ctx.want_dx = bool(ctx.needs_input_grad[0])
+        if ctx.want_dx:
+            # (ours) the positions ask for a gradient - a hash-grid SDF network differentiates the encoder w.r.t. its input: the forward also writes kernel_grid's
+            # dy_dx output (HashEncode.h:205-251; the reference compiles that branch but passes nullptr, grid_encode.py:96) and backward contracts it with dL/dy
+            out, dy_dx = ops.hash_encode_fwd_dydx(x.detach(), table, enc.level_table)
+            ctx.save_for_backward(x, dy_dx)
+            return out
         ctx.save_for_backward(x)
         return ops.hash_encode_fwd(x, table, enc.level_table)
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
         enc = ctx.enc
-        enc.accumulate_grad(x, dy.contiguous(), ops.LAYOUT_AOS)
-        return None, None, None
+        dy = dy.contiguous()
+        enc.accumulate_grad(x.detach(), dy, ops.LAYOUT_AOS)
+        if ctx.want_dx:
+            return ops.hash_encode_bwd_input(dy, ctx.saved_tensors[1], ops.LAYOUT_AOS), None, None
+        return None, None, None          # the reference's contract (grid_encode.py:190: `return None, grid_grad`)
 
 
 @ENCODERS.register_module()

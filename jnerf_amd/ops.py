@@ -104,6 +104,27 @@ def hash_encode_fwd(pos, table, level_tbl, out=None, layout=LAYOUT_AOS, n_valid=
     return out
 
 
+def hash_encode_fwd_dydx(pos, table, level_tbl, out=None, layout=LAYOUT_AOS, n_valid=None, dy_dx=None):
+    """forward + d(encoding)/d(position) (kernel_grid's dy_dx branch, HashEncode.h:205-251) -> (out, dy_dx f32[n,3,32])"""
+    pos, stride = _rows(pos, 3)
+    n = pos.shape[0]
+    if out is None:
+        out = torch.empty((n, 32) if layout == LAYOUT_AOS else (16, n, 2), dtype=table.dtype, device=pos.device)
+    if dy_dx is None:
+        dy_dx = torch.empty((n, 3, 32), dtype=torch.float32, device=pos.device)
+    check(L.lib().ngp_hash_encode_fwd_dydx(_stream(), n, _p(pos), stride, _p(table), _tbl(level_tbl), _p(out), _dt(table), layout, _p(n_valid), _p(dy_dx)), "ngp_hash_encode_fwd_dydx")
+    return out, dy_dx
+
+
+def hash_encode_bwd_input(dLdy, dy_dx, layout=LAYOUT_AOS, n_valid=None):
+    """dL/dpos [n,3] f32 = sum_k dLdy[:, k] * dy_dx[:, :, k]"""
+    n = dy_dx.shape[0]
+    assert dLdy.is_contiguous() and dy_dx.is_contiguous() and dy_dx.dtype == torch.float32
+    out = torch.empty((n, 3), dtype=torch.float32, device=dy_dx.device)
+    check(L.lib().ngp_hash_encode_bwd_input(_stream(), n, _p(dLdy), _dt(dLdy), layout, _p(dy_dx), _p(out), _p(n_valid)), "ngp_hash_encode_bwd_input")
+    return out
+
+
 def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, layout=LAYOUT_AOS, zero_first=True, n_valid=None, fixed_point_scratch=None, workspace=None):
     """fixed_point_scratch: device f32[16] -> fixed-point LDS accumulation; workspace: uint8 tensor of >= hash_bwd_workspace_bytes(level_tbl) ->
     atomic-free dense levels (ngp_hash_encode_bwd_ws)"""

@@ -174,6 +174,46 @@ EXPORT void orc_hash_encode_fwd(uint32_t n, const float *x /*[n,3]*/, const void
 	}
 }
 
+/* Forward with d(encoding)/d(position): the `dy_dx` branch of kernel_grid, HashEncode.h:205-251 (compiled in the reference but never enabled by grid_encode.py:96 -
+ * the prerequisite of a hash-grid NeuS).  dydx [n][3][32] fp32: dydx[i][d][2l+f] = d out[i][2l+f] / d x[i][d]; per derivative dimension the
+ * four (left, right) corner pairs in the reference's idx order, weight = scale * w(non-grad dim 0) * w(non-grad dim 1), pos_derivative = 1 (identity interpolation). */
+EXPORT void orc_hash_encode_fwd_dydx(uint32_t n, const float *x /*[n,3]*/, const void *grid, const uint32_t *table, void *out /*[n,32]*/, float *dydx /*[n,3,32]*/, int is_half) {
+	orc_hash_encode_fwd(n, x, grid, table, out, is_half);
+	for (uint32_t i = 0; i < n; ++i) for (uint32_t l = 0; l < 16; ++l) {
+		const uint32_t off = table[4 * l], size = table[4 * l + 1], res = table[4 * l + 2];
+		float scale; memcpy(&scale, &table[4 * l + 3], 4);
+		float w[3]; uint32_t g[3];
+		for (int d = 0; d < 3; ++d) pos_fract(x[3 * i + d], scale, &w[d], &g[d]);
+		for (uint32_t gd = 0; gd < 3; ++gd) {
+			float a0 = 0.f, a1 = 0.f;
+			for (uint32_t idx = 0; idx < 4; ++idx) {
+				float weight = scale; uint32_t gl[3];
+				for (uint32_t nd = 0; nd < 2; ++nd) {
+					const uint32_t dim = nd >= gd ? nd + 1 : nd;
+					if ((idx & (1u << nd)) == 0) { weight *= 1 - w[dim]; gl[dim] = g[dim]; }
+					else { weight *= w[dim]; gl[dim] = g[dim] + 1; }
+				}
+				gl[gd] = g[gd];
+				const size_t il = (size_t)off * 2 + grid_index(size, res, gl);
+				gl[gd] = g[gd] + 1;
+				const size_t ir = (size_t)off * 2 + grid_index(size, res, gl);
+				a0 += weight * (ldT(grid, ir, is_half) - ldT(grid, il, is_half)) * 1.0f;
+				a1 += weight * (ldT(grid, ir + 1, is_half) - ldT(grid, il + 1, is_half)) * 1.0f;
+			}
+			dydx[(size_t)i * 96 + gd * 32 + 2 * l] = a0; dydx[(size_t)i * 96 + gd * 32 + 2 * l + 1] = a1;
+		}
+	}
+}
+/* dL/dx[i][d] = sum_k dL/dy[i][k] * dydx[i][d][k], fp32, k ascending.  The reference has NO kernel for this (GridEncode.grad returns None for the positions,
+ * grid_encode.py:190): this is the contraction its autograd would need - parity unpinned, restated from the chain rule. */
+EXPORT void orc_hash_encode_bwd_input(uint32_t n, const void *dy /*[n,32]*/, const float *dydx, float *dLdx /*[n,3]*/, int is_half) {
+	for (uint32_t i = 0; i < n; ++i) for (uint32_t d = 0; d < 3; ++d) {
+		float a = 0.f;
+		for (uint32_t k = 0; k < 32; ++k) a += ldT(dy, (size_t)i * 32 + k, is_half) * dydx[(size_t)i * 96 + d * 32 + k];
+		dLdx[3 * i + d] = a;
+	}
+}
+
 /* Backward: HashEncode.h:299-396 (+memset grid_encode.py:153, transpose_gradients :270-284).
  * Serial accumulation in thread order (level-major, sample-minor) like the serial launcher; T adds (:345-356). */
 EXPORT void orc_hash_encode_bwd(uint32_t n, const float *x, const void *dy /*[n,32]*/, const uint32_t *table, void *grad, uint64_t n_params, int is_half) {

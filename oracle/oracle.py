@@ -86,6 +86,24 @@ def hash_encode_fwd(x, grid, table):
     return out
 
 
+def hash_encode_fwd_dydx(x, grid, table):
+    """-> (out [n,32] T, dydx [n,3,32] f32): HashEncode.h:117-251 with the dy_dx branch enabled"""
+    x = _c(x, np.float32)
+    n = x.shape[0]
+    out = np.zeros((n, 32), grid.dtype)
+    dydx = np.zeros((n, 3, 32), np.float32)
+    lib().orc_hash_encode_fwd_dydx(C.c_uint32(n), _p(x), _p(grid), _p(table), _p(out), _p(dydx), _is_half(grid))
+    return out, dydx
+
+
+def hash_encode_bwd_input(dy, dydx):
+    dy = np.ascontiguousarray(dy)
+    n = dy.shape[0]
+    dLdx = np.zeros((n, 3), np.float32)
+    lib().orc_hash_encode_bwd_input(C.c_uint32(n), _p(dy), _p(_c(dydx, np.float32)), _p(dLdx), _is_half(dy))
+    return dLdx
+
+
 def hash_encode_bwd(x, dy, table, n_params):
     x = _c(x, np.float32)
     dy = np.ascontiguousarray(dy)

@@ -73,6 +73,15 @@ def hash_fwd(x, grid, offsets, aabb_scale):
     return out
 
 
+def hash_fwd_dydx(x, grid, offsets, aabb_scale):
+    """kernel_grid with its dy_dx output enabled (HashEncode.h:205-251): -> (out [n,32] T, dydx [n,3,32] f32)"""
+    x = _c(x, np.float32)
+    out = np.zeros((x.shape[0], 32), grid.dtype)
+    dydx = np.zeros((x.shape[0], 3, 32), np.float32)
+    getattr(_l("hash"), "ref_hash_fwd_dydx_" + _sfx(grid))(C.c_uint32(x.shape[0]), _p(x), _p(grid), _p(_c(offsets, np.uint32)), C.c_double(per_level_scale(aabb_scale)), _p(out), _p(dydx))
+    return out, dydx
+
+
 def hash_bwd(x, dy, offsets, aabb_scale, n_params):
     x = _c(x, np.float32)
     dy = np.ascontiguousarray(dy)

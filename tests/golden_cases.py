@@ -7,7 +7,7 @@ import numpy as np
 import synth
 
 _G = None
-CASES = ["case_pcg32", "case_hash", "case_sh", "case_march_lego", "case_march_fox", "case_grid"]
+CASES = ["case_pcg32", "case_hash", "case_hash_dydx", "case_sh", "case_march_lego", "case_march_fox", "case_grid"]
 
 
 def load():
@@ -53,6 +53,37 @@ def case_hash(I, g, exact):
             nz = np.flatnonzero(grad)
             assert len(np.setxor1d(nz, idx)) <= max(4, len(idx) // 2000), "scatter touched different table entries"
             close(grad[idx], val, atol=2e-4 if dt == np.float16 else 2e-7, rtol=2e-2 if dt == np.float16 else 1e-4, what=f"hash bwd s{s} {nm}")
+
+
+_GD = None
+
+
+def case_hash_dydx(I, g, exact):
+    """kernel_grid with its dy_dx output enabled (HashEncode.h:205-251) against golden_dydx_v1.npz (minted from oracle/_ref by tests/golden/make_golden_dydx.py): the derivative
+    rows are sums of four fp32 products in a fixed order - bit-exact for every implementation"""
+    global _GD
+    if _GD is None:
+        _GD = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_dydx_v1.npz")))
+    x = _GD["x"]
+    for s in (1, 4):
+        table, offsets, n_params = I.level_table(s)
+        for dt, nm in ((np.float32, "f32"), (np.float16, "f16")):
+            grid = synth.table(n_params, dt, amp=2.0)
+            out, dydx = I.hash_encode_fwd_dydx(x, grid, table)
+            close(out, _GD[f"out_s{s}_{nm}"], atol=4e-3 if dt == np.float16 else 3e-5, what=f"hash fwd (dydx call) s{s} {nm}")
+            assert dydx.shape == (x.shape[0], 3, 32) and dydx.dtype == np.float32
+            assert np.array_equal(dydx, _GD[f"dydx_s{s}_{nm}"]), f"dy_dx s{s} {nm}: max |diff| {np.abs(dydx - _GD[f'dydx_s{s}_{nm}']).max():.3e}"
+            # and it IS the derivative: central differences of the forward along each axis, in the interior of a cell (fp32 table, coarse levels: cells much wider than the step)
+            if dt == np.float32 and s == 1:
+                h = np.float32(2e-4)
+                xi = x[6:70].copy()
+                for d in range(3):
+                    e = np.zeros(3, np.float32); e[d] = h
+                    fp, fm = I.hash_encode_fwd(xi + e, grid, table).astype(np.float64), I.hash_encode_fwd(xi - e, grid, table).astype(np.float64)
+                    fd = (fp - fm) / (2.0 * float(h))
+                    an = dydx[6:70, d, :8].astype(np.float64)                 # levels 0..3 (resolution <= 43: a 2e-4 step rarely crosses a cell face)
+                    ok = np.abs(fd[:, :8] - an) <= 2e-2 * np.abs(an).max() + 1e-3
+                    assert ok.mean() > 0.97, (d, ok.mean())
 
 
 def case_sh(I, g, exact):

@@ -28,6 +28,15 @@ def hash_encode_fwd(x, grid, table, layout=ops.LAYOUT_AOS):
     return N(out)
 
 
+def hash_encode_fwd_dydx(x, grid, table):
+    out, dydx = ops.hash_encode_fwd_dydx(T(x.astype(np.float32)), T(grid), table)
+    return N(out), N(dydx)
+
+
+def hash_encode_bwd_input(dy, dydx):
+    return N(ops.hash_encode_bwd_input(T(dy), T(dydx)))
+
+
 def hash_encode_bwd(x, dy, table, n_params, grad_dtype=None, layout=ops.LAYOUT_AOS):
     g = ops.hash_encode_bwd(T(x.astype(np.float32)), T(dy), table, n_params, grad_dtype=grad_dtype, layout=layout)
     return N(g)

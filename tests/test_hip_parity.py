@@ -19,7 +19,7 @@ def H():
 
 def test_extension_loaded_and_mfma_layout(H):
     from jnerf_amd import ops, _lib
-    assert _lib.lib().ngp_abi_version() == 1
+    assert _lib.lib().ngp_abi_version() == 2
     bad, magic = ops.selftest_mfma()
     assert magic == 0xC0FFEE, "self-test kernel did not run"
     assert bad == 0, f"MFMA fragment layout assumption violated for {bad} elements"
@@ -51,6 +51,55 @@ def test_hash_fwd_fp32_bit_exact_vs_oracle(H, aabb_scale):
     out16 = H.hash_encode_fwd(x, g16, table)
     GC.close(out16, O.hash_encode_fwd(x, g16, table), atol=3e-3, what="fp16 fwd")
     assert H.hash_encode_fwd(x[:0], grid, table).shape == (0, 32)    # empty input
+
+
+@pytest.mark.parametrize("aabb_scale", [1, 4])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_hash_fwd_dydx_and_input_gradient(H, aabb_scale, dtype):
+    """encoder dL/dx: ngp_hash_encode_fwd_dydx == kernel_grid's dy_dx branch (bit-exact vs the oracle, which is bit-exact vs oracle/_ref),
+    ngp_hash_encode_bwd_input == the fp32 contraction, and HashEncoder returns that gradient through autograd when the positions require one"""
+    from jnerf_amd import ops
+    table, offsets, n_params = O.level_table(aabb_scale)
+    x = synth.uniform_positions(4099, seed=15)
+    x[:4] = [[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0.5, 0.5, 0.5]]
+    grid = synth.table(n_params, dtype, amp=2.0)
+    ref_out, ref_d = O.hash_encode_fwd_dydx(x, grid, table)
+    out, d = H.hash_encode_fwd_dydx(x, grid, table)
+    assert np.array_equal(out, H.hash_encode_fwd(x, grid, table))           # same forward as the plain call
+    assert np.array_equal(d, ref_d), np.abs(d - ref_d).max()
+    dy = (np.random.default_rng(3).standard_normal((x.shape[0], 32)) * 1e-2).astype(dtype)
+    gx_ref = O.hash_encode_bwd_input(dy, ref_d)
+    gx = H.hash_encode_bwd_input(dy, d)
+    GC.close(gx, gx_ref, atol=1e-6 * float(np.abs(gx_ref).max()), rtol=1e-5, what="dL/dx")
+    assert ops.hash_encode_fwd_dydx(torch.zeros((0, 3), device="cuda"), H.T(grid), table)[1].shape == (0, 3, 32)      # empty input
+
+
+def test_hash_encoder_module_returns_position_gradient():
+    """the module API: HashEncoder(x) with x.requires_grad back-propagates into x (and still into the table); without it the reference's contract (no input gradient)"""
+    from jnerf_amd.presets import ngp_cfg
+    from jnerf_amd.utils.config import get_cfg
+    from jnerf_amd.utils.registry import build_from_cfg, ENCODERS, DATASETS
+    ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=2, W=16, H=16)
+    cfg = get_cfg()
+    cfg.dataset_obj = build_from_cfg(cfg.dataset.train, DATASETS)
+    enc = build_from_cfg(cfg.encoder.pos_encoder, ENCODERS)
+    with torch.no_grad():
+        enc.m_grid.copy_(torch.from_numpy(synth.table(enc.n_params, np.float32, amp=2.0)))
+    x0 = torch.from_numpy(synth.uniform_positions(512, seed=4)).cuda()
+    w = torch.from_numpy(np.random.default_rng(1).standard_normal(32).astype(np.float32)).cuda()
+    w[8:] = 0                                         # coarse levels only: a finite difference of step 1e-4 stays inside a cell almost always
+    x = x0.clone().requires_grad_(True)
+    (enc(x) * w).sum().backward()
+    assert x.grad is not None and x.grad.shape == (512, 3) and enc.m_grid.grad is not None and float(enc.m_grid.grad.abs().sum()) > 0
+    h = 1e-4
+    for d in range(3):
+        e = torch.zeros(3, device="cuda"); e[d] = h
+        with torch.no_grad():
+            fd = ((enc(x0 + e) * w).sum(1) - (enc(x0 - e) * w).sum(1)) / (2 * h)
+        ok = (fd - x.grad[:, d]).abs() <= 2e-2 * x.grad[:, d].abs().max() + 1e-3
+        assert float(ok.float().mean()) > 0.97
+    y = enc(x0)                                       # positions without requires_grad: plain forward, no dy_dx buffer
+    assert not y.requires_grad or y.grad_fn is not None
 
 
 @pytest.mark.parametrize("dtype,grad_dtype", [(np.float32, None), (np.float16, None), (np.float16, torch.float32)])

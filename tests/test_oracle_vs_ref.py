@@ -38,6 +38,21 @@ def test_hash_encode(aabb_scale, dtype):
     assert np.allclose(ga.astype(np.float32), gb.astype(np.float32), rtol=0, atol=2e-3 if dtype == np.float16 else 1e-6)
 
 
+@pytest.mark.parametrize("aabb_scale", [1, 4])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_hash_encode_dydx(aabb_scale, dtype):
+    """the dy_dx branch of the reference's kernel_grid (HashEncode.h:205-251), compiled into oracle/_ref with the output pointer set: the restatement is bit-identical"""
+    table, offsets, n_params = O.level_table(aabb_scale)
+    x = synth.uniform_positions(2048, seed=9)
+    x[:8] = [[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0.5, 0.5, 0.5], [0.999999, 0.3, 0.7], [1e-7, 1, 0], [0.25, 0.75, 1], [1, 1, 0]]
+    grid = np.random.default_rng(2).uniform(-1, 1, n_params).astype(dtype)
+    oa, da = O.hash_encode_fwd_dydx(x, grid, table)
+    ob, db = R.hash_fwd_dydx(x, grid, offsets, aabb_scale)
+    assert np.array_equal(oa, O.hash_encode_fwd(x, grid, table)) and (oa == ob).mean() > 0.98
+    assert np.array_equal(da, db)
+    assert np.abs(db).max() > 1.0                      # derivatives scale with the level resolution: not a vacuous comparison
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
 def test_sh(dtype):
     d = synth.unit_dirs01(4096)
