@@ -341,11 +341,12 @@ def main():
             roof = dict(bound="hbm", **hbm)
         # the hash-backward STAGE is four launches under four kernel names (abs-max, two record passes, accumulate): one roofline for the stage, from the probe steps
         stage = None
-        if all(k in probe_ms for k in HASH_BWD_STAGE):
-            st_ms = sum(max(sum(batch_class(probe_ms[k])) / len(batch_class(probe_ms[k])) - ev_overhead, 0.0) for k in HASH_BWD_STAGE)
+        st_kernels = [k for k in HASH_BWD_STAGE if k in probe_ms]      # (k_level_absmax is absent when the field backward kernel's epilogue computes the maxima)
+        if "k_bin_accumulate" in st_kernels:
+            st_ms = sum(max(sum(batch_class(probe_ms[k])) / len(batch_class(probe_ms[k])) - ev_overhead, 0.0) * (len(probe_ms[k]) / probe if k == "k_bin_accumulate" else 1.0) for k in st_kernels)
             T_ = 2 if fp16 else 4
             st_bytes = mean_valid * (12 + 32 * T_ + 16 * 8 * 2 * 4)                 # §8(d): pos + dL/dy + 128 scattered fp32 updates per sample
-            stage = {"name": "hash_backward", "kernels": list(HASH_BWD_STAGE), "ms": round(st_ms, 4), "alg_bytes": int(st_bytes), "achieved": round(st_bytes / (st_ms * 1e-3) / 1e9, 1),
+            stage = {"name": "hash_backward", "kernels": st_kernels, "ms": round(st_ms, 4), "alg_bytes": int(st_bytes), "achieved": round(st_bytes / (st_ms * 1e-3) / 1e9, 1),
                      "peak": 8000.0, "unit": "GB/s", "frac": round(st_bytes / (st_ms * 1e-3) / 8e12, 4)}
         roof.update({"kernel": dom, "traffic": traffic, "traffic_source": traffic_source, "stage": stage, "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_raw": round(avg_raw, 4), "event_pair_overhead_ms": round(ev_overhead, 4),
                      "launches_timed": len(cls), "launches_other_size_class": len(dom_ms) - len(cls), "alg_bytes_per_launch": int(nbytes),

@@ -5,6 +5,9 @@
 // here it is a wave64 reduction + one atomic per workgroup, and the four max-pool launches stay separate because each level
 // depends on the previous one across workgroups.
 #include "ngp_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #pragma clang fp contract(off)
 
 #define G3 (NGP_GRIDSIZE * NGP_GRIDSIZE * NGP_GRIDSIZE)
@@ -74,7 +77,12 @@ __global__ void k_grid_ema(uint32_t n, float decay, float *__restrict__ grid, co
 	grid[i] = (prev < 0.f) ? prev : fmaxf(prev * decay, tmp[i]);
 }
 
-__global__ __launch_bounds__(256) void k_grid_mean(const float *__restrict__ grid, float *__restrict__ mean) {
+// Mean of cascade 0 in two deterministic stages (r3): every workgroup writes its partial sum to a slot of its own, and every workgroup of the bitfield kernel adds the
+// MEAN_PARTS partials in the same fixed order.  (Rounds 1-2 added the partials with one float atomic per workgroup: the sum then depended on the order the 2048 workgroups
+// retired in, the threshold min(0.01, mean) moved by an ulp from run to run, now and then a cell of the bitfield flipped - and two runs of the same seed drifted apart.
+// It was the only order-dependent float operation of the training path.)
+#define MEAN_PARTS (G3 / 4 / 256)
+__global__ __launch_bounds__(256) void k_grid_mean(const float *__restrict__ grid, float *__restrict__ partials) {
 	__shared__ float sh[4];
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;        // G3/4 float4 elements, grid = G3/4/256 blocks
 	const float4 v = reinterpret_cast<const float4 *>(grid)[i];
@@ -83,12 +91,21 @@ __global__ __launch_bounds__(256) void k_grid_mean(const float *__restrict__ gri
 	for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
 	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
 	__syncthreads();
-	if (threadIdx.x == 0) atomicAdd(mean, sh[0] + sh[1] + sh[2] + sh[3]);
+	if (threadIdx.x == 0) partials[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ void k_grid_to_bitfield(uint32_t n, const float *__restrict__ grid, uint8_t *__restrict__ bitfield, const float *__restrict__ mean) {
+__global__ __launch_bounds__(256) void k_grid_to_bitfield(uint32_t n, const float *__restrict__ grid, uint8_t *__restrict__ bitfield, const float *__restrict__ partials, float *__restrict__ mean) {
+	__shared__ float sh[4];
+	float ps = 0.f;
+#pragma unroll
+	for (uint32_t k = 0; k < MEAN_PARTS / 256u; ++k) ps += partials[threadIdx.x + 256u * k];
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ps;
+	__syncthreads();
+	const float m = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+	if (blockIdx.x == 0 && threadIdx.x == 0) *mean = m;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	const float m = *mean;
 	const float thresh = 0.01f < m ? 0.01f : m;
 	const float4 a = reinterpret_cast<const float4 *>(grid)[2 * (size_t)i], b = reinterpret_cast<const float4 *>(grid)[2 * (size_t)i + 1];
 	uint8_t bits = 0;
@@ -156,10 +173,20 @@ NGP_API int ngp_grid_update_bitfield(void *stream, const float *grid, int cascad
 	NGP_REQUIRE(grid && mean && bitfield && cascades >= 1 && cascades <= 8, NGP_E_ARG, "ngp_grid_update_bitfield: bad arguments");
 	NGP_REQUIRE(((uintptr_t)grid & 15) == 0, NGP_E_ALIGN, "ngp_grid_update_bitfield: grid must be 16-byte aligned (update_bitfield.h:14-17)");
 	hipStream_t s = (hipStream_t)stream;
-	hipError_t e = hipMemsetAsync(mean, 0, 4, s);
-	if (e != hipSuccess) { ngp_set_error("ngp_grid_update_bitfield: %s", hipGetErrorString(e)); return (int)e; }
-	NGP_LAUNCH(k_grid_mean, dim3(G3 / 4 / 256), dim3(256), 0, s, grid, mean);
-	NGP_LAUNCH(k_grid_to_bitfield, dim3(div_up(G3 / 8 * cascades, 256)), dim3(256), 0, s, G3 / 8 * (uint32_t)cascades, grid, bitfield, (const float *)mean);
+	// the partial sums of the mean: 8 KiB of library-owned scratch per (device, stream) - launches on one stream are ordered, so one buffer per stream is enough
+	static std::mutex mu;
+	static std::map<std::pair<int, hipStream_t>, float *> pool;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { ngp_set_error("ngp_grid_update_bitfield: hipGetDevice failed"); return NGP_E_ARG; }
+	float *partials;
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		float *&slot = pool[{dev, s}];
+		if (!slot) { hipError_t e = hipMalloc((void **)&slot, (size_t)MEAN_PARTS * sizeof(float)); if (e != hipSuccess) { slot = nullptr; ngp_set_error("ngp_grid_update_bitfield: hipMalloc(mean partials): %s", hipGetErrorString(e)); return (int)e; } }
+		partials = slot;
+	}
+	NGP_LAUNCH(k_grid_mean, dim3(MEAN_PARTS), dim3(256), 0, s, grid, partials);
+	NGP_LAUNCH(k_grid_to_bitfield, dim3(div_up(G3 / 8 * cascades, 256)), dim3(256), 0, s, G3 / 8 * (uint32_t)cascades, grid, bitfield, (const float *)partials, mean);
 	for (int level = 1; level < cascades; ++level)
 		NGP_LAUNCH(k_bitfield_max_pool, dim3(div_up(G3 / 64, 256)), dim3(256), 0, s, G3 / 64, (const uint8_t *)(bitfield + (size_t)G3 * (level - 1) / 8), bitfield + (size_t)G3 * level / 8);
 	NGP_LAUNCH_CHECK("ngp_grid_update_bitfield");

@@ -15,6 +15,7 @@
 //  * backward recomputes the forward, runs dgrad with transposed fragments, and contracts the weight gradients over SAMPLES through LDS ([neuron][sample]
 //    rows, five staging phases that reuse one 66-KiB region), one fp32 slab per workgroup, summed by ngp_reduce_slabs (deterministic, no atomics).
 #include "ngp_common.h"
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -392,6 +393,330 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd(uint32_t n, const float 
 	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, stage, 8); }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- backward, ping-pong variant (r3)
+// k_field32_bwd above ran at 68 % of the MFMA pipe: its eight waves walk through the five staging phases in lock step, so whenever they all write their activations to
+// LDS (240 KB per 128-sample trip at the ~64 B/clk a CU's LDS takes from ds_write_b32: ~3.7 k of the trip's 29 k MFMA cycles) or wait at one of the ten barriers, no
+// wave on the CU has a matrix instruction to issue - one workgroup per CU, nothing else resident.  Here the two halves of the workgroup (waves 0-3 / 4-7: one wave
+// of each half per SIMD) are ROLE-SPECIALISED and half a trip out of phase:
+//   role X  forward recompute + dgrad chain of the half's NEXT 64 samples - 300 MFMAs per wave, registers and read-only weight fragments only;
+//   role Y  weight gradients of the 64 samples the half did in its previous X: five (stage, barrier, 16..64 MFMAs, barrier) phases through ONE 35-KiB region.
+// Every iteration one half is in X and the other in Y, then they swap.  Both code paths execute exactly ten barriers per iteration (X after each of its ten layer
+// blocks), so the workgroup barrier pairs an X block with a Y phase: while the Y waves write LDS or drain at a barrier, the X wave on the same SIMD keeps issuing
+// MFMAs; while they accumulate, both feed the pipe.  The activations a wave needs in Y are still in its registers from X (same wave): nothing is recomputed twice.
+#define HT32 64                 // samples per half trip: 4 waves x 16
+#define RSH32 (HT32 + 4)        // LDS row stride in floats (272 B: 16-byte aligned rows, consecutive rows shift by one 16-byte slot)
+#define PP_BAR() __syncthreads()
+__device__ __forceinline__ void st_tiles_h(float *stage, int row0, int col, int g, const floatx4 *v) {
+#pragma unroll
+	for (int t = 0; t < 4; ++t)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) stage[(row0 + 16 * t + 4 * g + r) * RSH32 + col] = v[t][r];
+}
+__device__ __forceinline__ floatx4 wgrad_tile_h(const float *stage, int row_a, int row_b, int o, int g, floatx4 acc) {
+#pragma unroll
+	for (int c = 0; c < HT32; c += 16) {
+		const floatx4 a = *reinterpret_cast<const floatx4 *>(stage + (row_a + o) * RSH32 + c + 4 * g), b = *reinterpret_cast<const floatx4 *>(stage + (row_b + o) * RSH32 + c + 4 * g);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], b[j], acc);
+	}
+	return acc;
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(512, 2) void k_field32_bwd_pp(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+                                                           const float *__restrict__ packed, const float *__restrict__ dout,
+                                                           float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
+	extern __shared__ __attribute__((aligned(16))) float smem32[];
+	float *wl = smem32;                                   // 76 fragments
+	float *stage = smem32 + NF32_ALL * 256;               // [128][RSH32]
+	stage_weights32(wl, packed, NF32_ALL);
+	const float *wb = wl + NF32_FWD * 256;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6, half = w >> 2, wq = w & 3;
+	const uint32_t n_ht = (lim + HT32 - 1) / HT32;
+	const uint32_t K = blockIdx.x < n_ht ? (n_ht - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;      // half trips of this workgroup: blockIdx.x, + gridDim.x, ...
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	floatx4 aV1[4] = {z, z, z, z}, aW0[2] = {z, z}, aV0[2] = {z, z}, aW1 = z, aV2 = z;            // this wave's ten weight-gradient tiles (summed over its half's samples)
+	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+	__syncthreads();
+	struct Inputs { float f[8]; float d3[3]; float go[4]; };
+	auto fetch = [&](uint32_t k, Inputs &in) {
+		const uint32_t i = (blockIdx.x + k * gridDim.x) * HT32 + 16u * wq + s;
+		const bool valid = i < lim;
+		const uint32_t ic = valid ? i : lim - 1;
+		load_feat32<LAYOUT>(feat, n, ic, g, in.f);
+		in.d3[0] = dir[(size_t)ic * dir_stride]; in.d3[1] = dir[(size_t)ic * dir_stride + 1]; in.d3[2] = dir[(size_t)ic * dir_stride + 2];
+		in.go[0] = in.go[1] = in.go[2] = in.go[3] = 0.f;
+		if (valid) { const float4 v = *reinterpret_cast<const float4 *>(dout + (size_t)i * 4); in.go[0] = v.x; in.go[1] = v.y; in.go[2] = v.z; in.go[3] = v.w; }
+	};
+	// what role X leaves in registers for role Y
+	Inputs cur;
+	float sh[4] = {0.f, 0.f, 0.f, 0.f};
+	Fwd32 st;
+	floatx4 dO = z, dG1[4], dG0[4], dH[4], dD = z;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) { st.h[u] = z; st.g0[u] = z; st.g1[u] = z; dG1[u] = z; dG0[u] = z; dH[u] = z; }
+	st.den = z; st.rgb = z;
+#pragma unroll
+	for (int q = 0; q < 8; ++q) cur.f[q] = 0.f;
+	if ((uint32_t)half < K) fetch((uint32_t)half, cur);           // half h does X on k = h, h + 2, ...
+	const int o = lane & 15, col = 16 * wq + s;
+	for (uint32_t it = 0; it <= K; ++it) {
+		const bool role_x = (int)(it & 1u) == half;
+		if (role_x) {
+			// ------------------------------------------------------------ role X: forward recompute + dgrad of half trip `it` (ten blocks, a barrier after each)
+			const bool work = it < K;
+			const uint32_t i = (blockIdx.x + it * gridDim.x) * HT32 + 16u * wq + s;
+			const bool valid = work && i < lim;
+			floatx4 acc[4] = {z, z, z, z};
+			if (work) {
+				sh4_32(cur.d3, g, sh);
+#pragma unroll
+				for (int kq = 0; kq < 2; ++kq) {                       // L0: 32 -> 64
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 2 * u + kq, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+#pragma unroll
+						for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], cur.f[4 * kq + j], acc[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) st.h[u] = relu4(acc[u]);
+			}
+			PP_BAR();                                                  // 1
+			if (work) {
+				floatx4 d0 = z, d1 = z;                                // L1: 64 -> 16
+#pragma unroll
+				for (int kq = 0; kq < 4; ++kq) {
+					const floatx4 a = ld_frag32(wl, 8 + kq, lane);
+					d0 = MFMA32(a[0], st.h[kq][0], d0); d1 = MFMA32(a[1], st.h[kq][1], d1);
+					d0 = MFMA32(a[2], st.h[kq][2], d0); d1 = MFMA32(a[3], st.h[kq][3], d1);
+				}
+				st.den = d0 + d1;
+			}
+			PP_BAR();                                                  // 2
+			if (work) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) acc[u] = z;
+#pragma unroll
+				for (int kq = 0; kq < 2; ++kq) {                       // L2: [density(16) | SH(16)] -> 64
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 12 + 2 * u + kq, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						const float b = kq == 0 ? st.den[j] : sh[j];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], b, acc[u]);
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) st.g0[u] = relu4(acc[u]);
+			}
+			PP_BAR();                                                  // 3
+			if (work) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) acc[u] = z;
+#pragma unroll
+				for (int kq = 0; kq < 4; ++kq) {                       // L3: 64 -> 64
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 20 + 4 * u + kq, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+#pragma unroll
+						for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], st.g0[kq][j], acc[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) st.g1[u] = relu4(acc[u]);
+			}
+			PP_BAR();                                                  // 4
+			// (L4, the rgb output, is not needed by the backward pass: dL/d(rgb logits) comes in from the compositor)
+			if (work) {
+				dO = z;                                                // register j <-> gradient of output neuron 4g+j; only neurons 0..2 (g == 0) are non-zero
+				if (g == 0) { dO[0] = cur.go[0]; dO[1] = cur.go[1]; dO[2] = cur.go[2]; }
+				floatx4 a[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, u, lane); dG1[u] = z; }
+#pragma unroll
+				for (int j = 0; j < 3; ++j)
+#pragma unroll
+					for (int u = 0; u < 4; ++u) dG1[u] = MFMA32(a[u][j], dO[j], dG1[u]);
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dG1[u] = mask4(dG1[u], st.g1[u]);
+			}
+			PP_BAR();                                                  // 5
+			if (work) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dG0[u] = z;
+#pragma unroll
+				for (int t = 0; t < 2; ++t) {
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wb, 4 + 4 * u + t, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+#pragma unroll
+						for (int u = 0; u < 4; ++u) dG0[u] = MFMA32(a[u][j], dG1[t][j], dG0[u]);
+				}
+			}
+			PP_BAR();                                                  // 6
+			if (work) {
+#pragma unroll
+				for (int t = 2; t < 4; ++t) {
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wb, 4 + 4 * u + t, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+#pragma unroll
+						for (int u = 0; u < 4; ++u) dG0[u] = MFMA32(a[u][j], dG1[t][j], dG0[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dG0[u] = mask4(dG0[u], st.g0[u]);
+			}
+			PP_BAR();                                                  // 7
+			if (work) {
+				floatx4 d0 = z, d1 = z;
+#pragma unroll
+				for (int t = 0; t < 4; ++t) {
+					const floatx4 a = ld_frag32(wb, 20 + t, lane);
+					d0 = MFMA32(a[0], dG0[t][0], d0); d1 = MFMA32(a[1], dG0[t][1], d1);
+					d0 = MFMA32(a[2], dG0[t][2], d0); d1 = MFMA32(a[3], dG0[t][3], d1);
+				}
+				dD = d0 + d1;
+				if (g == 0) dD[0] += cur.go[3];                       // out[:,3] = den[:,0]  (ngp_network.py:83)
+				floatx4 a[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, 24 + u, lane); dH[u] = z; }
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+#pragma unroll
+					for (int u = 0; u < 4; ++u) dH[u] = MFMA32(a[u][j], dD[j], dH[u]);
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dH[u] = mask4(dH[u], st.h[u]);
+			}
+			PP_BAR();                                                  // 8
+			floatx4 dF[2] = {z, z};
+			if (work) {
+#pragma unroll
+				for (int t = 0; t < 2; ++t) {
+					const floatx4 a0 = ld_frag32(wb, 28 + t, lane), a1 = ld_frag32(wb, 32 + t, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) { dF[0] = MFMA32(a0[j], dH[t][j], dF[0]); dF[1] = MFMA32(a1[j], dH[t][j], dF[1]); }
+				}
+			}
+			PP_BAR();                                                  // 9
+			if (work) {
+#pragma unroll
+				for (int t = 2; t < 4; ++t) {
+					const floatx4 a0 = ld_frag32(wb, 28 + t, lane), a1 = ld_frag32(wb, 32 + t, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) { dF[0] = MFMA32(a0[j], dH[t][j], dF[0]); dF[1] = MFMA32(a1[j], dH[t][j], dF[1]); }
+				}
+				if (valid) {                                          // feature 16u+4g+r  ->  level 8u+2g+(r>>1), component r&1
+#pragma unroll
+					for (int u = 0; u < 2; ++u)
+#pragma unroll
+						for (int pr = 0; pr < 2; ++pr) {
+							const float2 v = make_float2(dF[u][2 * pr], dF[u][2 * pr + 1]);
+							const uint32_t level = 8 * u + 2 * g + pr;
+							lmax[u][pr] = fmaxf(lmax[u][pr], fmaxf(fabsf(v.x), fabsf(v.y)));
+							if (LAYOUT == NGP_LAYOUT_SOA) reinterpret_cast<float2 *>(dfeat)[(size_t)level * n + i] = v;
+							else *reinterpret_cast<float2 *>(dfeat + (size_t)i * 32 + 2 * level) = v;
+						}
+				}
+			}
+			PP_BAR();                                                  // 10
+		} else {
+			// ------------------------------------------------------------ role Y: weight gradients of half trip `it - 1` (whose activations this wave holds), five phases
+			const bool work = it >= 1;
+			// phase A: dG1 rows 0..63 | G0 rows 64..127 -> V1: wave wq owns output tile `wq` against the four input tiles
+			if (work) { st_tiles_h(stage, 0, col, g, dG1); st_tiles_h(stage, 64, col, g, st.g0); }
+			PP_BAR();                                                  // 1
+			if (work) {
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) aV1[ti] = wgrad_tile_h(stage, 16 * wq, 64 + 16 * ti, o, g, aV1[ti]);
+			}
+			PP_BAR();                                                  // 2
+			// phase B1: dH 0..63 | F 64..95 -> W0
+			if (work) {
+				st_tiles_h(stage, 0, col, g, dH);
+#pragma unroll
+				for (int q = 0; q < 8; ++q) stage[(64 + 8 * g + q) * RSH32 + col] = cur.f[q];
+			}
+			PP_BAR();                                                  // 3
+			if (work) {
+				aW0[0] = wgrad_tile_h(stage, 16 * wq, 64, o, g, aW0[0]);
+				aW0[1] = wgrad_tile_h(stage, 16 * wq, 80, o, g, aW0[1]);
+			}
+			PP_BAR();                                                  // 4
+			// phase B2: dG0 0..63 | IN2 = [density(16) | SH(16)] 64..95 -> V0
+			if (work) {
+				st_tiles_h(stage, 0, col, g, dG0);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) { stage[(64 + 4 * g + r) * RSH32 + col] = st.den[r]; stage[(80 + 4 * g + r) * RSH32 + col] = sh[r]; }
+			}
+			PP_BAR();                                                  // 5
+			if (work) {
+				aV0[0] = wgrad_tile_h(stage, 16 * wq, 64, o, g, aV0[0]);
+				aV0[1] = wgrad_tile_h(stage, 16 * wq, 80, o, g, aV0[1]);
+			}
+			PP_BAR();                                                  // 6
+			// phase C1: dD 0..15 | H 16..79 -> W1: input tile wq
+			if (work) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RSH32 + col] = dD[r];
+				st_tiles_h(stage, 16, col, g, st.h);
+			}
+			PP_BAR();                                                  // 7
+			if (work) aW1 = wgrad_tile_h(stage, 0, 16 + 16 * wq, o, g, aW1);
+			PP_BAR();                                                  // 8
+			// phase C2: dO 0..15 | G1 16..79 -> V2
+			if (work) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RSH32 + col] = dO[r];
+				st_tiles_h(stage, 16, col, g, st.g1);
+			}
+			PP_BAR();                                                  // 9
+			if (work) aV2 = wgrad_tile_h(stage, 0, 16 + 16 * wq, o, g, aV2);
+			if (it + 1 < K) fetch(it + 1, cur);                       // inputs of this half's next X (half trip it + 1): in flight across the last barrier
+			PP_BAR();                                                  // 10
+		}
+	}
+	// ---- the two halves hold partial sums of the same ten tiles per wave index: half 1 hands its sums over through LDS (the fragment region is free now), half 0
+	// adds and writes the workgroup's slab, packed like the weights (wd part 0..3071, wc part 3072..10239); C rows = 4g+r, cols = lane&15
+	float *xch = wl + (size_t)wq * 10 * 256;                    // [wave][10 tiles][64 lanes][4]
+	auto put = [&](int tile, const floatx4 &v) { *reinterpret_cast<floatx4 *>(xch + tile * 256 + lane * 4) = v; };
+	auto get = [&](int tile) { return *reinterpret_cast<const floatx4 *>(xch + tile * 256 + lane * 4); };
+	__syncthreads();
+	if (half == 1) {
+#pragma unroll
+		for (int t = 0; t < 4; ++t) put(t, aV1[t]);
+		put(4, aW0[0]); put(5, aW0[1]); put(6, aV0[0]); put(7, aV0[1]); put(8, aW1); put(9, aV2);
+	}
+	__syncthreads();
+	if (half == 0) {
+#pragma unroll
+		for (int t = 0; t < 4; ++t) aV1[t] += get(t);
+		aW0[0] += get(4); aW0[1] += get(5); aV0[0] += get(6); aV0[1] += get(7); aW1 += get(8); aV2 += get(9);
+		float *slab = slabs + (size_t)blockIdx.x * 10240;
+		const int ci = lane & 15;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int ro = 4 * g + r;
+#pragma unroll
+			for (int ti = 0; ti < 4; ++ti) slab[3072 + 2048 + (16 * wq + ro) * 64 + 16 * ti + ci] = aV1[ti][r];
+#pragma unroll
+			for (int tj = 0; tj < 2; ++tj) { slab[(16 * wq + ro) * 32 + 16 * tj + ci] = aW0[tj][r]; slab[3072 + (16 * wq + ro) * 32 + 16 * tj + ci] = aV0[tj][r]; }
+			slab[2048 + ro * 64 + 16 * wq + ci] = aW1[r];
+			slab[3072 + 6144 + ro * 64 + 16 * wq + ci] = aV2[r];
+		}
+	}
+	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, stage, 8); }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- fused tail of the fp32 step (r3)
 // Adam+EMA sweep of the flat weight pack (10240 floats, EMA aliasing the parameter like k_adam_ema<float, 2>) and the MFMA fragments of the UPDATED weights for the
 // next iteration, one single-workgroup launch instead of k_adam_ema (pack) + next step's k_pack_frags32: two launches and their boundaries less per iteration.
@@ -496,6 +821,19 @@ int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, 
 	const dim3 grid(n_slabs), block(512);
 	hipStream_t s = (hipStream_t)stream;
 	const float *packed = pack_weights32("ngp_field32_bwd", s, wd, wc, NF32_ALL, layout_flags); if (!packed) return NGP_E_ARG;
+	static const int variant = [] { const char *e = getenv("NGP_FIELD32_BWD"); return e ? atoi(e) : 1; }();      // 1 = ping-pong (r3), 0 = lock-step phases (r2)
+	if (variant == 1) {
+		const size_t shmem_pp = ((size_t)NF32_ALL * 256 + (size_t)128 * RSH32) * sizeof(float);
+#define GOPP(L) do { \
+	static bool attr_set = false; \
+	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_pp<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_pp); \
+		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
+	NGP_LAUNCH((k_field32_bwd_pp<L>), grid, block, shmem_pp, s, n, feat, dir, dir_stride, packed, dLdout, dLdfeat, wgrad_slabs, n_valid, am); } while (0)
+		if (layout == NGP_LAYOUT_SOA) GOPP(NGP_LAYOUT_SOA); else GOPP(NGP_LAYOUT_AOS);
+#undef GOPP
+		NGP_LAUNCH_CHECK("ngp_field32_bwd");
+		return 0;
+	}
 #define GO(L) do { \
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \

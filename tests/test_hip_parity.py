@@ -79,6 +79,7 @@ def test_hash_encoder_module_returns_position_gradient():
     from jnerf_amd.presets import ngp_cfg
     from jnerf_amd.utils.config import get_cfg
     from jnerf_amd.utils.registry import build_from_cfg, ENCODERS, DATASETS
+    import jnerf_amd.runner  # noqa: F401  (registers the modules)
     ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=2, W=16, H=16)
     cfg = get_cfg()
     cfg.dataset_obj = build_from_cfg(cfg.dataset.train, DATASETS)
