@@ -263,12 +263,23 @@ typedef struct NgpTrainStep {
 	/* != 0: packed_weights already holds the fragments of the CURRENT weights - the previous ngp_train_step's sweep wrote them (fp32 network with the flat 10240-float pack
 	 * among the optimiser tensors: its Adam+EMA sweep and the fragment packing are one launch) and nothing has changed the weights since - so this call skips its packing launch */
 	int32_t frags_fresh;
+	/* wait_flag != NULL: the call starts with ngp_flag_wait(stream, wait_flag, wait_value, wait_status) - the batch was produced on another stream that ended it with
+	 * ngp_flag_signal (cheaper than an event hand-over between two HIP streams, see below) */
+	const uint32_t *wait_flag; uint32_t *wait_status; uint32_t wait_value; uint32_t pad4;
 } NgpTrainStep;
 enum { NGP_PHASE_ALL = 0, NGP_PHASE_BACKWARD = 1, NGP_PHASE_SWEEP = 2 };
 enum { NGP_STAGE_PACK = 0, NGP_STAGE_HASH_FWD, NGP_STAGE_FIELD_FWD, NGP_STAGE_COMPOSITE_FWD, NGP_STAGE_COMPOSITE_BWD, NGP_STAGE_FIELD_BWD, NGP_STAGE_REDUCE_SLABS,
        NGP_STAGE_HASH_BWD, NGP_STAGE_ADAM /* the largest parameter tensor's sweep */,
        NGP_STAGE_BOUNDARY /* not a stage: from the end of one call's last launch to the start of the next call's first launch (main-stream idle + waits) */ };
 int ngp_train_step(void *stream, const NgpTrainStep *args_host);
+
+/* ---- hand-over between streams by device flag: ngp_flag_signal is a one-thread launch that stores `value` to *flag (device u32) - issued on the producing stream
+ * BEHIND the producing kernels, so they have completed and released their writes; ngp_flag_wait is a one-wavefront launch that returns once (int32)(*flag - value) >= 0,
+ * ahead of the consuming kernels on their stream (which acquire at their own launch).  The wait is bounded (2 s): on expiry it ORs 1 into *status (device u32, may be
+ * NULL) and lets the stream continue rather than hang the GPU - the host must check status.  No reference counterpart (the reference runs on one stream and calls
+ * .sync() after every op, SURVEY.md §8b "Threading/streams"). */
+int ngp_flag_signal(void *stream, uint32_t *flag, uint32_t value);
+int ngp_flag_wait(void *stream, const uint32_t *flag, uint32_t value, uint32_t *status);
 
 /* ---- one inference chunk from native code --------------------------------------------------------------------------------------------------------------
  * The loop body of Runner.render_img (runner/runner.py:211-226: sampler.sample -> model -> rays2rgb(inference)) for `n_rays` rays: march + compaction

@@ -28,7 +28,8 @@ class NgpTrainStep(C.Structure):
                 ("n_opt", _i32), ("step", _u32), ("lr", _f32), ("beta0", _f32), ("beta1", _f32), ("eps", _f32), ("ema_decay", _f32), ("pad2", _f32),
                 ("p", _vp * 4), ("g", _vp * 4), ("m", _vp * 4), ("v", _vp * 4), ("ema", _vp * 4), ("p_half", _vp * 4), ("numel", _u64 * 4),
                 ("timed_stage", _i32), ("grad_overwrite", _i32),
-                ("phase", _i32), ("dp_overlap", _i32), ("dp_table", _i32), ("dp_gather_master", _i32), ("comm", _vp), ("dp", _vp), ("grad_wire", _vp), ("wire_scale", _f32), ("frags_fresh", _i32)]
+                ("phase", _i32), ("dp_overlap", _i32), ("dp_table", _i32), ("dp_gather_master", _i32), ("comm", _vp), ("dp", _vp), ("grad_wire", _vp), ("wire_scale", _f32), ("frags_fresh", _i32),
+                ("wait_flag", _vp), ("wait_status", _vp), ("wait_value", _u32), ("pad4", _u32)]
 
 
 PHASE_ALL, PHASE_BACKWARD, PHASE_SWEEP = 0, 1, 2      # NGP_PHASE_*
@@ -100,6 +101,8 @@ SIGNATURES = {
     "ngp_adam_ema_step": (C.c_int, [_vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _f32, _i32]),
     "ngp_prof_enable": (C.c_int, [C.c_char_p]),
     "ngp_prof_read": (C.c_int, [_i32, _vp, _i32, _vp, _i32]),
+    "ngp_flag_signal": (C.c_int, [_vp, _vp, _u32]),
+    "ngp_flag_wait": (C.c_int, [_vp, _vp, _u32, _vp]),
     "ngp_comm_unique_id": (C.c_int, [_vp]),
     "ngp_comm_init": (C.c_int, [C.POINTER(_vp), _i32, _i32, _vp]),
     "ngp_comm_destroy": (C.c_int, [_vp]),

@@ -821,7 +821,7 @@ int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, 
 	const dim3 grid(n_slabs), block(512);
 	hipStream_t s = (hipStream_t)stream;
 	const float *packed = pack_weights32("ngp_field32_bwd", s, wd, wc, NF32_ALL, layout_flags); if (!packed) return NGP_E_ARG;
-	static const int variant = [] { const char *e = getenv("NGP_FIELD32_BWD"); return e ? atoi(e) : 1; }();      // 1 = ping-pong (r3), 0 = lock-step phases (r2)
+	static const int variant = [] { const char *e = getenv("NGP_FIELD32_BWD"); return e ? atoi(e) : 0; }();      // 0 = lock-step phases (r2; 144 us), 1 = ping-pong (r3; measured 151 us: ten barrier-separated blocks per role expose the fragment-load latency ten times - kept as an experiment)
 	if (variant == 1) {
 		const size_t shmem_pp = ((size_t)NF32_ALL * 256 + (size_t)128 * RSH32) * sizeof(float);
 #define GOPP(L) do { \

@@ -47,6 +47,35 @@ NGP_API int ngp_train_step_timings(float *ms_out, int max) {
 	return n;
 }
 
+// ---- batch hand-over by device flag (r3).  The sampling streams march batches two steps ahead; handing batch i to the training stream through an event costs that
+// stream ~29 us per iteration on MI355X (a marker packet on one queue, a barrier packet on the other - profiles/r02_lego_timeline.txt), although the batch has been
+// ready for a whole iteration.  Instead the sampling stream ends a batch with k_flag_signal (its own launch: the producing kernels have completed and released their
+// writes when it runs) and ngp_train_step starts with k_flag_wait, one wavefront that finds the flag already set in the normal case.  Kernel boundaries on both sides
+// provide the release / acquire; the spin is bounded (2 s) and reports through `status` instead of hanging the GPU.
+__global__ void k_flag_signal(uint32_t *flag, uint32_t value) {
+	if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_flag_wait(const uint32_t *flag, uint32_t value, uint32_t *status) {
+	if (threadIdx.x != 0) return;
+	const unsigned long long t0 = wall_clock64();                // constant 100 MHz counter
+	while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+		__builtin_amdgcn_s_sleep(16);
+		if (wall_clock64() - t0 > 200000000ull) { if (status) atomicOr(status, 1u); break; }
+	}
+}
+NGP_API int ngp_flag_signal(void *stream, uint32_t *flag, uint32_t value) {
+	NGP_REQUIRE(flag, NGP_E_ARG, "ngp_flag_signal: null flag");
+	NGP_LAUNCH(k_flag_signal, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value);
+	NGP_LAUNCH_CHECK("ngp_flag_signal");
+	return 0;
+}
+NGP_API int ngp_flag_wait(void *stream, const uint32_t *flag, uint32_t value, uint32_t *status) {
+	NGP_REQUIRE(flag, NGP_E_ARG, "ngp_flag_wait: null flag");
+	NGP_LAUNCH(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, status);
+	NGP_LAUNCH_CHECK("ngp_flag_wait");
+	return 0;
+}
+
 // ---- data parallel, overlapped variant: the library's communication stream and the two markers of one iteration (created on first use, per process)
 namespace {
 struct DpSide {
@@ -96,6 +125,7 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	}
 #define STAGE(id, call) do { Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
 	const int T = a->dtype, ow = a->grad_overwrite != 0;
+	if (do_bwd && a->wait_flag && (rc = ngp_flag_wait(stream, a->wait_flag, a->wait_value, a->wait_status))) return rc;      // the batch's hand-over from the sampling stream
 	// the flat fp32 weight pack among the optimiser tensors (fp32 network): its sweep also writes the next iteration's MFMA fragments (ngp_mlp32_sweep_pack)
 	int t_pack = -1;
 	if (T == NGP_F32) for (int t = 0; t < a->n_opt; ++t)

@@ -144,6 +144,11 @@ class FusedTrainStep:
         a.timed_stage = -1 if self.timed_stage is None else L.STAGES[self.timed_stage]
         a.coords, a.pos, a.numsteps, a.numsteps_compacted, a.n_valid = coords.data_ptr(), s._pos_train.data_ptr(), numsteps.data_ptr(), numsteps_c.data_ptr(), s._n_valid.data_ptr()
         a.bg, a.target = b["bg"].data_ptr(), b["target"].data_ptr()
+        fl = b.get("flag")             # (flag tensor, value, status tensor): the batch was marched on a sampling stream and handed over by device flag (Runner.train_step)
+        if fl is not None:
+            a.wait_flag, a.wait_value, a.wait_status = fl[0].data_ptr(), fl[1] & 0xFFFFFFFF, fl[2].data_ptr()
+        else:
+            a.wait_flag, a.wait_value, a.wait_status = None, 0, None
         a.table, a.wd, a.wc = table.data_ptr(), wd.data_ptr(), wc.data_ptr()
         a.rgb, a.loss, a.loss_grad = rgb.data_ptr(), loss.data_ptr(), lgrad.data_ptr()
         if self._dp_host_collective:

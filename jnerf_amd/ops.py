@@ -443,6 +443,15 @@ def generate_rays(pixel_index, W, H, focal, metadata, xforms, images=None, bg=No
     return img, o, d, target
 
 
+def flag_signal(flag, value):
+    """one-thread launch on the current stream: *flag = value (device int32 / uint32 scalar view), see ngp_flag_signal"""
+    check(L.lib().ngp_flag_signal(_stream(), _p(flag), int(value) & 0xFFFFFFFF), "ngp_flag_signal")
+
+
+def flag_wait(flag, value, status=None):
+    check(L.lib().ngp_flag_wait(_stream(), _p(flag), int(value) & 0xFFFFFFFF, _p(status)), "ngp_flag_wait")
+
+
 def selftest_mfma(device="cuda"):
     res = torch.zeros(4, dtype=torch.int32, device=device)
     check(L.lib().ngp_selftest_mfma(_stream(), _p(res)), "ngp_selftest_mfma")

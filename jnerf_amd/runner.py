@@ -105,6 +105,8 @@ class Runner:
         for st in self._sides:
             st.synchronize()
         self._queue.clear()
+        if getattr(self, "_flags", None) is not None and int(self._flags[-1].item()) != 0:
+            raise RuntimeError("a batch hand-over timed out on the GPU (ngp_flag_wait waited 2 s for a sampling stream): the results of this run are not valid")
         if hasattr(self.sampler, "finish_batch_rays_update"):
             self.sampler.finish_batch_rays_update()
 
@@ -149,8 +151,18 @@ class Runner:
         cfg = self.cfg
         main = torch.cuda.current_stream() if torch.cuda.is_available() else None
         b = self._queue.pop(i, None)
+        if self._fast is None:
+            from .fastpath import FusedTrainStep
+            self._fast = FusedTrainStep(self) if FusedTrainStep.applicable(self) else False
         if b is not None:
-            main.wait_event(b["ready"])
+            # hand-over of a batch marched on a sampling stream.  Native step: by device flag - the sampling stream ended the batch with ngp_flag_signal and the library's
+            # call starts with ngp_flag_wait (csrc/train_step.hip) - an event hand-over between two HIP streams costs the training stream ~29 us per iteration here.
+            # `flag_handover = False` in the config, and the module path, wait for the batch's event instead.
+            if self._fast and self._fast.native and b.get("flag") is not None and cfg.flag_handover is not False:
+                pass
+            else:
+                b["flag"] = None
+                main.wait_event(b["ready"])
             self.sampler.import_batch_state(b["state"])
         else:
             b = self._make_batch(i)                      # on the main stream: first step, refresh steps, pipeline off
@@ -158,9 +170,6 @@ class Runner:
                 self._grid_event.record(main)            # side streams must not read the bitfield before this refresh has finished
                 self._grid_valid = True
         cfg.m_training_step = i
-        if self._fast is None:
-            from .fastpath import FusedTrainStep
-            self._fast = FusedTrainStep(self) if FusedTrainStep.applicable(self) else False
         if self._fast:
             loss = self._fast(b)                         # same kernels, same order, no autograd / nn.Module overhead (fastpath.py)
         else:
@@ -179,6 +188,7 @@ class Runner:
             self._ready = [torch.cuda.Event() for _ in range(n_sets)]            # persistent events, re-recorded (no create/destroy per step)
             self._done = [torch.cuda.Event() for _ in range(n_sets // P + 2)]
             self._grid_event, self._grid_valid = torch.cuda.Event(), False
+            self._flags = torch.zeros(n_sets + 1, dtype=torch.int32, device=self.sampler.device)      # one hand-over flag per buffer set + the wait kernels' status word
             if self.sampler.grid_updated_in_last_sample:
                 self._grid_event.record(main); self._grid_valid = True
         # `done` checkpoint of the training stream, every P-th step only: an event record is a marker packet in the stream's queue and costs ~15 us of dead time
@@ -204,6 +214,9 @@ class Runner:
                 cur_state = self.sampler.export_batch_state()
             with torch.cuda.stream(side):
                 nb = self._make_batch(k)
+                from . import ops as _ops
+                _ops.flag_signal(self._flags[k % n_sets:k % n_sets + 1], k + 1)         # behind the batch's kernels on this stream: the training stream's ngp_flag_wait
+                nb["flag"] = (self._flags[k % n_sets:k % n_sets + 1], k + 1, self._flags[n_sets:])
                 nb["ready"] = self._ready[k % n_sets]
                 nb["ready"].record(side)
             for t in (nb["bg"], nb["target"]) + tuple(nb["keep"]):
