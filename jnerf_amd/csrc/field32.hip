@@ -717,19 +717,331 @@ __global__ __launch_bounds__(512, 2) void k_field32_bwd_pp(uint32_t n, const flo
 	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, stage, 8); }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- backward, two free-running groups (r3)
+// What the ping-pong variant taught: pairing the forward/dgrad chain with the other half's staging phases through SHARED barriers chops the chain into ten blocks, and
+// every block start exposes the latency of its fragment loads (151 us vs 144).  What it needs is the overlap without the coupling: here the two halves of the workgroup
+// (waves 0-3 / 4-7, one wave of each per SIMD) are two INDEPENDENT groups that share nothing but the read-only weight fragments - own staging region (2 x 34 KiB), own
+// barrier (an LDS arrival counter the group's four waves poll: s_barrier would stop the other group too), own half trips.  Each group runs the plain sequence - 284
+// MFMAs of forward + dgrad without any synchronisation, then the five staging phases - and group 1 starts half an iteration late, so one group's LDS-write / barrier
+// phases fall into the other group's MFMA stretch on the same SIMD.  It is what two workgroups per CU would do if 76 KiB of fragments fitted twice.
+template <int LAYOUT>
+__global__ __launch_bounds__(512, 2) void k_field32_bwd_2g(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+                                                           const float *__restrict__ packed, const float *__restrict__ dout,
+                                                           float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
+	extern __shared__ __attribute__((aligned(16))) float smem32[];
+	float *wl = smem32;                                   // 76 fragments
+	float *stage = smem32 + NF32_ALL * 256 + (size_t)((threadIdx.x >> 8) * 128 * RSH32);      // [128][RSH32], one region per GROUP (waves 0-3 / 4-7)
+	__shared__ uint32_t gctr[2];                            // arrival counters of the two groups' barriers (monotonic)
+	if (threadIdx.x < 2) gctr[threadIdx.x] = 0u;
+	__shared__ uint32_t gstart;                             // group 0 -> group 1: "my first forward/dgrad block is done" (the two groups run half an iteration apart)
+	if (threadIdx.x == 2) gstart = 0u;
+	stage_weights32(wl, packed, NF32_ALL);
+	const float *wb = wl + NF32_FWD * 256;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6, half = w >> 2, wq = w & 3;
+	const uint32_t n_ht = (lim + HT32 - 1) / HT32;
+	const uint32_t K = blockIdx.x < n_ht ? (n_ht - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;      // half trips of this workgroup: blockIdx.x, + gridDim.x, ...
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	floatx4 aV1[4] = {z, z, z, z}, aW0[2] = {z, z}, aV0[2] = {z, z}, aW1 = z, aV2 = z;            // this wave's ten weight-gradient tiles (summed over its half's samples)
+	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+	__syncthreads();
+	struct Inputs { float f[8]; float d3[3]; float go[4]; };
+	auto fetch = [&](uint32_t k, Inputs &in) {
+		const uint32_t i = (blockIdx.x + k * gridDim.x) * HT32 + 16u * wq + s;
+		const bool valid = i < lim;
+		const uint32_t ic = valid ? i : lim - 1;
+		load_feat32<LAYOUT>(feat, n, ic, g, in.f);
+		in.d3[0] = dir[(size_t)ic * dir_stride]; in.d3[1] = dir[(size_t)ic * dir_stride + 1]; in.d3[2] = dir[(size_t)ic * dir_stride + 2];
+		in.go[0] = in.go[1] = in.go[2] = in.go[3] = 0.f;
+		if (valid) { const float4 v = *reinterpret_cast<const float4 *>(dout + (size_t)i * 4); in.go[0] = v.x; in.go[1] = v.y; in.go[2] = v.z; in.go[3] = v.w; }
+	};
+	// what role X leaves in registers for role Y
+	Inputs cur;
+	float sh[4] = {0.f, 0.f, 0.f, 0.f};
+	Fwd32 st;
+	floatx4 dO = z, dG1[4], dG0[4], dH[4], dD = z;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) { st.h[u] = z; st.g0[u] = z; st.g1[u] = z; dG1[u] = z; dG0[u] = z; dH[u] = z; }
+	st.den = z; st.rgb = z;
+#pragma unroll
+	for (int q = 0; q < 8; ++q) cur.f[q] = 0.f;
+	if ((uint32_t)half < K) fetch((uint32_t)half, cur);           // half h does X on k = h, h + 2, ...
+	const int o = lane & 15, col = 16 * wq + s;
+	uint32_t gepoch = 0;
+#define GROUP_BAR() do { gepoch += 4u; if (lane == 0) __hip_atomic_fetch_add(&gctr[half], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
+	for (uint32_t spin_ = 0; __hip_atomic_load(&gctr[half], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < gepoch && spin_ < (1u << 24); ++spin_) __builtin_amdgcn_s_sleep(1); } while (0)   /* (bounded: a bug must not hang the GPU) */
+	if (half == 1 && K >= 1u) for (uint32_t spin_ = 0; __hip_atomic_load(&gstart, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u && spin_ < (1u << 22); ++spin_) __builtin_amdgcn_s_sleep(4);      // start half an iteration late
+	for (uint32_t it = (uint32_t)half; it < K; it += 2u) {
+		{
+			// ------------------------------------------------------------ forward recompute + dgrad of half trip `it`: 284 MFMAs per wave, no synchronisation at all
+			const bool work = true;
+			const uint32_t i = (blockIdx.x + it * gridDim.x) * HT32 + 16u * wq + s;
+			const bool valid = work && i < lim;
+			floatx4 acc[4] = {z, z, z, z};
+			if (work) {
+				sh4_32(cur.d3, g, sh);
+#pragma unroll
+				for (int kq = 0; kq < 2; ++kq) {                       // L0: 32 -> 64
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 2 * u + kq, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+#pragma unroll
+						for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], cur.f[4 * kq + j], acc[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) st.h[u] = relu4(acc[u]);
+			}
+			if (work) {
+				floatx4 d0 = z, d1 = z;                                // L1: 64 -> 16
+#pragma unroll
+				for (int kq = 0; kq < 4; ++kq) {
+					const floatx4 a = ld_frag32(wl, 8 + kq, lane);
+					d0 = MFMA32(a[0], st.h[kq][0], d0); d1 = MFMA32(a[1], st.h[kq][1], d1);
+					d0 = MFMA32(a[2], st.h[kq][2], d0); d1 = MFMA32(a[3], st.h[kq][3], d1);
+				}
+				st.den = d0 + d1;
+			}
+			if (work) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) acc[u] = z;
+#pragma unroll
+				for (int kq = 0; kq < 2; ++kq) {                       // L2: [density(16) | SH(16)] -> 64
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 12 + 2 * u + kq, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						const float b = kq == 0 ? st.den[j] : sh[j];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], b, acc[u]);
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) st.g0[u] = relu4(acc[u]);
+			}
+			if (work) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) acc[u] = z;
+#pragma unroll
+				for (int kq = 0; kq < 4; ++kq) {                       // L3: 64 -> 64
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 20 + 4 * u + kq, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+#pragma unroll
+						for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], st.g0[kq][j], acc[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) st.g1[u] = relu4(acc[u]);
+			}
+			// (L4, the rgb output, is not needed by the backward pass: dL/d(rgb logits) comes in from the compositor)
+			if (work) {
+				dO = z;                                                // register j <-> gradient of output neuron 4g+j; only neurons 0..2 (g == 0) are non-zero
+				if (g == 0) { dO[0] = cur.go[0]; dO[1] = cur.go[1]; dO[2] = cur.go[2]; }
+				floatx4 a[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, u, lane); dG1[u] = z; }
+#pragma unroll
+				for (int j = 0; j < 3; ++j)
+#pragma unroll
+					for (int u = 0; u < 4; ++u) dG1[u] = MFMA32(a[u][j], dO[j], dG1[u]);
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dG1[u] = mask4(dG1[u], st.g1[u]);
+			}
+			if (work) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dG0[u] = z;
+#pragma unroll
+				for (int t = 0; t < 2; ++t) {
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wb, 4 + 4 * u + t, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+#pragma unroll
+						for (int u = 0; u < 4; ++u) dG0[u] = MFMA32(a[u][j], dG1[t][j], dG0[u]);
+				}
+			}
+			if (work) {
+#pragma unroll
+				for (int t = 2; t < 4; ++t) {
+					floatx4 a[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wb, 4 + 4 * u + t, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+#pragma unroll
+						for (int u = 0; u < 4; ++u) dG0[u] = MFMA32(a[u][j], dG1[t][j], dG0[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dG0[u] = mask4(dG0[u], st.g0[u]);
+			}
+			if (work) {
+				floatx4 d0 = z, d1 = z;
+#pragma unroll
+				for (int t = 0; t < 4; ++t) {
+					const floatx4 a = ld_frag32(wb, 20 + t, lane);
+					d0 = MFMA32(a[0], dG0[t][0], d0); d1 = MFMA32(a[1], dG0[t][1], d1);
+					d0 = MFMA32(a[2], dG0[t][2], d0); d1 = MFMA32(a[3], dG0[t][3], d1);
+				}
+				dD = d0 + d1;
+				if (g == 0) dD[0] += cur.go[3];                       // out[:,3] = den[:,0]  (ngp_network.py:83)
+				floatx4 a[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, 24 + u, lane); dH[u] = z; }
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+#pragma unroll
+					for (int u = 0; u < 4; ++u) dH[u] = MFMA32(a[u][j], dD[j], dH[u]);
+#pragma unroll
+				for (int u = 0; u < 4; ++u) dH[u] = mask4(dH[u], st.h[u]);
+			}
+			floatx4 dF[2] = {z, z};
+			if (work) {
+#pragma unroll
+				for (int t = 0; t < 2; ++t) {
+					const floatx4 a0 = ld_frag32(wb, 28 + t, lane), a1 = ld_frag32(wb, 32 + t, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) { dF[0] = MFMA32(a0[j], dH[t][j], dF[0]); dF[1] = MFMA32(a1[j], dH[t][j], dF[1]); }
+				}
+			}
+			if (work) {
+#pragma unroll
+				for (int t = 2; t < 4; ++t) {
+					const floatx4 a0 = ld_frag32(wb, 28 + t, lane), a1 = ld_frag32(wb, 32 + t, lane);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) { dF[0] = MFMA32(a0[j], dH[t][j], dF[0]); dF[1] = MFMA32(a1[j], dH[t][j], dF[1]); }
+				}
+				if (valid) {                                          // feature 16u+4g+r  ->  level 8u+2g+(r>>1), component r&1
+#pragma unroll
+					for (int u = 0; u < 2; ++u)
+#pragma unroll
+						for (int pr = 0; pr < 2; ++pr) {
+							const float2 v = make_float2(dF[u][2 * pr], dF[u][2 * pr + 1]);
+							const uint32_t level = 8 * u + 2 * g + pr;
+							lmax[u][pr] = fmaxf(lmax[u][pr], fmaxf(fabsf(v.x), fabsf(v.y)));
+							if (LAYOUT == NGP_LAYOUT_SOA) reinterpret_cast<float2 *>(dfeat)[(size_t)level * n + i] = v;
+							else *reinterpret_cast<float2 *>(dfeat + (size_t)i * 32 + 2 * level) = v;
+						}
+				}
+			}
+		}
+		if (half == 0 && it == 0u && lane == 0 && wq == 0) __hip_atomic_store(&gstart, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		{
+			// ------------------------------------------------------------ weight gradients of the same half trip: five phases through the GROUP's staging region, barriers among the group's four waves only
+			const bool work = true;
+			// phase A: dG1 rows 0..63 | G0 rows 64..127 -> V1: wave wq owns output tile `wq` against the four input tiles
+			if (work) { st_tiles_h(stage, 0, col, g, dG1); st_tiles_h(stage, 64, col, g, st.g0); }
+			GROUP_BAR();                                                  // 1
+			if (work) {
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) aV1[ti] = wgrad_tile_h(stage, 16 * wq, 64 + 16 * ti, o, g, aV1[ti]);
+			}
+			GROUP_BAR();                                                  // 2
+			// phase B1: dH 0..63 | F 64..95 -> W0
+			if (work) {
+				st_tiles_h(stage, 0, col, g, dH);
+#pragma unroll
+				for (int q = 0; q < 8; ++q) stage[(64 + 8 * g + q) * RSH32 + col] = cur.f[q];
+			}
+			GROUP_BAR();                                                  // 3
+			if (work) {
+				aW0[0] = wgrad_tile_h(stage, 16 * wq, 64, o, g, aW0[0]);
+				aW0[1] = wgrad_tile_h(stage, 16 * wq, 80, o, g, aW0[1]);
+			}
+			GROUP_BAR();                                                  // 4
+			// phase B2: dG0 0..63 | IN2 = [density(16) | SH(16)] 64..95 -> V0
+			if (work) {
+				st_tiles_h(stage, 0, col, g, dG0);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) { stage[(64 + 4 * g + r) * RSH32 + col] = st.den[r]; stage[(80 + 4 * g + r) * RSH32 + col] = sh[r]; }
+			}
+			GROUP_BAR();                                                  // 5
+			if (work) {
+				aV0[0] = wgrad_tile_h(stage, 16 * wq, 64, o, g, aV0[0]);
+				aV0[1] = wgrad_tile_h(stage, 16 * wq, 80, o, g, aV0[1]);
+			}
+			GROUP_BAR();                                                  // 6
+			// phase C1: dD 0..15 | H 16..79 -> W1: input tile wq
+			if (work) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RSH32 + col] = dD[r];
+				st_tiles_h(stage, 16, col, g, st.h);
+			}
+			GROUP_BAR();                                                  // 7
+			if (work) aW1 = wgrad_tile_h(stage, 0, 16 + 16 * wq, o, g, aW1);
+			GROUP_BAR();                                                  // 8
+			// phase C2: dO 0..15 | G1 16..79 -> V2
+			if (work) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RSH32 + col] = dO[r];
+				st_tiles_h(stage, 16, col, g, st.g1);
+			}
+			GROUP_BAR();                                                  // 9
+			if (work) aV2 = wgrad_tile_h(stage, 0, 16 + 16 * wq, o, g, aV2);
+			if (it + 2u < K) fetch(it + 2u, cur);                     // inputs of this group's next half trip
+			GROUP_BAR();                                                  // 10
+		}
+	}
+	// ---- the two halves hold partial sums of the same ten tiles per wave index: half 1 hands its sums over through LDS (the fragment region is free now), half 0
+	// adds and writes the workgroup's slab, packed like the weights (wd part 0..3071, wc part 3072..10239); C rows = 4g+r, cols = lane&15
+	float *xch = wl + (size_t)wq * 10 * 256;                    // [wave][10 tiles][64 lanes][4]
+	auto put = [&](int tile, const floatx4 &v) { *reinterpret_cast<floatx4 *>(xch + tile * 256 + lane * 4) = v; };
+	auto get = [&](int tile) { return *reinterpret_cast<const floatx4 *>(xch + tile * 256 + lane * 4); };
+	__syncthreads();
+	if (half == 1) {
+#pragma unroll
+		for (int t = 0; t < 4; ++t) put(t, aV1[t]);
+		put(4, aW0[0]); put(5, aW0[1]); put(6, aV0[0]); put(7, aV0[1]); put(8, aW1); put(9, aV2);
+	}
+	__syncthreads();
+	if (half == 0) {
+#pragma unroll
+		for (int t = 0; t < 4; ++t) aV1[t] += get(t);
+		aW0[0] += get(4); aW0[1] += get(5); aV0[0] += get(6); aV0[1] += get(7); aW1 += get(8); aV2 += get(9);
+		float *slab = slabs + (size_t)blockIdx.x * 10240;
+		const int ci = lane & 15;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int ro = 4 * g + r;
+#pragma unroll
+			for (int ti = 0; ti < 4; ++ti) slab[3072 + 2048 + (16 * wq + ro) * 64 + 16 * ti + ci] = aV1[ti][r];
+#pragma unroll
+			for (int tj = 0; tj < 2; ++tj) { slab[(16 * wq + ro) * 32 + 16 * tj + ci] = aW0[tj][r]; slab[3072 + (16 * wq + ro) * 32 + 16 * tj + ci] = aV0[tj][r]; }
+			slab[2048 + ro * 64 + 16 * wq + ci] = aW1[r];
+			slab[3072 + 6144 + ro * 64 + 16 * wq + ci] = aV2[r];
+		}
+	}
+	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, smem32 + NF32_ALL * 256, 8); }      // (one scratch for both groups: group 0's staging region)
+}
+
+#undef GROUP_BAR
+
 // ---------------------------------------------------------------------------------------------------------------- fused tail of the fp32 step (r3)
 // Adam+EMA sweep of the flat weight pack (10240 floats, EMA aliasing the parameter like k_adam_ema<float, 2>) and the MFMA fragments of the UPDATED weights for the
 // next iteration, one single-workgroup launch instead of k_adam_ema (pack) + next step's k_pack_frags32: two launches and their boundaries less per iteration.
 __global__ __launch_bounds__(1024) void k_mlp32_sweep_pack(float *__restrict__ pack, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, AdamConsts c,
                                                            float *__restrict__ packed_out) {
 	__shared__ float w[10240];
-	for (int i = threadIdx.x; i < 10240; i += 1024) {
-		float P = pack[i], M = m[i], V = v[i], E = P;
-		adam_ema_update<true>(P, M, V, E, grad[i], c);
-		pack[i] = P; m[i] = M; v[i] = V; w[i] = P;
+	// one workgroup, ten elements per thread: all forty loads of a thread are issued before the first use (a loop of dependent load -> update -> store round trips
+	// made this launch 15 us long for 160 KB of traffic)
+	float P[10], M[10], V[10], G[10];
+#pragma unroll
+	for (int k = 0; k < 10; ++k) { const int i = threadIdx.x + 1024 * k; P[k] = pack[i]; M[k] = m[i]; V[k] = v[i]; G[k] = grad[i]; }
+#pragma unroll
+	for (int k = 0; k < 10; ++k) {
+		const int i = threadIdx.x + 1024 * k;
+		float E = P[k];
+		adam_ema_update<true>(P[k], M[k], V[k], E, G[k], c);
+		pack[i] = P[k]; m[i] = M[k]; v[i] = V[k]; w[i] = P[k];
 	}
 	__syncthreads();
-	for (int idx = threadIdx.x; idx < NF32_ALL * 256; idx += 1024) {
+#pragma unroll
+	for (int k = 0; k < NF32_ALL / 4; ++k) {                  // 19 rounds of 1024 fragment values: the gathers from LDS are independent, the stores coalesced
+		const int idx = threadIdx.x + 1024 * k;
 		const int f = idx >> 8, lane = (idx >> 2) & 63, j = idx & 3;
 		packed_out[idx] = frag_value32(w, w + 3072, f, lane & 15, lane >> 4, j);
 	}
@@ -822,6 +1134,18 @@ int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, 
 	hipStream_t s = (hipStream_t)stream;
 	const float *packed = pack_weights32("ngp_field32_bwd", s, wd, wc, NF32_ALL, layout_flags); if (!packed) return NGP_E_ARG;
 	static const int variant = [] { const char *e = getenv("NGP_FIELD32_BWD"); return e ? atoi(e) : 0; }();      // 0 = lock-step phases (r2; 144 us), 1 = ping-pong (r3; measured 151 us: ten barrier-separated blocks per role expose the fragment-load latency ten times - kept as an experiment)
+	if (variant == 2) {
+		const size_t shmem_2g = ((size_t)NF32_ALL * 256 + (size_t)2 * 128 * RSH32) * sizeof(float);
+#define GO2G(L) do { \
+	static bool attr_set = false; \
+	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_2g<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_2g); \
+		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
+	NGP_LAUNCH((k_field32_bwd_2g<L>), grid, block, shmem_2g, s, n, feat, dir, dir_stride, packed, dLdout, dLdfeat, wgrad_slabs, n_valid, am); } while (0)
+		if (layout == NGP_LAYOUT_SOA) GO2G(NGP_LAYOUT_SOA); else GO2G(NGP_LAYOUT_AOS);
+#undef GO2G
+		NGP_LAUNCH_CHECK("ngp_field32_bwd");
+		return 0;
+	}
 	if (variant == 1) {
 		const size_t shmem_pp = ((size_t)NF32_ALL * 256 + (size_t)128 * RSH32) * sizeof(float);
 #define GOPP(L) do { \

@@ -214,9 +214,78 @@ def synthetic_field(p):
     return sigma, torch.clamp(rgb * stripes, 0.0, 1.0)
 
 
+def _hash01(ix, iy, iz, salt=0):
+    """integer lattice -> [0, 1): a cheap integer hash (any fixed function would do - it only has to be the same for every ray that sees the cell)"""
+    h = (ix * 73856093) ^ (iy * 19349663) ^ (iz * 83492791) ^ (salt * 2654435761)
+    h = (h ^ (h >> 13)) * 1274126177
+    h = h ^ (h >> 16)
+    return (h & 0xFFFFFF).to(torch.float32) / float(1 << 24)
+
+
+def bricks_field(p, d):
+    """A lego-DIFFICULTY stand-in (NeRF-synthetic lego itself cannot be fetched here): a bulldozer-shaped hull (body, cabin, blade, two tracks with
+    gaps, two thin pipes: ~2.5 % of the unit cube, ~5 % of the 128^3 occupancy cells) built from staggered bricks with mortar gaps and studs, hard surfaces, a palette
+    colour per brick, a printed texture at about one pixel footprint, and view-dependent shading (diffuse + a specular lobe the degree-4 SH head cannot fully follow).
+    p, d [n,3] (ngp world coordinates, unit directions) -> sigma [n], rgb [n,3]."""
+    c = p - 0.5
+    x, y, z = c[:, 0], c[:, 1], c[:, 2]
+
+    def box(cx, cy, cz, hx, hy, hz):
+        return ((x - cx).abs() < hx) & ((y - cy).abs() < hy) & ((z - cz).abs() < hz)
+    body = box(0.0, 0.0, -0.025, 0.22, 0.12, 0.075)
+    cabin = box(0.05, 0.0, 0.11, 0.08, 0.09, 0.06) & ~box(0.05, 0.0, 0.115, 0.07, 0.10, 0.035)          # a cabin with window openings through it
+    blade = box(0.255, 0.0, -0.05, 0.015, 0.20, 0.07)
+    track_gap = (torch.remainder(x + 0.25, 0.05) < 0.041)                                                 # track links with gaps between them
+    tracks = (box(0.0, 0.15, -0.095, 0.25, 0.018, 0.045) | box(0.0, -0.15, -0.095, 0.25, 0.018, 0.045)) & track_gap
+    hull = body | cabin | blade | tracks
+    # staggered bricks: 0.05 x 0.05 x 0.03, every other layer shifted by half a brick; a 1.5e-3 mortar gap all round; ~12 % of the bricks missing
+    bsx, bsy, bsz, gap = 0.05, 0.05, 0.03, 0.0015
+    layer = torch.floor(z / bsz)
+    xs = x + 0.5 * bsx * torch.remainder(layer, 2.0)
+    ix, iy, iz = torch.floor(xs / bsx).to(torch.int64), torch.floor(y / bsy).to(torch.int64), layer.to(torch.int64)
+    lx, ly, lz = xs - (ix.to(torch.float32) + 0.5) * bsx, y - (iy.to(torch.float32) + 0.5) * bsy, z - (iz.to(torch.float32) + 0.5) * bsz
+    hsh = _hash01(ix, iy, iz)
+    in_brick = (lx.abs() < 0.5 * bsx - gap) & (ly.abs() < 0.5 * bsy - gap) & (lz.abs() < 0.5 * bsz - gap)
+    solid = hull & in_brick & (hsh > 0.12)
+    # studs: 2 x 2 cylinders (radius 6e-3, height 5e-3) on top of every brick whose cell above is outside the hull - tested from the cell above
+    below = _hash01(ix, iy, iz - 1) > 0.12
+    sx, sy = torch.remainder(xs, 0.5 * bsx) - 0.25 * bsx, torch.remainder(y, 0.5 * bsy) - 0.25 * bsy
+    stud = (~hull) & below & (lz < -0.5 * bsz + 0.005) & (sx * sx + sy * sy < 0.006 ** 2)
+    zb = z - bsz                                                                                            # the stud belongs to the brick one layer down: that one must be in the hull
+    stud = stud & (((x).abs() < 0.22) & (y.abs() < 0.12) & ((zb + 0.025).abs() < 0.075) | ((x - 0.05).abs() < 0.08) & (y.abs() < 0.09) & ((zb - 0.11).abs() < 0.06))
+    # two thin pipes (radius 5e-3) from the cabin roof down to the blade
+    def pipe(a, b):
+        a = torch.tensor(a, device=p.device); b = torch.tensor(b, device=p.device)
+        ab = b - a
+        t = ((c - a) @ ab / (ab @ ab)).clamp(0.0, 1.0)
+        return ((c - (a + t[:, None] * ab)) ** 2).sum(-1) < 0.005 ** 2
+    pipes = pipe([0.05, 0.07, 0.17], [0.25, 0.16, 0.02]) | pipe([0.05, -0.07, 0.17], [0.25, -0.16, 0.02])
+    occ = solid | stud | pipes
+    sigma = 500.0 * occ.to(torch.float32)
+    # ---- appearance: palette colour per brick, a printed texture (cells of 1/640: about one pixel footprint of the 800 x 800 views), face normal from the dominant
+    # axis of the offset inside the brick, diffuse + specular under a fixed light
+    palette = torch.tensor([[0.85, 0.12, 0.10], [0.95, 0.78, 0.10], [0.10, 0.35, 0.80], [0.12, 0.60, 0.25], [0.88, 0.88, 0.86], [0.15, 0.15, 0.17]], device=p.device)
+    base = palette[(hsh * 5.999).to(torch.int64).clamp(0, 5)]
+    base = torch.where(pipes[:, None], torch.tensor([0.6, 0.6, 0.65], device=p.device).expand_as(base), base)
+    tex = 0.93 + 0.14 * _hash01(torch.floor(p[:, 0] * 640).to(torch.int64), torch.floor(p[:, 1] * 640).to(torch.int64), torch.floor(p[:, 2] * 640).to(torch.int64), salt=7)
+    tex = tex * (0.9 + 0.1 * torch.sign(torch.sin(c[:, 0] * 400.0) * torch.sin(c[:, 1] * 400.0)))      # a fine checker print
+    ax = torch.stack([lx.abs() / bsx, ly.abs() / bsy, lz.abs() / bsz], -1)
+    dom = ax.argmax(-1)
+    sgn = torch.sign(torch.stack([lx, ly, lz], -1).gather(1, dom[:, None])[:, 0])
+    nrm = torch.nn.functional.one_hot(dom, 3).to(torch.float32) * sgn[:, None]
+    light = torch.nn.functional.normalize(torch.tensor([0.4, 0.3, 0.86], device=p.device), dim=0)
+    diffuse = 0.55 + 0.45 * (nrm @ light).clamp_min(0.0)
+    half = torch.nn.functional.normalize(light[None] - d, dim=-1)
+    spec = 0.45 * ((nrm * half).sum(-1).clamp_min(0.0)) ** 40
+    rgb = (base * (tex * diffuse)[:, None] + spec[:, None]).clamp(0.0, 1.0)
+    return sigma, rgb
+
+
 @DATASETS.register_module()
 class SyntheticNerfDataset(_RayDatasetBase):
-    def __init__(self, batch_size, n_images=50, W=400, H=400, aabb_scale=4, radius=1.3, fov_deg=40.0, mode="train", seed=0, n_steps=192, **_):
+    def __init__(self, batch_size, n_images=50, W=400, H=400, aabb_scale=4, radius=1.3, fov_deg=40.0, mode="train", seed=0, n_steps=None, scene="spheres", **_):
+        self.scene = scene                   # "spheres": four soft striped spheres (rounds 1-2; trains to > 50 dB) | "bricks": the lego-difficulty stand-in (bricks_field)
+        n_steps = n_steps or (640 if scene == "bricks" else 192)
         self.batch_size, self.mode, self.W, self.H, self.aabb_scale, self.n_images = batch_size, mode, W, H, aabb_scale, n_images
         self.scale, self.offset, self.correct_pose, self.have_img = NERF_SCALE, [0.5, 0.5, 0.5], [1, -1, -1], True
         cfg = get_cfg()
@@ -234,7 +303,7 @@ class SyntheticNerfDataset(_RayDatasetBase):
     @torch.no_grad()
     def _render_ground_truth(self, n_steps):
         out = torch.empty((self.n_images, self.H * self.W, 4), dtype=torch.float32, device=self.device)
-        chunk = 1 << 16
+        chunk = (1 << 16) if n_steps <= 256 else (1 << 13)
         t = torch.linspace(0.0, 1.0, n_steps, device=self.device)
         for i in range(self.n_images):
             index = torch.arange(self.H * self.W, device=self.device, dtype=torch.int64) + i * self.H * self.W
@@ -246,7 +315,10 @@ class SyntheticNerfDataset(_RayDatasetBase):
                 ts = t0[:, None] + (t1 - t0)[:, None] * t[None]
                 dt = ((t1 - t0) / (n_steps - 1))[:, None]
                 p = oo[:, None, :] + ts[..., None] * dd[:, None, :]
-                sigma, rgb = synthetic_field(p.reshape(-1, 3))
+                if self.scene == "bricks":
+                    sigma, rgb = bricks_field(p.reshape(-1, 3), dd[:, None, :].expand_as(p).reshape(-1, 3))
+                else:
+                    sigma, rgb = synthetic_field(p.reshape(-1, 3))
                 sigma, rgb = sigma.view(-1, n_steps), rgb.view(-1, n_steps, 3)
                 alpha = 1.0 - torch.exp(-sigma * dt)
                 T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha[:, :-1]], 1), 1)

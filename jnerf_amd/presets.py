@@ -4,8 +4,8 @@ from .utils.config import reset_cfg
 
 
 def ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda", rank=0, world_size=1, tot_train_steps=40000,
-            n_rays_per_batch=4096, target_batch_size=1 << 18, exp_name="synth", log_dir="./logs", **extra):
-    ds = dict(type="SyntheticNerfDataset", batch_size=n_rays_per_batch, n_images=n_images, W=W, H=H, aabb_scale=aabb_scale)
+            n_rays_per_batch=4096, target_batch_size=1 << 18, exp_name="synth", log_dir="./logs", scene="spheres", **extra):
+    ds = dict(type="SyntheticNerfDataset", batch_size=n_rays_per_batch, n_images=n_images, W=W, H=H, aabb_scale=aabb_scale, scene=scene)
     return reset_cfg(
         sampler=dict(type="DensityGridSampler", update_den_freq=16),
         encoder=dict(pos_encoder=dict(type="HashEncoder"), dir_encoder=dict(type="SHEncoder")),

@@ -156,9 +156,10 @@ class Runner:
             self._fast = FusedTrainStep(self) if FusedTrainStep.applicable(self) else False
         if b is not None:
             # hand-over of a batch marched on a sampling stream.  Native step: by device flag - the sampling stream ended the batch with ngp_flag_signal and the library's
-            # call starts with ngp_flag_wait (csrc/train_step.hip) - an event hand-over between two HIP streams costs the training stream ~29 us per iteration here.
-            # `flag_handover = False` in the config, and the module path, wait for the batch's event instead.
-            if self._fast and self._fast.native and b.get("flag") is not None and cfg.flag_handover is not False:
+            # call starts with ngp_flag_wait (csrc/train_step.hip).  Built on round 2's reading of the timeline (an event hand-over costing the training stream ~29 us per
+            # iteration); measured in round 3 it changes nothing (gpurun_out/r3d_*: 1471 vs 1477 it/s) - the boundary gap is not the event - so it is OPT-IN
+            # (`flag_handover = True` in the config); by default, and on the module path, the batch's event is waited for.
+            if self._fast and self._fast.native and b.get("flag") is not None and cfg.flag_handover is True:
                 pass
             else:
                 b["flag"] = None

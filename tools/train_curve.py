@@ -1,5 +1,6 @@
 """PSNR-vs-wall-time of the FULL reference schedule (40 000 iterations, ExpDecay at 20 k / 30 k) on the bench scene: BASELINE.json's second headline
-("PSNR@5min") restated for a scene that exists on the GPU box.  Writes a markdown table.  usage: train_curve.py out.md [steps] [lego|fox]
+("PSNR@5min") restated for a scene that exists on the GPU box.  Writes a markdown table.  usage: train_curve.py out.md [steps] [lego|fox|bricks]
+bricks = the ngp_base.py hyper-parameters on the lego-DIFFICULTY stand-in (jnerf_amd/dataset.py: bricks_field - hard surfaces, thin parts, pixel-scale texture, specular shading)
 lego = projects/ngp/configs/ngp_base.py hyper-parameters (fp32, aabb 1, constant step) on the 100 x 800 x 800 procedural scene; fox = ngp_fox.py's on 50 x 400 x 400."""
 import os
 import sys
@@ -15,9 +16,9 @@ out = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 which = sys.argv[3] if len(sys.argv) > 3 else "lego"
 torch.manual_seed(1234)
-if which == "lego":
-    ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=100, W=800, H=800, device="cuda:0", tot_train_steps=steps)
-    title = "procedural 100 x 800 x 800 RGBA, ngp_base.py (lego) hyper-parameters, fp32"
+if which in ("lego", "bricks"):
+    ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=100, W=800, H=800, device="cuda:0", tot_train_steps=steps, scene="bricks" if which == "bricks" else "spheres")
+    title = ("lego-difficulty stand-in `bricks`" if which == "bricks" else "procedural") + " 100 x 800 x 800 RGBA, ngp_base.py (lego) hyper-parameters, fp32"
 else:
     ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0", tot_train_steps=steps)
     title = "procedural 50 x 400 x 400 RGBA, fox hyper-parameters, fp16"
@@ -44,6 +45,12 @@ with r.training_stream():                                   # as Runner.train do
             r.drain(); torch.cuda.synchronize()
             train_s += time.perf_counter() - t0
             rows.append((i + 1, train_s, psnr_now(), r.optimizer._nested_optimizer.lr, r.sampler.n_rays_per_batch))
+            if i + 1 == steps:
+                ds = r.dataset["train"]
+                bits = r.sampler.density_grid_bitfield[:128 ** 3 // 8].to(torch.int32)
+                occ = float((((bits[:, None] >> torch.arange(8, device=bits.device)[None]) & 1).float().mean()).item())
+                extra_note = (f"occupied cells of the 128^3 grid (cascade 0) at the end: {100 * occ:.2f} %; alpha coverage of the training images {float(ds.image_data[..., 3].mean().item()):.3f}; "
+                              f"samples per ray at the end {(1 << 18) / max(r.sampler.n_rays_per_batch, 1):.1f}")
             print(rows[-1], flush=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -53,4 +60,5 @@ with open(out, "w") as f:
     f.write("training time excludes the evaluation renders.\n\n| iteration | training seconds | it/s so far | test PSNR (dB) | lr | rays / batch |\n|---|---|---|---|---|---|\n")
     for it, s, p, lr, nr in rows:
         f.write(f"| {it} | {s:.2f} | {it / s:.0f} | {p:.2f} | {lr:.4g} | {nr} |\n")
+    f.write("\n" + extra_note + "\n")
 print(open(out).read())
