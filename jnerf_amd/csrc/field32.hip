@@ -1133,7 +1133,9 @@ int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, 
 	const dim3 grid(n_slabs), block(512);
 	hipStream_t s = (hipStream_t)stream;
 	const float *packed = pack_weights32("ngp_field32_bwd", s, wd, wc, NF32_ALL, layout_flags); if (!packed) return NGP_E_ARG;
-	static const int variant = [] { const char *e = getenv("NGP_FIELD32_BWD"); return e ? atoi(e) : 0; }();      // 0 = lock-step phases (r2; 144 us), 1 = ping-pong (r3; measured 151 us: ten barrier-separated blocks per role expose the fragment-load latency ten times - kept as an experiment)
+	// 2 = two free-running groups (r3, default: 138 us, +1 % it/s), 0 = lock-step phases (r2: 145 us), 1 = ping-pong roles sharing barriers (r3 experiment: 151 us - ten
+	// barrier-separated blocks per role expose the fragment-load latency ten times); same results up to the order the two groups' partial weight-gradient sums are added in
+	static const int variant = [] { const char *e = getenv("NGP_FIELD32_BWD"); return e ? atoi(e) : 2; }();
 	if (variant == 2) {
 		const size_t shmem_2g = ((size_t)NF32_ALL * 256 + (size_t)2 * 128 * RSH32) * sizeof(float);
 #define GO2G(L) do { \

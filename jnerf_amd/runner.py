@@ -185,7 +185,10 @@ class Runner:
         # read-back, and the main stream should have step i queued while the host waits for it.
         n_sets, P = len(self.sampler._sets), self.done_period
         if not self._sides:
-            self._sides = [torch.cuda.Stream() for _ in range(2)]
+            # (probe knobs, tools/gpu_r3_g.sh: HIP multiplexes streams onto a few hardware queues in creation order, and which streams end up together moves the
+            # iteration time by +-4 % - `pipeline_dummy_streams` unused streams created first shift that mapping, `pipeline_side_streams` = 1 marches on one stream)
+            self._dummy_streams = [torch.cuda.Stream() for _ in range(int(cfg.pipeline_dummy_streams or 0))]
+            self._sides = [torch.cuda.Stream(priority=int(cfg.pipeline_side_priority or 0)) for _ in range(int(cfg.pipeline_side_streams or 2))]
             self._ready = [torch.cuda.Event() for _ in range(n_sets)]            # persistent events, re-recorded (no create/destroy per step)
             self._done = [torch.cuda.Event() for _ in range(n_sets // P + 2)]
             self._grid_event, self._grid_valid = torch.cuda.Event(), False
@@ -204,7 +207,7 @@ class Runner:
                 break                                    # never across a refresh
             if k in self._queue:
                 continue
-            side = self._sides[k & 1]
+            side = self._sides[k % len(self._sides)]
             if k - n_sets >= 0:                          # the buffer set batch k writes was last read by step k - n_sets: wait for the first checkpoint at or after it
                 c = (k - n_sets) // P * P + P - 1            # (<= i: n_sets >= pipeline_depth + P - 1, checked in __init__)
                 if c in self._done_steps:
