@@ -138,6 +138,14 @@ int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const float *ray
                                  float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                                  uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch, float *pos_out);
 
+/* same, with the occupied bounds of the bitfield (ngp_grid_occupied_bounds, device i32[cascades][6]; NULL = off): rays that cannot meet an occupied cell are dropped before
+ * the traversal and every ray stops behind the last occupied box.  Results are IDENTICAL to the call without bounds - a sample is only ever emitted inside an occupied cell -
+ * the traversal just no longer evaluates the ~1400 candidates of a ray that sees nothing but background (most rays of an object-centred scene's training batch). */
+int ngp_march_rays_compacted_bounds(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
+                                    float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
+                                    uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch, float *pos_out,
+                                    const int32_t *occ_bounds);
+
 /* replaces CalcRgb.execute / .grad / .inference (calc_rgb.py:45-68, 78-104, 120-144; op_header/calc_rgb.h) */
 int ngp_composite_fwd(void *stream, uint32_t n_rays, const void *net_out, int dtype, const float *coords, const uint32_t *numsteps,
                       const uint32_t *numsteps_compacted, const float *bg /*[n,3]*/, int cascades, float *rgb_out);
@@ -165,6 +173,9 @@ int ngp_grid_splat_max(void *stream, uint32_t n, const uint32_t *indices, const 
 int ngp_grid_ema(void *stream, uint32_t n_elements, float decay, float *grid, const float *grid_tmp);
 /* mean over cascade 0 -> mean[0]; grid_to_bitfield; 4x bitfield_max_pool (update_bitfield.py:15-37) */
 int ngp_grid_update_bitfield(void *stream, const float *grid, int cascades, float *mean /*[1]*/, uint8_t *bitfield);
+/* (ours) integer bounding box of the occupied cells of every cascade of the bitfield: bounds i32[cascades][6] = {min x, y, z, max x, y, z} (min > max: empty cascade); what
+ * ngp_march_rays_compacted_bounds / NgpRenderChunk.occ_bounds take.  Call after ngp_grid_update_bitfield, on the same stream. */
+int ngp_grid_occupied_bounds(void *stream, const uint8_t *bitfield, int cascades, int32_t *bounds);
 
 /* ---- optimiser: Adam (optims/adam.py + Jittor nn.Adam) -> ExpDecay lr (host) -> EMA.ema_step (optims/ema.py:26-37), one sweep.
  * p/m/v/ema are fp32 masters; p_half (may be NULL) receives the fp16 copy the kernels gather from; g is fp32 or fp16 (g_dtype) and is
@@ -304,6 +315,7 @@ typedef struct NgpRenderChunk {
 	void *out;                               /* T[cap,4] */
 	float *rgb_out, *alpha_out;              /* [n_rays,3], [n_rays,1]: this chunk's rows of the image */
 	uint64_t *totals;                        /* device u64[2], accumulated */
+	const int32_t *occ_bounds;               /* (ABI 2) ngp_grid_occupied_bounds of `bitfield`, or NULL */
 } NgpRenderChunk;
 int ngp_render_chunk(void *stream, const NgpRenderChunk *args_host);
 /* waits for the bracketed launches of earlier ngp_train_step calls (this thread's device) and writes up to `max` durations in milliseconds, oldest first;

@@ -48,7 +48,7 @@ class NgpRenderChunk(C.Structure):
                 ("aabb0", _f32), ("aabb1", _f32), ("near_distance", _f32), ("cone_angle", _f32),
                 ("rays_o", _vp), ("rays_d", _vp), ("bitfield", _vp), ("rng_state_host", _vp), ("coords", _vp), ("pos", _vp), ("numsteps", _vp), ("numsteps_compacted", _vp),
                 ("counters", _vp), ("scratch", _vp), ("table", _vp), ("level_table_host", _vp), ("packed_weights", _vp), ("feat", _vp), ("out", _vp),
-                ("rgb_out", _vp), ("alpha_out", _vp), ("totals", _vp)]
+                ("rgb_out", _vp), ("alpha_out", _vp), ("totals", _vp), ("occ_bounds", _vp)]
 
 
 SIGNATURES = {
@@ -81,6 +81,8 @@ SIGNATURES = {
     "ngp_march_scratch_elems": (C.c_uint64, [_u32]),
     "ngp_march_rays_compacted": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
     "ngp_march_rays_compacted_pos": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngp_march_rays_compacted_bounds": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ngp_grid_occupied_bounds": (C.c_int, [_vp, _vp, _i32, _vp]),
     "ngp_composite_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ngp_composite_fwd_huber": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp]),
     "ngp_composite_bwd": (C.c_int, [_vp, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),

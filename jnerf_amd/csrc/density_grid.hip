@@ -169,6 +169,43 @@ NGP_API int ngp_grid_ema(void *stream, uint32_t n_elements, float decay, float *
 	NGP_LAUNCH_CHECK("ngp_grid_ema");
 	return 0;
 }
+// ---------------------------------------------------------------------------------------------------------------- occupied bounds (r3)
+// Per cascade, the integer bounding box of the occupied cells of the bitfield: bounds[c] = {min x, min y, min z, max x, max y, max z} in cell coordinates (min > max: the
+// cascade is empty).  One byte of the Morton-ordered bitfield is a 2x2x2 block of cells; a non-zero byte counts as a whole block (conservative).  Integer atomicMin / Max:
+// order-independent.  The marcher uses the boxes to drop rays that cannot meet an occupied cell and to stop a ray behind the last box (csrc/sampler.hip: occ_range) -
+// in the training batches of an object-centred scene most rays only see background, and the cooperative marcher used to evaluate all ~1400 candidates of such a ray.
+__global__ void k_occ_bounds_reset(int32_t *__restrict__ bounds, int cascades) {
+	const int i = threadIdx.x;
+	if (i < cascades * 6) bounds[i] = (i % 6) < 3 ? (int)NGP_GRIDSIZE : -1;
+}
+__global__ __launch_bounds__(256) void k_occ_bounds(const uint8_t *__restrict__ bitfield, int32_t *__restrict__ bounds) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;              // byte within the cascade blockIdx.y (G3 / 8 bytes each)
+	const uint32_t c = blockIdx.y;
+	int lo[3] = {(int)NGP_GRIDSIZE, (int)NGP_GRIDSIZE, (int)NGP_GRIDSIZE}, hi[3] = {-1, -1, -1};
+	if (i < G3 / 8 && bitfield[(size_t)c * (G3 / 8) + i]) {
+		const uint32_t m = i * 8u;
+		const int x = (int)morton3D_invert(m), y = (int)morton3D_invert(m >> 1), z = (int)morton3D_invert(m >> 2);
+		lo[0] = x; lo[1] = y; lo[2] = z; hi[0] = x + 1; hi[1] = y + 1; hi[2] = z + 1;
+	}
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) { lo[k] = min(lo[k], __shfl_xor(lo[k], off)); hi[k] = max(hi[k], __shfl_xor(hi[k], off)); }
+	}
+	if ((threadIdx.x & 63u) == 0 && hi[0] >= 0) {
+#pragma unroll
+		for (int k = 0; k < 3; ++k) { atomicMin(&bounds[c * 6 + k], lo[k]); atomicMax(&bounds[c * 6 + 3 + k], hi[k]); }
+	}
+}
+NGP_API int ngp_grid_occupied_bounds(void *stream, const uint8_t *bitfield, int cascades, int32_t *bounds) {
+	NGP_REQUIRE(bitfield && bounds && cascades >= 1 && cascades <= 8, NGP_E_ARG, "ngp_grid_occupied_bounds: bad arguments");
+	hipStream_t s = (hipStream_t)stream;
+	NGP_LAUNCH(k_occ_bounds_reset, dim3(1), dim3(64), 0, s, bounds, cascades);
+	NGP_LAUNCH(k_occ_bounds, dim3(div_up(G3 / 8, 256), cascades), dim3(256), 0, s, bitfield, bounds);
+	NGP_LAUNCH_CHECK("ngp_grid_occupied_bounds");
+	return 0;
+}
+
 NGP_API int ngp_grid_update_bitfield(void *stream, const float *grid, int cascades, float *mean, uint8_t *bitfield) {
 	NGP_REQUIRE(grid && mean && bitfield && cascades >= 1 && cascades <= 8, NGP_E_ARG, "ngp_grid_update_bitfield: bad arguments");
 	NGP_REQUIRE(((uintptr_t)grid & 15) == 0, NGP_E_ALIGN, "ngp_grid_update_bitfield: grid must be 16-byte aligned (update_bitfield.h:14-17)");

@@ -18,6 +18,7 @@ struct MarchParams {
 	float a0, a1, near_distance, cone_angle;
 	int const_dt, cascades;
 	uint64_t rng_state, rng_inc;
+	const int32_t *occ_bounds;        // device i32[cascades][6] from ngp_grid_occupied_bounds, or nullptr (no culling)
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }
@@ -95,12 +96,42 @@ __device__ __forceinline__ float ray_start(const MarchParams &p, uint32_t i, con
 	return startt;
 }
 
+// Occupied-bounds culling (r3), EXACT: a candidate emits a sample only if the cell it falls into at its mip level is occupied, i.e. only at positions inside that cascade's
+// occupied box.  occ_range intersects the ray with every cascade's box, grown by one cell (plus the clamp: a box that touches the grid's border extends to infinity there,
+// because positions beyond the grid are clamped into the border cells) - conservative against every rounding of pos = o + t d.  No intersection at or after t_start: the
+// ray emits nothing, whatever the walk does.  Otherwise nothing is emitted behind t_stop, the last exit, so the traversal may end there.  (The stretch BEFORE the first box
+// still has to be walked: where the skip chain lands at the box decides which candidates are visited inside.)
+__device__ __forceinline__ bool occ_range(const MarchParams &p, const float o[3], const float d[3], float t_start, float &t_stop) {
+	const float inf = __builtin_inff();
+	bool any = false; t_stop = -inf;
+	for (int c = 0; c < p.cascades; ++c) {
+		const int32_t *b = p.occ_bounds + c * 6;
+		if (b[3] < b[0]) continue;                                            // empty cascade
+		const float sc = scalbnf(1.0f, c), cell = sc / NGP_GRIDSIZE;
+		float tmin = t_start, tmax = inf;
+		bool hit = true;
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			const float lo = b[k] <= 0 ? -inf : 0.5f + ((float)b[k] / NGP_GRIDSIZE - 0.5f) * sc - 1.001f * cell;
+			const float hi = b[3 + k] >= (int)NGP_GRIDSIZE - 1 ? inf : 0.5f + ((float)(b[3 + k] + 1) / NGP_GRIDSIZE - 0.5f) * sc + 1.001f * cell;
+			if (d[k] == 0.0f) { if (o[k] < lo || o[k] > hi) hit = false; continue; }
+			float t0 = (lo - o[k]) / d[k], t1 = (hi - o[k]) / d[k];
+			if (t0 > t1) { const float t = t0; t0 = t1; t1 = t; }
+			// (an infinite bound gives +-inf, never NaN: o and d are finite and d[k] != 0)
+			tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1);
+		}
+		if (hit && tmin <= tmax) { any = true; t_stop = fmaxf(t_stop, tmax); }
+	}
+	if (any) t_stop = t_stop + fabsf(t_stop) * 1e-5f + 1e-4f;               // slack for the rounding of the slab arithmetic itself (the boxes are already a cell too large)
+	return any;
+}
+
 // One traversal of a ray.  WRITE=false: count occupied steps (limit NERF_STEPS).  WRITE=true: emit the first `limit` records.
 #define NGP_TCACHE NGP_STEPS   // per-ray cache [n_rays][NGP_STEPS] of the sample parameters t (only touched entries cost anything): the write pass never marches again
 
 template <bool WRITE>
 __device__ __forceinline__ uint32_t march(const MarchParams &p, const uint8_t *__restrict__ bitfield, const float o[3], const float d[3], float startt,
-                                          uint32_t limit, float *__restrict__ out, float *__restrict__ tcache = nullptr, uint32_t tstride = 0) {
+                                          uint32_t limit, float *__restrict__ out, float *__restrict__ tcache = nullptr, uint32_t tstride = 0, float t_stop = __builtin_inff()) {
 	const float idir[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
 	float wdir[3];
 	if (WRITE) { wdir[0] = (d[0] + 1.0f) * 0.5f; wdir[1] = (d[1] + 1.0f) * 0.5f; wdir[2] = (d[2] + 1.0f) * 0.5f; }
@@ -110,7 +141,7 @@ __device__ __forceinline__ uint32_t march(const MarchParams &p, const uint8_t *_
 	for (;;) {
 #pragma unroll
 		for (int k = 0; k < 3; ++k) pos[k] = o[k] + t * d[k];
-		if (!(contains(p, pos) && j < limit)) break;
+		if (!(contains(p, pos) && j < limit) || t > t_stop) break;                   // (t_stop: nothing is emitted behind the last occupied box, occ_range)
 		const float dt = calc_dt(t, p);
 		const uint32_t mip = (uint32_t)mip_from_dt(dt, pos, p.cascades);
 		if (occupied_at(pos, bitfield, mip)) {
@@ -135,7 +166,9 @@ __global__ __launch_bounds__(128) void k_march_count(uint32_t n_rays, MarchParam
 	if (i >= n_rays) return;
 	const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]}, d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
 	const float startt = ray_start(p, i, o, d);
-	steps[i] = march<false>(p, bitfield, o, d, startt, NGP_STEPS, nullptr, startts ? startts + (size_t)i * NGP_TCACHE : nullptr, 1);
+	float t_stop = __builtin_inff();
+	if (p.occ_bounds && !occ_range(p, o, d, startt, t_stop)) { steps[i] = 0; return; }
+	steps[i] = march<false>(p, bitfield, o, d, startt, NGP_STEPS, nullptr, startts ? startts + (size_t)i * NGP_TCACHE : nullptr, 1, t_stop);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- wave-cooperative count pass
@@ -192,10 +225,13 @@ __global__ __launch_bounds__(64) void k_march_wave(uint32_t n_rays, MarchParams 
 		for (int k = 0; k < 3; ++k) pos[k] = o[k] + t_round * d[k];
 		if (!contains(p, pos)) { if (lane == 0) steps[i] = 0; return; }     // the ray misses the box (or starts behind it): the reference's loop does not run
 	}
+	float t_stop = __builtin_inff();
+	if (p.occ_bounds && !occ_range(p, o, d, t_round, t_stop)) { if (lane == 0) steps[i] = 0; return; }      // cannot meet an occupied cell: no samples (exact)
 	const float big_neg = -__builtin_inff();
 	uint32_t j0 = 0;
 	float pend = big_neg;
 	for (;;) {
+		if (t_round > t_stop) { if (lane == 0) steps[i] = j0; return; }      // every remaining candidate lies behind the last occupied box: nothing more is emitted
 		__syncthreads();                                      // (one wavefront: orders this round's LDS writes after the last round's reads; also publishes mlut)
 		// ---- chain: tch[0 .. NC] = the next NC + 1 values of the ray's fixed sequence
 		if (CONST_DT) {
@@ -549,7 +585,7 @@ static int check_march_args(const char *fn, uint32_t n_rays, const void *a, cons
 	return 0;
 }
 static MarchParams make_params(float a0, float a1, float near_distance, float cone, int const_dt, int cascades, uint64_t *rng_state_host) {
-	MarchParams p{a0, a1, near_distance, cone, const_dt, cascades, rng_state_host[0], rng_state_host[1]};
+	MarchParams p{a0, a1, near_distance, cone, const_dt, cascades, rng_state_host[0], rng_state_host[1], nullptr};
 	Pcg32 r{rng_state_host[0], rng_state_host[1]};
 	r.advance(1ull << 32);                                                          // host-side rng.advance(), ray_sampler.py:61
 	rng_state_host[0] = r.state;
@@ -588,10 +624,18 @@ NGP_API int ngp_march_rays_compacted(void *stream, uint32_t n_rays, const float 
 NGP_API int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
                                          float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                                          uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch, float *pos_out) {
+	return ngp_march_rays_compacted_bounds(stream, n_rays, rays_o, rays_d, bitfield, aabb0, aabb1, near_distance, cone_angle, const_dt, cascades, rng_state_host, max_samples,
+	                                       cap, coords_out, numsteps, numsteps_compacted, counters, scratch, pos_out, nullptr);
+}
+NGP_API int ngp_march_rays_compacted_bounds(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
+                                            float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
+                                            uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch, float *pos_out,
+                                            const int32_t *occ_bounds) {
 	int rc = check_march_args("ngp_march_rays_compacted", n_rays, rays_o, rays_d, bitfield, coords_out, cascades); if (rc) return rc;
 	NGP_REQUIRE(counters && rng_state_host && (n_rays == 0 || (numsteps && numsteps_compacted && scratch)), NGP_E_ARG, "ngp_march_rays_compacted: null pointer");
 	hipStream_t s = (hipStream_t)stream;
-	const MarchParams p = make_params(aabb0, aabb1, near_distance, cone_angle, const_dt, cascades, rng_state_host);
+	MarchParams p = make_params(aabb0, aabb1, near_distance, cone_angle, const_dt, cascades, rng_state_host);
+	p.occ_bounds = getenv("NGP_MARCH_NO_BOUNDS") ? nullptr : occ_bounds;
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 16, s); return 0; }
 	// scratch = steps[n_rays] | pad to 1024 | t-cache[NGP_TCACHE][n_rays]  (ngp_march_scratch_elems(n_rays) u32 elements)
 	float *tcache = reinterpret_cast<float *>(scratch + ((n_rays + 1023u) & ~1023u));

@@ -231,8 +231,8 @@ NGP_API int ngp_render_chunk(void *stream, const NgpRenderChunk *a) {
 	if (a->n_rays == 0) return 0;
 	int rc;
 	const int lay = NGP_LAYOUT_SOA | NGP_WEIGHTS_PACKED;
-	if ((rc = ngp_march_rays_compacted_pos(stream, a->n_rays, a->rays_o, a->rays_d, a->bitfield, a->aabb0, a->aabb1, a->near_distance, a->cone_angle, a->const_dt, a->cascades,
-	                                       a->rng_state_host, a->max_samples, a->cap, a->coords, a->numsteps, a->numsteps_compacted, a->counters, a->scratch, a->pos))) return rc;
+	if ((rc = ngp_march_rays_compacted_bounds(stream, a->n_rays, a->rays_o, a->rays_d, a->bitfield, a->aabb0, a->aabb1, a->near_distance, a->cone_angle, a->const_dt, a->cascades,
+	                                          a->rng_state_host, a->max_samples, a->cap, a->coords, a->numsteps, a->numsteps_compacted, a->counters, a->scratch, a->pos, a->occ_bounds))) return rc;
 	const uint32_t *n_valid = a->counters + 3;
 	if ((rc = ngp_hash_encode_fwd(stream, a->cap, a->pos, 3, a->table, a->level_table_host, a->feat, a->dtype, NGP_LAYOUT_SOA, n_valid))) return rc;
 	if (a->dtype == NGP_F16) rc = ngp_field_fwd(stream, a->cap, a->feat, lay, a->coords + 4, 7, a->packed_weights, nullptr, a->out, NGP_F16, n_valid);

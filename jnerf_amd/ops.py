@@ -311,7 +311,7 @@ def march_scratch_elems(n_rays):
 
 
 def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng_state, max_samples, cap, cone_angle=1.0 / 256, near=0.2, const_dt=True, cascades=5,
-                         coords_out=None, numsteps=None, numsteps_c=None, counters=None, scratch=None, pos_out=None):
+                         coords_out=None, numsteps=None, numsteps_c=None, counters=None, scratch=None, pos_out=None, occ_bounds=None):
     n = rays_o.shape[0]
     dev = rays_o.device
     if coords_out is None:
@@ -326,9 +326,9 @@ def march_rays_compacted(rays_o, rays_d, bitfield, aabb, rng_state, max_samples,
     if scratch is None:
         scratch = torch.empty(need, dtype=torch.int32, device=dev)
     assert scratch.numel() >= need, "march scratch too small: use ops.march_scratch_elems(n_rays)"
-    check(L.lib().ngp_march_rays_compacted_pos(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
-                                               rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch),
-                                               _p(pos_out)), "ngp_march_rays_compacted_pos")
+    check(L.lib().ngp_march_rays_compacted_bounds(_stream(), n, _p(rays_o), _p(rays_d), _p(bitfield), aabb[0], aabb[1], near, cone_angle, int(const_dt), cascades,
+                                                  rng_state.ctypes.data_as(C.c_void_p), max_samples, cap, _p(coords_out), _p(numsteps), _p(numsteps_c), _p(counters), _p(scratch),
+                                                  _p(pos_out), _p(occ_bounds)), "ngp_march_rays_compacted_bounds")
     return coords_out, numsteps, numsteps_c, counters
 
 
@@ -409,6 +409,14 @@ def grid_splat_max(indices, density, grid_tmp):
 def grid_ema(grid, grid_tmp, decay=0.95):
     check(L.lib().ngp_grid_ema(_stream(), grid.shape[0], decay, _p(grid), _p(grid_tmp)), "ngp_grid_ema")
     return grid
+
+
+def grid_occupied_bounds(bitfield, cascades=5, out=None):
+    """i32[cascades, 6] = (min x, y, z, max x, y, z) of the occupied cells per cascade (min > max: empty), see ngp_grid_occupied_bounds"""
+    if out is None:
+        out = torch.empty((cascades, 6), dtype=torch.int32, device=bitfield.device)
+    check(L.lib().ngp_grid_occupied_bounds(_stream(), _p(bitfield), cascades, _p(out)), "ngp_grid_occupied_bounds")
+    return out
 
 
 def grid_update_bitfield(grid, cascades=5, mean=None, bitfield=None):

@@ -438,6 +438,8 @@ class Runner:
             a.counters, a.scratch = b["counters"].data_ptr(), b["scratch"].data_ptr()
             a.table, a.level_table_host, a.packed_weights = table.data_ptr(), enc.level_table.ctypes.data, packed.data_ptr()
             a.feat, a.out, a.totals = b["feat"].data_ptr(), b["out"].data_ptr(), counts.data_ptr()
+            ob = s.occupancy_bounds() if hasattr(s, "occupancy_bounds") else None
+            a.occ_bounds = ob.data_ptr() if ob is not None else None
             args.append(a)
         n = rays_o_total.shape[0]
         main = torch.cuda.current_stream()

@@ -76,6 +76,10 @@ class DensityGridSampler(nn.Module):
         self.register_buffer("density_grid_bitfield", torch.zeros(self.density_n_elements // 8, dtype=torch.uint8, device=dev))
         self.register_buffer("density_grid_mean", torch.zeros(1, dtype=torch.float32, device=dev))
         self.register_buffer("density_grid_ema_step", torch.zeros(1, dtype=torch.int32, device=dev))
+        # (ours) bounding boxes of the occupied cells, refreshed with the bitfield: the marcher drops rays that cannot meet an occupied cell and stops behind the last box -
+        # identical samples (`march_occupancy_bounds = False` in the config turns it off)
+        self._occ_bounds = torch.zeros((self.NERF_CASCADES, 6), dtype=torch.int32, device=dev) if torch.device(dev).type == "cuda" else None
+        self._occ_bounds_valid = False
         self.max_samples = 4096 * self.MAX_STEP                        # ray_sampler.py:15 — fixed even after the ray count grows
         # the reference's global pcg32{1337} (ops/code_ops/global_vars.py:13-16); multi-GPU ranks take disjoint sub-streams
         from .rng import pcg32_seed
@@ -140,7 +144,7 @@ class DensityGridSampler(nn.Module):
                 self._counters = self._inf_bufs[2]
                 ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.max_samples,
                                          self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
-                                         coords_out=coords, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=self._scratch)
+                                         coords_out=coords, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=self._scratch, occ_bounds=self.occupancy_bounds())
                 self._coords = coords
                 self._rays_numsteps = numsteps_c
                 self._n_valid = self._counters[3:4]
@@ -167,7 +171,8 @@ class DensityGridSampler(nn.Module):
         scratch = self._march_scratch[key]
         ops.march_rays_compacted(rays_o, rays_d, self.density_grid_bitfield, self.aabb_range, self.rng_state, self.max_samples, self.target_batch_size,
                                  self.cone_angle_constant, self.near_distance, self.const_dt, self.NERF_CASCADES,
-                                 coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=scratch, pos_out=bs["pos"])
+                                 coords_out=self._coords_train, numsteps=numsteps, numsteps_c=numsteps_c, counters=self._counters, scratch=scratch, pos_out=bs["pos"],
+                                 occ_bounds=self.occupancy_bounds())
         self._pos_train = bs["pos"]                                    # compact [n,3] copy of coords[:, :3], written by the marcher's write pass
         # two side streams may be marching at once: their read-modify-writes of the running sample count are ordered by an event chain
         # (the wait sits AFTER this batch's march kernels in stream order, so the marches themselves still overlap)
@@ -233,6 +238,17 @@ class DensityGridSampler(nn.Module):
         ops.grid_ema(self.density_grid, self.density_grid_tmp, self.density_grid_decay)
         self.density_grid_ema_step += 1
         ops.grid_update_bitfield(self.density_grid, self.NERF_CASCADES, mean=self.density_grid_mean, bitfield=self.density_grid_bitfield)
+        if self._occ_bounds is not None and self.cfg.march_occupancy_bounds is not False:
+            ops.grid_occupied_bounds(self.density_grid_bitfield, self.NERF_CASCADES, out=self._occ_bounds)
+            self._occ_bounds_valid = True
+
+    def occupancy_bounds(self):
+        """the bounds tensor while it describes the current bitfield (it is refreshed with it; a bitfield loaded from a checkpoint invalidates it), else None"""
+        return self._occ_bounds if self._occ_bounds_valid else None
+
+    def load_state_dict(self, *a, **k):
+        self._occ_bounds_valid = False
+        return super().load_state_dict(*a, **k)
 
     def update_density_grid(self):
         alpha = pow(self.density_grid_decay, self.n_training_steps / 16)

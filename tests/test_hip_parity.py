@@ -352,6 +352,59 @@ def test_march_compacted_equals_march_then_compact(H, const_dt, aabb, count_pass
     assert e[1].shape == (0, 2) and not e[2].any()
 
 
+def _blob_bitfield(centre, half, cascades=5, border=False):
+    """an object-like occupancy: a box of cells around `centre` (world coordinates) at every cascade that contains it, plus - `border` - a few cells on the grid's border
+    (positions beyond a cascade's grid are clamped into its border cells, so a box that touches the border must count as unbounded there)"""
+    g = 128
+    bits = np.zeros(cascades * g ** 3 // 8, np.uint8)
+    ii = np.arange(g)
+    X, Y, Z = np.meshgrid(ii, ii, ii, indexing="ij")
+    m = synth.morton3D(X.ravel(), Y.ravel(), Z.ravel())
+    P = np.stack([X.ravel(), Y.ravel(), Z.ravel()], -1)
+    for c in range(cascades):
+        p = ((P + 0.5) / g - 0.5) * 2.0 ** c + 0.5
+        occ = (np.abs(p - np.asarray(centre)) < np.asarray(half) + 0.5 * 2.0 ** c / g).all(-1)
+        if border and c == cascades - 1:
+            occ |= (P[:, 0] == 0) & (P[:, 1] > 60) & (P[:, 1] < 64) & (P[:, 2] == 127)
+        cell = m[occ] + np.uint32(c * g ** 3)
+        np.bitwise_or.at(bits, cell // 8, (np.uint8(1) << (cell % 8).astype(np.uint8)))
+    return bits
+
+
+@pytest.mark.parametrize("count_pass", ["serial", "coop"])
+@pytest.mark.parametrize("const_dt,aabb,border", [(True, (0.0, 1.0), False), (False, (-1.5, 2.5), False), (False, (-1.5, 2.5), True), (True, (-7.5, 8.5), True)])
+def test_occupied_bounds_culling_changes_nothing(H, const_dt, aabb, border, count_pass):
+    """r3: the marcher drops rays that cannot meet an occupied cell and stops every ray behind the last occupied box (ngp_grid_occupied_bounds +
+    ngp_march_rays_compacted_bounds).  A sample is only ever emitted inside an occupied cell, so counts, bases, records and counters must be the SAME BITS with and without
+    the bounds - for an off-centre object most rays miss, for rays through the scene box from inside and outside, for an occupancy that touches the grid border (clamping)."""
+    import ctypes
+    from jnerf_amd import _lib, ops
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.ngp_x_march_count_mode(1 if count_pass == "serial" else 2)
+    try:
+        bits = _blob_bitfield((0.62, 0.41, 0.55), (0.11, 0.07, 0.16), border=border)
+        xf, focal, meta = synth.camera_ring(12, radius=1.3)
+        img, o, d, _ = synth.rays_from_cameras(xf, focal, meta, 96, 64, 6000, seed=21)
+        rng = np.random.default_rng(3)
+        o[:500] = 0.5 + (rng.random((500, 3), dtype=np.float32) - 0.5) * 0.6           # origins inside the box, some inside the object
+        d[100:110] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0]]     # axis-parallel directions (zero components)
+        tb = H.T(bits)
+        bounds = ops.grid_occupied_bounds(tb, 5)
+        b = bounds.cpu().numpy()
+        assert (b[:, 3] >= b[:, 0]).all() and (b[0, 3:] - b[0, :3] < 60).all()         # cascade 0: a small box
+        cap = 1 << 18
+        res = []
+        for ob in (None, bounds):
+            c, ns, nsc, cnt = ops.march_rays_compacted(H.T(o), H.T(d), tb, aabb, O.PCG32(1337).st, 4096 * 1024, cap, const_dt=const_dt, occ_bounds=ob)
+            res.append((H.N(c), H.u32(ns), H.u32(nsc), H.u32(cnt)))
+        (c0, n0, m0, k0), (c1, n1, m1, k1) = res
+        valid = int(min(k0[3], cap))
+        assert np.array_equal(n0, n1) and np.array_equal(m0, m1) and np.array_equal(k0, k1) and np.array_equal(c0[:valid], c1[:valid])
+        assert 0 < (n0[:, 0] > 0).mean() < 0.8 and k0[1] > 1000                          # some rays hit, many miss
+    finally:
+        lib.ngp_x_march_count_mode(0)
+
+
 @pytest.mark.parametrize("const_dt,aabb,density", [(True, (0.0, 1.0), 0.05), (True, (0.0, 1.0), 0.5), (True, (-1.5, 2.5), 0.2), (False, (-1.5, 2.5), 0.2), (False, (0.0, 1.0), 0.95)])
 def test_count_passes_agree_on_a_noisy_grid(H, const_dt, aabb, density):
     """A random occupancy grid (every cell independent: the hardest case for the cooperative pass - skips of every length, landing fuzz, rays that reach
