@@ -19,6 +19,7 @@ struct MarchParams {
 	int const_dt, cascades;
 	uint64_t rng_state, rng_inc;
 	const int32_t *occ_bounds;        // device i32[cascades][6] from ngp_grid_occupied_bounds, or nullptr (no culling)
+	int occ_cascades;                 // cascades 0 .. occ_cascades-1 can be selected for a candidate inside the scene box (host: occ_cascades_for)
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }
@@ -104,7 +105,7 @@ __device__ __forceinline__ float ray_start(const MarchParams &p, uint32_t i, con
 __device__ __forceinline__ bool occ_range(const MarchParams &p, const float o[3], const float d[3], float t_start, float &t_stop) {
 	const float inf = __builtin_inff();
 	bool any = false; t_stop = -inf;
-	for (int c = 0; c < p.cascades; ++c) {
+	for (int c = 0; c < p.occ_cascades; ++c) {
 		const int32_t *b = p.occ_bounds + c * 6;
 		if (b[3] < b[0]) continue;                                            // empty cascade
 		const float sc = scalbnf(1.0f, c), cell = sc / NGP_GRIDSIZE;
@@ -585,7 +586,7 @@ static int check_march_args(const char *fn, uint32_t n_rays, const void *a, cons
 	return 0;
 }
 static MarchParams make_params(float a0, float a1, float near_distance, float cone, int const_dt, int cascades, uint64_t *rng_state_host) {
-	MarchParams p{a0, a1, near_distance, cone, const_dt, cascades, rng_state_host[0], rng_state_host[1], nullptr};
+	MarchParams p{a0, a1, near_distance, cone, const_dt, cascades, rng_state_host[0], rng_state_host[1], nullptr, cascades};
 	Pcg32 r{rng_state_host[0], rng_state_host[1]};
 	r.advance(1ull << 32);                                                          // host-side rng.advance(), ray_sampler.py:61
 	rng_state_host[0] = r.state;
@@ -636,6 +637,17 @@ NGP_API int ngp_march_rays_compacted_bounds(void *stream, uint32_t n_rays, const
 	hipStream_t s = (hipStream_t)stream;
 	MarchParams p = make_params(aabb0, aabb1, near_distance, cone_angle, const_dt, cascades, rng_state_host);
 	p.occ_bounds = getenv("NGP_MARCH_NO_BOUNDS") ? nullptr : occ_bounds;
+	// Which cascades can a candidate select?  mip = max(mip_from_pos, mip_from_dt) (ray_sampler_header.h:60-77).  Candidates lie inside the scene box, so
+	// mip_from_pos <= the value at the box's largest |coordinate - 0.5| (frexp is monotone); with the constant step mip_from_dt adds nothing (dt * 256 < 1).  The max-pooled
+	// coarser cascades are occupied around the object too, and one-cell margins of THEIR cells would cover the whole unit cube - they must not enter the union when the
+	// traversal can never consult them (ngp_base.py: cascades 0 and 1 only).  Cone stepping can raise the mip anywhere along the ray: all cascades.
+	if (const_dt) {
+		const float ext = fmaxf(fabsf(aabb0 - 0.5f), fabsf(aabb1 - 0.5f));
+		int e; (void)frexpf(ext, &e);
+		int top = e + 1; if (top < 1) top = 1;            // (>= 1: frexp(0) has exponent 0, so the exact centre of the grid selects cascade 1)
+		if (top > cascades - 1) top = cascades - 1;
+		p.occ_cascades = top + 1;
+	}
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 16, s); return 0; }
 	// scratch = steps[n_rays] | pad to 1024 | t-cache[NGP_TCACHE][n_rays]  (ngp_march_scratch_elems(n_rays) u32 elements)
 	float *tcache = reinterpret_cast<float *>(scratch + ((n_rays + 1023u) & ~1023u));
