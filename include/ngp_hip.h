@@ -138,7 +138,7 @@ int ngp_march_rays_compacted_pos(void *stream, uint32_t n_rays, const float *ray
                                  float near_distance, float cone_angle, int const_dt, int cascades, uint64_t *rng_state_host, uint32_t max_samples,
                                  uint32_t cap, float *coords_out, uint32_t *numsteps, uint32_t *numsteps_compacted, uint32_t *counters, uint32_t *scratch, float *pos_out);
 
-/* same, with the occupied bounds of the bitfield (ngp_grid_occupied_bounds, device i32[cascades][6]; NULL = off): rays that cannot meet an occupied cell are dropped before
+/* same, with the occupied bounds of the bitfield (the buffer ngp_grid_occupied_bounds fills; NULL = off): rays that cannot meet an occupied cell are dropped before
  * the traversal and every ray stops behind the last occupied box.  Results are IDENTICAL to the call without bounds - a sample is only ever emitted inside an occupied cell -
  * the traversal just no longer evaluates the ~1400 candidates of a ray that sees nothing but background (most rays of an object-centred scene's training batch). */
 int ngp_march_rays_compacted_bounds(void *stream, uint32_t n_rays, const float *rays_o, const float *rays_d, const uint8_t *bitfield, float aabb0, float aabb1,
@@ -173,8 +173,13 @@ int ngp_grid_splat_max(void *stream, uint32_t n, const uint32_t *indices, const 
 int ngp_grid_ema(void *stream, uint32_t n_elements, float decay, float *grid, const float *grid_tmp);
 /* mean over cascade 0 -> mean[0]; grid_to_bitfield; 4x bitfield_max_pool (update_bitfield.py:15-37) */
 int ngp_grid_update_bitfield(void *stream, const float *grid, int cascades, float *mean /*[1]*/, uint8_t *bitfield);
-/* (ours) integer bounding box of the occupied cells of every cascade of the bitfield: bounds i32[cascades][6] = {min x, y, z, max x, y, z} (min > max: empty cascade); what
- * ngp_march_rays_compacted_bounds / NgpRenderChunk.occ_bounds take.  Call after ngp_grid_update_bitfield, on the same stream. */
+/* (ours) where the occupied cells are, for the marcher's culling (ngp_march_rays_compacted_bounds / NgpRenderChunk.occ_bounds).  `bounds` is a device buffer of
+ * NGP_OCC_BOUNDS_INTS i32: [6 c .. 6 c + 5] = {min x, y, z, max x, y, z} of cascade c's occupied cells (min > max: empty cascade); from int NGP_OCC_COARSE_OFFSET_INTS on,
+ * NGP_OCC_COARSE^3 bytes: the dilated 32^3 coarse map of the unit cube (cascades 0 and 1), then the same number of scratch bytes.  Call after ngp_grid_update_bitfield, on the
+ * same stream. */
+#define NGP_OCC_COARSE 32
+#define NGP_OCC_COARSE_OFFSET_INTS 64
+#define NGP_OCC_BOUNDS_INTS (NGP_OCC_COARSE_OFFSET_INTS + 2 * NGP_OCC_COARSE * NGP_OCC_COARSE * NGP_OCC_COARSE / 4)
 int ngp_grid_occupied_bounds(void *stream, const uint8_t *bitfield, int cascades, int32_t *bounds);
 
 /* ---- optimiser: Adam (optims/adam.py + Jittor nn.Adam) -> ExpDecay lr (host) -> EMA.ema_step (optims/ema.py:26-37), one sweep.

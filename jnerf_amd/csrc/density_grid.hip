@@ -197,11 +197,40 @@ __global__ __launch_bounds__(256) void k_occ_bounds(const uint8_t *__restrict__ 
 		for (int k = 0; k < 3; ++k) { atomicMin(&bounds[c * 6 + k], lo[k]); atomicMax(&bounds[c * 6 + 3 + k], hi[k]); }
 	}
 }
+// Coarse map of the unit cube (NGP_OCC_COARSE^3 = 32^3 cells of 4^3 fine cells): a coarse cell is marked when any cascade-0 cell inside it, or any cascade-1 cell
+// overlapping it, is occupied (those are the only cascades a constant-step traversal of a scene box inside the unit cube can consult, see sampler.hip); then the map is
+// DILATED by one coarse cell.  A ray sampled every 1/32 that finds no sample in the dilated map cannot pass through an occupied cell (csrc/sampler.hip: occ_coarse_range).
+// Both groups of 64 (cascade 0) / 8 (cascade 1) fine cells are contiguous in Morton order: one 8-byte / one 1-byte load per coarse cell.
+__global__ __launch_bounds__(256) void k_occ_coarse(const uint8_t *__restrict__ bitfield, int cascades, uint8_t *__restrict__ raw) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;              // coarse cell, x fastest
+	if (i >= NGP_OCC_COARSE * NGP_OCC_COARSE * NGP_OCC_COARSE) return;
+	const uint32_t X = i % NGP_OCC_COARSE, Y = (i / NGP_OCC_COARSE) % NGP_OCC_COARSE, Z = i / (NGP_OCC_COARSE * NGP_OCC_COARSE);
+	const uint2 b0 = reinterpret_cast<const uint2 *>(bitfield)[morton3D(X, Y, Z)];                       // cascade 0: Morton indices 64 m .. 64 m + 63 = the 4x4x4 block at (4X, 4Y, 4Z)
+	bool occ = (b0.x | b0.y) != 0u;
+	if (cascades > 1) occ = occ || bitfield[G3 / 8 + morton3D(16u + X, 16u + Y, 16u + Z)] != 0;        // cascade 1: the 2x2x2 block at (32 + 2X, ...), Morton index 8 m'
+	raw[i] = occ ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_occ_dilate(const uint8_t *__restrict__ raw, uint8_t *__restrict__ dilated) {
+	const int i = blockIdx.x * 256 + threadIdx.x, C = NGP_OCC_COARSE;
+	if (i >= C * C * C) return;
+	const int X = i % C, Y = (i / C) % C, Z = i / (C * C);
+	uint8_t v = 0;
+	for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+		const int x = X + dx, y = Y + dy, z = Z + dz;
+		if (x >= 0 && x < C && y >= 0 && y < C && z >= 0 && z < C) v |= raw[(z * C + y) * C + x];
+	}
+	dilated[i] = v;
+}
 NGP_API int ngp_grid_occupied_bounds(void *stream, const uint8_t *bitfield, int cascades, int32_t *bounds) {
 	NGP_REQUIRE(bitfield && bounds && cascades >= 1 && cascades <= 8, NGP_E_ARG, "ngp_grid_occupied_bounds: bad arguments");
+	NGP_REQUIRE(((uintptr_t)bitfield & 7) == 0, NGP_E_ALIGN, "ngp_grid_occupied_bounds: bitfield must be 8-byte aligned");
 	hipStream_t s = (hipStream_t)stream;
 	NGP_LAUNCH(k_occ_bounds_reset, dim3(1), dim3(64), 0, s, bounds, cascades);
 	NGP_LAUNCH(k_occ_bounds, dim3(div_up(G3 / 8, 256), cascades), dim3(256), 0, s, bitfield, bounds);
+	uint8_t *dil = reinterpret_cast<uint8_t *>(bounds + NGP_OCC_COARSE_OFFSET_INTS), *raw = dil + NGP_OCC_COARSE * NGP_OCC_COARSE * NGP_OCC_COARSE;
+	const uint32_t nc = NGP_OCC_COARSE * NGP_OCC_COARSE * NGP_OCC_COARSE;
+	NGP_LAUNCH(k_occ_coarse, dim3(div_up(nc, 256)), dim3(256), 0, s, bitfield, cascades, raw);
+	NGP_LAUNCH(k_occ_dilate, dim3(div_up(nc, 256)), dim3(256), 0, s, (const uint8_t *)raw, dil);
 	NGP_LAUNCH_CHECK("ngp_grid_occupied_bounds");
 	return 0;
 }

@@ -19,7 +19,8 @@ struct MarchParams {
 	int const_dt, cascades;
 	uint64_t rng_state, rng_inc;
 	const int32_t *occ_bounds;        // device i32[cascades][6] from ngp_grid_occupied_bounds, or nullptr (no culling)
-	int occ_cascades;                 // cascades 0 .. occ_cascades-1 can be selected for a candidate inside the scene box (host: occ_cascades_for)
+	int occ_cascades;                 // cascades 0 .. occ_cascades-1 can be selected for a candidate inside the scene box
+	int occ_coarse;                   // the dilated coarse map behind the boxes may be used: only cascades 0 / 1 can be consulted and the scene box lies inside the unit cube
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }
@@ -127,6 +128,41 @@ __device__ __forceinline__ bool occ_range(const MarchParams &p, const float o[3]
 	return any;
 }
 
+// Second, tighter stage of the culling for the wave-per-ray kernel when only cascades 0 / 1 can be consulted and the scene box lies inside the unit cube (ngp_base.py):
+// the ray is sampled every h = 1/32 between the box entry and t_stop (64 lanes: one or two rounds), each sample looked up in the DILATED coarse map.  An emitting
+// position p lies in an occupied coarse cell C; the sample nearest to it along the ray is at most h / 2 away (Euclidean, hence Chebyshev), so - clamped into the cube -
+// it lies in C or one of C's 26 neighbours, which the dilation marked.  No sample in the map: no emission (exact).  Otherwise nothing is emitted more than h / 2 behind the
+// last marked sample: t_stop shrinks to it (+ h).  The AABB test alone keeps every ray that passes the object's bounding box - about twice as many as meet the object.
+__device__ __forceinline__ bool occ_coarse_range(const MarchParams &p, const float o[3], const float d[3], float t_start, float &t_stop, uint32_t lane) {
+	const uint8_t *dil = reinterpret_cast<const uint8_t *>(p.occ_bounds + NGP_OCC_COARSE_OFFSET_INTS);
+	{   // the map covers the unit cube only; a cascade-1 cell beyond it (never produced by the max-pool of cascade 0, but a loaded bitfield may hold anything) is consulted
+		// by candidates exactly on the cube's faces: then this stage stands aside
+		const int32_t *b1 = p.occ_bounds + 6;
+		if (p.cascades > 1 && b1[3] >= b1[0] && (b1[0] < 32 || b1[1] < 32 || b1[2] < 32 || b1[3] > 95 || b1[4] > 95 || b1[5] > 95)) return true;
+	}
+	const float dn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+	if (!(dn > 0.f) || !(t_stop < 3.0e38f)) return true;                     // (degenerate direction / unbounded range: keep the ray)
+	const float h = (1.0f / NGP_OCC_COARSE) / dn * 0.999f;                    // spacing in t for a spatial spacing just under one coarse cell
+	const float span = t_stop - t_start;
+	const uint32_t n = (uint32_t)fminf(ceilf(span / h) + 2.0f, 4096.0f);
+	float last = -__builtin_inff();
+	for (uint32_t base = 0; base < n; base += 64u) {
+		const float t = t_start + (float)(base + lane) * h;
+		bool in = false;
+		if (base + lane < n) {
+			int c[3];
+#pragma unroll
+			for (int k = 0; k < 3; ++k) { const int q = (int)floorf((o[k] + t * d[k]) * NGP_OCC_COARSE); c[k] = min(max(q, 0), NGP_OCC_COARSE - 1); }
+			in = dil[(c[2] * NGP_OCC_COARSE + c[1]) * NGP_OCC_COARSE + c[0]] != 0;
+		}
+		const unsigned long long m = __ballot(in);
+		if (m) last = t_start + (float)(base + 63u - (uint32_t)__builtin_clzll(m)) * h;
+	}
+	if (last == -__builtin_inff()) return false;
+	t_stop = fminf(t_stop, last + 2.0f * h + fabsf(last) * 1e-5f);
+	return true;
+}
+
 // One traversal of a ray.  WRITE=false: count occupied steps (limit NERF_STEPS).  WRITE=true: emit the first `limit` records.
 #define NGP_TCACHE NGP_STEPS   // per-ray cache [n_rays][NGP_STEPS] of the sample parameters t (only touched entries cost anything): the write pass never marches again
 
@@ -228,6 +264,7 @@ __global__ __launch_bounds__(64) void k_march_wave(uint32_t n_rays, MarchParams 
 	}
 	float t_stop = __builtin_inff();
 	if (p.occ_bounds && !occ_range(p, o, d, t_round, t_stop)) { if (lane == 0) steps[i] = 0; return; }      // cannot meet an occupied cell: no samples (exact)
+	if (p.occ_bounds && p.occ_coarse && !occ_coarse_range(p, o, d, t_round, t_stop, lane)) { if (lane == 0) steps[i] = 0; return; }
 	const float big_neg = -__builtin_inff();
 	uint32_t j0 = 0;
 	float pend = big_neg;
@@ -586,7 +623,7 @@ static int check_march_args(const char *fn, uint32_t n_rays, const void *a, cons
 	return 0;
 }
 static MarchParams make_params(float a0, float a1, float near_distance, float cone, int const_dt, int cascades, uint64_t *rng_state_host) {
-	MarchParams p{a0, a1, near_distance, cone, const_dt, cascades, rng_state_host[0], rng_state_host[1], nullptr, cascades};
+	MarchParams p{a0, a1, near_distance, cone, const_dt, cascades, rng_state_host[0], rng_state_host[1], nullptr, cascades, 0};
 	Pcg32 r{rng_state_host[0], rng_state_host[1]};
 	r.advance(1ull << 32);                                                          // host-side rng.advance(), ray_sampler.py:61
 	rng_state_host[0] = r.state;
@@ -647,6 +684,7 @@ NGP_API int ngp_march_rays_compacted_bounds(void *stream, uint32_t n_rays, const
 		int top = e + 1; if (top < 1) top = 1;            // (>= 1: frexp(0) has exponent 0, so the exact centre of the grid selects cascade 1)
 		if (top > cascades - 1) top = cascades - 1;
 		p.occ_cascades = top + 1;
+		p.occ_coarse = (top <= 1 && aabb0 >= 0.0f && aabb1 <= 1.0f && getenv("NGP_MARCH_NO_COARSE") == nullptr) ? 1 : 0;
 	}
 	if (n_rays == 0) { hipMemsetAsync(counters, 0, 16, s); return 0; }
 	// scratch = steps[n_rays] | pad to 1024 | t-cache[NGP_TCACHE][n_rays]  (ngp_march_scratch_elems(n_rays) u32 elements)

@@ -411,10 +411,14 @@ def grid_ema(grid, grid_tmp, decay=0.95):
     return grid
 
 
+OCC_BOUNDS_INTS = 64 + 2 * 32 ** 3 // 4      # NGP_OCC_BOUNDS_INTS
+
+
 def grid_occupied_bounds(bitfield, cascades=5, out=None):
-    """i32[cascades, 6] = (min x, y, z, max x, y, z) of the occupied cells per cascade (min > max: empty), see ngp_grid_occupied_bounds"""
+    """i32[OCC_BOUNDS_INTS]: [6c .. 6c+5] = (min x, y, z, max x, y, z) of cascade c's occupied cells (min > max: empty), then the dilated 32^3 coarse map; see ngp_grid_occupied_bounds"""
     if out is None:
-        out = torch.empty((cascades, 6), dtype=torch.int32, device=bitfield.device)
+        out = torch.empty(OCC_BOUNDS_INTS, dtype=torch.int32, device=bitfield.device)
+    assert out.numel() >= OCC_BOUNDS_INTS
     check(L.lib().ngp_grid_occupied_bounds(_stream(), _p(bitfield), cascades, _p(out)), "ngp_grid_occupied_bounds")
     return out
 

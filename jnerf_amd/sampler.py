@@ -78,7 +78,7 @@ class DensityGridSampler(nn.Module):
         self.register_buffer("density_grid_ema_step", torch.zeros(1, dtype=torch.int32, device=dev))
         # (ours) bounding boxes of the occupied cells, refreshed with the bitfield: the marcher drops rays that cannot meet an occupied cell and stops behind the last box -
         # identical samples (`march_occupancy_bounds = False` in the config turns it off)
-        self._occ_bounds = torch.zeros((self.NERF_CASCADES, 6), dtype=torch.int32, device=dev) if torch.device(dev).type == "cuda" else None
+        self._occ_bounds = torch.zeros(ops.OCC_BOUNDS_INTS, dtype=torch.int32, device=dev) if torch.device(dev).type == "cuda" else None
         self._occ_bounds_valid = False
         self.max_samples = 4096 * self.MAX_STEP                        # ray_sampler.py:15 — fixed even after the ray count grows
         # the reference's global pcg32{1337} (ops/code_ops/global_vars.py:13-16); multi-GPU ranks take disjoint sub-streams

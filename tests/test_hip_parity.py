@@ -390,8 +390,10 @@ def test_occupied_bounds_culling_changes_nothing(H, const_dt, aabb, border, coun
         d[100:110] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0]]     # axis-parallel directions (zero components)
         tb = H.T(bits)
         bounds = ops.grid_occupied_bounds(tb, 5)
-        b = bounds.cpu().numpy()
+        b = bounds.cpu().numpy()[:30].reshape(5, 6)
         assert (b[:, 3] >= b[:, 0]).all() and (b[0, 3:] - b[0, :3] < 60).all()         # cascade 0: a small box
+        dil = bounds.cpu().numpy()[64:64 + 32 ** 3 // 4].view(np.uint8).reshape(32, 32, 32)      # [z][y][x]: the dilated coarse map of the unit cube
+        assert 0 < dil.mean() < 0.5 and dil[int(0.55 * 32), int(0.41 * 32), int(0.62 * 32)] == 1
         cap = 1 << 18
         res = []
         for ob in (None, bounds):

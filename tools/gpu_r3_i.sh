@@ -9,9 +9,9 @@ run() { name=$1; shift; timeout 300 env "$@" python bench.py $Q $EXTRA > gpurun_
 EXTRA="" run cull X=1
 EXTRA="" run nocull NGP_MARCH_NO_BOUNDS=1
 EXTRA="" run cull2 X=1
-EXTRA="" run nocull2 NGP_MARCH_NO_BOUNDS=1
+EXTRA="" run nocoarse NGP_MARCH_NO_COARSE=1
 EXTRA="--config fox" run fox_cull X=1
-EXTRA="--config fox" run fox_nocull NGP_MARCH_NO_BOUNDS=1
+EXTRA="" run nocoarse2 NGP_MARCH_NO_COARSE=1
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r3i_*.json")):
