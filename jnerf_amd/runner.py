@@ -307,24 +307,37 @@ class Runner:
             from .optim import sync_all_sharded
             sync_all_sharded()      # (multi-rank runs: train() has done it on every rank - it is a collective, and save_ckpt runs on rank 0 only)
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        torch.save({"global_step": self.cfg.m_training_step, "model": self.model.state_dict(), "sampler": self.sampler.state_dict(),
-                    "optimizer": self.optimizer.state_dict(), "nested_optimizer": self.optimizer._nested_optimizer.state_dict(),
-                    "ema_optimizer": self.ema_optimizer.state_dict(),
-                    "extra": {"rng_state": self.sampler.rng_state.copy(), "n_rays_per_batch": self.sampler.n_rays_per_batch}}, path)
+        ck = {"global_step": self.cfg.m_training_step, "model": self.model.state_dict(), "sampler": self.sampler.state_dict(),
+              "optimizer": self.optimizer.state_dict(), "nested_optimizer": self.optimizer._nested_optimizer.state_dict(),
+              "ema_optimizer": self.ema_optimizer.state_dict(),
+              "extra": {"rng_state": self.sampler.rng_state.copy(), "n_rays_per_batch": self.sampler.n_rays_per_batch}}
+        if self.cfg.ckpt_format == "jittor":     # the reference's container: the six keys of runner.py:124-131 as numpy arrays (jt.load reads it); our "extra" entry has no counterpart there
+            from .utils import jittor_pickle
+            ck.pop("extra")
+            jittor_pickle.dump(ck, path)
+        else:
+            torch.save(ck, path)
 
     def load_ckpt(self, path):
         print("Loading ckpt from:", path)
-        try:
-            ckpt = torch.load(path, map_location="cpu", weights_only=False)
-        except Exception as e:
-            raise RuntimeError(f"{path} is not a checkpoint written by this Runner (torch.save container).  Checkpoints pickled by the reference's Jittor Runner "
-                               f"(jt.save, runner/runner.py:123-135) hold jittor.Var payloads and need Jittor to unpickle; convert them with tools/convert_ckpt.py "
-                               f"on a machine that has Jittor.  Original error: {e!r}") from e
+        from .utils import jittor_pickle
+        with open(path, "rb") as f:
+            head = f.read()
+        if head.endswith(jittor_pickle.MAGIC) or self.cfg.ckpt_format == "jittor":
+            # the reference's own container (jt.save: a pickle of numpy arrays + sha1 + magic, utils/jittor_pickle.py) - read without Jittor
+            ckpt = jittor_pickle.to_torch(jittor_pickle.loads(head, path))
+        else:
+            try:
+                ckpt = torch.load(path, map_location="cpu", weights_only=False)
+            except Exception as e:
+                raise RuntimeError(f"{path} is neither a torch.save container nor a jt.save file (no HCAJSLHD trailer; set `ckpt_format = 'jittor'` in the config to "
+                                   f"read a bare pickle of numpy arrays).  Original error: {e!r}") from e
         if not (isinstance(ckpt, dict) and "model" in ckpt and "global_step" in ckpt):
             raise RuntimeError(f"{path}: unexpected checkpoint layout (keys {list(ckpt)[:8] if isinstance(ckpt, dict) else type(ckpt)}); expected the keys of runner/runner.py:123-135")
         self.start = ckpt["global_step"]
-        self.model.load_state_dict(ckpt["model"])
-        self.sampler.load_state_dict(ckpt["sampler"])
+        ref_file = "extra" not in ckpt          # written by the reference's Runner: its module tree may hold buffers ours does not register (and vice versa)
+        self.model.load_state_dict(ckpt["model"], strict=not ref_file)
+        self.sampler.load_state_dict(ckpt["sampler"], strict=not ref_file)
         self.optimizer.load_state_dict(ckpt["optimizer"])
         self.optimizer._nested_optimizer.load_state_dict(ckpt["nested_optimizer"])
         self.ema_optimizer.load_state_dict(ckpt["ema_optimizer"])

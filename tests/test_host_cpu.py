@@ -281,3 +281,31 @@ def test_balanced_forward_map_covers_every_chunk_once():
                 assert (cov == 1).all(), (aabb, light, nblk)
                 if nblk >= 64:
                     assert cost.max() - cost.min() <= 0.05 * cost.mean() + 2.0, (aabb, light, nblk, cost)
+
+
+def test_jittor_pickle_container_round_trip(tmp_path):
+    """the container jt.save / jt.load use for .pkl files (pickle protocol 4 of numpy arrays + sha1 + b'HCAJSLHD'), restated from Jittor's published
+    source and read / written WITHOUT Jittor: round trip, trailer, corruption detection, a bare pickle without trailer, and refusal to import code."""
+    import hashlib, pickle
+    import torch
+    from jnerf_amd.utils import jittor_pickle as JP
+    ck = {"global_step": 123, "model": {"pos_encoder.m_grid": torch.arange(12, dtype=torch.float32), "density_mlp.con_weights": torch.ones(4).half()},
+          "nested_optimizer": {"defaults": {"lr": 0.1, "param_groups": [{"values": [torch.zeros(3)], "m": [torch.ones(3)]}]}}}
+    p = tmp_path / "params.pkl"
+    JP.dump(ck, str(p))
+    raw = p.read_bytes()
+    assert raw.endswith(b"HCAJSLHD") and hashlib.sha1(raw[:-28]).digest() == raw[-28:-8]
+    plain = pickle.loads(raw[:-28])                                    # what jt.load hands to the reference's Runner: numpy arrays and Python scalars only
+    assert isinstance(plain["model"]["pos_encoder.m_grid"], np.ndarray) and plain["global_step"] == 123
+    back = JP.to_torch(JP.load(str(p)))
+    assert torch.equal(back["model"]["pos_encoder.m_grid"], ck["model"]["pos_encoder.m_grid"])
+    assert back["model"]["density_mlp.con_weights"].dtype == torch.float32          # fp16 payloads become fp32 masters
+    assert torch.equal(back["nested_optimizer"]["defaults"]["param_groups"][0]["m"][0], torch.ones(3)) and back["nested_optimizer"]["defaults"]["lr"] == 0.1
+    bad = bytearray(raw); bad[10] ^= 0xFF
+    with pytest.raises(ValueError, match="checksum"):
+        JP.loads(bytes(bad))
+    assert JP.loads(pickle.dumps({"a": np.arange(3)}, 4))["a"].tolist() == [0, 1, 2]     # no trailer: unpickled as is (safeunpickle's fallback)
+    import os as _os
+    evil = pickle.dumps(_os.getcwd)                                    # a pickle that imports something other than numpy must be refused
+    with pytest.raises(pickle.UnpicklingError):
+        JP.loads(evil)

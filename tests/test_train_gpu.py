@@ -49,6 +49,24 @@ def test_training_converges(fp16, aabb_scale, const_dt, min_psnr, max_loss_ratio
     r.model.pos_encoder.m_grid.data.zero_()
     r.load_ckpt(p)
     assert torch.equal(r.model.pos_encoder.m_grid.detach(), before)
+    # the same through the reference's own container (jt.save: pickle of numpy arrays + sha1 + magic, read and written without Jittor - utils/jittor_pickle.py)
+    from jnerf_amd.utils import jittor_pickle
+    pj = str(tmp_path / "params_jittor.pkl")
+    r.cfg.ckpt_format = "jittor"
+    r.save_ckpt(pj)
+    r.cfg.ckpt_format = None
+    plain = jittor_pickle.load(pj)
+    assert set(plain) == {"global_step", "model", "sampler", "optimizer", "nested_optimizer", "ema_optimizer"}          # exactly runner.py:124-131's keys
+    assert isinstance(plain["model"]["pos_encoder.m_grid"], np.ndarray) and isinstance(plain["nested_optimizer"]["defaults"]["param_groups"][0]["m"][0], np.ndarray)
+    m_before = [t.clone() for t in r.optimizer._nested_optimizer.param_groups[0]["m"]]
+    r.model.pos_encoder.m_grid.data.zero_()
+    for t in r.optimizer._nested_optimizer.param_groups[0]["m"]:
+        t.zero_()
+    r.load_ckpt(pj)                                   # recognised by its trailer
+    assert torch.equal(r.model.pos_encoder.m_grid.detach(), before)
+    assert all(torch.equal(a, b) for a, b in zip(r.optimizer._nested_optimizer.param_groups[0]["m"], m_before))
+    assert np.isfinite(float(r.train_step(400).mean().item()))           # and training goes on from it
+    r.drain()
 
 
 def test_module_api_standalone():
