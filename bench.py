@@ -169,10 +169,19 @@ def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
     # 20 480 FLOP / sample forward, 40 960 backward.  (The backward kernels also RECOMPUTE the forward - 61 440 executed - which is the kernel's own
     # choice, not algorithmic work: `roofline.frac` is on the §8(d) figure, the executed figure is reported next to it.)
     flops = {"k_field_fwd": 20480.0 * n, "k_field_bwd": 40960.0 * n, "k_field32_fwd": 20480.0 * n, "k_field32_bwd": 40960.0 * n}
+    for alias, base in KERNEL_VARIANTS.items():         # the same work under another kernel name (csrc variants selected by environment / default since r3)
+        if base in d:
+            d[alias] = d[base]
+        if base in flops:
+            flops[alias] = flops[base]
     return d, flops
 
 
-EXECUTED_FLOPS_PER_SAMPLE = {"k_field_fwd": 20480.0, "k_field_bwd": 61440.0, "k_field32_fwd": 20480.0, "k_field32_bwd": 61440.0}
+# kernel variants: same algorithmic bytes / flops as the kernel they replace
+KERNEL_VARIANTS = {"k_field32_bwd_2g": "k_field32_bwd", "k_field32_bwd_pp": "k_field32_bwd", "k_field_bwd_g": "k_field_bwd", "k_hash_fwd_bal": "k_hash_fwd", "k_hash_fwd_dydx": "k_hash_fwd"}
+# FLOP per sample the kernels EXECUTE: the backward kernels recompute the forward (their choice, not algorithmic work); the r3 fp32 variants skip the rgb layer the backward never reads
+EXECUTED_FLOPS_PER_SAMPLE = {"k_field_fwd": 20480.0, "k_field_bwd": 61440.0, "k_field32_fwd": 20480.0, "k_field32_bwd": 61440.0, "k_field32_bwd_2g": 59392.0, "k_field32_bwd_pp": 59392.0,
+                             "k_field_bwd_g": 61440.0}
 HASH_BWD_STAGE = ("k_level_absmax", "k_bin_records_runs", "k_bin_records", "k_bin_accumulate")
 
 

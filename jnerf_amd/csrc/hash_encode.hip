@@ -116,6 +116,29 @@ static FwdMap fwd_map_helpers(const LevelTable &lt, uint32_t nblk, float help) {
 	}
 	return m;
 }
+// Variant 3: every fine level keeps its own XCD and ALL its chunks (L2 residency untouched); only the coherent levels move - instead of following a fine level on the same
+// XCD (the second phase of the round-1 map) they are dealt to the XCDs that hold no fine level at all, which would otherwise idle.  No helper XCD (fox: eight fine levels): unchanged.
+static FwdMap fwd_map_light_aside(const LevelTable &lt, uint32_t nblk) {
+	FwdMap m; memset(&m, 0, sizeof(m));
+	bool heavy[16]; for (int l = 0; l < 16; ++l) heavy[l] = lt.v[4 * l + 2] > 300u;
+	int helpers[8], n_help = 0;
+	for (int x = 0; x < 8; ++x) if (!heavy[15 - x] && !heavy[x]) helpers[n_help++] = x;
+	uint32_t seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	auto add = [&](int x, uint32_t level) { if (seg[x] < FWD_MAP_SEGS) { m.level[x][seg[x]] = level; m.begin[x][seg[x]] = 0u; m.count[x][seg[x]] = nblk; ++seg[x]; } };
+	int rr = 0;
+	for (int phase = 0; phase < 2; ++phase)
+		for (int x = 0; x < 8; ++x) {
+			const uint32_t l = phase == 0 ? 15u - x : (uint32_t)x;
+			if (heavy[l] || n_help == 0) add(x, l);
+			else { add(helpers[rr % n_help], l); ++rr; }
+		}
+	for (int x = 0; x < 8; ++x) {
+		uint32_t c = 0;
+		for (int g = 0; g < FWD_MAP_SEGS; ++g) if (m.count[x][g]) c += div_up(m.count[x][g], fwd_map_span(lt, m.level[x][g]));
+		if (c > m.slots) m.slots = c;
+	}
+	return m;
+}
 __device__ __forceinline__ bool block_to_level_chunk_map(const FwdMap &m, const LevelTable &lt, uint32_t &level, uint32_t &chunk, uint32_t &chunk_end) {
 	const uint32_t b = blockIdx.x, xcd = b & 7u;
 	uint32_t slot = b >> 3;
@@ -606,7 +629,7 @@ NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint
 	static const float light = [] { const char *e = getenv("NGP_HASH_FWD_LIGHT"); return e ? (float)atof(e) : 0.12f; }();
 	static const float help = [] { const char *e = getenv("NGP_HASH_FWD_HELP"); return e ? (float)atof(e) : 0.15f; }();
 	if (balance) {
-		const FwdMap map = balance == 2 ? fwd_map_helpers(lt, nblk, help) : fwd_map_balanced(lt, nblk, light);
+		const FwdMap map = balance == 3 ? fwd_map_light_aside(lt, nblk) : balance == 2 ? fwd_map_helpers(lt, nblk, help) : fwd_map_balanced(lt, nblk, light);
 		const dim3 grid(8 * map.slots);
 #define GO(T, L) NGP_LAUNCH((k_hash_fwd_bal<T, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)table, lt, (T *)out, nblk, n_valid, map)
 		if (dtype == NGP_F32) { if (out_layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
@@ -1314,7 +1337,7 @@ NGP_API int ngp_hash_encode_bwd_ws(void *stream, uint32_t n, const float *pos, u
 
 // test hook (tests/test_host_cpu.py): the balanced forward map as host arrays, u32[8][FWD_MAP_SEGS][3] = (level, first chunk, chunks); returns blocks per XCD
 NGP_API uint32_t ngp_x_fwd_map(const uint32_t *level_table_host, uint32_t nblk, float light, uint32_t *out_host) {
-	const FwdMap m = light < 0.f ? fwd_map_helpers(load_table(level_table_host), nblk, -light) : fwd_map_balanced(load_table(level_table_host), nblk, light);
+	const FwdMap m = light == -3.0f ? fwd_map_light_aside(load_table(level_table_host), nblk) : light < 0.f ? fwd_map_helpers(load_table(level_table_host), nblk, -light) : fwd_map_balanced(load_table(level_table_host), nblk, light);
 	for (int x = 0; x < 8; ++x) for (int g = 0; g < FWD_MAP_SEGS; ++g) { out_host[(x * FWD_MAP_SEGS + g) * 3] = m.level[x][g]; out_host[(x * FWD_MAP_SEGS + g) * 3 + 1] = m.begin[x][g]; out_host[(x * FWD_MAP_SEGS + g) * 3 + 2] = m.count[x][g]; }
 	return m.slots;
 }

@@ -218,9 +218,10 @@ class Runner:
                 cur_state = self.sampler.export_batch_state()
             with torch.cuda.stream(side):
                 nb = self._make_batch(k)
-                from . import ops as _ops
-                _ops.flag_signal(self._flags[k % n_sets:k % n_sets + 1], k + 1)         # behind the batch's kernels on this stream: the training stream's ngp_flag_wait
-                nb["flag"] = (self._flags[k % n_sets:k % n_sets + 1], k + 1, self._flags[n_sets:])
+                if cfg.flag_handover is True:
+                    from . import ops as _ops
+                    _ops.flag_signal(self._flags[k % n_sets:k % n_sets + 1], k + 1)     # behind the batch's kernels on this stream: the training stream's ngp_flag_wait
+                    nb["flag"] = (self._flags[k % n_sets:k % n_sets + 1], k + 1, self._flags[n_sets:])
                 nb["ready"] = self._ready[k % n_sets]
                 nb["ready"].record(side)
             for t in (nb["bg"], nb["target"]) + tuple(nb["keep"]):

@@ -242,7 +242,11 @@ def test_field_bwd_vs_oracle(H, n):
         # bound the tail instead of the single worst element
         assert np.linalg.norm(dfeat - rdf) <= 2e-2 * np.linalg.norm(rdf), np.linalg.norm(dfeat - rdf) / np.linalg.norm(rdf)
         assert np.quantile(np.abs(dfeat - rdf), 0.999) <= 3e-2 * np.abs(rdf).max()
-        assert np.abs(dfeat - rdf).max() <= 0.25 * np.abs(rdf).max()
+        # counted outliers instead of one loose worst-element bound: measured on the GPU (tools/probe_field_bwd_err.py) 1.6e-5 .. 4.2e-5 of the elements are off by
+        # more than 5 % of the largest entry (n = 1000 .. 65536), the worst one by 9-12 %
+        err = np.abs(dfeat - rdf) / np.abs(rdf).max()
+        assert (err > 0.05).sum() <= max(2, int(2e-4 * err.size)), ((err > 0.05).sum(), err.size)
+        assert err.max() <= 0.15
         GC.close(dw[:3072], rdwd, atol=3e-2 * np.abs(rdwd).max(), what="dL/dW density")
         GC.close(dw[3072:], rdwc, atol=3e-2 * np.abs(rdwc).max(), what="dL/dW rgb")
         assert not dw[3072 + 6144 + 3 * 64:].any()       # padded rows of the last layer stay zero (fully_fused_mlp.py:136)
