@@ -60,7 +60,7 @@ class _RayDatasetBase:
         self.idx_now += self.batch_size
         return self.generate_random_data(index, self.batch_size)
 
-    def next_fused(self, bg):
+    def next_fused(self, bg, out=None):
         """(ours) next(ds) with the target compositing of runner.py:68 (rgb*a + bg*(1-a)) done inside the ray-generation kernel:
         -> (img_ids, rays_o, rays_d, target[R,3])"""
         if self.shuffle_index is None or self.idx_now + self.batch_size >= self.shuffle_index.shape[0]:
@@ -69,7 +69,7 @@ class _RayDatasetBase:
         self.idx_now += self.batch_size
         if index.is_cuda:
             index.record_stream(torch.cuda.current_stream())       # the permutation may have been drawn on another (side) stream
-        return ops.generate_rays(index, self.W, self.H, self.focal_lengths, self.metadata, self.transforms_gpu, images=self.image_data, bg=bg)
+        return ops.generate_rays(index, self.W, self.H, self.focal_lengths, self.metadata, self.transforms_gpu, images=self.image_data, bg=bg, out=out)
 
     def generate_random_data(self, index, bs):
         img_ids, rays_o, rays_d, _ = ops.generate_rays(index, self.W, self.H, self.focal_lengths, self.metadata, self.transforms_gpu)

@@ -444,13 +444,18 @@ def adam_ema_step(p, g, m, v, ema, p_half, lr, step, b0=0.9, b1=0.99, eps=1e-15,
                                            float(grad_mul)), "ngp_adam_ema_step")
 
 
-def generate_rays(pixel_index, W, H, focal, metadata, xforms, images=None, bg=None):
+def generate_rays(pixel_index, W, H, focal, metadata, xforms, images=None, bg=None, out=None):
+    """`out` = (img int32[cap], o [cap,3], d [cap,3], target [cap,3]) persistent buffers with cap >= n: the results are views of their first n rows (nothing is allocated)"""
     n = pixel_index.shape[0]
     dev = pixel_index.device
-    img = torch.empty(n, dtype=torch.int32, device=dev)
-    o = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    d = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    target = torch.empty((n, 3), dtype=torch.float32, device=dev) if images is not None else None
+    if out is not None:
+        img, o, d = out[0][:n], out[1][:n], out[2][:n]
+        target = out[3][:n] if images is not None else None
+    else:
+        img = torch.empty(n, dtype=torch.int32, device=dev)
+        o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        d = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        target = torch.empty((n, 3), dtype=torch.float32, device=dev) if images is not None else None
     check(L.lib().ngp_generate_rays(_stream(), n, _p(pixel_index), int(W), int(H), _p(focal), _p(metadata), _p(xforms), _p(images), _p(bg), _p(img), _p(o), _p(d), _p(target)), "ngp_generate_rays")
     return img, o, d, target
 

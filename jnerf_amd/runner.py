@@ -117,9 +117,10 @@ class Runner:
             pass
 
     # ---- one training iteration == the body of Runner.train (runner.py:64-76)
-    def _make_batch(self, step):
+    def _make_batch(self, step, bufs=None):
         """ray generation, random background, target compositing (runner.py:65-68) and occupancy-grid sampling (runner.py:70) of ONE batch, on the
-        current stream"""
+        current stream.  `bufs` = persistent ray buffers of the batch's buffer set (pipelined batches): nothing is allocated, so nothing has to be handed
+        between the streams' allocator pools."""
         self.cfg.m_training_step = step
         ds = self.dataset["train"]
         if hasattr(self.sampler, "finish_batch_rays_update"):
@@ -128,8 +129,12 @@ class Runner:
         if cur is not None and self._rays_event is not None:
             cur.wait_event(self._rays_event)    # batches are generated on alternating streams: the dataset's permutation / cursor state is handed on in order
         if hasattr(ds, "next_fused"):       # same values as the three lines of runner.py:65-68, one kernel
-            bg = torch.rand((ds.batch_size, 3), device=ds.device)
-            img_ids, rays_o, rays_d, rgb_target = ds.next_fused(bg)
+            if bufs is not None:
+                bg = torch.rand((ds.batch_size, 3), out=bufs["bg"][:ds.batch_size])
+                img_ids, rays_o, rays_d, rgb_target = ds.next_fused(bg, out=(bufs["img"], bufs["o"], bufs["d"], bufs["target"]))
+            else:
+                bg = torch.rand((ds.batch_size, 3), device=ds.device)
+                img_ids, rays_o, rays_d, rgb_target = ds.next_fused(bg)
         else:
             img_ids, rays_o, rays_d, rgb_target = next(ds)
             bg = torch.rand((rgb_target.shape[0], 3), device=rgb_target.device)
@@ -193,6 +198,17 @@ class Runner:
             self._done = [torch.cuda.Event() for _ in range(n_sets // P + 2)]
             self._grid_event, self._grid_valid = torch.cuda.Event(), False
             self._flags = torch.zeros(n_sets + 1, dtype=torch.int32, device=self.sampler.device)      # one hand-over flag per buffer set + the wait kernels' status word
+            # Persistent ray buffers, one per buffer set, sized for the largest ray count update_batch_rays can choose.  Round 2 / early round 3 allocated bg / target /
+            # rays per batch on the sampling stream and `record_stream`ed them for the training stream: when the batch was released, the caching allocator put one
+            # event record PER TENSOR into the training stream's queue - five marker packets between the sweep and the next step's first kernel, ~6 us each: that was
+            # the "unexplained" 30 us at the step boundary (HIP API trace, gpurun_out/r3l_api_timeline.txt: 10 hipEventRecord + 7 hipEventQuery per step).  The sets are
+            # recycled under the same `done` checkpoints as the sampler's.
+            cap, dev = int(self.sampler.target_batch_size), self.sampler.device
+            ds = self.dataset["train"]
+            self._ray_bufs = None
+            if hasattr(ds, "next_fused") and cfg.pipeline_persistent_rays is not False and os.environ.get("NGP_PIPELINE_ALLOC_RAYS") != "1":
+                self._ray_bufs = [dict(bg=torch.empty((cap, 3), device=dev), target=torch.empty((cap, 3), device=dev), o=torch.empty((cap, 3), device=dev),
+                                       d=torch.empty((cap, 3), device=dev), img=torch.empty(cap, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
             if self.sampler.grid_updated_in_last_sample:
                 self._grid_event.record(main); self._grid_valid = True
         # `done` checkpoint of the training stream, every P-th step only: an event record is a marker packet in the stream's queue and costs ~15 us of dead time
@@ -217,16 +233,17 @@ class Runner:
             if cur_state is None:
                 cur_state = self.sampler.export_batch_state()
             with torch.cuda.stream(side):
-                nb = self._make_batch(k)
+                nb = self._make_batch(k, self._ray_bufs[k % n_sets] if self._ray_bufs is not None else None)
                 if cfg.flag_handover is True:
                     from . import ops as _ops
                     _ops.flag_signal(self._flags[k % n_sets:k % n_sets + 1], k + 1)     # behind the batch's kernels on this stream: the training stream's ngp_flag_wait
                     nb["flag"] = (self._flags[k % n_sets:k % n_sets + 1], k + 1, self._flags[n_sets:])
                 nb["ready"] = self._ready[k % n_sets]
                 nb["ready"].record(side)
-            for t in (nb["bg"], nb["target"]) + tuple(nb["keep"]):
-                if torch.is_tensor(t):
-                    t.record_stream(main)
+            if self._ray_bufs is None:
+                for t in (nb["bg"], nb["target"]) + tuple(nb["keep"]):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
             self._queue[k] = nb
         if cur_state is not None:
             self.sampler.import_batch_state(cur_state)
