@@ -52,6 +52,16 @@ int ngp_hash_encode_fwd_dydx(void *stream, uint32_t n, const float *pos, uint32_
 /* dL/dpos[i][d] = sum_k dLdy[i][k] * dy_dx[i][d][k] -> f32[n,3].  GridEncode.grad returns None for the positions (grid_encode.py:190) and the reference has no kernel
  * for this contraction: it is what that `None` would have to become. */
 int ngp_hash_encode_bwd_input(void *stream, uint32_t n, const void *dLdy, int dtype, int in_layout, const float *dy_dx, float *dLdpos, const uint32_t *n_valid);
+/* Second-order terms for a network trained on its own input gradient (NeuS over a hash-grid SDF network, BASELINE configs[4]: the eikonal term and the normal fed to
+ * the colour network, python/jnerf/models/samplers/neus_render/renderer.py:214,258-260 through neus_network.py:99-108, back-propagate through dL/dpos).  For an
+ * upstream gradient u = d loss / d (dL/dpos), f32[n,3]:
+ *   ..._bwd_dy:   ddLdy[i][k] = sum_d u[i][d] * dy_dx[i][d][k]   (AoS [n,32], dtype f32|f16) - the gradient w.r.t. the dLdy that ngp_hash_encode_bwd_input was given;
+ *   ..._bwd_grid: grad[entry][f] += dLdy[i][2 level + f] * sum_d u[i][d] * d w_corner / d pos_d   (fp32 atomics into the table gradient, NOT zeroed first) - the
+ *                 gradient w.r.t. the table that dy_dx was computed from.  dLdy is AoS [n,32].
+ * The reference has no counterpart (its dy_dx branch is compiled but never enabled, grid_encode.py:96); the gradient w.r.t. pos itself is not produced. */
+int ngp_hash_encode_bwd_input_bwd_dy(void *stream, uint32_t n, const float *u, const float *dy_dx, void *ddLdy, int dtype);
+int ngp_hash_encode_bwd_input_bwd_grid(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, int dtype, const float *u,
+                                       const uint32_t *level_table_host, float *grad, uint64_t n_params);
 /* replaces GridEncode.grad (grid_encode.py:137-184: memset + transpose_gradients + kernel_grid_backward).
  * grad_dtype may be NGP_F32 with dtype NGP_F16 (fp32 accumulation of fp16 gradients). zero_first!=0 clears `grad` (n_params elements). */
 int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, const uint32_t *level_table_host,

@@ -5,6 +5,7 @@ SHEncoder    <- python/jnerf/models/position_encoders/sh_encoder/sh_encoder.py:1
 FrequencyEncoder <- python/jnerf/models/position_encoders/freq_encoder/freq_encoder.py:11-52 (plain torch ops, "plumbing" configs only)
 
 Parameters are fp32 masters; with cfg.fp16 the kernels gather from an fp16 shadow that the fused Adam+EMA sweep refreshes."""
+import contextlib
 import torch
 from torch import nn
 from . import ops
@@ -12,8 +13,45 @@ from .utils.config import get_cfg
 from .utils.registry import ENCODERS
 
 
+@contextlib.contextmanager
+def input_gradient_only(enc):
+    """While active, the backward of `enc` (a HashEncoder; anything else: no-op) serves `torch.autograd.grad(y, x)` - the SDF network's own input gradient
+    (neus_network.py:99-108): only dL/dx is produced, dL/dy is NOT scattered into the table gradient (it is not a loss gradient).  The table gradient of the loss
+    arrives later, when loss.backward() runs the same backward without the flag plus _HashEncodeBwdInput.backward for the second-order terms."""
+    if not isinstance(enc, HashEncoder):
+        yield
+        return
+    old, enc._input_grad_only = enc._input_grad_only, True
+    try:
+        yield
+    finally:
+        enc._input_grad_only = old
+
+
+class _HashEncodeBwdInput(torch.autograd.Function):
+    """dL/dx = contraction of dL/dy with kernel_grid's dy_dx, as a differentiable node: a network trained on its own input gradient (eikonal term) back-propagates
+    through it - w.r.t. dL/dy (ngp_hash_encode_bwd_input_bwd_dy) and w.r.t. the table (ngp_hash_encode_bwd_input_bwd_grid, added into m_grid.grad like the
+    first-order scatter).  The mixed second derivative w.r.t. x is not produced (sample positions carry no parameters)."""
+
+    @staticmethod
+    def forward(ctx, dy, x, grid, dy_dx, enc):
+        ctx.enc = enc
+        ctx.save_for_backward(dy, x, dy_dx)
+        return ops.hash_encode_bwd_input(dy, dy_dx, ops.LAYOUT_AOS)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u):
+        dy, x, dy_dx = ctx.saved_tensors
+        u = u.contiguous().float()
+        enc = ctx.enc
+        ops.hash_encode_bwd_input_bwd_grid(x.detach(), dy.detach(), u, enc.level_table, enc.grad_buffer())
+        return ops.hash_encode_bwd_input_bwd_dy(u, dy_dx, dtype=dy.dtype), None, None, None, None
+
+
 class _HashEncode(torch.autograd.Function):
-    """GridEncode.execute / .grad (grid_encode.py:71-125, 137-190): no gradient w.r.t. the positions, table gradient by atomic scatter."""
+    """GridEncode.execute / .grad (grid_encode.py:71-125, 137-190): table gradient by scatter; the reference returns no gradient w.r.t. the positions - here they get one
+    when they ask for it (x.requires_grad), from kernel_grid's dy_dx branch."""
 
     @staticmethod
     def forward(ctx, x, grid, enc):
@@ -24,7 +62,7 @@ class _HashEncode(torch.autograd.Function):
             # (ours) the positions ask for a gradient - a hash-grid SDF network differentiates the encoder w.r.t. its input: the forward also writes kernel_grid's
             # dy_dx output (HashEncode.h:205-251; the reference compiles that branch but passes nullptr, grid_encode.py:96) and backward contracts it with dL/dy
             out, dy_dx = ops.hash_encode_fwd_dydx(x.detach(), table, enc.level_table)
-            ctx.save_for_backward(x, dy_dx)
+            ctx.save_for_backward(x, grid, dy_dx)
             return out
         ctx.save_for_backward(x)
         return ops.hash_encode_fwd(x, table, enc.level_table)
@@ -34,9 +72,11 @@ class _HashEncode(torch.autograd.Function):
         x = ctx.saved_tensors[0]
         enc = ctx.enc
         dy = dy.contiguous()
-        enc.accumulate_grad(x.detach(), dy, ops.LAYOUT_AOS)
+        if not enc._input_grad_only:
+            enc.accumulate_grad(x.detach(), dy.detach(), ops.LAYOUT_AOS)
         if ctx.want_dx:
-            return ops.hash_encode_bwd_input(dy, ctx.saved_tensors[1], ops.LAYOUT_AOS), None, None
+            _, grid, dy_dx = ctx.saved_tensors
+            return _HashEncodeBwdInput.apply(dy, x, grid, dy_dx, enc), None, None
         return None, None, None          # the reference's contract (grid_encode.py:190: `return None, grid_grad`)
 
 
@@ -46,7 +86,7 @@ class HashEncoder(nn.Module):
         super().__init__()
         self.cfg = get_cfg()
         self.using_fp16 = bool(self.cfg.fp16)
-        aabb_scale = self.cfg.dataset_obj.aabb_scale
+        aabb_scale = getattr(self.cfg.dataset_obj, "aabb_scale", None) or 1          # (NeuS data sets have no aabb_scale: the unit cube)
         # like the reference (hash_encoder.py:17-18) the geometry is fixed: L=16, F=2, T=2^19, base 16, whatever the ctor args say
         self.level_table, self.offsets, self.n_params = ops.level_table(aabb_scale)
         self.grad_type = "float16" if self.using_fp16 else "float32"
@@ -59,6 +99,7 @@ class HashEncoder(nn.Module):
         self.fixed_point_grad = self.cfg.hash_grad_fixed_point is True
         self._fx_scratch = None
         self._bwd_ws = None
+        self._input_grad_only = False
         self.out_dim = 32
         self.out_dtype = torch.float16 if self.using_fp16 else torch.float32
 

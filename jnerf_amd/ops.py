@@ -125,6 +125,25 @@ def hash_encode_bwd_input(dLdy, dy_dx, layout=LAYOUT_AOS, n_valid=None):
     return out
 
 
+def hash_encode_bwd_input_bwd_dy(u, dy_dx, dtype=torch.float32):
+    """gradient of hash_encode_bwd_input w.r.t. its dLdy for an upstream gradient u [n,3]: [n,32] = sum_d u[:, d] * dy_dx[:, d, :]"""
+    n = dy_dx.shape[0]
+    assert dtype in (torch.float32, torch.float16)
+    assert u.is_contiguous() and u.dtype == torch.float32 and u.shape == (n, 3) and dy_dx.is_contiguous() and dy_dx.dtype == torch.float32
+    out = torch.empty((n, 32), dtype=dtype, device=dy_dx.device)
+    check(L.lib().ngp_hash_encode_bwd_input_bwd_dy(_stream(), n, _p(u), _p(dy_dx), _p(out), F32 if dtype == torch.float32 else F16), "ngp_hash_encode_bwd_input_bwd_dy")
+    return out
+
+
+def hash_encode_bwd_input_bwd_grid(pos, dLdy, u, level_tbl, grad):
+    """gradient of hash_encode_bwd_input w.r.t. the table (through dy_dx), ADDED into grad (fp32, n_params elements)"""
+    pos, stride = _rows(pos, 3)
+    n = pos.shape[0]
+    assert dLdy.is_contiguous() and dLdy.shape == (n, 32) and u.is_contiguous() and u.dtype == torch.float32 and u.shape == (n, 3) and grad.dtype == torch.float32 and grad.is_contiguous()
+    check(L.lib().ngp_hash_encode_bwd_input_bwd_grid(_stream(), n, _p(pos), stride, _p(dLdy), _dt(dLdy), _p(u), _tbl(level_tbl), _p(grad), grad.numel()), "ngp_hash_encode_bwd_input_bwd_grid")
+    return grad
+
+
 def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, layout=LAYOUT_AOS, zero_first=True, n_valid=None, fixed_point_scratch=None, workspace=None):
     """fixed_point_scratch: device f32[16] -> fixed-point LDS accumulation; workspace: uint8 tensor of >= hash_bwd_workspace_bytes(level_tbl) ->
     atomic-free dense levels (ngp_hash_encode_bwd_ws)"""

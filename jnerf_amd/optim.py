@@ -197,6 +197,7 @@ class Adam:
     @torch.no_grad()
     def _sweep(self, ema):
         pg = self.param_groups[0]
+        lr = pg.get("lr", self.lr)          # Jittor's optimisers read a per-group learning rate first (`pg.get("lr", self.lr)`): NeuSRunner.update_learning_rate writes it there
         for i, p in enumerate(pg["params"]):
             if p.grad is None:
                 continue
@@ -204,7 +205,7 @@ class Adam:
             # the fused kernel streams 16-byte vectors; a 1- or 3-element bias (OriginNeRFNetworks' alpha / rgb heads) takes the same update in plain torch ops
             if p.is_cuda and p.numel() % 4 == 0 and p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 and p.is_contiguous():
                 g_eff = self._eff_grad.pop(id(p), None)            # reduced fp16 gradient of the data-parallel path (p.grad was zeroed by the conversion pass)
-                ops.adam_ema_step(p.data, g_eff.view_as(p.grad) if g_eff is not None else p.grad, pg["m"][i], pg["values"][i], e, self._half.get(id(p)), self.lr, self.n_step, self.betas[0], self.betas[1], self.eps,
+                ops.adam_ema_step(p.data, g_eff.view_as(p.grad) if g_eff is not None else p.grad, pg["m"][i], pg["values"][i], e, self._half.get(id(p)), lr, self.n_step, self.betas[0], self.betas[1], self.eps,
                                   ema.decay if ema is not None else 0.0, zero_grad=True, grad_mul=(1.0 / self.DP_HALF_SCALE) if g_eff is not None else 1.0)
             else:                                   # CPU tensors (gloo unit tests of the data-parallel logic) and tiny / unaligned tensors: same math in torch
                 b0, b1 = self.betas
@@ -212,7 +213,7 @@ class Adam:
                 m, v = pg["m"][i], pg["values"][i]
                 m.mul_(b0).add_(g, alpha=1 - b0)
                 v.mul_(b1).addcmul_(g, g, value=1 - b1)
-                step_size = self.lr * (1 - b1 ** self.n_step) ** 0.5 / (1 - b0 ** self.n_step)
+                step_size = lr * (1 - b1 ** self.n_step) ** 0.5 / (1 - b0 ** self.n_step)
                 # fused-EMA mode stores the EMA IN the parameter (EMA.attach aliases values[i] = p.data): the blend must read the value from BEFORE the Adam
                 # update, exactly like the kernel's `E = P` (without the snapshot the EMA of these tensors was a silent no-op)
                 e_old = p.data.clone() if (ema is not None and e.data_ptr() == p.data_ptr()) else e

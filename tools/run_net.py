@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Command line of the reference's tools/run_net.py (tools/run_net.py:14-72) on the MI355X path:
     python tools/run_net.py --config-file projects/ngp/configs/ngp_fox.py --task {train,test,render}
---type mesh / --task validate_mesh (NeuS) are out of scope."""
+    python tools/run_net.py --config-file projects/neus/configs/neus_womask.py --type mesh --task {train,validate_mesh}      (NeuS: jnerf_amd/neus_runner.py)"""
 import argparse
 import os
 import sys
@@ -19,19 +19,23 @@ def main():
     args = parser.parse_args()
     assert args.type in ["novel_view", "mesh"], f"{args.type} not support, please choose [novel_view, mesh]"
     assert args.task in ["train", "test", "render", "validate_mesh"], f"{args.task} not support, please choose [train, test, render, validate_mesh]"
-    if args.type == "mesh" or args.task == "validate_mesh":
-        raise SystemExit("NeuS / mesh extraction is outside the Instant-NGP hot path this build covers (DESIGN.md §8)")
     from jnerf_amd.utils.config import init_cfg
-    from jnerf_amd.runner import Runner
     if args.config_file:
         init_cfg(args.config_file)
-    runner = Runner()
+    if args.type == "mesh":
+        from jnerf_amd.neus_runner import NeuSRunner
+        runner = NeuSRunner(is_continue=args.task == "validate_mesh")
+    else:
+        from jnerf_amd.runner import Runner
+        runner = Runner()
     if args.task == "train":
         runner.train()
     elif args.task == "test":
         runner.test(True)
     elif args.task == "render":
         runner.render(True, args.save_dir)                   # demo.mp4 with cv2, a PNG sequence next to it without (jnerf_amd/runner.py)
+    elif args.task == "validate_mesh":
+        runner.validate_mesh(world_space=False, resolution=512, threshold=args.mcube_threshold)
 
 if __name__ == "__main__":
     main()
