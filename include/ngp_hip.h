@@ -238,6 +238,20 @@ int ngp_dp_plan(const uint32_t *level_table_host, uint64_t n_params, int world, 
 /* all-gather, in place, of every rank's shards of n_bufs buffers laid out like the table (parameters every step; masters and Adam moments before a checkpoint) */
 int ngp_dp_allgather(void *comm, void *stream, const NgpDpPlan *plan_host, int n_bufs, void *const *bufs_host, const int *dtypes_host);
 
+/* ---- NeuS: the SDF -> opacity -> weights -> colour chain of NeuSRenderer.render_core (python/jnerf/models/samplers/neus_render/renderer.py:216-252; ~25 Jittor tensor ops
+ * and their autograd there), one wavefront per ray.  Rays have a fixed number of sections: n inside the unit sphere (sdf, cosv = ray . SDF gradient, dists, color[.,3],
+ * inside = 1|0: f32[n_rays, n]) and, with a background model (bg_alpha / bg_color: f32[n_rays, n_total(,3)], NULL without), n_total - n more behind them; inside the
+ * first n the background takes over where inside == 0 (:238-244).  inv_s: DEVICE scalar (the variance network's exp(10 v), clipped).  n_total <= 512.
+ * fwd writes colour f32[n_rays,3], weights / alpha f32[n_rays,n_total] and p, c f32[n_rays,n] (the 'p', 'c' / 'cdf' entries of render_core's result).
+ * bwd takes dL/dcolour and (or NULL) dL/dweights and writes dL/d{sdf, cosv, color} like their inputs, dL/d{bg_alpha, bg_color} (when given) and one partial of
+ * dL/dinv_s per ray (the caller sums them).  The [0,1] clip of the opacity is Jittor's safe_clip: value clamped, gradient passed through. */
+int ngp_neus_composite_fwd(void *stream, uint32_t n_rays, uint32_t n, uint32_t n_total, const float *sdf, const float *cosv, const float *dists, const float *inv_s,
+                           const float *color, const float *inside, const float *bg_alpha, const float *bg_color, float cos_anneal_ratio,
+                           float *out_color, float *weights, float *alpha, float *p, float *c);
+int ngp_neus_composite_bwd(void *stream, uint32_t n_rays, uint32_t n, uint32_t n_total, const float *sdf, const float *cosv, const float *dists, const float *inv_s,
+                           const float *color, const float *inside, const float *bg_alpha, const float *bg_color, float cos_anneal_ratio,
+                           const float *g_color, const float *g_weights, float *d_sdf, float *d_cos, float *d_inv_s_partial, float *d_color, float *d_bg_alpha, float *d_bg_color);
+
 /* ---- one training iteration's launch sequence, issued from native code -------------------------------------------------------------------
  * The body of Runner.train for one already-sampled batch (runner/runner.py:71-76: model(pos, dir) -> sampler.rays2rgb -> HuberLoss ->
  * optimizer.step -> ema_optimizer.ema_step), i.e. exactly these calls in this order on `stream`:

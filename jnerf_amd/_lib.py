@@ -62,6 +62,8 @@ SIGNATURES = {
     "ngp_hash_encode_bwd_input": (C.c_int, [_vp, _u32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ngp_hash_encode_bwd_input_bwd_dy": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _i32]),
     "ngp_hash_encode_bwd_input_bwd_grid": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _i32, _vp, _vp, _vp, _u64]),
+    "ngp_neus_composite_fwd": (C.c_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "ngp_neus_composite_bwd": (C.c_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngp_hash_encode_bwd": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp]),
     "ngp_hash_encode_bwd_fx": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ngp_hash_bwd_workspace_bytes": (C.c_uint64, [_vp, _u32]),

@@ -162,7 +162,7 @@ class NeuSRenderer:
 
         if self._use_fused(sdf):
             from . import neus_ops
-            color, weights, alpha, p, c, sampled_color = neus_ops.composite(
+            color, weights, alpha, p, c = neus_ops.composite(
                 sdf.reshape(batch_size, n_samples), true_cos.reshape(batch_size, n_samples), dists, inv_s.reshape(()), sampled_color, inside_sphere,
                 background_alpha, background_sampled_color, float(cos_anneal_ratio))
             p, c = p.reshape(-1, 1), c.reshape(-1, 1)
@@ -216,7 +216,7 @@ class NeuSRenderer:
             n_samples = self.n_samples + self.n_importance
 
         if self.n_outside > 0:
-            z_vals_feed, _ = torch.sort(torch.cat([z_vals, z_vals_outside.expand(batch_size, -1) if z_vals_outside.dim() == 1 else z_vals_outside], -1), dim=-1)
+            z_vals_feed, _ = torch.sort(torch.cat([z_vals, z_vals_outside], -1), dim=-1)
             ret_outside = self.render_core_outside(rays_o, rays_d, z_vals_feed, sample_dist, self.nerf)
             background_sampled_color, background_alpha = ret_outside["sampled_color"], ret_outside["alpha"]
 

@@ -238,3 +238,23 @@ def test_neus_runner_trains_saves_and_validates_on_cpu(tmp_path):
     assert again.iter_step == 40
     for k, v in again.neus_network.state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+def test_torch_hash_reference_of_the_gpu_tests_equals_the_c_oracle():
+    """tests/test_neus_gpu.py checks the second-order hash kernels against fp64 autograd of a pure-torch hash encoding; that encoding is pinned here to the C oracle
+    (itself bit-exact against the reference's kernel_grid incl. its dy_dx branch, tests/test_oracle_vs_ref.py): values and the dL/dx contraction"""
+    from oracle import oracle as O
+    from tests.test_neus_gpu import _hash_encode_ref
+    for aabb in (1, 4):
+        lt, _, n_params = O.level_table(aabb)
+        rng = np.random.default_rng(aabb)
+        x = (rng.random((257, 3)) * 0.98 + 0.01).astype(np.float32)
+        table = (rng.normal(size=n_params) * 0.1).astype(np.float32)
+        y, dydx = O.hash_encode_fwd_dydx(x, table, lt)
+        x64 = torch.tensor(x.astype(np.float64), requires_grad=True)
+        yr = _hash_encode_ref(x64, torch.tensor(table.astype(np.float64)), lt)
+        assert np.abs(yr.detach().numpy() - y).max() < 2e-7
+        v = rng.normal(size=(257, 32)).astype(np.float32)
+        (g,) = torch.autograd.grad(yr, x64, torch.tensor(v.astype(np.float64)))
+        want = O.hash_encode_bwd_input(v, dydx)
+        assert np.abs(g.numpy() - want).max() < 2e-6 * np.abs(want).max()

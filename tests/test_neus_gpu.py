@@ -1,0 +1,262 @@
+"""NeuS on the GPU (BASELINE.json configs[4]): the HIP compositing kernels (csrc/neus.hip) against the numpy restatement and the torch expression, the second-order
+hash-encoder kernels against fp64 autograd of a pure-torch hash encoding, and NeuSRunner training runs on the procedural DTU-layout scene - frequency-encoded (the
+reference's configuration, reduced) and hash-grid SDF network (ours)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from tests import synth_dtu
+from tests.test_neus_cpu import tiny_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _inputs(rng, B, n, n_out, dtype=torch.float64, dev="cpu"):
+    t = lambda a: torch.tensor(a, dtype=dtype, device=dev)
+    d = dict(sdf=t(rng.normal(size=(B, n)) * 0.15), cos=t(rng.uniform(-1.3, 1.3, size=(B, n))), dists=t(rng.uniform(0.004, 0.05, size=(B, n))),
+             color=t(rng.random((B, n, 3))), inside=t((rng.random((B, n)) < 0.8).astype(np.float64)))
+    if n_out is not None:
+        d["bg_alpha"], d["bg_color"] = t(rng.random((B, n + n_out)) * 0.25), t(rng.random((B, n + n_out, 3)))
+    return d
+
+
+def _torch_chain(d, inv_s, ratio):
+    """renderer.py:216-252 as NeuSRenderer.render_core's CPU branch writes it (fp64)"""
+    from jnerf_amd import neus_renderer as R
+    from jnerf_amd.neus_network import safe_clip
+    n = d["sdf"].shape[1]
+    a, p, c = R.neus_alpha(d["sdf"], d["cos"], d["dists"], inv_s, ratio)
+    alpha, col = safe_clip(a, 0.0, 1.0), d["color"]
+    if "bg_alpha" in d:
+        ins = d["inside"]
+        alpha = torch.cat([alpha * ins + d["bg_alpha"][:, :n] * (1 - ins), d["bg_alpha"][:, n:]], -1)
+        col = torch.cat([col * ins[..., None] + d["bg_color"][:, :n] * (1 - ins)[..., None], d["bg_color"][:, n:]], 1)
+    w = R._transmittance_weights(alpha)
+    return (col * w[..., None]).sum(1), w, alpha, p, c
+
+
+@pytest.mark.parametrize("B,n,n_out", [(37, 128, 32), (5, 70, None), (9, 300, 100), (1, 1, None), (4, 64, 0)])
+def test_neus_composite_kernels(B, n, n_out):
+    from oracle import neus_oracle as O
+    from jnerf_amd import neus_ops
+    rng = np.random.default_rng(B * 1000 + n)
+    for ratio in (0.0, 0.4, 1.0):
+        ref = _inputs(rng, B, n, n_out)
+        inv_s_ref = torch.tensor(20.0 + 60.0 * rng.random(), dtype=torch.float64, requires_grad=True)
+        leaves = [k for k in ("sdf", "cos", "color", "bg_alpha", "bg_color") if k in ref]
+        for k in leaves:
+            ref[k].requires_grad_(True)
+        col_r, w_r, a_r, p_r, c_r = _torch_chain(ref, inv_s_ref, ratio)
+        gc, gw = torch.tensor(rng.normal(size=(B, 3))), torch.tensor(rng.normal(size=w_r.shape) * 0.3)
+        ((col_r * gc).sum() + (w_r * gw).sum()).backward()
+        dev = {k: v.detach().float().to(DEV) for k, v in ref.items()}
+        for k in leaves:
+            dev[k].requires_grad_(True)
+        inv_s = torch.tensor(float(inv_s_ref), dtype=torch.float32, device=DEV, requires_grad=True)
+        col, w, a, p, c = neus_ops.composite(dev["sdf"], dev["cos"], dev["dists"], inv_s, dev["color"], dev["inside"], dev.get("bg_alpha"), dev.get("bg_color"), ratio)
+        ((col * gc.float().to(DEV)).sum() + (w * gw.float().to(DEV)).sum()).backward()
+        # forward: against the numpy loops and the fp64 torch chain.  fp32 sigmoids of arguments up to ~60: 1e-5 absolute on quantities <= 1
+        np_in = {k: v.detach().numpy() for k, v in ref.items()}
+        oc, ow, oa = O.composite(np_in["sdf"], np_in["cos"], np_in["dists"], float(inv_s_ref), np_in["color"], np_in["inside"], np_in.get("bg_alpha"), np_in.get("bg_color"), ratio)
+        assert np.allclose(a.cpu().numpy(), oa, atol=2e-5) and np.allclose(w.cpu().numpy(), ow, atol=2e-5) and np.allclose(col.cpu().numpy(), oc, atol=5e-5)
+        for got, want in ((col, col_r), (w, w_r), (a, a_r), (p, p_r), (c, c_r)):
+            assert torch.allclose(got.cpu().double(), want.detach(), atol=5e-5), float((got.cpu().double() - want.detach()).abs().max())
+        # backward: against fp64 autograd of the same formulas (safe_clip = straight-through clamp on both sides)
+        for k in leaves:
+            g, gr = dev[k].grad.cpu().double(), ref[k].grad
+            scale = float(gr.abs().max()) + 1e-12
+            assert float((g - gr).abs().max()) < 2e-4 * scale + 1e-6, (k, ratio, float((g - gr).abs().max()), scale)
+        assert abs(float(inv_s.grad) - float(inv_s_ref.grad)) < 2e-4 * abs(float(inv_s_ref.grad)) + 1e-6
+
+
+def _hash_encode_ref(x, table, lt):
+    """pure-torch fp64 multiresolution hash encoding (HashEncode.h:68-203 restated with tensor ops; differentiable w.r.t. x AND the table): the autograd reference for
+    the second-order kernels, which have no counterpart in the reference's code"""
+    outs = []
+    M = 0xFFFFFFFF
+    for l in range(16):
+        off, size, res = int(lt[l, 0]), int(lt[l, 1]), int(lt[l, 2])
+        scale = float(np.array([lt[l, 3]], np.uint32).view(np.float32)[0])
+        stride, dense = 1, True
+        for _ in range(3):
+            if stride <= size:
+                stride *= res
+        dense = not (size < stride)
+        # positions as the kernels form them - fp32 multiply-add, floor, fraction (HashEncode.h:106-115) - so that cell and weights are the kernels' bit for bit;
+        # the fp64 expression carries the derivative (d w / d x = scale)
+        p32 = x.detach().float() * np.float32(scale) + np.float32(0.5)
+        fl32 = torch.floor(p32)
+        p = x * scale + 0.5
+        w = p - fl32.double()
+        w = w + ((p32 - fl32).double() - w).detach()
+        g = fl32.long()
+        acc = 0
+        for k in range(8):
+            cx, cy, cz = g[:, 0] + (k & 1), g[:, 1] + ((k >> 1) & 1), g[:, 2] + (k >> 2)
+            if dense:
+                idx = (cx + cy * res + cz * res * res) & M
+            else:
+                idx = (cx & M) ^ ((cy * 19349663) & M) ^ ((cz * 83492791) & M)
+            idx = idx & (size - 1) if (size & (size - 1)) == 0 else idx % size
+            wk = (w[:, 0] if k & 1 else 1 - w[:, 0]) * (w[:, 1] if (k >> 1) & 1 else 1 - w[:, 1]) * (w[:, 2] if k >> 2 else 1 - w[:, 2])
+            acc = acc + wk[:, None] * table.view(-1, 2)[off + idx]
+        outs.append(acc)
+    return torch.cat(outs, -1)
+
+
+@pytest.mark.parametrize("aabb", [1, 4])
+def test_hash_encoder_second_order_terms(aabb):
+    from jnerf_amd import ops
+    rng = np.random.default_rng(11 + aabb)
+    lt, _, n_params = ops.level_table(aabb)
+    n = 700
+    x64 = torch.tensor(rng.random((n, 3)) * 0.98 + 0.01, dtype=torch.float64)
+    x64 = torch.tensor(x64.float().double().numpy(), requires_grad=True)             # positions exactly representable in fp32
+    table64 = torch.tensor(rng.normal(size=n_params) * 0.1, dtype=torch.float32).double().requires_grad_(True)
+    v64 = torch.tensor(rng.normal(size=(n, 32)), dtype=torch.float32).double().requires_grad_(True)     # plays dL/dy
+    u64 = torch.tensor(rng.normal(size=(n, 3)), dtype=torch.float32).double()                            # upstream gradient of dL/dx
+    y = _hash_encode_ref(x64, table64, lt)
+    (g,) = torch.autograd.grad(y, x64, v64, create_graph=True)
+    (g * u64).sum().backward()
+    x, table, v, u = x64.detach().float().to(DEV), table64.detach().float().to(DEV), v64.detach().float().to(DEV), u64.float().to(DEV)
+    out, dy_dx = ops.hash_encode_fwd_dydx(x, table, lt)
+    assert torch.allclose(out.cpu().double(), y.detach(), atol=1e-5)
+    assert torch.allclose(ops.hash_encode_bwd_input(v, dy_dx).cpu().double(), g.detach(), rtol=1e-4, atol=1e-3 * float(g.detach().abs().max()))
+    ddy = ops.hash_encode_bwd_input_bwd_dy(u, dy_dx)
+    assert float((ddy.cpu().double() - v64.grad).abs().max()) < 1e-5 * float(v64.grad.abs().max())
+    grad = torch.zeros(n_params, dtype=torch.float32, device=DEV)
+    ops.hash_encode_bwd_input_bwd_grid(x, v, u, lt, grad)
+    ref = table64.grad
+    assert float((grad.cpu().double() - ref).abs().max()) < 2e-5 * float(ref.abs().max()), float((grad.cpu().double() - ref).abs().max())
+    ops.hash_encode_bwd_input_bwd_grid(x, v, u, lt, grad)                              # adds, does not overwrite
+    assert float((grad.cpu().double() - 2 * ref).abs().max()) < 4e-5 * float(ref.abs().max())
+    half = ops.hash_encode_bwd_input_bwd_dy(u, dy_dx, dtype=torch.float16)
+    assert float((half.float() - ddy).abs().max()) < 2e-3 * float(ddy.abs().max())
+    grad_h = torch.zeros(n_params, dtype=torch.float32, device=DEV)
+    ops.hash_encode_bwd_input_bwd_grid(x, v.half(), u, lt, grad_h)
+    assert float((grad_h.cpu().double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
+def test_hash_sdf_network_eikonal_gradient_through_the_module(tmp_path):
+    """SDFNetwork over HashEncoder: gradient() and the parameter gradients of an eikonal + value loss equal fp64 autograd through the pure-torch encoding"""
+    from jnerf_amd.neus_network import SDFNetwork
+    synth_dtu.make_scene(str(tmp_path), n_images=2, W=16, H=12)
+    cfg = tiny_cfg(str(tmp_path), device=DEV)
+    cfg.encoder.sdf_encoder = dict(type="HashEncoder")
+    torch.manual_seed(1)
+    net = SDFNetwork(d_out=17, d_hidden=32, n_layers=2, skip_in=[], bias=0.5, scale=1.0, geometric_init=True, weight_norm=True)
+    enc = net.embed_fn_fine
+    with torch.no_grad():
+        enc.m_grid.normal_(0.0, 0.05)                       # large enough for the table to matter
+    x = (torch.rand(500, 3, device=DEV) * 1.6 - 0.8)
+    sdf = net.sdf(x)
+    g = net.gradient(x)
+    loss = ((g.norm(dim=-1) - 1.0) ** 2).mean() + 0.3 * sdf.square().mean()
+    net.zero_grad()
+    enc.grad_buffer().zero_()
+    loss.backward()
+    got_table = enc.m_grid.grad.detach().cpu().double().clone()
+    got_w = net.lin0.weight.grad.detach().cpu().double().clone()
+    # fp64 reference: same network, pure-torch encoding
+    ref = SDFNetwork(d_out=17, d_hidden=32, n_layers=2, skip_in=[], bias=0.5, scale=1.0, geometric_init=True, weight_norm=True)
+    ref.load_state_dict(net.state_dict())
+    ref = ref.cpu().double()
+    table = enc.m_grid.detach().cpu().double().requires_grad_(True)
+    lt = enc.level_table
+    ref._embed = lambda p: torch.cat([p, _hash_encode_ref((p * 0.5 + 0.5).clamp(0.0, 1.0), table, lt)], -1)
+    x64 = x.cpu().double().requires_grad_(True)
+    s64 = ref.sdf(x64)
+    (g64,) = torch.autograd.grad(s64, x64, torch.ones_like(s64), create_graph=True)
+    loss64 = ((g64.norm(dim=-1) - 1.0) ** 2).mean() + 0.3 * s64.square().mean()
+    loss64.backward()
+    assert torch.allclose(g.detach().cpu().double(), g64.detach(), atol=2e-4 * float(g64.abs().max()))
+    assert abs(float(loss) - float(loss64)) < 1e-4 * abs(float(loss64))
+    assert float((got_w - ref.lin0.weight.grad).abs().max()) < 1e-3 * float(ref.lin0.weight.grad.abs().max())
+    assert float((got_table - table.grad).abs().max()) < 1e-3 * float(table.grad.abs().max()), (float((got_table - table.grad).abs().max()), float(table.grad.abs().max()))
+
+
+def _train(tmp_path, steps, **over):
+    from jnerf_amd.neus_runner import NeuSRunner
+    truth = synth_dtu.make_scene(str(tmp_path), n_images=16, W=128, H=96)
+    base = dict(device=DEV, batch_size=512, end_iter=steps, warm_up_end=50, anneal_end=0, mask_weight=0.1,
+                render=dict(type="NeuSRenderer", n_samples=32, n_importance=32, n_outside=0, up_sample_steps=2, perturb=1.0))
+    base.update(over)
+    cfg = tiny_cfg(str(tmp_path), **base)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    runner = NeuSRunner()
+    perm = runner.get_image_perm()
+    runner.update_learning_rate()
+    log = []
+    for it in range(steps):
+        out = runner.train_step(perm[it % len(perm)])
+        runner.update_learning_rate()
+        if it % 50 == 49:
+            log.append({k: float(v) for k, v in out.items()})
+    return runner, truth, log
+
+
+def _quality(runner, truth, idx=3):
+    img = runner.validate_image(idx=idx, resolution_level=2) / 256.0                       # BGR
+    want = np.asarray(runner.dataset.image_at(idx, 2), np.float32) / 256.0
+    psnr = -10 * np.log10(np.mean((img - want) ** 2))
+    verts, tris = runner.validate_mesh(resolution=64)
+    err = np.abs(synth_dtu.scene_sdf(verts)) if len(verts) else np.array([1.0])
+    return psnr, float(err.mean()), len(tris)
+
+
+def test_neus_trains_on_the_procedural_dtu_scene(tmp_path):
+    """the reference's configuration family (frequency encodings, mask loss), reduced: colour PSNR and the extracted surface against the scene's exact SDF"""
+    runner, truth, log = _train(tmp_path, 1200,
+                                model=dict(type="NeuS", nerf_network=dict(D=3, W=32, output_ch=4, skips=[1], use_viewdirs=True),
+                                           sdf_network=dict(d_out=129, d_hidden=128, n_layers=4, skip_in=[2], bias=0.5, scale=1.0, geometric_init=True, weight_norm=True),
+                                           variance_network=dict(init_val=0.3),
+                                           rendering_network=dict(d_feature=128, mode="idr", d_out=3, d_hidden=128, n_layers=2, weight_norm=True, squeeze_out=True)),
+                                encoder=dict(nerf_pos_encoder=dict(type="FrequencyEncoder", multires=4, input_dims=4), nerf_dir_encoder=dict(type="FrequencyEncoder", multires=2, input_dims=3),
+                                             sdf_encoder=dict(type="FrequencyEncoder", multires=6, input_dims=3), rendering_encoder=dict(type="FrequencyEncoder", multires=4, input_dims=3)),
+                                optim=dict(type="Adam", lr=1e-3, eps=1e-15, betas=(0.9, 0.99)))
+    psnr, surf_err, n_tris = _quality(runner, truth)
+    print("neus freq:", log[0], log[-1], psnr, surf_err, n_tris)
+    assert log[-1]["color_loss"] < 0.5 * log[0]["color_loss"] and np.isfinite(log[-1]["loss"])
+    assert psnr > 20.0 and n_tris > 500 and surf_err < 0.05
+
+
+def test_hash_neus_trains_on_the_procedural_dtu_scene(tmp_path):
+    """BASELINE configs[4] as built here: the HIP hash grid under a small SDF network, eikonal term through the second-order kernels, fused compositing"""
+    runner, truth, log = _train(tmp_path, 1200,
+                                model=dict(type="NeuS", nerf_network=dict(D=3, W=32, output_ch=4, skips=[1], use_viewdirs=True),
+                                           sdf_network=dict(d_out=33, d_hidden=64, n_layers=2, skip_in=[], bias=0.5, scale=1.0, geometric_init=True, weight_norm=True),
+                                           variance_network=dict(init_val=0.3),
+                                           rendering_network=dict(d_feature=32, mode="idr", d_out=3, d_hidden=64, n_layers=2, weight_norm=True, squeeze_out=True)),
+                                encoder=dict(nerf_pos_encoder=dict(type="FrequencyEncoder", multires=4, input_dims=4), nerf_dir_encoder=dict(type="FrequencyEncoder", multires=2, input_dims=3),
+                                             sdf_encoder=dict(type="HashEncoder"), rendering_encoder=dict(type="FrequencyEncoder", multires=4, input_dims=3)),
+                                optim=dict(type="Adam", lr=2e-3, eps=1e-15, betas=(0.9, 0.99)))
+    assert runner.neus_network.sdf_network.hash_input and runner.renderer._use_fused(torch.zeros(1, device=DEV))
+    psnr, surf_err, n_tris = _quality(runner, truth)
+    print("neus hash:", log[0], log[-1], psnr, surf_err, n_tris)
+    assert log[-1]["color_loss"] < 0.5 * log[0]["color_loss"] and np.isfinite(log[-1]["loss"])
+    assert psnr > 20.0 and n_tris > 500 and surf_err < 0.06
+
+
+def test_fused_and_torch_compositing_agree_inside_the_renderer(tmp_path):
+    from jnerf_amd.neus_runner import NeuSRunner
+    synth_dtu.make_scene(str(tmp_path), n_images=4, W=64, H=48)
+    tiny_cfg(str(tmp_path), device=DEV)
+    torch.manual_seed(0)
+    runner = NeuSRunner()
+    data = runner.dataset.gen_random_rays_at(1, 96)
+    rays_o, rays_d = data[:, :3], data[:, 3:6]
+    near, far = runner.dataset.near_far_from_sphere(rays_o, rays_d)
+    outs = []
+    for fused in (False, True):
+        runner.renderer.fused_composite = fused
+        torch.manual_seed(5)
+        out = runner.renderer.render(rays_o, rays_d, near, far, cos_anneal_ratio=0.3, background_rgb=torch.ones([1, 3], device=DEV))
+        runner.neus_network.zero_grad()
+        (out["color_fine"].sum() + 0.1 * out["gradient_error"] + out["weight_sum"].mean()).backward()
+        outs.append((out["color_fine"].detach().clone(), out["weights"].detach().clone(), runner.neus_network.sdf_network.lin1.weight.grad.clone(),
+                     runner.neus_network.deviation_network.variance.grad.clone(), runner.neus_network.nerf_outside.alpha_linear.weight.grad.clone()))
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) < 2e-4 * float(a.abs().max()) + 1e-6, (float((a - b).abs().max()), float(a.abs().max()))
