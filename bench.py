@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-fox", action="store_true", help="skip the real-fox leg (extra.fox)")
+    ap.add_argument("--no-neus", action="store_true", help="skip the NeuS leg (extra.neus: BASELINE configs[4] on the procedural DTU-layout scene)")
     ap.add_argument("--images", type=int, default=0)
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event brackets (then no roofline object)")
@@ -411,6 +412,8 @@ def main():
         del runner
         torch.cuda.empty_cache()
         extra["fox"] = fox_leg()
+    if rank == 0 and not use_dist and not args.no_neus:
+        extra["neus"] = neus_leg()
     if rank == 0:
         wl = ("Instant-NGP lego config (projects/ngp/configs/ngp_base.py hyper-parameters: aabb_scale 1, L=16, T=2^19, F=2, fp32 table + fp32 field network, const_dt=True, 2^18-sample batches), "
               if lego else "Instant-NGP fox config (ngp_fox.py hyper-parameters: aabb_scale 4, L=16, T=2^19, F=2, fp16 fused MLP, const_dt=False, 2^18-sample batches), ")
@@ -425,6 +428,55 @@ def main():
         from jnerf_amd import dp as _dp
         _dp.destroy()
         dist.destroy_process_group()
+
+
+def neus_leg(warm=100, timed=200):
+    """BASELINE config [4] as this build has it (NOT part of `value`): NeuSRunner on the procedural DTU-layout scene of tests/synth_dtu.py, the HIP hash grid under a small
+    SDF network (projects/neus/configs/neus_hash.py's shape, 512 rays x 128 sections per iteration), eikonal term through the second-order hash kernels, HIP
+    compositing.  The networks themselves are plain torch (rocBLAS + autograd double backward), as the reference's are plain Jittor ops: iterations/s here measure that."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    root = tempfile.mkdtemp(prefix="neus_bench_")
+    try:
+        sys.path.insert(0, ROOT)
+        from tests import synth_dtu
+        from jnerf_amd.utils.config import init_cfg, get_cfg
+        from jnerf_amd.neus_runner import NeuSRunner
+        synth_dtu.make_scene(root, n_images=16, W=128, H=96)
+        init_cfg(os.path.join(ROOT, "projects", "neus", "configs", "neus_hash.py"))
+        cfg = get_cfg()
+        cfg.device = "cuda"
+        cfg.dataset.dataset_dir = root
+        cfg.base_exp_dir = os.path.join(root, "log")
+        cfg.end_iter, cfg.warm_up_end = 2000, 50
+        torch.manual_seed(3)
+        np.random.seed(3)
+        r = NeuSRunner()
+        perm = r.get_image_perm()
+        r.update_learning_rate()
+        first = None
+        for i in range(warm):
+            out = r.train_step(perm[i % len(perm)])
+            r.update_learning_rate()
+            first = float(out["color_loss"]) if first is None else first
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(warm, warm + timed):
+            out = r.train_step(perm[i % len(perm)])
+            r.update_learning_rate()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        res = {"config": "projects/neus/configs/neus_hash.py (hash-grid SDF network, mask loss, no background model) on tests/synth_dtu.py 16x128x96", "iters_per_s": round(timed / dt, 1),
+               "ms_per_step": round(dt / timed * 1e3, 3), "rays_per_iter": r.batch_size, "sections_per_ray": r.renderer.n_samples + r.renderer.n_importance,
+               "color_loss_first": round(first, 4), "color_loss_last": round(float(out["color_loss"]), 4), "eikonal_last": round(float(out["eikonal_loss"]), 4),
+               "fused_composite": bool(r.renderer._use_fused(torch.zeros(1, device="cuda"))), "dtype": "f32"}
+        del r
+        get_cfg().clear()
+        return res
+    except Exception as e:            # an extra leg must never take the headline line down with it
+        return {"failed": repr(e)[:300]}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def fox_leg(burn_in=1024, timed=200, total=3000):

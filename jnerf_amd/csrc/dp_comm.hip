@@ -158,9 +158,9 @@ NGP_API int ngp_dp_allgather(void *comm, void *stream, const NgpDpPlan *plan, in
 	NgpComm *c = (NgpComm *)comm;
 	NGP_REQUIRE(plan->world == c->world && plan->rank == c->rank, NGP_E_ARG, "ngp_dp_allgather: plan is for rank %d of %d, communicator is rank %d of %d", plan->rank, plan->world, c->rank, c->world);
 	if (n_bufs == 0) return 0;
+	for (int i = 0; i < n_bufs; ++i) NGP_REQUIRE(dtypes_host[i] == NGP_F32 || dtypes_host[i] == NGP_F16, NGP_E_DTYPE, "ngp_dp_allgather: bad dtype %d", dtypes_host[i]);   // (before the group opens: an early return must not leave it open)
 	RCCL_CALL(g_rccl.GroupStart(), "ncclGroupStart");
 	for (int i = 0; i < n_bufs; ++i) {
-		NGP_REQUIRE(dtypes_host[i] == NGP_F32 || dtypes_host[i] == NGP_F16, NGP_E_DTYPE, "ngp_dp_allgather: bad dtype %d", dtypes_host[i]);
 		const size_t es = dtypes_host[i] == NGP_F16 ? 2 : 4;
 		for (uint32_t b = 0; b < plan->n_buckets; ++b) {
 			if (!plan->shard_count[b]) continue;

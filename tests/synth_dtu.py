@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 # the object in the NORMALISED frame (inside the unit sphere): union of two spheres
-_SPHERES = [(np.array([0.0, 0.0, 0.0]), 0.5), (np.array([0.35, 0.1, 0.15]), 0.28)]
+# (deliberately NOT the sphere of radius 0.5 around the origin that IDR's geometric initialisation starts the SDF network from)
+_SPHERES = [(np.array([-0.12, 0.05, 0.0]), 0.36), (np.array([0.3, 0.1, 0.15]), 0.26)]
 _SCALE, _SHIFT = 2.0, np.array([0.3, -0.2, 0.1])        # scale_mat: normalised -> world
 
 
