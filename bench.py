@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event brackets (then no roofline object)")
     ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: still create the process group and run the data-parallel sequence (RCCL all-reduce at world size 1)")
     ap.add_argument("--dp-overlap", action="store_true", help="data parallel: two gradient buckets, the coarse levels' reduce-scatter on the library's communication stream under the fine levels' accumulate")
+    ap.add_argument("--dp-host-sharded", action="store_true", help="(tests, --backend gloo) the sharded sweep without RCCL: the host sums the gradient and gathers the updated shards")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     args = ap.parse_args()
 
@@ -241,7 +242,7 @@ def main():
     res = args.res or (800 if lego else 400)
     share = world if args.scaling == "strong" else 1
     ngp_cfg(fp16=fp16, aabb_scale=aabb_scale, const_dt=const_dt, n_images=n_images, W=res, H=res, device=f"cuda:{local_rank}", rank=rank, world_size=world,
-            target_batch_size=(1 << 18) // share, n_rays_per_batch=4096 // share, dp_force_collectives=bool(args.force_dist), dp_overlap=bool(args.dp_overlap),
+            target_batch_size=(1 << 18) // share, n_rays_per_batch=4096 // share, dp_force_collectives=bool(args.force_dist), dp_overlap=bool(args.dp_overlap), dp_host_sharded=bool(args.dp_host_sharded),
             **json.loads(os.environ.get("BENCH_EXTRA_CFG", "{}")))       # probe hook: extra config keys as JSON, e.g. {"pipeline_sampling": false}
     runner = Runner()
     import contextlib
@@ -406,7 +407,7 @@ def main():
         dist.all_gather(sigs, sig)
         extra["replicas_identical"] = bool(all(torch.equal(sigs[0], x) for x in sigs))
         dist.barrier()
-        extra["dp"] = {"exchange": "rccl in-library: reduce-scatter -> sharded sweep -> all-gather" if (dist.get_backend() == "nccl") else "host all-reduce between the two phases of the native step",
+        extra["dp"] = {"exchange": "rccl in-library: reduce-scatter -> sharded sweep -> all-gather" if (dist.get_backend() == "nccl") else ("host all-reduce -> sharded sweep -> host all-gather around the two phases of the native step" if args.dp_host_sharded else "host all-reduce between the two phases of the native step"),
                        "overlap": bool(args.dp_overlap)}
     if rank == 0 and not use_dist and not args.no_fox:
         del runner
@@ -480,7 +481,8 @@ def neus_leg(warm=100, timed=200):
 
 
 def fox_leg(burn_in=1024, timed=200, total=3000):
-    """BASELINE config [1] on the REAL scene: projects/ngp/configs/ngp_fox.py unchanged (fp16 fused MLP, aabb_scale 4, cone stepping) on data/fox
+    """BASELINE config [1] on the REAL scene: this repository's projects/ngp/configs/ngp_fox.py - the reference's file restated with `_base_` inheritance, equal key by key
+    (tests/test_host_cpu.py) - i.e. fp16 fused MLP, aabb_scale 4, cone stepping, on data/fox
     (50 photographs 1080x1920, copied from the reference checkout by build()): iters/s in steady state and PSNR on the scene's own test split."""
     import numpy as np
     import torch
@@ -515,7 +517,7 @@ def fox_leg(burn_in=1024, timed=200, total=3000):
         for v in range(r.dataset["test"].n_images):
             img, _, tar = r.render_img("test", v)
             ps.append(float(-10 * np.log10(np.mean((img - tar) ** 2))))
-        out = {"config": "projects/ngp/configs/ngp_fox.py (unchanged), data/fox: %d images %dx%d" % (r.dataset["train"].n_images, r.W, r.H), "iters_per_s": round(timed / dt, 1),
+        out = {"config": "projects/ngp/configs/ngp_fox.py (the reference's values, restated), data/fox: %d images %dx%d" % (r.dataset["train"].n_images, r.W, r.H), "iters_per_s": round(timed / dt, 1),
                "ms_per_step": round(dt / timed * 1e3, 4), "steps_timed": timed, "burn_in_steps": burn_in, "psnr_test_split_after_%d_steps" % total: round(float(np.mean(ps)), 2),
                "rays_per_batch": r.sampler.n_rays_per_batch, "load_s": round(t_load, 1), "dtype": "f16"}
         del r

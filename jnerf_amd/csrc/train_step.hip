@@ -110,6 +110,14 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		NGP_REQUIRE(a->dp->tail_begin + a->dp->tail_count == a->n_params, NGP_E_ARG, "ngp_train_step: plan covers %llu elements, table has %llu", (unsigned long long)(a->dp->tail_begin + a->dp->tail_count), (unsigned long long)a->n_params);
 		NGP_REQUIRE(!a->grad_wire || (a->wire_scale > 0.f), NGP_E_ARG, "ngp_train_step: wire_scale must be positive");
 	}
+	// host-driven exchange (a process group without RCCL): NGP_PHASE_SWEEP with a plan but no communicator sweeps this rank's shard (+ the replicated tail) only - the
+	// caller has summed the gradient over the ranks and gathers the updated shards itself.  Same shard arithmetic as the in-library path, which is how two ranks
+	// sharing one GPU (tests) exercise it.
+	const bool host_sharded = !dp && a->dp != nullptr && a->phase == NGP_PHASE_SWEEP;
+	if (host_sharded) {
+		NGP_REQUIRE(a->dp_table >= 0 && a->dp_table < a->n_opt && a->g[a->dp_table] == a->table_grad, NGP_E_ARG, "ngp_train_step: a plan needs dp_table naming the hash table among the optimiser tensors");
+		NGP_REQUIRE(a->dp->tail_begin + a->dp->tail_count == a->n_params, NGP_E_ARG, "ngp_train_step: plan covers %llu elements, table has %llu", (unsigned long long)(a->dp->tail_begin + a->dp->tail_count), (unsigned long long)a->n_params);
+	}
 	if (do_bwd) NGP_REQUIRE(a->coords && a->pos && a->numsteps && a->numsteps_compacted && a->bg && a->target && a->rgb && a->loss_grad, NGP_E_ARG, "ngp_train_step: null batch pointer");
 	const int lay = NGP_LAYOUT_SOA | NGP_WEIGHTS_PACKED;
 	const float *dirs = a->coords + 4;                       // NerfCoordinate = {pos[3], dt, dir[3]}: directions at stride 7
@@ -187,7 +195,7 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		for (int t = 1; t < a->n_opt; ++t) if (a->numel[t] > a->numel[largest]) largest = t;
 		for (int t = 0; t < a->n_opt; ++t) {
 			Bracket br(hs, a->timed_stage == NGP_STAGE_ADAM && t == largest);
-			if (dp && t == a->dp_table) {                    // this rank's shards (1/N of the 28 B/parameter stream) + the replicated tail
+			if ((dp || host_sharded) && t == a->dp_table) {  // this rank's shards (1/N of the 28 B/parameter stream) + the replicated tail
 				const NgpDpPlan *pl = a->dp;
 				for (uint32_t b = 0; b < pl->n_buckets; ++b) if ((rc = sweep_range(stream, a, t, pl->shard_begin[b], pl->shard_count[b], wire, 0))) return rc;
 				if ((rc = sweep_range(stream, a, t, pl->tail_begin, pl->tail_count, false, 0))) return rc;

@@ -106,6 +106,16 @@ class FusedTrainStep:
             comm = dp.library_comm()
             if comm is None:
                 self._dp_host_collective = True           # gloo (tests): BACKWARD -> dist.all_reduce -> SWEEP, see _call_native
+                if r.cfg.dp_host_sharded:
+                    # (tests) the SHARDED sweep without RCCL: the sweep phase updates this rank's shard only and the host gathers the shards - the same plan and shard
+                    # arithmetic as the in-library exchange, executed with more than one rank on a box that has one GPU
+                    table_g = enc.grad_buffer().data_ptr()
+                    a.dp_table = next(i for i in range(a.n_opt) if a.g[i] == table_g)
+                    self._dp_plan = dp.plan(enc.level_table, enc.n_params, n_buckets=2 if r.cfg.dp_overlap else 1)
+                    self._host_sharded_dp = C.addressof(self._dp_plan)
+                    gather_master = not self.half
+                    self._host_gather = [pg["params"][self._table_index].data] if gather_master else [adam._half[id(pg["params"][self._table_index])]]
+                    adam.register_sharded(self._dp_plan, [pg["m"][self._table_index], pg["values"][self._table_index]] + ([] if gather_master else [pg["params"][self._table_index].data]))
             else:
                 cfg = r.cfg
                 table_g = enc.grad_buffer().data_ptr()
@@ -158,7 +168,14 @@ class FusedTrainStep:
             for g in (enc.grad_buffer(), m._flat_weight_grad()):
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
             a.phase = L.PHASE_SWEEP
+            sharded = getattr(self, "_host_sharded_dp", None)
+            a.dp = sharded
             L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step(sweep)")
+            a.dp = None
+            if sharded:
+                from . import dp
+                dp.allgather_shards_host(self._dp_plan, self._host_gather)
+                adam.mark_sharded_dirty()
             self._frags_token = (adam.n_step, getattr(m, "_weights_version", 0), m._packed.data_ptr())
             return loss
         L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step")

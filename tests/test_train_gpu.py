@@ -154,6 +154,30 @@ def test_two_ranks_data_parallel_on_one_gpu(scaling):
     assert d["extra"]["native_step"] is True                  # data parallel keeps the one-call native step (here: two phases around gloo's all-reduce)
 
 
+@pytest.mark.parametrize("config,overlap", [("fox", False), ("lego", True)])
+def test_sharded_sweep_with_two_ranks_equals_the_replicated_sweep(config, overlap):
+    """The in-library exchange (reduce-scatter -> sweep of the rank's shard -> all-gather) needs one GPU per rank, which this box does not have; its SHARD ARITHMETIC -
+    ngp_dp_plan for rank 1, the sweep of a shard that does not start at element 0, the replicated tail, Adam moments (fp16 mode: the fp32 master too) living on their
+    owner's shard until sync_sharded_state() - runs here with two ranks on one GPU: the host sums the gradient (gloo) and gathers the shards (`--dp-host-sharded`,
+    NGP_PHASE_SWEEP with a plan and no communicator).  The parameters must equal, bit for bit, those of the same two-rank run with the replicated full sweep."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sigs = []
+    for sharded in (False, True):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "8", "--burn-in", "32", "--config", config, "--images", "4", "--res", "64",
+               "--no-psnr", "--no-kernel-events"] + (["--dp-host-sharded"] if sharded else []) + (["--dp-overlap"] if overlap else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+        d = json.loads(lines[0])
+        assert d["extra"]["replicas_identical"] is True and d["extra"]["native_step"] is True and np.isfinite(d["loss"])
+        assert ("sharded sweep" in d["extra"]["dp"]["exchange"]) == sharded
+        sigs.append((d["extra"]["param_signature"], d["loss"]))
+    assert sigs[0] == sigs[1], sigs
+
+
 def _run_bench(extra_args, timeout=900, env=None):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
