@@ -15,6 +15,7 @@
 //  * backward recomputes the forward, runs dgrad with transposed fragments, and contracts the weight gradients over SAMPLES through LDS ([neuron][sample]
 //    rows, five staging phases that reuse one 66-KiB region), one fp32 slab per workgroup, summed by ngp_reduce_slabs (deterministic, no atomics).
 #include "ngp_common.h"
+#include "field_split.h"
 #include <stdlib.h>
 #include <map>
 #include <mutex>
@@ -24,7 +25,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define NF32_FWD 40
 #define NF32_BWD 36
-#define NF32_ALL (NF32_FWD + NF32_BWD)          // == NGP_PACKED32_WEIGHT_FLOATS / 256
+#define NF32_ALL (NF32_FWD + NF32_BWD)          // fp32 fragments; the packed buffer continues with the forward's split fp16 fragments (field_split.h): NGP_PACKED32_WEIGHT_FLOATS = NF32_ALL * 256 + NSPLIT_HALVES / 2
+static_assert(NGP_PACKED32_WEIGHT_FLOATS == NF32_ALL * 256 + NSPLIT_HALVES / 2, "packed fp32 weight buffer layout");
 
 // value j (0..3) of weight fragment f for lane (s = lane&15: row of the A tile, g = lane>>4: k index of the MFMA).  fp32 packs, (out,in) row-major:
 // wd: W0 @0 [64][32], W1 @2048 [16][64];  wc: V0 @0 [64][32], V1 @2048 [64][64], V2 @6144 [16][64]   (ngp_network.py:21-29)
@@ -1045,6 +1047,9 @@ __global__ __launch_bounds__(1024) void k_mlp32_sweep_pack(float *__restrict__ p
 		const int f = idx >> 8, lane = (idx >> 2) & 63, j = idx & 3;
 		packed_out[idx] = frag_value32(w, w + 3072, f, lane & 15, lane >> 4, j);
 	}
+	_Float16 *split_out = reinterpret_cast<_Float16 *>(packed_out + NF32_ALL * 256);      // the forward kernel's split fp16 fragments of the same updated weights
+#pragma unroll
+	for (int k = 0; k < NSPLIT_HALVES / 1024; ++k) { const int idx = threadIdx.x + 1024 * k; split_out[idx] = split_frag_half(w, w + 3072, idx); }
 }
 int ngp_mlp32_sweep_pack(void *stream, float *pack, const float *grad, float *m, float *v, float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, float *packed_out) {
 	NGP_REQUIRE(pack && grad && m && v && packed_out && step >= 1, NGP_E_ARG, "ngp_mlp32_sweep_pack: bad arguments");
@@ -1064,6 +1069,13 @@ static int check_field32(const char *fn, const void *feat, const void *wd, const
 	NGP_REQUIRE(((uintptr_t)feat & 15) == 0, NGP_E_ALIGN, "%s: feature pointer must be 16-byte aligned", fn);
 	return 0;
 }
+// forward kernel: split fp16 operands on v_mfma_f32_16x16x32_f16 (field_split.hip, default) | exact fp32 products on v_mfma_f32_16x16x4_f32 (NGP_FIELD32_FWD=mfma32)
+static bool fwd_split() {
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("NGP_FIELD32_FWD"); v = (e && (e[0] == 'm' || e[0] == '0')) ? 0 : 1; }
+	return v == 1;
+}
+// n_frags fp32 fragments (n_frags < 0: the first -n_frags split fp16 fragments of the forward instead) of raw weight packs in a per-(device, stream) scratch, or the caller's packed buffer
 static const float *pack_weights32(const char *fn, hipStream_t s, const void *wd, const void *wc, int n_frags, int layout_flags) {
 	if (layout_flags & NGP_WEIGHTS_PACKED) return (const float *)wd;
 	static std::mutex mu;
@@ -1074,9 +1086,10 @@ static const float *pack_weights32(const char *fn, hipStream_t s, const void *wd
 	{
 		std::lock_guard<std::mutex> lk(mu);
 		float *&slot = pool[{dev, s}];
-		if (!slot) { hipError_t e = hipMalloc((void **)&slot, (size_t)NF32_ALL * 256 * sizeof(float)); if (e != hipSuccess) { slot = nullptr; ngp_set_error("%s: hipMalloc(fragment scratch): %s", fn, hipGetErrorString(e)); return nullptr; } }
+		if (!slot) { hipError_t e = hipMalloc((void **)&slot, (size_t)NGP_PACKED32_WEIGHT_FLOATS * sizeof(float)); if (e != hipSuccess) { slot = nullptr; ngp_set_error("%s: hipMalloc(fragment scratch): %s", fn, hipGetErrorString(e)); return nullptr; } }
 		buf = slot;
 	}
+	if (n_frags < 0) { if (ngp_field32_pack_split(s, (const float *)wd, (const float *)wc, buf + NF32_ALL * 256, -n_frags)) return nullptr; return buf; }
 	NGP_LAUNCH(k_pack_frags32, dim3(div_up((uint32_t)n_frags * 256u, 256u)), dim3(256), 0, s, (const float *)wd, (const float *)wc, buf, n_frags);
 	return buf;
 }
@@ -1087,7 +1100,7 @@ NGP_API int ngp_field32_pack_weights(void *stream, const float *wd, const float 
 	NGP_REQUIRE(((uintptr_t)packed_out & 15) == 0, NGP_E_ALIGN, "ngp_field32_pack_weights: output must be 16-byte aligned");
 	NGP_LAUNCH(k_pack_frags32, dim3(div_up((uint32_t)NF32_ALL * 256u, 256u)), dim3(256), 0, (hipStream_t)stream, wd, wc, packed_out, NF32_ALL);
 	NGP_LAUNCH_CHECK("ngp_field32_pack_weights");
-	return 0;
+	return ngp_field32_pack_split(stream, wd, wc, packed_out + NF32_ALL * 256, NSPLIT_FRAGS);
 }
 NGP_API int ngp_field32_fwd(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const float *wd, const float *wc,
                             float *out, const uint32_t *n_valid) {
@@ -1096,7 +1109,8 @@ NGP_API int ngp_field32_fwd(void *stream, uint32_t n, const float *feat, int lay
 	NGP_REQUIRE(dir && out && dir_stride >= 3, NGP_E_ARG, "ngp_field32_fwd: bad dir/out");
 	if (n == 0) return 0;
 	hipStream_t s = (hipStream_t)stream;
-	const float *packed = pack_weights32("ngp_field32_fwd", s, wd, wc, NF32_FWD, layout_flags); if (!packed) return NGP_E_ARG;
+	const float *packed = pack_weights32("ngp_field32_fwd", s, wd, wc, fwd_split() ? -NSPLIT_FRAGS : NF32_FWD, layout_flags); if (!packed) return NGP_E_ARG;
+	if (fwd_split()) return ngp_field32_fwd_split(stream, n, feat, layout, dir, dir_stride, packed + NF32_ALL * 256, out, n_valid, 0);
 	const dim3 grid(fwd32_grid(n)), block(256);
 	if (layout == NGP_LAYOUT_SOA) NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_SOA, false>), grid, block, 0, s, n, feat, dir, dir_stride, packed, out, n_valid);
 	else NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_AOS, false>), grid, block, 0, s, n, feat, dir, dir_stride, packed, out, n_valid);
@@ -1109,7 +1123,8 @@ NGP_API int ngp_density32_fwd(void *stream, uint32_t n, const float *feat, int l
 	NGP_REQUIRE(out, NGP_E_ARG, "ngp_density32_fwd: null out");
 	if (n == 0) return 0;
 	hipStream_t s = (hipStream_t)stream;
-	const float *packed = pack_weights32("ngp_density32_fwd", s, wd, wd, 12, layout_flags); if (!packed) return NGP_E_ARG;
+	const float *packed = pack_weights32("ngp_density32_fwd", s, wd, wd, fwd_split() ? -6 : 12, layout_flags); if (!packed) return NGP_E_ARG;
+	if (fwd_split()) return ngp_field32_fwd_split(stream, n, feat, layout, nullptr, 3u, packed + NF32_ALL * 256, out, nullptr, 1);
 	const dim3 grid(fwd32_grid(n)), block(256);
 	if (layout == NGP_LAYOUT_SOA) NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_SOA, true>), grid, block, 0, s, n, feat, (const float *)nullptr, 3u, packed, out, (const uint32_t *)nullptr);
 	else NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_AOS, true>), grid, block, 0, s, n, feat, (const float *)nullptr, 3u, packed, out, (const uint32_t *)nullptr);

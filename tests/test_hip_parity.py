@@ -290,6 +290,45 @@ def test_field32_fwd_vs_oracle(H, n):
     GC.close(o3[:k], ref[:k], atol=1e-5 * scale, what="field32 n_valid"); assert (o3[k:] == -5.0).all()
 
 
+@pytest.mark.parametrize("mag", [1e-5, 1e-4, 1e-2, 1.0, 40.0])
+def test_field32_split_forward_accuracy_over_magnitudes(H, mag):
+    """the default fp32 forward runs on the fp16 matrix cores with split operands (csrc/field_split.hip: x = h + m 2^-11, three MFMAs per product sum): against an
+    fp64 evaluation of the same chain the error must stay at fp32 level - 2e-6 of the output scale - for feature magnitudes from far below fp16's normal range
+    (hash tables start at 1e-4) to large activations; and the exact-product kernel (NGP_FIELD32_FWD=mfma32) must still be selectable"""
+    from jnerf_amd import ops
+    n = 3000
+    feat, d, wd, wc = _field32_inputs(n, seed=77)
+    feat = (feat * np.float32(mag)).astype(np.float32)
+    ref, den = _field32_chain_fp64(feat, d, wd, wc)
+    out = H.N(ops.field32_fwd(H.T(feat), H.T(d), H.T(wd), H.T(wc))).astype(np.float64)
+    scale = np.abs(ref).max()
+    assert np.abs(out - ref).max() <= 2e-6 * scale, (mag, np.abs(out - ref).max() / scale)
+    dn = H.N(ops.density32_fwd(H.T(feat), H.T(wd), n)).astype(np.float64)
+    assert np.abs(dn - den[:, 0]).max() <= 2e-6 * max(np.abs(den).max(), 1e-30), (mag, np.abs(dn - den[:, 0]).max() / np.abs(den).max())
+    if mag == 1.0:
+        import subprocess, sys, os, tempfile
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        with tempfile.TemporaryDirectory() as td:
+            np.savez(os.path.join(td, "in.npz"), feat=feat, d=d, wd=wd, wc=wc)
+            code = ("import numpy as np, torch, sys; sys.path.insert(0, %r); from jnerf_amd import ops; z = np.load(%r); t = lambda a: torch.from_numpy(a).cuda();"
+                    "np.save(%r, ops.field32_fwd(t(z['feat']), t(z['d']), t(z['wd']), t(z['wc'])).cpu().numpy())") % (root, os.path.join(td, "in.npz"), os.path.join(td, "out.npy"))
+            subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, NGP_FIELD32_FWD="mfma32"), timeout=300)
+            exact = np.load(os.path.join(td, "out.npy")).astype(np.float64)
+        assert np.abs(exact - ref).max() <= 2e-6 * scale and np.abs(exact - out).max() <= 2e-6 * scale and not np.array_equal(exact, out)
+
+
+def _field32_chain_fp64(feat, d, wd, wc):
+    """ngp_network.py:59-84 without biases, in fp64: (out [n,4] = rgb(3) | density logit, density head [n,16])"""
+    sh = O.sh_encode(d, np.float32).astype(np.float64)
+    W0, W1 = wd[:2048].reshape(64, 32).astype(np.float64), wd[2048:].reshape(16, 64).astype(np.float64)
+    V0, V1, V2 = wc[:2048].reshape(64, 32).astype(np.float64), wc[2048:6144].reshape(64, 64).astype(np.float64), wc[6144:].reshape(16, 64).astype(np.float64)
+    h = np.maximum(feat.astype(np.float64) @ W0.T, 0)
+    den = h @ W1.T
+    g0 = np.maximum(np.concatenate([den, sh], 1) @ V0.T, 0)
+    g1 = np.maximum(g0 @ V1.T, 0)
+    return np.concatenate([(g1 @ V2.T)[:, :3], den[:, :1]], 1), den
+
+
 @pytest.mark.parametrize("n", [64, 1000, 8192 + 17])
 def test_field32_bwd_vs_oracle(H, n):
     from jnerf_amd import ops

@@ -211,12 +211,13 @@ def _volume_iou(runner):
 
 
 def _quality(runner, truth, idx=3):
-    """(colour PSNR of a training view at half resolution, silhouette IoU of the rendered opacity against the view's mask, volume IoU, triangles of the 64^3 mesh)"""
+    """(colour PSNR over the object's pixels of a training view at half resolution, silhouette IoU of the rendered opacity against the view's mask, volume IoU, triangles of the 64^3 mesh)"""
     img = runner.validate_image(idx=idx, resolution_level=2) / 256.0                       # BGR
     want = np.asarray(runner.dataset.image_at(idx, 2), np.float32) / 256.0
-    psnr = float(-10 * np.log10(np.mean((img - want) ** 2)))
     rays_o, rays_d = runner.dataset.gen_rays_at(idx, resolution_level=2)
     H, W, _ = rays_o.shape
+    inside = truth["masks"][idx][::2, ::2][:H, :W]
+    psnr = float(-10 * np.log10(np.mean(((img - want) ** 2)[inside])))        # object pixels only: with mask supervision and no background model the backdrop is not learnt
     acc = []
     for o, d in zip(rays_o.reshape(-1, 3).split(runner.batch_size), rays_d.reshape(-1, 3).split(runner.batch_size)):
         near, far = runner.dataset.near_far_from_sphere(o, d)
