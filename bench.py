@@ -178,10 +178,14 @@ def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
 
 
 # kernel variants: same algorithmic bytes / flops as the kernel they replace
-KERNEL_VARIANTS = {"k_field32_bwd_2g": "k_field32_bwd", "k_field32_bwd_pp": "k_field32_bwd", "k_field_bwd_g": "k_field_bwd", "k_hash_fwd_bal": "k_hash_fwd", "k_hash_fwd_dydx": "k_hash_fwd"}
+KERNEL_VARIANTS = {"k_field32_bwd_2g": "k_field32_bwd", "k_field32_bwd_pp": "k_field32_bwd", "k_field_bwd_g": "k_field_bwd", "k_hash_fwd_bal": "k_hash_fwd", "k_hash_fwd_dydx": "k_hash_fwd",
+                   "k_field32_fwd_split": "k_field32_fwd", "k_field32_bwd_split": "k_field32_bwd"}
+# kernels that do fp32-accurate work on the fp16 matrix cores (split operands, three v_mfma_f32_16x16x32_f16 per product sum, csrc/field_split.hip): the algorithmic
+# FLOPs are SURVEY.md §8(d)'s, the pipe they run on peaks at 2.5 PFLOP/s dense, and they execute 3x the products
+SPLIT_FP16_KERNELS = ("k_field32_fwd_split", "k_field32_bwd_split")
 # FLOP per sample the kernels EXECUTE: the backward kernels recompute the forward (their choice, not algorithmic work); the r3 fp32 variants skip the rgb layer the backward never reads
 EXECUTED_FLOPS_PER_SAMPLE = {"k_field_fwd": 20480.0, "k_field_bwd": 61440.0, "k_field32_fwd": 20480.0, "k_field32_bwd": 61440.0, "k_field32_bwd_2g": 59392.0, "k_field32_bwd_pp": 59392.0,
-                             "k_field_bwd_g": 61440.0}
+                             "k_field_bwd_g": 61440.0, "k_field32_fwd_split": 3 * 20480.0, "k_field32_bwd_split": 3 * 59392.0}
 HASH_BWD_STAGE = ("k_level_absmax", "k_bin_records_runs", "k_bin_records", "k_bin_accumulate")
 
 
@@ -341,7 +345,7 @@ def main():
                 pass
         hbm = {"achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4)}
         if dom in flops:    # the fused field kernels are MFMA work (fp16 16x16x32: dense peak 2.5 PFLOP/s; fp32 16x16x4: 157.3 TFLOP/s); their HBM side is reported next to it
-            peak = 2500.0 if fp16 else 157.3
+            peak = 2500.0 if (fp16 or dom in SPLIT_FP16_KERNELS) else 157.3
             tf = flops[dom] / (avg_ms * 1e-3) / 1e12
             tf_exec = EXECUTED_FLOPS_PER_SAMPLE[dom] * mean_valid / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "hbm": hbm,
@@ -380,6 +384,8 @@ def main():
                    "frac_hbm": round(alg.get(k, 0.0) / (ms * 1e-3) / 8e12, 4)}
             if k in flops:
                 row["TFLOPs"] = round(flops[k] / (ms * 1e-3) / 1e12, 1)
+                if k in SPLIT_FP16_KERNELS:
+                    row["pipe"] = "fp16 MFMA, split operands (3 products per fp32-accurate product); TFLOPs = fp32-equivalent algorithmic rate (fp32 MFMA peak: 157.3)"
             pk[k] = row
         extra["probe_kernels"] = pk
     if not args.no_psnr and rank == 0:

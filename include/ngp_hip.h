@@ -114,7 +114,7 @@ int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs, uint32_
  * projects/ngp/configs/ngp_base.py - the lego headline - runs).  Same fused structure on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).
  * wd f32[3072] / wc f32[7168]: the same pack layout as above; feat / dLdfeat f32 in `feat_layout`; out / dLdout f32 [n,4]; slabs as ngp_field_bwd.
  * ngp_field32_pack_weights builds the MFMA-ordered fragments once per step (f32[NGP_PACKED32_WEIGHT_FLOATS], 16-byte aligned; pass with NGP_WEIGHTS_PACKED). */
-#define NGP_PACKED32_WEIGHT_FLOATS 29696   /* 76 fp32 fragments of 256 floats (forward + transposed) + the forward's 2 x 20 split fp16 fragments of 512 halves */
+#define NGP_PACKED32_WEIGHT_FLOATS 40960   /* 76 fp32 fragments of 256 floats (forward + transposed) + 2 x 42 split fp16 fragments of 512 halves (csrc/field_split.h) */
 int ngp_field32_pack_weights(void *stream, const float *wd, const float *wc, float *packed_out);
 int ngp_field32_fwd(void *stream, uint32_t n, const float *feat, int feat_layout, const float *dir, uint32_t dir_stride_floats,
                     const float *wd, const float *wc, float *out, const uint32_t *n_valid);

@@ -25,7 +25,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define NF32_FWD 40
 #define NF32_BWD 36
-#define NF32_ALL (NF32_FWD + NF32_BWD)          // fp32 fragments; the packed buffer continues with the forward's split fp16 fragments (field_split.h): NGP_PACKED32_WEIGHT_FLOATS = NF32_ALL * 256 + NSPLIT_HALVES / 2
+#define NGP_FIELD32_BWD_DEFAULT 2       // (3 = split fp16 operands, field_split.hip: correct and equally fast on MI355X today - 137 us, LDS- and VALU-bound; opt-in)
+#define NF32_ALL (NF32_FWD + NF32_BWD)          // fp32 fragments; the packed buffer continues with the split fp16 fragments (field_split.h: forward + transposed): NGP_PACKED32_WEIGHT_FLOATS = NF32_ALL * 256 + NSPLIT_HALVES / 2
 static_assert(NGP_PACKED32_WEIGHT_FLOATS == NF32_ALL * 256 + NSPLIT_HALVES / 2, "packed fp32 weight buffer layout");
 
 // value j (0..3) of weight fragment f for lane (s = lane&15: row of the A tile, g = lane>>4: k index of the MFMA).  fp32 packs, (out,in) row-major:
@@ -1147,10 +1148,12 @@ int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, 
 	const size_t shmem = ((size_t)NF32_ALL * 256 + (size_t)N_ROWS32 * RS32) * sizeof(float);
 	const dim3 grid(n_slabs), block(512);
 	hipStream_t s = (hipStream_t)stream;
-	const float *packed = pack_weights32("ngp_field32_bwd", s, wd, wc, NF32_ALL, layout_flags); if (!packed) return NGP_E_ARG;
+	// 3 = split fp16 operands on the fp16 matrix cores (field_split.hip, r3), 2 = two free-running groups on fp32 MFMAs, 0 / 1: see below
+	static const int variant = [] { const char *e = getenv("NGP_FIELD32_BWD"); return e ? atoi(e) : NGP_FIELD32_BWD_DEFAULT; }();
+	const float *packed = pack_weights32("ngp_field32_bwd", s, wd, wc, variant == 3 ? -NSPLIT_FRAGS : NF32_ALL, layout_flags); if (!packed) return NGP_E_ARG;
+	if (variant == 3) return ngp_field32_bwd_split(stream, n, feat, layout, dir, dir_stride, packed + NF32_ALL * 256, dLdout, dLdfeat, wgrad_slabs, n_slabs, n_valid, am_in);
 	// 2 = two free-running groups (r3, default: 138 us, +1 % it/s), 0 = lock-step phases (r2: 145 us), 1 = ping-pong roles sharing barriers (r3 experiment: 151 us - ten
 	// barrier-separated blocks per role expose the fragment-load latency ten times); same results up to the order the two groups' partial weight-gradient sums are added in
-	static const int variant = [] { const char *e = getenv("NGP_FIELD32_BWD"); return e ? atoi(e) : 2; }();
 	if (variant == 2) {
 		const size_t shmem_2g = ((size_t)NF32_ALL * 256 + (size_t)2 * 128 * RSH32) * sizeof(float);
 #define GO2G(L) do { \

@@ -7,20 +7,28 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
-#define NSPLIT_FRAGS 20                         // forward fragments of the five layers, 512 halves each, in field_mlp.hip's order and permutation
+#define NSPLIT_FWD 20                           // forward fragments of the five layers, 512 halves each, in field_mlp.hip's order and permutation
+#define NSPLIT_BWD 22                           // transposed fragments of the dgrad chain (field_mlp.hip's fragments 20..41)
+#define NSPLIT_FRAGS (NSPLIT_FWD + NSPLIT_BWD)
 #define NSPLIT_HALVES (2 * NSPLIT_FRAGS * 512)  // [part: h | m][fragment][lane][8]
 #define SPLIT_SCALE 2048.0f
 
 __device__ __forceinline__ int sp_k32(int g, int j) { return 8 * g + j; }
 __device__ __forceinline__ int sp_k64(int kb, int g, int j) { return 32 * kb + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)); }
-// fp32 weight behind slot j of forward fragment f for lane (o = lane & 15: output neuron of the 16-row tile, g = lane >> 4).  Packs, (out,in) row-major:
-// wd: W0 @0 [64][32], W1 @2048 [16][64];  wc: V0 @0 [64][32], V1 @2048 [64][64], V2 @6144 [16][64]   (ngp_network.py:21-29)
+// fp32 weight behind slot j of fragment f for lane (o = lane & 15: row of the 16-row A tile, g = lane >> 4).  Packs, (out,in) row-major:
+// wd: W0 @0 [64][32], W1 @2048 [16][64];  wc: V0 @0 [64][32], V1 @2048 [64][64], V2 @6144 [16][64]   (ngp_network.py:21-29).  f < 20: A = W (forward), else A = W^T.
 __device__ __forceinline__ float split_frag_weight(const float *wd, const float *wc, int f, int o, int g, int j) {
 	if (f < 4) return wd[(16 * f + o) * 32 + sp_k32(g, j)];                                          // L0  tile f
 	if (f < 6) return wd[2048 + o * 64 + sp_k64(f - 4, g, j)];                                       // L1
 	if (f < 10) return wc[(16 * (f - 6) + o) * 32 + sp_k64(0, g, j)];                                // L2  input = [density(16) | SH(16)]
 	if (f < 18) { const int t = (f - 10) >> 1, kb = (f - 10) & 1; return wc[2048 + (16 * t + o) * 64 + sp_k64(kb, g, j)]; }    // L3
-	return wc[6144 + o * 64 + sp_k64(f - 18, g, j)];                                                 // L4
+	if (f < 20) return wc[6144 + o * 64 + sp_k64(f - 18, g, j)];                                     // L4
+	f -= 20;
+	if (f < 4) return j < 4 ? wc[6144 + (4 * g + j) * 64 + 16 * f + o] : 0.f;                        // dG1 = V2^T dO   (K = 16, upper slots zero)
+	if (f < 12) { const int t = (f - 4) >> 1, kb = (f - 4) & 1; return wc[2048 + sp_k64(kb, g, j) * 64 + 16 * t + o]; }         // dG0 = V1^T dG1
+	if (f < 14) return wc[sp_k64(f - 12, g, j) * 32 + o];                                            // dD  = (V0^T dG0)[0:16]
+	if (f < 18) return j < 4 ? wd[2048 + (4 * g + j) * 64 + 16 * (f - 14) + o] : 0.f;                // dH  = W1^T dD   (K = 16)
+	{ const int t = (f - 18) >> 1, kb = (f - 18) & 1; return wd[sp_k64(kb, g, j) * 32 + 16 * t + o]; }                          // dF  = W0^T dH
 }
 // element idx of the split fragment buffer: idx = (part * NSPLIT_FRAGS + f) * 512 + lane * 8 + j
 __device__ __forceinline__ _Float16 split_frag_half(const float *wd, const float *wc, int idx) {

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_pack_split(const float *__restrict__ wd
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx < NSPLIT_HALVES && ((idx % (NSPLIT_FRAGS * 512)) >> 9) < n_frags) out[idx] = split_frag_half(wd, wc, idx);
 }
-// n_frags = 6: the density network only (wc is not read), NSPLIT_FRAGS: everything
+// n_frags = 6: the density network only (wc is not read), NSPLIT_FRAGS: everything (forward + transposed)
 int ngp_field32_pack_split(void *stream, const float *wd, const float *wc, void *out_halves, int n_frags) {
 	NGP_LAUNCH(k_pack_split, dim3(div_up(NSPLIT_HALVES, 256)), dim3(256), 0, (hipStream_t)stream, wd, wc, (_Float16 *)out_halves, n_frags);
 	NGP_LAUNCH_CHECK("ngp_field32_pack_split");
@@ -44,8 +44,10 @@ __device__ __forceinline__ B2 split_relu(floatx4 a, floatx4 b) {
 struct Acc { floatx4 main, corr; };
 __device__ __forceinline__ half8 ld_half8(const _Float16 *lds, int f, int lane) { return *reinterpret_cast<const half8 *>(lds + f * 512 + lane * 8); }
 // acc += W-fragment f x B: the leading product and the two cross terms (kept in an accumulator of their own: they are 2^-11 smaller)
+// (wl: the h parts of a fragment set in LDS, the m parts `mstride` halves behind them)
+template <int MSTRIDE>
 __device__ __forceinline__ void mma3(const _Float16 *wl, int f, int lane, const B2 &b, Acc &acc) {
-	const half8 ah = ld_half8(wl, f, lane), am = ld_half8(wl + NSPLIT_FRAGS * 512, f, lane);
+	const half8 ah = ld_half8(wl, f, lane), am = ld_half8(wl + MSTRIDE, f, lane);
 	acc.main = MFMA16(ah, b.h, acc.main);
 	acc.corr = MFMA16(ah, b.m, acc.corr);
 	acc.corr = MFMA16(am, b.h, acc.corr);
@@ -81,7 +83,7 @@ __device__ __forceinline__ void load_feat_split(const float *__restrict__ feat, 
 	}
 }
 
-template <bool DENSITY_ONLY>
+template <bool DENSITY_ONLY, int MSTRIDE>
 __device__ __forceinline__ void forward_split(const _Float16 *wl, int lane, const float feat[8], const float sh[4], floatx4 &den, floatx4 &rgb) {
 	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
 	float fs[8];
@@ -90,9 +92,9 @@ __device__ __forceinline__ void forward_split(const _Float16 *wl, int lane, cons
 	const B2 b0 = split8(fs);
 	floatx4 c0[4];
 #pragma unroll
-	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3(wl, t, lane, b0, a); c0[t] = combine(a, 1.0f / FEAT_PRESCALE); }        // L0: 32 -> 64
+	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, t, lane, b0, a); c0[t] = combine(a, 1.0f / FEAT_PRESCALE); }        // L0: 32 -> 64
 	const B2 h0 = split_relu(c0[0], c0[1]), h1 = split_relu(c0[2], c0[3]);
-	{ Acc a = {z, z}; mma3(wl, 4, lane, h0, a); mma3(wl, 5, lane, h1, a); den = combine(a, 1.0f / HID_PRESCALE); }               // L1: 64 -> 16
+	{ Acc a = {z, z}; mma3<MSTRIDE>(wl, 4, lane, h0, a); mma3<MSTRIDE>(wl, 5, lane, h1, a); den = combine(a, 1.0f / HID_PRESCALE); }               // L1: 64 -> 16
 	if (DENSITY_ONLY) return;
 	float in2[8];
 #pragma unroll
@@ -100,24 +102,24 @@ __device__ __forceinline__ void forward_split(const _Float16 *wl, int lane, cons
 	const B2 b2 = split8(in2);
 	floatx4 c2[4];
 #pragma unroll
-	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3(wl, 6 + t, lane, b2, a); c2[t] = combine(a, 1.0f / HID_PRESCALE); }                       // L2: [density(16) | SH(16)] -> 64
+	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, 6 + t, lane, b2, a); c2[t] = combine(a, 1.0f / HID_PRESCALE); }                       // L2: [density(16) | SH(16)] -> 64
 	const B2 g00 = split_relu(c2[0], c2[1]), g01 = split_relu(c2[2], c2[3]);
 	floatx4 c3[4];
 #pragma unroll
-	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3(wl, 10 + 2 * t, lane, g00, a); mma3(wl, 11 + 2 * t, lane, g01, a); c3[t] = combine(a, 1.0f / HID_PRESCALE); }   // L3: 64 -> 64
+	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, 10 + 2 * t, lane, g00, a); mma3<MSTRIDE>(wl, 11 + 2 * t, lane, g01, a); c3[t] = combine(a, 1.0f / HID_PRESCALE); }   // L3: 64 -> 64
 	const B2 g10 = split_relu(c3[0], c3[1]), g11 = split_relu(c3[2], c3[3]);
-	{ Acc a = {z, z}; mma3(wl, 18, lane, g10, a); mma3(wl, 19, lane, g11, a); rgb = combine(a, 1.0f / HID_PRESCALE); }                          // L4: 64 -> 16 (3 used)
+	{ Acc a = {z, z}; mma3<MSTRIDE>(wl, 18, lane, g10, a); mma3<MSTRIDE>(wl, 19, lane, g11, a); rgb = combine(a, 1.0f / HID_PRESCALE); }                          // L4: 64 -> 16 (3 used)
 }
 
 template <int LAYOUT, bool DENSITY_ONLY>
 __global__ __launch_bounds__(256) void k_field32_fwd_split(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                            const _Float16 *__restrict__ packed, float *__restrict__ out, const uint32_t *__restrict__ n_valid) {
-	__shared__ __attribute__((aligned(16))) _Float16 wl[NSPLIT_HALVES];
-	{	// both parts of the fragments this variant reads (density only: layers 0 and 1)
-		const int nf = DENSITY_ONLY ? 6 : NSPLIT_FRAGS;
+	__shared__ __attribute__((aligned(16))) _Float16 wl[2 * NSPLIT_FWD * 512];
+	{	// both parts of the forward fragments this variant reads (density only: layers 0 and 1); the buffer holds NSPLIT_FRAGS fragments per part
+		const int nf = DENSITY_ONLY ? 6 : NSPLIT_FWD;
 		const uint4 *src = reinterpret_cast<const uint4 *>(packed);
 		uint4 *dst = reinterpret_cast<uint4 *>(wl);
-		for (int idx = threadIdx.x; idx < nf * 64; idx += 256) { dst[idx] = src[idx]; dst[NSPLIT_FRAGS * 64 + idx] = src[NSPLIT_FRAGS * 64 + idx]; }
+		for (int idx = threadIdx.x; idx < nf * 64; idx += 256) { dst[idx] = src[idx]; dst[NSPLIT_FWD * 64 + idx] = src[NSPLIT_FRAGS * 64 + idx]; }
 	}
 	__syncthreads();
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void k_field32_fwd_split(uint32_t n, const flo
 		float sh[4] = {0.f, 0.f, 0.f, 0.f};
 		if (!DENSITY_ONLY) sh4_split(d, g, sh);
 		floatx4 den, rgb;
-		forward_split<DENSITY_ONLY>(wl, lane, f, sh, den, rgb);
+		forward_split<DENSITY_ONLY, NSPLIT_FWD * 512>(wl, lane, f, sh, den, rgb);
 		if (g == 0 && i < lim) {
 			if (DENSITY_ONLY) out[i] = den[0];
 			else *reinterpret_cast<float4 *>(out + (size_t)i * 4) = make_float4(rgb[0], rgb[1], rgb[2], den[0]);
@@ -150,6 +152,249 @@ __global__ __launch_bounds__(256) void k_field32_fwd_split(uint32_t n, const flo
 			d[0] = dn[0]; d[1] = dn[1]; d[2] = dn[2];
 		}
 	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward
+// dL/dfeatures + the five weight gradients of the fp32 network on split fp16 operands: forward recompute (as above, without the colour head's last layer), the
+// register-resident dgrad chain on the transposed fragments, and the weight-gradient contraction over samples through LDS - every matrix product three MFMAs.
+// Gradients have no fixed magnitude (dL/dout carries the loss scale and the compositing weights: 1e-8 .. 1e-2), so every 128-sample trip derives a power of two
+// sigma from the largest |dL/dout| of ITS samples (one extra workgroup barrier), runs the chain on sigma-scaled gradients (max ~2^7: room for a 500-fold growth
+// through the three transposed layers before fp16 overflows) and takes sigma out again - exactly - when dL/dfeatures is stored and when a trip's weight-gradient
+// tiles are folded into the persistent fp32 accumulators.  Activations carry the forward kernel's prescales (features 2^8, everything else 2^4).
+// LDS: 2 x 42 fragments (84 KiB) + a staging region of 2 planes (h, m) x 128 rows x 136 halves (68 KiB); five staging phases per trip like k_field32_bwd:
+//   A : dG1 0..63 | G0 64..127  -> V1     B1: dH 0..63 | F 64..95 -> W0     B2: dG0 0..63 | IN2 64..95 -> V0
+//   C1: dD 0..15 | H 16..79     -> W1     C2: dO 0..15 | G1 16..79 -> V2    (W1 / V2: tile w & 3 over the samples of half w >> 2, joined at the end)
+#define SBT 128
+#define SRS (SBT + 8)                         // row stride in halves (272 B: 16-byte aligned rows, breaks the 128-byte bank period)
+#define SROWS 128
+#define SPLANE (SROWS * SRS)
+#define GRAD_TARGET_EXP 7                     // sigma brings the trip's largest |dL/dout| to [2^7, 2^8)
+
+__device__ __forceinline__ B2 split_masked(floatx4 a, floatx4 b, uint32_t mask) {           // relu'(pre-activation) * gradient, split
+	float v[8];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { v[k] = (mask >> k) & 1u ? a[k] : 0.f; v[4 + k] = (mask >> (4 + k)) & 1u ? b[k] : 0.f; }
+	return split8(v);
+}
+__device__ __forceinline__ uint32_t relu_mask8(floatx4 a, floatx4 b) {
+	uint32_t m = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { m |= a[k] > 0.f ? (1u << k) : 0u; m |= b[k] > 0.f ? (1u << (4 + k)) : 0u; }
+	return m;
+}
+// the lane's eight slots of two k64 half-fragments (64 neurons) / one k32 fragment / the low four slots into the rows of both planes, column `col`
+__device__ __forceinline__ void st_rows64_2(_Float16 *stage, int row0, int col, int g, const B2 &lo, const B2 &hi) {
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const int r0 = (row0 + sp_k64(0, g, j)) * SRS + col, r1 = (row0 + sp_k64(1, g, j)) * SRS + col;
+		stage[r0] = lo.h[j]; stage[SPLANE + r0] = lo.m[j]; stage[r1] = hi.h[j]; stage[SPLANE + r1] = hi.m[j];
+	}
+}
+__device__ __forceinline__ void st_rows32_2(_Float16 *stage, int row0, int col, int g, const B2 &v, bool k32_order) {
+#pragma unroll
+	for (int j = 0; j < 8; ++j) { const int r = (row0 + (k32_order ? sp_k32(g, j) : sp_k64(0, g, j))) * SRS + col; stage[r] = v.h[j]; stage[SPLANE + r] = v.m[j]; }
+}
+__device__ __forceinline__ void st_rows16_2(_Float16 *stage, int row0, int col, int g, const B2 &v) {
+#pragma unroll
+	for (int j = 0; j < 4; ++j) { const int r = (row0 + 4 * g + j) * SRS + col; stage[r] = v.h[j]; stage[SPLANE + r] = v.m[j]; }
+}
+// one 16x16 weight-gradient tile over the staged samples [c0, c1): A = gradient rows row_a + o, B = activation rows row_b + o, k = 32 samples per step
+__device__ __forceinline__ floatx4 wgrad3(const _Float16 *stage, int row_a, int row_b, int o, int g, int c0, int c1) {
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	Acc acc = {z, z};
+	for (int c = c0; c < c1; c += 32) {
+		const int cs = c + 8 * g;
+		const half8 ah = *reinterpret_cast<const half8 *>(stage + (row_a + o) * SRS + cs), am = *reinterpret_cast<const half8 *>(stage + SPLANE + (row_a + o) * SRS + cs);
+		const half8 bh = *reinterpret_cast<const half8 *>(stage + (row_b + o) * SRS + cs), bm = *reinterpret_cast<const half8 *>(stage + SPLANE + (row_b + o) * SRS + cs);
+		acc.main = MFMA16(ah, bh, acc.main);
+		acc.corr = MFMA16(ah, bm, acc.corr);
+		acc.corr = MFMA16(am, bh, acc.corr);
+	}
+	return combine(acc, 1.0f);
+}
+__device__ __forceinline__ floatx4 fma4(floatx4 acc, floatx4 v, float s) {
+#pragma unroll
+	for (int k = 0; k < 4; ++k) acc[k] += v[k] * s;
+	return acc;
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+                                                              const _Float16 *__restrict__ packed, const float *__restrict__ dout,
+                                                              float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
+	extern __shared__ __attribute__((aligned(16))) _Float16 smem_split[];
+	__shared__ float smax[8];
+	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // running max |dL/dfeature| of levels 8t + 2g + pr over this lane's samples (absmax_epilogue)
+	_Float16 *wl = smem_split;                             // [2 parts][42 fragments][512]
+	_Float16 *stage = smem_split + NSPLIT_HALVES;          // [2 planes][SROWS][SRS]
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(packed);
+		uint4 *dst = reinterpret_cast<uint4 *>(wl);
+		for (int idx = threadIdx.x; idx < NSPLIT_HALVES / 8; idx += 512) dst[idx] = src[idx];
+	}
+	const _Float16 *wb = wl + NSPLIT_FWD * 512;            // transposed fragments (h parts; the m parts NSPLIT_FRAGS * 512 halves behind, like the forward ones)
+	constexpr int MS = NSPLIT_FRAGS * 512;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+	const uint32_t n_bt = (lim + SBT - 1) / SBT;
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	const int to = w >> 1, ti0 = 2 * (w & 1), tj = w & 1, tx = w & 3, half = w >> 2;
+	floatx4 aV1[2] = {z, z}, aW0 = z, aV0 = z, aW1 = z, aV2 = z;
+	__syncthreads();
+	struct Inputs { float f[8]; float d3[3]; float go[4]; };
+	auto fetch = [&](uint32_t bt, Inputs &in) {
+		const uint32_t i = bt * SBT + 16u * w + s;
+		const bool valid = i < lim;
+		const uint32_t ic = valid ? i : lim - 1;
+		load_feat_split<LAYOUT>(feat, n, ic, g, in.f);
+		in.d3[0] = dir[(size_t)ic * dir_stride]; in.d3[1] = dir[(size_t)ic * dir_stride + 1]; in.d3[2] = dir[(size_t)ic * dir_stride + 2];
+		in.go[0] = in.go[1] = in.go[2] = in.go[3] = 0.f;
+		if (valid) { const float4 v = *reinterpret_cast<const float4 *>(dout + (size_t)i * 4); in.go[0] = v.x; in.go[1] = v.y; in.go[2] = v.z; in.go[3] = v.w; }
+	};
+	Inputs cur, nxt;
+	if (blockIdx.x < n_bt) fetch(blockIdx.x, cur);
+	for (uint32_t bt = blockIdx.x; bt < n_bt; bt += gridDim.x) {
+		const uint32_t i = bt * SBT + 16u * w + s;
+		const bool valid = i < lim;
+		const bool more = bt + gridDim.x < n_bt;
+		if (more) fetch(bt + gridDim.x, nxt);
+		// ---- the trip's gradient scale: sigma = 2^(GRAD_TARGET_EXP - floor(log2(max |dL/dout|)))
+		{
+			float mx = fmaxf(fmaxf(fabsf(cur.go[0]), fabsf(cur.go[1])), fmaxf(fabsf(cur.go[2]), fabsf(cur.go[3])));     // (every lane group loaded the sample's four values)
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+			if (lane == 0) smax[w] = mx;
+		}
+		__syncthreads();
+		float sigma = 1.0f, inv_sigma = 1.0f;
+		{
+			float mx = 0.f;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) mx = fmaxf(mx, smax[k]);
+			const uint32_t e = (__float_as_uint(mx) >> 23) & 0xffu;                   // biased exponent (0: zero / subnormal maximum - leave the gradients alone)
+			if (e != 0u && e != 0xffu) {
+				int sb = 127 + GRAD_TARGET_EXP - ((int)e - 127);
+				sb = sb < 1 ? 1 : (sb > 253 ? 253 : sb);
+				sigma = __uint_as_float((uint32_t)sb << 23); inv_sigma = __uint_as_float((uint32_t)(254 - sb) << 23);
+			}
+		}
+		// ---- forward recompute (the colour head's output layer is not needed)
+		float sh[4]; sh4_split(cur.d3, g, sh);
+		float fs[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) fs[k] = cur.f[k] * FEAT_PRESCALE;
+		const B2 b0 = split8(fs);
+		floatx4 c[4];
+#pragma unroll
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wl, t, lane, b0, a); c[t] = combine(a, 1.0f / FEAT_PRESCALE); }
+		const B2 h0 = split_relu(c[0], c[1]), h1 = split_relu(c[2], c[3]);
+		const uint32_t mh0 = relu_mask8(c[0], c[1]), mh1 = relu_mask8(c[2], c[3]);
+		floatx4 den;
+		{ Acc a = {z, z}; mma3<MS>(wl, 4, lane, h0, a); mma3<MS>(wl, 5, lane, h1, a); den = combine(a, 1.0f / HID_PRESCALE); }
+		float in2[8];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { in2[k] = den[k] * HID_PRESCALE; in2[4 + k] = sh[k] * HID_PRESCALE; }
+		const B2 b2 = split8(in2);
+#pragma unroll
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wl, 6 + t, lane, b2, a); c[t] = combine(a, 1.0f / HID_PRESCALE); }
+		const B2 g00 = split_relu(c[0], c[1]), g01 = split_relu(c[2], c[3]);
+		const uint32_t mg00 = relu_mask8(c[0], c[1]), mg01 = relu_mask8(c[2], c[3]);
+#pragma unroll
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wl, 10 + 2 * t, lane, g00, a); mma3<MS>(wl, 11 + 2 * t, lane, g01, a); c[t] = combine(a, 1.0f / HID_PRESCALE); }
+		const B2 g10 = split_relu(c[0], c[1]), g11 = split_relu(c[2], c[3]);
+		const uint32_t mg10 = relu_mask8(c[0], c[1]), mg11 = relu_mask8(c[2], c[3]);
+		// ---- dgrad chain on sigma-scaled gradients (register resident, transposed fragments), interleaved with the five weight-gradient phases in the order that
+		// releases registers soonest: a phase runs as soon as its gradient exists, and its activations (only the ReLU masks feed the chain) die with it.
+		// dW[o][i] += sum_s dY[s][o] X[s][i]   (A = dY^T rows o, B = X^T rows i, k = sample); a trip's tiles carry sigma and X's prescale.
+		const int col = 16 * w + s, o = lane & 15;
+		const float uH = inv_sigma * (1.0f / HID_PRESCALE), uF = inv_sigma * (1.0f / FEAT_PRESCALE);
+		float dov[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                       // slots j < 4 <-> output neuron 4g + j; only neurons 0..2 (g == 0) are non-zero
+		if (g == 0) { dov[0] = cur.go[0] * sigma; dov[1] = cur.go[1] * sigma; dov[2] = cur.go[2] * sigma; }
+		const B2 dO = split8(dov);
+		// phase C2: V2 = dO x G1 (W1 / V2: each tile's samples split between waves w and w + 4)
+		st_rows16_2(stage, 0, col, g, dO);
+		st_rows64_2(stage, 16, col, g, g10, g11);
+		__syncthreads();
+		aV2 = fma4(aV2, wgrad3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
+#pragma unroll
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, t, lane, dO, a); c[t] = combine(a, 1.0f); }
+		const B2 dG1lo = split_masked(c[0], c[1], mg10), dG1hi = split_masked(c[2], c[3], mg11);
+		__syncthreads();
+		// phase A: V1 = dG1 x G0
+		st_rows64_2(stage, 0, col, g, dG1lo, dG1hi);
+		st_rows64_2(stage, 64, col, g, g00, g01);
+		__syncthreads();
+		aV1[0] = fma4(aV1[0], wgrad3(stage, 16 * to, 64 + 16 * ti0, o, g, 0, SBT), uH);
+		aV1[1] = fma4(aV1[1], wgrad3(stage, 16 * to, 64 + 16 * (ti0 + 1), o, g, 0, SBT), uH);
+#pragma unroll
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 4 + 2 * t, lane, dG1lo, a); mma3<MS>(wb, 5 + 2 * t, lane, dG1hi, a); c[t] = combine(a, 1.0f); }
+		const B2 dG0lo = split_masked(c[0], c[1], mg00), dG0hi = split_masked(c[2], c[3], mg01);
+		__syncthreads();
+		// phase B2: V0 = dG0 x [density | SH]
+		st_rows64_2(stage, 0, col, g, dG0lo, dG0hi);
+		st_rows32_2(stage, 64, col, g, b2, false);
+		__syncthreads();
+		aV0 = fma4(aV0, wgrad3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uH);
+		floatx4 dD;
+		{ Acc a = {z, z}; mma3<MS>(wb, 12, lane, dG0lo, a); mma3<MS>(wb, 13, lane, dG0hi, a); dD = combine(a, 1.0f); }
+		if (g == 0) dD[0] += cur.go[3] * sigma;                                      // out[:,3] = den[:,0]  (ngp_network.py:83)
+		float ddv[8] = {dD[0], dD[1], dD[2], dD[3], 0.f, 0.f, 0.f, 0.f};
+		const B2 dDf = split8(ddv);
+		__syncthreads();
+		// phase C1: W1 = dD x H
+		st_rows16_2(stage, 0, col, g, dDf);
+		st_rows64_2(stage, 16, col, g, h0, h1);
+		__syncthreads();
+		aW1 = fma4(aW1, wgrad3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
+#pragma unroll
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 14 + t, lane, dDf, a); c[t] = combine(a, 1.0f); }
+		const B2 dHlo = split_masked(c[0], c[1], mh0), dHhi = split_masked(c[2], c[3], mh1);
+		__syncthreads();
+		// phase B1: W0 = dH x features
+		st_rows64_2(stage, 0, col, g, dHlo, dHhi);
+		st_rows32_2(stage, 64, col, g, b0, true);
+		__syncthreads();
+		aW0 = fma4(aW0, wgrad3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uF);
+		floatx4 dF[2];
+#pragma unroll
+		for (int t = 0; t < 2; ++t) { Acc a = {z, z}; mma3<MS>(wb, 18 + 2 * t, lane, dHlo, a); mma3<MS>(wb, 19 + 2 * t, lane, dHhi, a); dF[t] = combine(a, inv_sigma); }
+		if (valid) {                                                                 // feature 16t + 4g + r  ->  level 8t + 2g + (r >> 1), component r & 1
+#pragma unroll
+			for (int t = 0; t < 2; ++t)
+#pragma unroll
+				for (int pr = 0; pr < 2; ++pr) {
+					const float2 v = make_float2(dF[t][2 * pr], dF[t][2 * pr + 1]);
+					const uint32_t level = 8 * t + 2 * g + pr;
+					lmax[t][pr] = fmaxf(lmax[t][pr], fmaxf(fabsf(v.x), fabsf(v.y)));
+					if (LAYOUT == NGP_LAYOUT_SOA) reinterpret_cast<float2 *>(dfeat)[(size_t)level * n + i] = v;
+					else *reinterpret_cast<float2 *>(dfeat + (size_t)i * 32 + 2 * level) = v;
+				}
+		}
+		__syncthreads();
+		if (more) cur = nxt;
+	}
+	// ---- W1 / V2 partial sums of waves 4..7 join those of waves 0..3 through LDS, then one fp32 slab per workgroup, packed like the weights
+	float *xch = reinterpret_cast<float *>(stage);            // [4 tiles][2][64 lanes][4]
+	if (half == 1) {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) { xch[((tx * 2 + 0) * 64 + lane) * 4 + r] = aW1[r]; xch[((tx * 2 + 1) * 64 + lane) * 4 + r] = aV2[r]; }
+	}
+	__syncthreads();
+	float *slab = slabs + (size_t)blockIdx.x * 10240;
+	const int ci = lane & 15;
+#pragma unroll
+	for (int r = 0; r < 4; ++r) {
+		const int ro = 4 * g + r;
+#pragma unroll
+		for (int q = 0; q < 2; ++q) slab[3072 + 2048 + (16 * to + ro) * 64 + 16 * (ti0 + q) + ci] = aV1[q][r];
+		slab[(16 * to + ro) * 32 + 16 * tj + ci] = aW0[r];
+		slab[3072 + (16 * to + ro) * 32 + 16 * tj + ci] = aV0[r];
+		if (half == 0) {
+			slab[2048 + ro * 64 + 16 * tx + ci] = aW1[r] + xch[((tx * 2 + 0) * 64 + lane) * 4 + r];
+			slab[3072 + 6144 + ro * 64 + 16 * tx + ci] = aV2[r] + xch[((tx * 2 + 1) * 64 + lane) * 4 + r];
+		}
+	}
+	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, reinterpret_cast<float *>(stage), 8); }
 }
 
 static uint32_t split_grid(uint32_t n) { uint32_t b = div_up(div_up(n, 16), 4); return b < 1024 ? (b ? b : 1) : 1024; }
@@ -167,5 +412,25 @@ int ngp_field32_fwd_split(void *stream, uint32_t n, const float *feat, int layou
 		else NGP_LAUNCH((k_field32_fwd_split<NGP_LAYOUT_AOS, false>), grid, block, 0, s, n, feat, dir, dir_stride, p, out, n_valid);
 	}
 	NGP_LAUNCH_CHECK("ngp_field32_fwd_split");
+	return 0;
+}
+
+size_t ngp_field32_bwd_split_shmem() { return (size_t)(NSPLIT_HALVES + 2 * SPLANE) * sizeof(_Float16); }
+// launched by ngp_field32_bwd_am (field32.hip) when NGP_FIELD32_BWD selects the split variant
+int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const void *split_frags, const float *dout,
+                          float *dfeat, float *slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am_in) {
+	const AbsmaxOut am = am_in ? *am_in : AbsmaxOut{nullptr, nullptr, 0u, nullptr};
+	hipStream_t s = (hipStream_t)stream;
+	const size_t shmem = ngp_field32_bwd_split_shmem();
+	const dim3 grid(n_slabs), block(512);
+	const _Float16 *p = (const _Float16 *)split_frags;
+#define GO(L) do { \
+	static bool attr_set = false; \
+	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_split<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd(split): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
+	NGP_LAUNCH((k_field32_bwd_split<L>), grid, block, shmem, s, n, feat, dir, dir_stride, p, dout, dfeat, slabs, n_valid, am); } while (0)
+	if (layout == NGP_LAYOUT_SOA) GO(NGP_LAYOUT_SOA); else GO(NGP_LAYOUT_AOS);
+#undef GO
+	NGP_LAUNCH_CHECK("ngp_field32_bwd(split)");
 	return 0;
 }

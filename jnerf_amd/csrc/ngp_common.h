@@ -43,6 +43,8 @@ int ngp_field_bwd_am(void *stream, uint32_t n, const void *feat, int layout, con
 int ngp_mlp32_sweep_pack(void *stream, float *pack, const float *grad, float *m, float *v, float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, float *packed_out);
 // fp32 field forward on split fp16 operands (field_split.hip): the split fragments live behind the NF32_ALL fp32 fragments of the packed weight buffer
 int ngp_field32_pack_split(void *stream, const float *wd, const float *wc, void *out_halves, int n_frags);
+int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const void *split_frags, const float *dout, float *dfeat,
+                          float *slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am);
 int ngp_field32_fwd_split(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const void *split_frags, float *out, const uint32_t *n_valid, int density_only);
 int ngp_dp_reduce(void *comm, hipStream_t s, const NgpDpPlan *plan, void *grad, int dtype, uint32_t first_bucket, uint32_t last_bucket, float *tail_f32, float *extra_f32, uint64_t extra_count);
 

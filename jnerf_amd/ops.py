@@ -234,7 +234,7 @@ def field_bwd(feat, d, wd, wc, dLdout, layout=LAYOUT_AOS, dfeat=None, slabs=None
 
 
 # ---- fp32 field network (cfg.fp16 unset: ngp_base.py / lego) on v_mfma_f32_16x16x4_f32
-PACKED32_WEIGHT_FLOATS = 29696
+PACKED32_WEIGHT_FLOATS = 40960
 
 
 def field32_pack_weights(wd, wc, out=None):
