@@ -218,7 +218,9 @@ __device__ __forceinline__ floatx4 fma4(floatx4 acc, floatx4 v, float s) {
 	return acc;
 }
 
-template <int LAYOUT>
+// PROBE (timing experiments only, tools/probe_split_bwd.py; results are wrong for PROBE != 0): 1 = no staging stores, 2 = no weight-gradient loads / MFMAs,
+// 3 = neither (chain + barriers only), 4 = no barriers either
+template <int LAYOUT, int PROBE>
 __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                               const _Float16 *__restrict__ packed, const float *__restrict__ dout,
                                                               float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
@@ -312,49 +314,49 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 		if (g == 0) { dov[0] = cur.go[0] * sigma; dov[1] = cur.go[1] * sigma; dov[2] = cur.go[2] * sigma; }
 		const B2 dO = split8(dov);
 		// phase C2: V2 = dO x G1 (W1 / V2: each tile's samples split between waves w and w + 4)
-		st_rows16_2(stage, 0, col, g, dO);
-		st_rows64_2(stage, 16, col, g, g10, g11);
-		__syncthreads();
-		aV2 = fma4(aV2, wgrad3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
+		if (PROBE != 1 && PROBE < 3) st_rows16_2(stage, 0, col, g, dO);
+		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 16, col, g, g10, g11);
+		if (PROBE < 4) __syncthreads();
+		if (PROBE < 2) aV2 = fma4(aV2, wgrad3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
 #pragma unroll
 		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, t, lane, dO, a); c[t] = combine(a, 1.0f); }
 		const B2 dG1lo = split_masked(c[0], c[1], mg10), dG1hi = split_masked(c[2], c[3], mg11);
-		__syncthreads();
+		if (PROBE < 4) __syncthreads();
 		// phase A: V1 = dG1 x G0
-		st_rows64_2(stage, 0, col, g, dG1lo, dG1hi);
-		st_rows64_2(stage, 64, col, g, g00, g01);
-		__syncthreads();
-		aV1[0] = fma4(aV1[0], wgrad3(stage, 16 * to, 64 + 16 * ti0, o, g, 0, SBT), uH);
-		aV1[1] = fma4(aV1[1], wgrad3(stage, 16 * to, 64 + 16 * (ti0 + 1), o, g, 0, SBT), uH);
+		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 0, col, g, dG1lo, dG1hi);
+		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 64, col, g, g00, g01);
+		if (PROBE < 4) __syncthreads();
+		if (PROBE < 2) aV1[0] = fma4(aV1[0], wgrad3(stage, 16 * to, 64 + 16 * ti0, o, g, 0, SBT), uH);
+		if (PROBE < 2) aV1[1] = fma4(aV1[1], wgrad3(stage, 16 * to, 64 + 16 * (ti0 + 1), o, g, 0, SBT), uH);
 #pragma unroll
 		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 4 + 2 * t, lane, dG1lo, a); mma3<MS>(wb, 5 + 2 * t, lane, dG1hi, a); c[t] = combine(a, 1.0f); }
 		const B2 dG0lo = split_masked(c[0], c[1], mg00), dG0hi = split_masked(c[2], c[3], mg01);
-		__syncthreads();
+		if (PROBE < 4) __syncthreads();
 		// phase B2: V0 = dG0 x [density | SH]
-		st_rows64_2(stage, 0, col, g, dG0lo, dG0hi);
-		st_rows32_2(stage, 64, col, g, b2, false);
-		__syncthreads();
-		aV0 = fma4(aV0, wgrad3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uH);
+		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 0, col, g, dG0lo, dG0hi);
+		if (PROBE != 1 && PROBE < 3) st_rows32_2(stage, 64, col, g, b2, false);
+		if (PROBE < 4) __syncthreads();
+		if (PROBE < 2) aV0 = fma4(aV0, wgrad3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uH);
 		floatx4 dD;
 		{ Acc a = {z, z}; mma3<MS>(wb, 12, lane, dG0lo, a); mma3<MS>(wb, 13, lane, dG0hi, a); dD = combine(a, 1.0f); }
 		if (g == 0) dD[0] += cur.go[3] * sigma;                                      // out[:,3] = den[:,0]  (ngp_network.py:83)
 		float ddv[8] = {dD[0], dD[1], dD[2], dD[3], 0.f, 0.f, 0.f, 0.f};
 		const B2 dDf = split8(ddv);
-		__syncthreads();
+		if (PROBE < 4) __syncthreads();
 		// phase C1: W1 = dD x H
-		st_rows16_2(stage, 0, col, g, dDf);
-		st_rows64_2(stage, 16, col, g, h0, h1);
-		__syncthreads();
-		aW1 = fma4(aW1, wgrad3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
+		if (PROBE != 1 && PROBE < 3) st_rows16_2(stage, 0, col, g, dDf);
+		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 16, col, g, h0, h1);
+		if (PROBE < 4) __syncthreads();
+		if (PROBE < 2) aW1 = fma4(aW1, wgrad3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
 #pragma unroll
 		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 14 + t, lane, dDf, a); c[t] = combine(a, 1.0f); }
 		const B2 dHlo = split_masked(c[0], c[1], mh0), dHhi = split_masked(c[2], c[3], mh1);
-		__syncthreads();
+		if (PROBE < 4) __syncthreads();
 		// phase B1: W0 = dH x features
-		st_rows64_2(stage, 0, col, g, dHlo, dHhi);
-		st_rows32_2(stage, 64, col, g, b0, true);
-		__syncthreads();
-		aW0 = fma4(aW0, wgrad3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uF);
+		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 0, col, g, dHlo, dHhi);
+		if (PROBE != 1 && PROBE < 3) st_rows32_2(stage, 64, col, g, b0, true);
+		if (PROBE < 4) __syncthreads();
+		if (PROBE < 2) aW0 = fma4(aW0, wgrad3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uF);
 		floatx4 dF[2];
 #pragma unroll
 		for (int t = 0; t < 2; ++t) { Acc a = {z, z}; mma3<MS>(wb, 18 + 2 * t, lane, dHlo, a); mma3<MS>(wb, 19 + 2 * t, lane, dHhi, a); dF[t] = combine(a, inv_sigma); }
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 					else *reinterpret_cast<float2 *>(dfeat + (size_t)i * 32 + 2 * level) = v;
 				}
 		}
-		__syncthreads();
+		if (PROBE < 4) __syncthreads();
 		if (more) cur = nxt;
 	}
 	// ---- W1 / V2 partial sums of waves 4..7 join those of waves 0..3 through LDS, then one fp32 slab per workgroup, packed like the weights
@@ -424,13 +426,16 @@ int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layou
 	const size_t shmem = ngp_field32_bwd_split_shmem();
 	const dim3 grid(n_slabs), block(512);
 	const _Float16 *p = (const _Float16 *)split_frags;
-#define GO(L) do { \
+#define GOP(L, P) do { \
 	static bool attr_set = false; \
-	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_split<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_split<L, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd(split): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	NGP_LAUNCH((k_field32_bwd_split<L>), grid, block, shmem, s, n, feat, dir, dir_stride, p, dout, dfeat, slabs, n_valid, am); } while (0)
+	NGP_LAUNCH((k_field32_bwd_split<L, P>), grid, block, shmem, s, n, feat, dir, dir_stride, p, dout, dfeat, slabs, n_valid, am); } while (0)
+	static const int probe = [] { const char *e = getenv("NGP_SPLIT_PROBE"); return e ? atoi(e) : 0; }();
+#define GO(L) do { if (probe == 1) GOP(L, 1); else if (probe == 2) GOP(L, 2); else if (probe == 3) GOP(L, 3); else if (probe == 4) GOP(L, 4); else GOP(L, 0); } while (0)
 	if (layout == NGP_LAYOUT_SOA) GO(NGP_LAYOUT_SOA); else GO(NGP_LAYOUT_AOS);
 #undef GO
+#undef GOP
 	NGP_LAUNCH_CHECK("ngp_field32_bwd(split)");
 	return 0;
 }

@@ -9,7 +9,7 @@ WHAT=${1:-all}
 TAG=r03
 R=$PWD
 mkdir -p $R/gpurun_out
-BASE="python $R/bench.py --no-cpu-baseline --no-psnr --no-fox"
+BASE="python $R/bench.py --no-cpu-baseline --no-psnr --no-fox --no-neus"
 cd /tmp && export TMPDIR=/tmp
 if [ $WHAT = all ] || [ $WHAT = trace ]; then
 for cfg in lego fox; do

@@ -9,10 +9,12 @@ timeout 300 python tools/probe_field_bwd_err.py 2>&1 | tail -5
 bash tools/collect_profiles_r03.sh all > gpurun_out/r03_collect.log 2>&1; echo "collect rc=$?"; tail -3 gpurun_out/r03_collect.log
 cp gpurun_out/r03_pmc.json profiles/r03_pmc.json 2>/dev/null
 timeout 900 python bench.py > gpurun_out/r03_bench_lego.json 2> gpurun_out/r03_bench_lego.err; echo "bench lego rc=$?"
-timeout 900 python bench.py --config fox --no-fox > gpurun_out/r03_bench_fox.json 2> gpurun_out/r03_bench_fox.err; echo "bench fox rc=$?"
-timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-fox --no-cpu-baseline > gpurun_out/r03_bench_driver_style.json 2>/dev/null; echo "driver-style rc=$?"
-BENCH_EXTRA_CFG='{"scene": "bricks"}' timeout 600 python bench.py --no-fox --no-cpu-baseline > gpurun_out/r03_bench_bricks.json 2> gpurun_out/r03_bench_bricks.err; echo "bench bricks rc=$?"
-MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --force-dist --no-fox --no-cpu-baseline --no-psnr > gpurun_out/r03_bench_dist_world1.json 2>/dev/null; echo "dist rc=$?"
+timeout 900 python bench.py --config fox --no-fox --no-neus > gpurun_out/r03_bench_fox.json 2> gpurun_out/r03_bench_fox.err; echo "bench fox rc=$?"
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-fox --no-neus --no-cpu-baseline > gpurun_out/r03_bench_driver_style.json 2>/dev/null; echo "driver-style rc=$?"
+BENCH_EXTRA_CFG='{"scene": "bricks"}' timeout 600 python bench.py --no-fox --no-neus --no-cpu-baseline > gpurun_out/r03_bench_bricks.json 2> gpurun_out/r03_bench_bricks.err; echo "bench bricks rc=$?"
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --force-dist --no-fox --no-neus --no-cpu-baseline --no-psnr > gpurun_out/r03_bench_dist_world1.json 2>/dev/null; echo "dist rc=$?"
+timeout 600 python tools/train_curve.py gpurun_out/r03_train_curve_bricks.md 40000 bricks > gpurun_out/r03_train_curve.log 2>&1; echo "bricks curve rc=$?"; tail -3 gpurun_out/r03_train_curve.log
+timeout 600 python tools/neus_curve.py gpurun_out/r03_neus_curve.md 6000 2>&1 | grep "^|" | tail -14
 bash tools/gpu_timeline.sh > gpurun_out/r03_lego_timeline_raw.txt 2>&1; cp gpurun_out/timeline_step.txt gpurun_out/r03_lego_timeline_step.txt
 python - <<'PY'
 import json
@@ -21,7 +23,7 @@ for f in ("r03_bench_lego", "r03_bench_fox", "r03_bench_driver_style", "r03_benc
         d = json.loads([l for l in open(f"gpurun_out/{f}.json") if l.startswith('{"metric')][-1])
         r = d["roofline"] or {}
         print(f, d["value"], d["ms_per_step"], d["dtype"], r.get("kernel"), r.get("bound"), r.get("achieved"), r.get("frac"), r.get("executed_frac"), r.get("issued_frac"), r.get("pipe_util"), r.get("traffic"),
-              "stage", (r.get("stage") or {}), "cpu", (d.get("cpu_baseline") or {}).get("value"), "fox", (d["extra"].get("fox") or {}), {k: v for k, v in d["extra"].items() if k.startswith(("psnr", "render"))})
+              "stage", (r.get("stage") or {}), "cpu", (d.get("cpu_baseline") or {}).get("value"), "fox", (d["extra"].get("fox") or {}), "neus", (d["extra"].get("neus") or {}), {k: v for k, v in d["extra"].items() if k.startswith(("psnr", "render"))})
     except Exception as e:
         print(f, "failed", e)
 PY

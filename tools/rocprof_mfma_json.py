@@ -33,10 +33,11 @@ def main(db, out_json, out_md, key, fp16):
             continue
         dur_cyc = sqbusy / 32.0
         util = busy / 1024.0 / dur_cyc
-        tf = mfma * flop / (dur_cyc / 2.4e9) / 1e12
-        lines.append(f"| {key} | `{k}`{' <density only: occupancy refresh>' if dens else ''} | {mfma:,.0f} | {busy:,.0f} | {sqbusy:,.0f} | {dur_cyc / 1e3:.0f} | {100 * util:.1f} % | {tf:.0f} | {100 * tf / peak:.1f} % |")
+        k_flop, k_peak = (16384.0, 2500.0) if "split" in k else (flop, peak)          # the split-operand kernels of the fp32 configuration issue fp16 16x16x32 MFMAs (csrc/field_split.hip)
+        tf = mfma * k_flop / (dur_cyc / 2.4e9) / 1e12
+        lines.append(f"| {key} | `{k}`{' <density only: occupancy refresh>' if dens else ''} | {mfma:,.0f} | {busy:,.0f} | {sqbusy:,.0f} | {dur_cyc / 1e3:.0f} | {100 * util:.1f} % | {tf:.0f} | {100 * tf / k_peak:.1f} % |")
         if not dens:
-            res[key].setdefault(k, {}).update({"mfma_instructions_per_launch": int(mfma), "mfma_pipe_util": round(util, 4), "mfma_issued_frac": round(tf / peak, 4)})
+            res[key].setdefault(k, {}).update({"mfma_instructions_per_launch": int(mfma), "mfma_pipe_util": round(util, 4), "mfma_issued_frac": round(tf / k_peak, 4)})
     json.dump(res, open(out_json, "w"), indent=1)
     hdr = ("| config | kernel | MFMA instructions / launch | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | duration (k cycles) | MFMA pipe utilisation | TFLOP/s | fraction of dense peak |\n|---|---|---|---|---|---|---|---|---|\n")
     try:
