@@ -1076,6 +1076,11 @@ static bool fwd_split() {
 	if (v < 0) { const char *e = getenv("NGP_FIELD32_FWD"); v = (e && (e[0] == 'm' || e[0] == '0')) ? 0 : 1; }
 	return v == 1;
 }
+static bool dens_split() {       // (probe hook: NGP_DENSITY32_FWD=mfma32|split selects the density-only forward independently)
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("NGP_DENSITY32_FWD"); v = !e ? (fwd_split() ? 1 : 0) : ((e[0] == 'm' || e[0] == '0') ? 0 : 1); }
+	return v == 1;
+}
 // n_frags fp32 fragments (n_frags < 0: the first -n_frags split fp16 fragments of the forward instead) of raw weight packs in a per-(device, stream) scratch, or the caller's packed buffer
 static const float *pack_weights32(const char *fn, hipStream_t s, const void *wd, const void *wc, int n_frags, int layout_flags) {
 	if (layout_flags & NGP_WEIGHTS_PACKED) return (const float *)wd;
@@ -1124,8 +1129,8 @@ NGP_API int ngp_density32_fwd(void *stream, uint32_t n, const float *feat, int l
 	NGP_REQUIRE(out, NGP_E_ARG, "ngp_density32_fwd: null out");
 	if (n == 0) return 0;
 	hipStream_t s = (hipStream_t)stream;
-	const float *packed = pack_weights32("ngp_density32_fwd", s, wd, wd, fwd_split() ? -6 : 12, layout_flags); if (!packed) return NGP_E_ARG;
-	if (fwd_split()) return ngp_field32_fwd_split(stream, n, feat, layout, nullptr, 3u, packed + NF32_ALL * 256, out, nullptr, 1);
+	const float *packed = pack_weights32("ngp_density32_fwd", s, wd, wd, dens_split() ? -6 : 12, layout_flags); if (!packed) return NGP_E_ARG;
+	if (dens_split()) return ngp_field32_fwd_split(stream, n, feat, layout, nullptr, 3u, packed + NF32_ALL * 256, out, nullptr, 1);
 	const dim3 grid(fwd32_grid(n)), block(256);
 	if (layout == NGP_LAYOUT_SOA) NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_SOA, true>), grid, block, 0, s, n, feat, (const float *)nullptr, 3u, packed, out, (const uint32_t *)nullptr);
 	else NGP_LAUNCH((k_field32_fwd<NGP_LAYOUT_AOS, true>), grid, block, 0, s, n, feat, (const float *)nullptr, 3u, packed, out, (const uint32_t *)nullptr);

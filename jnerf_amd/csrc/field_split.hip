@@ -202,7 +202,8 @@ __device__ __forceinline__ void st_rows16_2(_Float16 *stage, int row0, int col, 
 __device__ __forceinline__ floatx4 wgrad3(const _Float16 *stage, int row_a, int row_b, int o, int g, int c0, int c1) {
 	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
 	Acc acc = {z, z};
-	for (int c = c0; c < c1; c += 32) {
+#pragma unroll 2
+	for (int c = c0; c < c1; c += 32) {      // (full unrolling lets the scheduler hoist every step's four fragment loads of every tile of a phase: 290 VGPRs wanted, 36 spilled)
 		const int cs = c + 8 * g;
 		const half8 ah = *reinterpret_cast<const half8 *>(stage + (row_a + o) * SRS + cs), am = *reinterpret_cast<const half8 *>(stage + SPLANE + (row_a + o) * SRS + cs);
 		const half8 bh = *reinterpret_cast<const half8 *>(stage + (row_b + o) * SRS + cs), bm = *reinterpret_cast<const half8 *>(stage + SPLANE + (row_b + o) * SRS + cs);

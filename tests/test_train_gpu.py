@@ -154,15 +154,76 @@ def test_two_ranks_data_parallel_on_one_gpu(scaling):
     assert d["extra"]["native_step"] is True                  # data parallel keeps the one-call native step (here: two phases around gloo's all-reduce)
 
 
+@pytest.mark.parametrize("world,n_buckets,half", [(2, 1, False), (2, 2, False), (3, 2, True), (8, 1, True), (8, 2, False)])
+def test_sharded_sweep_tiles_the_replicated_sweep(world, n_buckets, half):
+    """The in-library exchange (reduce-scatter -> sweep of the rank's shard -> all-gather) needs one GPU per rank, which this box does not have.  Its SHARD ARITHMETIC is
+    exercised here without a process group: for every rank of a `world`-rank plan, ngp_train_step(NGP_PHASE_SWEEP, plan of that rank, no communicator) sweeps the rank's
+    shards + the replicated tail of its own copy of (parameters, moments, fp16 shadow); stitching the ranks' shards together (the all-gather) must reproduce, bit for bit,
+    ONE replicated sweep of the whole table - parameters, both Adam moments and the fp16 shadow - and leave everything outside a rank's shards and the tail untouched."""
+    import ctypes as C
+    from jnerf_amd import _lib as L, ops, dp
+    lt, _, n_params = ops.level_table(1)
+    n_params_t = n_params - 3                                  # a ragged tail: not a multiple of 8 * world
+    torch.manual_seed(world * 10 + n_buckets)
+    dev = "cuda"
+    p0 = torch.randn(n_params_t, device=dev) * 1e-2
+    g0 = torch.randn(n_params_t, device=dev) * 1e-4
+    m0, v0 = torch.randn(n_params_t, device=dev) * 1e-5, torch.rand(n_params_t, device=dev) * 1e-9
+    lr, step, b0, b1, eps, decay = 1e-2, 7, 0.9, 0.99, 1e-15, 0.95
+    # the replicated sweep (EMA aliasing the parameter, as the training path has it)
+    pr, mr, vr = p0.clone(), m0.clone(), v0.clone()
+    hr = torch.zeros(n_params_t, dtype=torch.float16, device=dev) if half else None
+    ops.adam_ema_step(pr, g0.clone(), mr, vr, pr, hr, lr, step, b0, b1, eps, decay, zero_grad=False)
+    stitched = [torch.full_like(p0, float("nan")) for _ in range(3)]
+    stitched_h = torch.zeros(n_params_t, dtype=torch.float16, device=dev) if half else None
+    covered = torch.zeros(n_params_t, dtype=torch.int32, device=dev)
+    for rank in range(world):
+        plan = L.NgpDpPlan()
+        L.check(L.lib().ngp_dp_plan(ops._tbl(lt), n_params_t, world, rank, n_buckets, C.byref(plan)), "ngp_dp_plan")
+        p, m, v, g = p0.clone(), m0.clone(), v0.clone(), g0.clone()
+        h = torch.full((n_params_t,), -7.0, dtype=torch.float16, device=dev) if half else None
+        a = L.NgpTrainStep()
+        a.run_optimizer, a.phase, a.dtype, a.timed_stage, a.grad_overwrite = 1, L.PHASE_SWEEP, (L.F16 if half else L.F32), -1, 1
+        a.n_opt, a.step, a.lr, a.beta0, a.beta1, a.eps, a.ema_decay = 1, step, lr, b0, b1, eps, decay
+        a.p[0], a.g[0], a.m[0], a.v[0], a.ema[0], a.numel[0] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.data_ptr(), n_params_t
+        a.p_half[0] = h.data_ptr() if half else None
+        a.table_grad, a.n_params, a.dp_table, a.dp = g.data_ptr(), n_params_t, 0, C.addressof(plan)
+        L.check(L.lib().ngp_train_step(ops._stream(), C.byref(a)), "ngp_train_step(sweep, sharded)")
+        own = torch.zeros(n_params_t, dtype=torch.bool, device=dev)
+        for b in range(plan.n_buckets):
+            own[plan.shard_begin[b]:plan.shard_begin[b] + plan.shard_count[b]] = True
+        tail = torch.zeros_like(own)
+        tail[plan.tail_begin:plan.tail_begin + plan.tail_count] = True
+        assert int(plan.tail_begin + plan.tail_count) == n_params_t and 0 < int(plan.tail_count) < 8 * world
+        untouched = ~(own | tail)
+        assert torch.equal(p[untouched], p0[untouched]) and torch.equal(m[untouched], m0[untouched]) and torch.equal(v[untouched], v0[untouched])
+        if half:
+            assert bool((h[untouched] == -7.0).all())
+        for dst, src, whole in zip(stitched, (p, m, v), (pr, mr, vr)):
+            dst[own] = src[own]
+            assert torch.equal(src[tail], whole[tail])                                        # the tail is swept by every rank, identically
+        if half:
+            stitched_h[own] = h[own]
+            assert torch.equal(h[tail], hr[tail])
+        covered += own.int()
+    main = covered[:int(plan.tail_begin)]
+    assert bool((main == 1).all()) and bool((covered[int(plan.tail_begin):] == 0).all())         # every element of the main part belongs to exactly one rank
+    k = int(plan.tail_begin)
+    for got, want in zip(stitched, (pr, mr, vr)):
+        assert torch.equal(got[:k], want[:k])
+    if half:
+        assert torch.equal(stitched_h[:k], hr[:k])
+
+
 @pytest.mark.parametrize("config,overlap", [("fox", False), ("lego", True)])
-def test_sharded_sweep_with_two_ranks_equals_the_replicated_sweep(config, overlap):
-    """The in-library exchange (reduce-scatter -> sweep of the rank's shard -> all-gather) needs one GPU per rank, which this box does not have; its SHARD ARITHMETIC -
-    ngp_dp_plan for rank 1, the sweep of a shard that does not start at element 0, the replicated tail, Adam moments (fp16 mode: the fp32 master too) living on their
-    owner's shard until sync_sharded_state() - runs here with two ranks on one GPU: the host sums the gradient (gloo) and gathers the shards (`--dp-host-sharded`,
-    NGP_PHASE_SWEEP with a plan and no communicator).  The parameters must equal, bit for bit, those of the same two-rank run with the replicated full sweep."""
+def test_sharded_sweep_with_two_ranks_on_one_gpu(config, overlap):
+    """the same shard arithmetic end to end: two ranks on one GPU, the host sums the gradient (gloo) and gathers the shards (`--dp-host-sharded`: NGP_PHASE_SWEEP with a plan
+    and no communicator, Adam moments - fp16 mode: the fp32 master too - living on their owner's shard until sync_sharded_state()).  Replicas must end bit-identical and
+    train like the replicated sweep.  (Not compared bit for bit with a second run: with two PROCESSES time-sharing one GPU, runs of this configuration are not
+    reproducible to the last bit on this platform - DESIGN.md section 6 - while single-process runs are; the bitwise statement is the test above.)"""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sigs = []
+    res = []
     for sharded in (False, True):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
@@ -174,8 +235,10 @@ def test_sharded_sweep_with_two_ranks_equals_the_replicated_sweep(config, overla
         d = json.loads(lines[0])
         assert d["extra"]["replicas_identical"] is True and d["extra"]["native_step"] is True and np.isfinite(d["loss"])
         assert ("sharded sweep" in d["extra"]["dp"]["exchange"]) == sharded
-        sigs.append((d["extra"]["param_signature"], d["loss"]))
-    assert sigs[0] == sigs[1], sigs
+        res.append(d)
+    assert abs(res[0]["loss"] - res[1]["loss"]) < 0.05 * res[0]["loss"]
+    for x, y in zip(res[0]["extra"]["param_signature"], res[1]["extra"]["param_signature"]):
+        assert abs(x - y) <= 0.25 * max(abs(x), abs(y), 1.0), (res[0]["extra"]["param_signature"], res[1]["extra"]["param_signature"])
 
 
 def _run_bench(extra_args, timeout=900, env=None):
@@ -305,6 +368,7 @@ def test_fp32_fused_network_equals_linear_chain():
     from jnerf_amd.presets import ngp_cfg
     from jnerf_amd.utils.registry import build_from_cfg, NETWORKS, DATASETS
     from jnerf_amd.utils.config import get_cfg
+    import jnerf_amd.dataset, jnerf_amd.network, jnerf_amd.encoders  # noqa: F401  (register the modules: this test may be the first of its process)
     torch.manual_seed(3)
     outs = []
     sd = None
