@@ -345,13 +345,21 @@ def main():
                 pass
         hbm = {"achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4)}
         if dom in flops:    # the fused field kernels are MFMA work (fp16 16x16x32: dense peak 2.5 PFLOP/s; fp32 16x16x4: 157.3 TFLOP/s); their HBM side is reported next to it
-            peak = 2500.0 if (fp16 or dom in SPLIT_FP16_KERNELS) else 157.3
+            split = dom in SPLIT_FP16_KERNELS
+            # `peak` is the dense MFMA peak of the ARITHMETIC THE CONFIGURATION ASKS FOR: fp16 products (2.5 PFLOP/s) for ngp_fox.py, fp32 products (157.3 TFLOP/s) for
+            # ngp_base.py - also when the kernel obtains its fp32-accurate products from three fp16 MFMAs each (csrc/field_split.hip); what that kernel does to the pipe it
+            # actually runs on is reported separately in `fp16_pipe`
+            peak = 2500.0 if fp16 else 157.3
             tf = flops[dom] / (avg_ms * 1e-3) / 1e12
-            tf_exec = EXECUTED_FLOPS_PER_SAMPLE[dom] * mean_valid / (avg_ms * 1e-3) / 1e12
+            exec_fps = EXECUTED_FLOPS_PER_SAMPLE[dom] / (3.0 if split else 1.0)     # fp32-equivalent products the kernel evaluates (incl. its forward recompute)
+            tf_exec = exec_fps * mean_valid / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "hbm": hbm,
-                    "alg_flop_per_sample": flops[dom] / mean_valid, "executed_flop_per_sample": EXECUTED_FLOPS_PER_SAMPLE[dom],
+                    "alg_flop_per_sample": flops[dom] / mean_valid, "executed_flop_per_sample": exec_fps,
                     "executed_frac": round(tf_exec / peak, 4),                      # counts the in-kernel forward recompute of the backward as work
                     "issued_frac": counters.get("mfma_issued_frac"), "pipe_util": counters.get("mfma_pipe_util")}   # from the committed MFMA-counter pass (same source file as `traffic`), null if absent
+            if split:
+                roof["fp16_pipe"] = {"note": "split operands: every fp32-accurate product is three v_mfma_f32_16x16x32_f16 products; the kernel is LDS- and VALU-bound, not MFMA-bound",
+                                     "issued_TFLOPs": round(3.0 * tf_exec, 1), "peak": 2500.0, "frac": round(3.0 * tf_exec / 2500.0, 4)}
         else:
             roof = dict(bound="hbm", **hbm)
         # the hash-backward STAGE is four launches under four kernel names (abs-max, two record passes, accumulate): one roofline for the stage, from the probe steps

@@ -25,7 +25,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define NF32_FWD 40
 #define NF32_BWD 36
-#define NGP_FIELD32_BWD_DEFAULT 2       // (3 = split fp16 operands, field_split.hip: correct and equally fast on MI355X today - 137 us, LDS- and VALU-bound; opt-in)
+#define NGP_FIELD32_BWD_DEFAULT 3       // 3 = split fp16 operands (field_split.hip): 109 us in the training step vs 139 us for 2 = two free-running groups on fp32 MFMAs (+4.8 % it/s, A/B on one box)
 #define NF32_ALL (NF32_FWD + NF32_BWD)          // fp32 fragments; the packed buffer continues with the split fp16 fragments (field_split.h: forward + transposed): NGP_PACKED32_WEIGHT_FLOATS = NF32_ALL * 256 + NSPLIT_HALVES / 2
 static_assert(NGP_PACKED32_WEIGHT_FLOATS == NF32_ALL * 256 + NSPLIT_HALVES / 2, "packed fp32 weight buffer layout");
 

@@ -765,13 +765,14 @@ def test_grid_samples_morton_order_is_a_permutation(H, n):
     assert ((np.diff(cells) % (128 ** 3)) == 1).mean() > 0.85      # (n = 5 * 2^19: blocks of 2^19, the two top bits of the cell follow the carries)
 
 
-def test_field32_split_backward_variant_passes_the_same_tests():
-    """NGP_FIELD32_BWD=3 selects the split-operand backward (csrc/field_split.hip: forward recompute, dgrad chain and weight gradients on the fp16 matrix cores, three
-    MFMAs per product sum, per-trip power-of-two gradient scale).  The variant is chosen once per process, so the fp32 backward tests are re-run in a child process
-    under it - same oracle, same tolerances as the default exact-product kernel."""
+def test_field32_exact_product_backward_variant_passes_the_same_tests():
+    """The default fp32 backward is the split-operand kernel (csrc/field_split.hip: forward recompute, dgrad chain and weight gradients on the fp16 matrix cores, three
+    MFMAs per product sum, per-trip power-of-two gradient scale) - every fp32 test of this file and of test_train_gpu.py / test_trajectory_gpu.py runs through it.
+    NGP_FIELD32_BWD=2 selects the exact-product kernel (two free-running groups on v_mfma_f32_16x16x4_f32); the variant is chosen once per process, so the fp32 backward
+    tests are re-run in a child process under it - same oracle, same tolerances."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), os.path.join(root, "tests", "test_train_gpu.py"), "-q", "-m", "gpu", "-x",
                           "-k", "field32_bwd_vs_oracle or full_size_field or fp32_fused_network_equals"],
-                         capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, NGP_FIELD32_BWD="3"))
+                         capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, NGP_FIELD32_BWD="2", NGP_FIELD32_FWD="mfma32"))
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
