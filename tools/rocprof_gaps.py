@@ -3,7 +3,7 @@ import sqlite3, sys
 db = sys.argv[1]; nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 c = sqlite3.connect(db)
 rows = list(c.execute("select d.start, d.end, d.stream_id, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id order by d.start"))
-marks = [i for i, r in enumerate(rows) if "k_field_fwdI6__halfLi1ELb0" in r[3] or "k_field32_fwdILi1ELb0" in r[3]]      # one per training step (fp16 | fp32 network)
+marks = [i for i, r in enumerate(rows) if "k_field_fwdI6__halfLi1ELb0" in r[3] or "k_field32_fwdILi1ELb0" in r[3] or "k_field32_fwd_splitILi1ELb0" in r[3]]      # one per training step (fp16 | fp32 network)
 a, b = marks[-nsteps - 1], marks[-1]
 seg = rows[a:b]
 main = seg[0][2]

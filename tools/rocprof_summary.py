@@ -9,7 +9,7 @@ def main(db, out, title, last_steps=0):
     cutoff = 0
     if last_steps:      # restrict to the last N training steps: cut at the start of the N-th from last batch launch of the field network
         marks = [r[0] for r in c.execute("""select d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
-                                            where s.kernel_name like '%k_field32_fwdILi1ELb0%' or s.kernel_name like '%k_field_fwdI6__halfLi1ELb0%' order by d.start""")]      # one per training step
+                                            where s.kernel_name like '%k_field32_fwdILi1ELb0%' or s.kernel_name like '%k_field32_fwd_splitILi1ELb0%' or s.kernel_name like '%k_field_fwdI6__halfLi1ELb0%' order by d.start""")]      # one per training step
         if len(marks) > last_steps:
             cutoff = marks[-last_steps]
             title += f" — last {last_steps} training steps only"

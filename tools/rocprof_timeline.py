@@ -3,7 +3,7 @@ import sqlite3, sys
 db = sys.argv[1]
 c = sqlite3.connect(db)
 rows = list(c.execute("""select d.start, d.end, d.queue_id, d.stream_id, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id order by d.start"""))
-marks = [i for i, r in enumerate(rows) if "k_field_fwdI6__halfLi1ELb0" in r[4] or "k_field32_fwdILi1ELb0" in r[4]]
+marks = [i for i, r in enumerate(rows) if "k_field_fwdI6__halfLi1ELb0" in r[4] or "k_field32_fwdILi1ELb0" in r[4] or "k_field32_fwd_splitILi1ELb0" in r[4]]
 a, b = marks[-12], marks[-11]          # one step well inside the timed region (field_fwd to field_fwd)
 t0 = rows[a][0]
 busy = {}
