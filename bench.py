@@ -430,7 +430,10 @@ def main():
     if rank == 0 and not use_dist and not args.no_neus:
         extra["neus"] = neus_leg()
     if rank == 0:
-        wl = ("Instant-NGP lego config (projects/ngp/configs/ngp_base.py hyper-parameters: aabb_scale 1, L=16, T=2^19, F=2, fp32 table + fp32 field network, const_dt=True, 2^18-sample batches), "
+        exact = os.environ.get("NGP_FIELD32_FWD", "split")[:1] in ("m", "0") and os.environ.get("NGP_FIELD32_BWD", "3") != "3"
+        field = ("fp32 field network on fp32 MFMAs" if exact else
+                 "fp32 field network (fp32-accurate products from split fp16 operands on the fp16 matrix cores: 2e-7 of the largest magnitude vs fp64 in forward and gradients, profiles/r03_split_accuracy.md)")
+        wl = (f"Instant-NGP lego config (projects/ngp/configs/ngp_base.py hyper-parameters: aabb_scale 1, L=16, T=2^19, F=2, fp32 table + {field}, const_dt=True, 2^18-sample batches), "
               if lego else "Instant-NGP fox config (ngp_fox.py hyper-parameters: aabb_scale 4, L=16, T=2^19, F=2, fp16 fused MLP, const_dt=False, 2^18-sample batches), ")
         line = {"metric": "training iters/s", "value": round((world if args.scaling == "weak" else 1) * args.steps / dt, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16" if fp16 else "f32",
