@@ -1,10 +1,10 @@
-// Forward of the fp32 field network (NGPNetworks.execute_ / .density without cfg.fp16: models/networks/ngp_network.py:57-67, 77-89 - what ngp_base.py runs) on the
-// fp16 matrix cores at fp32 accuracy: split operands, three MFMAs per product sum (field_split.h).  Same "transposed" register-resident formulation as
+// The fp32 field network (NGPNetworks.execute_ / .density without cfg.fp16: models/networks/ngp_network.py:57-67, 77-89 - what ngp_base.py runs), forward AND backward,
+// on the fp16 matrix cores at fp32 accuracy: split operands, three MFMAs per product sum (field_split.h).  Same "transposed" register-resident formulation as
 // field_mlp.hip (weights = A operand from pre-permuted LDS fragments, 16 samples of a wave tile = B columns, a layer's C fragment is the next layer's B fragment),
-// fp32 features in, fp32 outputs out; between layers the fp32 accumulator is ReLU'd and split again in registers.
-// Replaces k_field32_fwd (v_mfma_f32_16x16x4_f32, 52 us per 2^18-sample batch at 0.58 of the fp32 MFMA peak) in ngp_field32_fwd / ngp_density32_fwd;
-// NGP_FIELD32_FWD=mfma32 selects the exact-product kernel again.  The backward kernel (field32.hip) is unchanged and recomputes its forward with fp32 MFMAs: the
-// two forwards agree to ~3e-7 of the output scale (tests/test_hip_parity.py::test_field32_split_forward...).
+// fp32 features / gradients in, fp32 outputs out; between layers the fp32 accumulator is ReLU'd (masked) and split again in registers.
+// Default kernels of ngp_field32_fwd / ngp_density32_fwd / ngp_field32_bwd since round 3 (forward 55 -> 31 us, backward 139 -> 109 us per 2^18-sample batch); the
+// exact-product kernels of field32.hip (v_mfma_f32_16x16x4_f32) stay selectable: NGP_FIELD32_FWD=mfma32, NGP_FIELD32_BWD=2.  Against an fp64 evaluation both pairs
+// are fp32-accurate in the forward (2.2e-7 of the output scale) and the split pair is the closer one in the gradients (profiles/r03_split_accuracy.md).
 #include "ngp_common.h"
 #include "field_split.h"
 
@@ -432,7 +432,10 @@ int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layou
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_split<L, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd(split): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
 	NGP_LAUNCH((k_field32_bwd_split<L, P>), grid, block, shmem, s, n, feat, dir, dir_stride, p, dout, dfeat, slabs, n_valid, am); } while (0)
-	static const int probe = [] { const char *e = getenv("NGP_SPLIT_PROBE"); return e ? atoi(e) : 0; }();
+	static const int probe = [] {
+		const char *e = getenv("NGP_SPLIT_PROBE"); const int v = e ? atoi(e) : 0;
+		if (v) fprintf(stderr, "libngp_hip: NGP_SPLIT_PROBE=%d - timing probe of the split backward: parts of the kernel are compiled out, ITS RESULTS ARE WRONG\n", v);
+		return v; }();
 #define GO(L) do { if (probe == 1) GOP(L, 1); else if (probe == 2) GOP(L, 2); else if (probe == 3) GOP(L, 3); else if (probe == 4) GOP(L, 4); else GOP(L, 0); } while (0)
 	if (layout == NGP_LAYOUT_SOA) GO(NGP_LAYOUT_SOA); else GO(NGP_LAYOUT_AOS);
 #undef GO
