@@ -27,6 +27,17 @@ def jt_norm(x, dim=-1, keepdim=False, eps=1e-6):
     return x.square().sum(dim, keepdim=keepdim).clamp_min(eps).sqrt()
 
 
+def jt_linear(in_features, out_features):
+    """nn.Linear with Jittor's default initialisation (jittor.nn.Linear: weight = init.invariant_uniform -> U(+-sqrt(3 / fan_in)), bias = U(+-1 / sqrt(fan_in))) instead of
+    torch's kaiming-uniform default, which is sqrt(3) times narrower in the weights.  Jittor is an external dependency of the reference: restated from its published
+    source, parity unpinned (same note as network.py:invariant_uniform)."""
+    lin = nn.Linear(in_features, out_features)
+    with torch.no_grad():
+        lin.weight.uniform_(-math.sqrt(3.0 / in_features), math.sqrt(3.0 / in_features))
+        lin.bias.uniform_(-1.0 / math.sqrt(in_features), 1.0 / math.sqrt(in_features))
+    return lin
+
+
 def _encoder(cfg_enc):
     """the reference builds an encoder only when multires > 0 (neus_network.py:31-35, 131-135, 188-194); a hash encoder has no multires and is always built"""
     if cfg_enc is None:
@@ -60,7 +71,7 @@ class SDFNetwork(nn.Module):
         embedded = self.embed_fn_fine is not None
         for l in range(self.num_layers - 1):
             out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
-            lin = nn.Linear(dims[l], out_dim)
+            lin = jt_linear(dims[l], out_dim)
             if geometric_init:                                   # neus_network.py:49-68: the network starts as the SDF of a sphere of radius `bias`
                 with torch.no_grad():
                     if l == self.num_layers - 2:
@@ -135,7 +146,7 @@ class RenderingNetwork(nn.Module):
             dims[0] += self.embedview_fn.out_dim - 3
         self.num_layers = len(dims)
         for l in range(self.num_layers - 1):
-            setattr(self, "lin" + str(l), nn.Linear(dims[l], dims[l + 1]))
+            setattr(self, "lin" + str(l), jt_linear(dims[l], dims[l + 1]))
         self.relu = nn.ReLU()
         self.to(self.cfg.device or "cuda")
 
@@ -167,14 +178,14 @@ class NeRF(nn.Module):
         self.input_ch_view = self.embed_fn_view.out_dim if self.embed_fn_view is not None else 3
         self.skips = list(skips)
         self.use_viewdirs = use_viewdirs
-        self.pts_linears = nn.ModuleList([nn.Linear(self.input_ch, W)] + [nn.Linear(W + self.input_ch, W) if i in self.skips else nn.Linear(W, W) for i in range(D - 1)])
-        self.views_linears = nn.ModuleList([nn.Linear(self.input_ch_view + W, W // 2)])
+        self.pts_linears = nn.ModuleList([jt_linear(self.input_ch, W)] + [jt_linear(W + self.input_ch, W) if i in self.skips else jt_linear(W, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([jt_linear(self.input_ch_view + W, W // 2)])
         if use_viewdirs:
-            self.feature_linear = nn.Linear(W, W)
-            self.alpha_linear = nn.Linear(W, 1)
-            self.rgb_linear = nn.Linear(W // 2, 3)
+            self.feature_linear = jt_linear(W, W)
+            self.alpha_linear = jt_linear(W, 1)
+            self.rgb_linear = jt_linear(W // 2, 3)
         else:
-            self.output_linear = nn.Linear(W, output_ch)
+            self.output_linear = jt_linear(W, output_ch)
         self.to(self.cfg.device or "cuda")
 
     def forward(self, input_pts, input_views):

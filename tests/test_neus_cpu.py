@@ -91,6 +91,12 @@ def test_neus_networks_keys_init_and_double_backward(tmp_path):
     expect |= {f"nerf_outside.pts_linears.{l}.{p}" for l in range(3) for p in ("weight", "bias")}
     expect |= {f"nerf_outside.{m}.{p}" for m in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear") for p in ("weight", "bias")}
     assert keys == expect, keys ^ expect
+    # layers without a special initialisation carry Jittor's nn.Linear default: weights U(+-sqrt(3 / fan_in)), biases U(+-1 / sqrt(fan_in))
+    for lin in (net.color_network.lin1, net.nerf_outside.pts_linears[2], net.nerf_outside.feature_linear):
+        fan_in = lin.weight.shape[1]
+        w, b = lin.weight.detach(), lin.bias.detach()
+        assert float(w.abs().max()) <= (3.0 / fan_in) ** 0.5 + 1e-6 and abs(float(w.std()) - (1.0 / fan_in) ** 0.5) < 0.15 * (1.0 / fan_in) ** 0.5
+        assert float(b.abs().max()) <= (1.0 / fan_in) ** 0.5 + 1e-6
     sdf_net = net.sdf_network
     # shapes follow neus_network.py:22-47: the layer before the skip layer shrinks by the width of the embedded input (3 + 3*2*4 = 27)
     assert sdf_net.lin1.weight.shape == (128 - 27, 128) and sdf_net.lin2.weight.shape == (128, 128) and sdf_net.lin0.weight.shape == (128, 27) and sdf_net.lin4.weight.shape == (33, 128)
