@@ -264,3 +264,18 @@ def test_torch_hash_reference_of_the_gpu_tests_equals_the_c_oracle():
         (g,) = torch.autograd.grad(yr, x64, torch.tensor(v.astype(np.float64)))
         want = O.hash_encode_bwd_input(v, dydx)
         assert np.abs(g.numpy() - want).max() < 2e-6 * np.abs(want).max()
+
+
+def test_neus_golden_fixture_matches_the_checkers_that_minted_it():
+    """tests/golden/golden_neus_v1.npz (minted by tests/golden/make_golden_neus.py) against a fresh evaluation of the numpy restatement: guards the fixture the GPU tests
+    compare the HIP kernels with against drifting away from oracle/neus_oracle.py"""
+    from oracle import neus_oracle as NO
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_neus_v1.npz"))
+    for tag in ("bg", "nobg", "long"):
+        inp = {k[len(f"comp_{tag}_in_"):]: g[k].astype(np.float64) for k in g.files if k.startswith(f"comp_{tag}_in_")}
+        oc, ow, oa = NO.composite(inp["sdf"], inp["cos"], inp["dists"], float(g[f"comp_{tag}_inv_s"]), inp["color"], inp["inside"], inp.get("bg_alpha"), inp.get("bg_color"),
+                                  float(g[f"comp_{tag}_ratio"]))
+        assert np.allclose(oc, g[f"comp_{tag}_out_color"], atol=1e-12) and np.allclose(ow, g[f"comp_{tag}_out_weights"], atol=1e-12) and np.allclose(oa, g[f"comp_{tag}_out_alpha"], atol=1e-12)
+        assert np.all(np.isfinite(g[f"comp_{tag}_grad_sdf"])) and abs(float(g[f"comp_{tag}_grad_inv_s"])) > 0
+    for aabb in (1, 4):
+        assert g[f"hash2_s{aabb}_ddy"].shape == (128, 32) and len(g[f"hash2_s{aabb}_grid_idx"]) > 10000 and np.all(np.diff(g[f"hash2_s{aabb}_grid_idx"]) > 0)

@@ -285,3 +285,43 @@ def test_fused_and_torch_compositing_agree_inside_the_renderer(tmp_path):
                      runner.neus_network.deviation_network.variance.grad.clone(), runner.neus_network.nerf_outside.alpha_linear.weight.grad.clone()))
     for a, b in zip(*outs):
         assert float((a - b).abs().max()) < 2e-4 * float(a.abs().max()) + 1e-6, (float((a - b).abs().max()), float(a.abs().max()))
+
+
+def test_neus_kernels_against_the_committed_golden_fixture():
+    """the HIP compositing kernels and the second-order hash kernels against tests/golden/golden_neus_v1.npz (inputs + expected outputs, minted on the CPU by
+    tests/golden/make_golden_neus.py from the numpy restatement / fp64 autograd; same tolerances as the live comparisons above)"""
+    from jnerf_amd import neus_ops, ops
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_neus_v1.npz"))
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=DEV)
+    for tag in ("bg", "nobg", "long"):
+        inp = {k[len(f"comp_{tag}_in_"):]: t(g[k]) for k in g.files if k.startswith(f"comp_{tag}_in_")}
+        leaves = [k for k in ("sdf", "cos", "color", "bg_alpha", "bg_color") if k in inp]
+        for k in leaves:
+            inp[k].requires_grad_(True)
+        inv_s = torch.tensor(float(g[f"comp_{tag}_inv_s"]), dtype=torch.float32, device=DEV, requires_grad=True)
+        col, w, a, p, c = neus_ops.composite(inp["sdf"], inp["cos"], inp["dists"], inv_s, inp["color"], inp["inside"], inp.get("bg_alpha"), inp.get("bg_color"), float(g[f"comp_{tag}_ratio"]))
+        ((col * t(g[f"comp_{tag}_g_color"])).sum() + (w * t(g[f"comp_{tag}_g_weights"])).sum()).backward()
+        for got, name in ((col, "color"), (w, "weights"), (a, "alpha"), (p, "p"), (c, "c")):
+            want = g[f"comp_{tag}_out_{name}"]
+            assert np.abs(got.detach().cpu().numpy().astype(np.float64) - want).max() < 5e-5, (tag, name)
+        for k in leaves:
+            want = g[f"comp_{tag}_grad_{k}"]
+            assert np.abs(inp[k].grad.cpu().numpy().astype(np.float64) - want).max() < 2e-4 * np.abs(want).max() + 1e-6, (tag, k)
+        want = float(g[f"comp_{tag}_grad_inv_s"])
+        assert abs(float(inv_s.grad) - want) < 2e-4 * abs(want) + 1e-6, tag
+    for aabb in (1, 4):
+        lt, _, n_params = ops.level_table(aabb)
+        table = t((np.random.default_rng(int(g[f"hash2_s{aabb}_table_seed"])).normal(size=n_params) * 0.1).astype(np.float32))
+        x, v, u = t(g[f"hash2_s{aabb}_x"]), t(g[f"hash2_s{aabb}_v"]), t(g[f"hash2_s{aabb}_u"])
+        _, dy_dx = ops.hash_encode_fwd_dydx(x, table, lt)
+        want = g[f"hash2_s{aabb}_dLdx"]
+        assert np.abs(ops.hash_encode_bwd_input(v, dy_dx).cpu().numpy() - want).max() < 1e-4 * np.abs(want).max()
+        want = g[f"hash2_s{aabb}_ddy"]
+        assert np.abs(ops.hash_encode_bwd_input_bwd_dy(u, dy_dx).cpu().numpy() - want).max() < 1e-5 * np.abs(want).max()
+        grad = torch.zeros(n_params, dtype=torch.float32, device=DEV)
+        ops.hash_encode_bwd_input_bwd_grid(x, v, u, lt, grad)
+        idx, val = g[f"hash2_s{aabb}_grid_idx"], g[f"hash2_s{aabb}_grid_val"]
+        got = grad.cpu().numpy().astype(np.float64)
+        assert np.abs(got[idx] - val).max() < 2e-5 * np.abs(val).max()
+        got[idx] = 0.0
+        assert not got.any()                                   # nothing outside the entries the reference touches
