@@ -99,16 +99,56 @@ def marching_tetrahedra(u, threshold=0.0):
     return vertices, faces.astype(np.int64)
 
 
-def write_ply(path, vertices, triangles):
-    """binary little-endian PLY (what trimesh's export writes for a .ply path)"""
-    vertices = np.asarray(vertices, dtype="<f4")
+def write_ply(path, vertices, triangles, colors=None):
+    """binary little-endian PLY (what trimesh's export writes for a .ply path); `colors` uint8 [nv, 3] adds the uchar red / green / blue vertex properties that
+    tools/extract_mesh.py:145-156 writes through plyfile"""
     triangles = np.asarray(triangles, dtype="<i4")
-    header = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
-              "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % (len(vertices), len(triangles)))
+    fields = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")]
+    props = "property float x\nproperty float y\nproperty float z\n"
+    if colors is not None:
+        fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
+        props += "property uchar red\nproperty uchar green\nproperty uchar blue\n"
+    vert = np.empty(len(vertices), dtype=fields)
+    v32 = np.asarray(vertices, dtype="<f4").reshape(-1, 3)
+    vert["x"], vert["y"], vert["z"] = v32[:, 0], v32[:, 1], v32[:, 2]
+    if colors is not None:
+        c8 = np.asarray(colors, dtype=np.uint8).reshape(-1, 3)
+        assert len(c8) == len(v32), "one colour per vertex"
+        vert["red"], vert["green"], vert["blue"] = c8[:, 0], c8[:, 1], c8[:, 2]
+    header = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\n%selement face %d\nproperty list uchar int vertex_indices\nend_header\n"
+              % (len(vert), props, len(triangles)))
     rec = np.empty(len(triangles), dtype=[("n", "u1"), ("v", "<i4", 3)])
     rec["n"] = 3
     rec["v"] = triangles
     with open(path, "wb") as f:
         f.write(header.encode("ascii"))
-        f.write(vertices.tobytes())
+        f.write(vert.tobytes())
         f.write(rec.tobytes())
+
+
+def read_ply(path):
+    """reads back what write_ply wrote: (vertices f32 [nv, 3], triangles i32 [nt, 3], colours u8 [nv, 3] or None)"""
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"ply" and f.readline().strip() == b"format binary_little_endian 1.0"
+        n_vert = n_face = 0
+        vert_props = []
+        section = None
+        while True:
+            line = f.readline().decode("ascii").strip()
+            if line == "end_header":
+                break
+            words = line.split()
+            if words[0] == "element":
+                section = words[1]
+                if section == "vertex":
+                    n_vert = int(words[2])
+                elif section == "face":
+                    n_face = int(words[2])
+            elif words[0] == "property" and section == "vertex":
+                vert_props.append((words[2], {"float": "<f4", "uchar": "u1"}[words[1]]))
+        vert = np.frombuffer(f.read(n_vert * np.dtype(vert_props).itemsize), dtype=vert_props)
+        face = np.frombuffer(f.read(n_face * 13), dtype=[("n", "u1"), ("v", "<i4", 3)])
+    assert (face["n"] == 3).all()
+    xyz = np.stack([vert["x"], vert["y"], vert["z"]], -1)
+    rgb = np.stack([vert["red"], vert["green"], vert["blue"]], -1) if "red" in vert.dtype.names else None
+    return xyz, face["v"].copy(), rgb

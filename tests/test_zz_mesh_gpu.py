@@ -1,0 +1,40 @@
+"""tools/extract_mesh.py's pipeline on a field trained on the GPU.  WRITTEN AFTER round 3's GPU minutes were spent: the host logic is covered on the CPU
+(tests/test_mesh_cpu.py) but this file has not run on an MI355X yet, so it is marked xfail(strict=False) - an XPASS in the driver's round-end run is its first
+hardware evidence, a failure does not stop the suite.  Remove the marker once it has been seen to pass."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first GPU run of the mesh path happens outside the authoring session")]
+
+
+def _distance_to_scene(p):
+    """|signed distance| to the union of the four spheres of dataset.synthetic_field (their soft shells end at the radius)"""
+    c = p - 0.5
+    centres = np.array([[0.0, 0.0, 0.0], [0.18, 0.1, -0.05], [-0.15, 0.12, 0.1], [0.02, -0.2, 0.12]])
+    radii = np.array([0.16, 0.09, 0.08, 0.07])
+    return np.abs(np.min(np.linalg.norm(c[:, None, :] - centres[None], axis=-1) - radii[None], axis=-1))
+
+
+def test_mesh_of_a_trained_field(tmp_path):
+    from jnerf_amd.presets import ngp_cfg
+    from jnerf_amd.runner import Runner
+    from jnerf_amd.mesh import extract_mesh
+    from jnerf_amd.utils.isosurface import read_ply
+    torch.manual_seed(0)
+    ngp_cfg(n_images=8, W=96, H=96, target_batch_size=1 << 16, n_rays_per_batch=1024, fp16=False, aabb_scale=1, const_dt=True, log_dir=str(tmp_path))
+    r = Runner()
+    for i in range(400):
+        r.train_step(i)
+    r.drain()
+    verts, tris, colors = extract_mesh(r, resolution=128, save_dir=str(tmp_path), log=lambda *a: None)
+    assert len(tris) > 1000 and verts.min() >= 0.0 and verts.max() <= 1.0
+    off = _distance_to_scene(verts.astype(np.float64))
+    print(f"mesh of the trained stand-in: {len(verts)} vertices, {len(tris)} triangles; distance to the analytic surface: median {np.median(off):.4f}, "
+          f"95th percentile {np.percentile(off, 95):.4f}; colour std {colors.std():.1f}")
+    assert np.percentile(off, 95) < 0.04                  # 8 views, 400 steps: the density's 1.0 level hugs the shells within a few 128-lattice cells
+    assert colors.std() > 10.0                            # striped, differently coloured spheres - not one flat colour
+    cv, ct, cc = read_ply(os.path.join(tmp_path, "mesh-color.ply"))
+    assert len(cv) == len(verts) and len(ct) == len(tris) and (cc == colors).all()
+    assert os.path.getsize(os.path.join(tmp_path, "mesh-origin.ply")) > 0
