@@ -1,0 +1,182 @@
+"""TEST INFRASTRUCTURE ONLY - a torch-backed stand-in for the handful of Jittor calls the reference's PURE-PYTHON modules make, so that those modules (NeuS networks and
+renderer, FrequencyEncoder, EMA, ExpDecay, HuberLoss, camera_path ...) can be EXECUTED in the build container, where Jittor is not installed and cannot be, and their
+outputs committed as golden fixtures (tests/golden/make_golden_pyref.py).  Nothing of the product imports this package; nothing under `-m gpu`, smoke() or bench.py does.
+
+What this pins and what it does not: the fixtures come out of the reference's own Python source - its control flow, formulas, index arithmetic, argument order - run
+line by line; the tensor primitives underneath are torch's, with Jittor's semantics restated HERE where the two libraries differ (each such place is marked "jittor:"
+below and follows Jittor's published source, jittor >= 1.3.5 as pinned by the reference's setup.py:22; Jittor itself is an un-vendored dependency).  So a transcription
+error in jnerf_amd's restatement of those modules shows up as a mismatch; a misreading of a Jittor primitive would be shared by both sides and does not."""
+import math
+import numpy as np
+import torch
+
+float32, float16, int32, int64 = torch.float32, torch.float16, torch.int32, torch.int64
+flags = type("flags", (), {"use_cuda": 0})()
+
+
+class _VarMeta(type):
+    def __instancecheck__(cls, obj):
+        return isinstance(obj, torch.Tensor)
+
+
+class Var(metaclass=_VarMeta):
+    """jt.Var(data) builds a float32 variable out of a Python number / list; isinstance(x, jt.Var) is true for every tensor"""
+    def __new__(cls, data, dtype=None):
+        if isinstance(data, torch.Tensor):
+            return data
+        arr = np.asarray(data)
+        if dtype is None:
+            dtype = torch.float32 if arr.dtype.kind == "f" else (torch.int32 if arr.dtype.kind in "iu" else torch.bool)
+        return torch.tensor(arr, dtype=dtype)
+
+
+def array(data, dtype=None):
+    return Var(data, dtype)
+
+
+# ---- methods Jittor's Var has and torch.Tensor lacks (patched onto torch.Tensor in THIS process only: the fixture generator)
+def _safe_clip(self, lo, hi):
+    """jittor: Var.safe_clip - the value is clamped, the gradient passes through unchanged (jittor/__init__.py: `return self.maximum(lo).minimum(hi)` under a
+    stop-gradient correction: x + (clip(x) - x).stop_grad())"""
+    return self + (self.clamp(lo, hi) - self).detach()
+
+
+def _update(self, other):
+    with torch.no_grad():
+        self.copy_(other)
+    return self
+
+
+torch.Tensor.safe_clip = _safe_clip
+torch.Tensor.float16 = lambda self: self.half()
+torch.Tensor.float32 = lambda self: self.float()
+torch.Tensor.int32 = lambda self: self.to(torch.int32)
+torch.Tensor.copy = lambda self: self.detach().clone()
+torch.Tensor.update = _update
+torch.Tensor.stop_grad = lambda self: self.detach()
+torch.Tensor.sync = lambda self: self
+_orig_numpy = torch.Tensor.numpy
+torch.Tensor.numpy = lambda self, *a, **k: _orig_numpy(self.detach(), *a, **k)
+
+
+def _kd(kw):
+    """Jittor spells it `keepdims`, accepts `keepdim` too"""
+    return bool(kw.get("keepdims", kw.get("keepdim", False)))
+
+
+def concat(arr, dim=0):
+    return torch.cat(list(arr), dim)
+
+
+def stack(arr, dim=0):
+    return torch.stack(list(arr), dim)
+
+
+def linspace(start, end, steps):
+    return torch.linspace(float(start), float(end), int(steps))
+
+
+def arange(*a):
+    return torch.arange(*a)
+
+
+def ones(shape, dtype=torch.float32):
+    return torch.ones(list(shape), dtype=dtype)
+
+
+def zeros(shape, dtype=torch.float32):
+    return torch.zeros(list(shape), dtype=dtype)
+
+
+ones_like, zeros_like = torch.ones_like, torch.zeros_like
+sigmoid, exp, log, sin, cos, abs, sqrt, matmul = torch.sigmoid, torch.exp, torch.log, torch.sin, torch.cos, torch.abs, torch.sqrt, torch.matmul
+maximum = lambda a, b: torch.maximum(a, b if isinstance(b, torch.Tensor) else torch.as_tensor(b, dtype=a.dtype))
+minimum = lambda a, b: torch.minimum(a, b if isinstance(b, torch.Tensor) else torch.as_tensor(b, dtype=a.dtype))
+where = torch.where
+
+
+def ternary(cond, a, b):
+    return torch.where(cond, a, b)
+
+
+def rand(*shape):
+    """uniform [0, 1) from torch's global generator (the fixture generator seeds it; jnerf_amd draws the same shapes in the same order)"""
+    if len(shape) == 1 and isinstance(shape[0], (list, tuple)):
+        shape = shape[0]
+    return torch.rand(list(shape))
+
+
+def sum(x, dim=None, **kw):
+    return x.sum() if dim is None else x.sum(dim, keepdim=_kd(kw))
+
+
+def mean(x, dim=None, **kw):
+    return x.mean() if dim is None else x.mean(dim, keepdim=_kd(kw))
+
+
+def max(x, dim=None, **kw):
+    """jittor: a reduction over `dim` returns the values only"""
+    return x.max() if dim is None else x.max(dim, keepdim=_kd(kw)).values
+
+
+def min(x, dim=None, **kw):
+    return x.min() if dim is None else x.min(dim, keepdim=_kd(kw)).values
+
+
+def norm(x, p=2, dim=-1, keepdim=False, keepdims=False, eps=1e-30):
+    """jittor: misc.py norm, p == 2: `(x.sqr()).sum(dim, keepdims).maximum(eps).sqrt()` - eps floors the SUM OF SQUARES"""
+    assert p == 2
+    return (x * x).sum(dim, keepdim=bool(keepdim or keepdims)).clamp_min(eps).sqrt()
+
+
+def cumsum(x, dim=-1):
+    return torch.cumsum(x, dim)
+
+
+def cumprod(x, dim=-1):
+    """jittor: misc.py cumprod = exp(cumsum(log(x)))"""
+    return torch.exp(torch.cumsum(torch.log(x), dim))
+
+
+def gather(x, dim, index):
+    return torch.gather(x, dim, index.long())
+
+
+def argsort(x, dim=-1, descending=False):
+    """jittor: returns (index, sorted values)"""
+    values, index = torch.sort(x, dim=dim, descending=descending, stable=True)
+    return index, values
+
+
+def searchsorted(sorted_seq, values, right=False):
+    return torch.searchsorted(sorted_seq.contiguous(), values.contiguous(), right=right)
+
+
+def meshgrid(*tensors):
+    return torch.meshgrid(*tensors, indexing="ij")
+
+
+def flip(x, dim=0):
+    return torch.flip(x, [dim] if isinstance(dim, int) else list(dim))
+
+
+def grad(y, x, retain_graph=True):
+    """jittor: d sum(y) / d x.  (x has to be part of the graph: the fixture generator marks the ray tensors as requiring a gradient)"""
+    (g,) = torch.autograd.grad(y.sum(), x, create_graph=True, retain_graph=True)
+    return g
+
+
+no_grad = torch.no_grad
+
+
+def gc():
+    pass
+
+
+def sync_all(*a):
+    pass
+
+
+from . import nn                                             # noqa: E402
+from .nn import Module                                       # noqa: E402,F401
+Function = object

@@ -1,9 +1,14 @@
 """TEST INFRASTRUCTURE ONLY - numpy restatement of the NeuS render arithmetic (python/jnerf/models/samplers/neus_render/renderer.py), the checker for
 jnerf_amd/neus_renderer.py and the HIP compositing kernel (csrc/neus.hip).  Only tests/ may import this.
 
-PARITY UNPINNED: the reference's NeuS is Jittor Python (no compilable source, Jittor itself is not in /root/reference and not installed), so these functions restate the
-formulas line by line - each cites the lines it follows - and cannot be checked against the reference's own execution here.  Loops are explicit (per ray, per sample)
-so that nothing is shared with the vectorised torch / HIP implementations under test."""
+PINNED THROUGH A STAND-IN (since round 3): the reference's NeuS is Jittor Python and Jittor is neither in /root/reference nor installable, so the reference cannot
+run as it is.  Its renderer / network FILES are however executed, unmodified and from where they lie, over oracle/jt_shim (torch primitives with Jittor's semantics
+restated where the libraries differ) by tests/golden/make_golden_pyref.py, and tests/test_pyref_golden.py holds these functions (sample_pdf_det, composite) and
+jnerf_amd's renderer to the resulting vectors (tests/golden/golden_pyref_v1.npz; agreement: one fp32 ulp).  That checks every formula, index and ordering decision of the
+reference's source; what it cannot check is Jittor's own primitives (norm's eps, safe_clip's gradient, cumprod as exp-sum-log), which are restated from Jittor's
+published source in the stand-in's header - for those, parity remains unpinned.  Each function still cites the reference lines it follows.  Loops are explicit (per ray,
+per sample) so that nothing is shared with the vectorised torch / HIP implementations under test.
+"""
 import numpy as np
 
 

@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""Golden vectors out of the reference's PURE-PYTHON modules, executed in the build container (where /root/reference exists) over the torch-backed Jittor stand-in
+oracle/jt_shim (Jittor itself is not installed and cannot be): the reference's files are loaded from where they lie, nothing of them is copied.
+
+    python tests/golden/make_golden_pyref.py          ->  tests/golden/golden_pyref_v1.npz
+
+What runs (reference file -> what the fixture holds):
+  models/networks/neus_network.py + models/position_encoders/freq_encoder/freq_encoder.py
+        NeuS networks with their geometric initialisation: every parameter, SDF / feature / gradient / colour / background outputs on fixed points
+  models/samplers/neus_render/renderer.py
+        sample_pdf (det and random), NeuSRenderer.render on a ray batch - without and with perturbation, with and without the background model - every entry of the
+        returned dict, plus the gradients of a scalar of those outputs w.r.t. every network parameter (torch autograd through the REFERENCE's forward code, eikonal
+        term included: a double backward)
+  optims/ema.py, optims/expdecay.py, models/losses/huber_loss.py, dataset/camera_path.py
+        EMA.ema_step trajectories, ExpDecay's learning-rate sequence on the ngp_base.py schedule, HuberLoss values, path_spherical poses
+  dataset/dataset.py (+ dataset_util.py)
+        NerfDataset on a small transforms_*.json data set written by tests/golden/pyref_scene.py: transforms, metadata, focal lengths, aabb, image data,
+        generate_random_data on fixed pixel indices, generate_rays_total, generate_rays_with_pose - the latter two called the way runner.py:207-208,243 call this
+        family: (W, H) handed to the parameters named (H, W), which is what makes their pixel grid row-major for non-square images
+        (generate_rays_total_test is NOT executed: it calls jt.gather with an index of lower rank than its input, whose reindex semantics the stand-in does not restate)
+The consumer is tests/test_pyref_golden.py (CPU): jnerf_amd's modules on the same inputs / weights / seeds against these vectors."""
+import importlib.util
+import os
+import sys
+import types
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference/python/jnerf"
+sys.path.insert(0, os.path.join(ROOT, "oracle", "jt_shim"))
+sys.path.insert(0, ROOT)
+import torch                                                  # noqa: E402
+import jittor as jt                                           # noqa: E402  (the stand-in)
+from tests.golden import pyref_scene                          # noqa: E402
+
+# jittor: binary operators promote mixed dtypes (camera_path.py multiplies an integer matrix into a float one)
+_mm = torch.Tensor.__matmul__
+torch.Tensor.__matmul__ = lambda a, b: _mm(*(t.to(torch.promote_types(a.dtype, b.dtype)) for t in (a, b)))
+# jittor: Var.transpose(*axes) / fuse_transpose(axes) permute
+_tr = torch.Tensor.transpose
+torch.Tensor.transpose = lambda self, *a: self.permute(*a) if len(a) > 2 else _tr(self, *a)
+torch.Tensor.fuse_transpose = lambda self, axes: self.permute(*axes)
+# jittor: a Python list operand becomes a Var (dataset.py adds the offset list to a pose column)
+_add = torch.Tensor.__add__
+torch.Tensor.__add__ = lambda a, b: _add(a, torch.tensor(b, dtype=a.dtype) if isinstance(b, (list, tuple)) else b)
+jt.randperm = lambda n: torch.randperm(int(n))
+jt.normalize = lambda x, p=2, dim=1, eps=1e-30: x / jt.norm(x, p, dim, keepdim=True, eps=eps)       # jittor: misc.py normalize
+jt.pow = torch.pow
+
+
+# ------------------------------------------------------------------ the few jnerf.* names the reference modules import, as stand-ins (none of this is reference code)
+class AttrDict(dict):
+    """attribute access, missing keys are None (jnerf/utils/config.py's Config behaves like this)"""
+    def __getattr__(self, k):
+        v = self.get(k)
+        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
+
+
+class Registry:
+    def __init__(self):
+        self.m = {}
+
+    def register_module(self, name=None):
+        def deco(cls):
+            self.m[name or cls.__name__] = cls
+            return cls
+        return deco
+
+
+def build_from_cfg(cfg, registry, **kw):
+    if cfg is None:
+        return None
+    args = dict(cfg)
+    args.update(kw)
+    return registry.m[args.pop("type")](**args)
+
+
+CFG = AttrDict()
+REG = {n: Registry() for n in ("SAMPLERS", "NETWORKS", "ENCODERS", "OPTIMS", "LOSSES", "DATASETS")}
+
+
+def stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+stub("jnerf")
+stub("jnerf.utils")
+stub("jnerf.utils.config", get_cfg=lambda: CFG, init_cfg=lambda *a: None)
+stub("jnerf.utils.registry", build_from_cfg=build_from_cfg, **REG)
+stub("jnerf.ops")
+stub("jnerf.ops.code_ops")
+stub("jnerf.ops.code_ops.global_vars", global_headers="", proj_options={})
+stub("mcubes")
+stub("cv2")
+stub("jittor_utils")
+stub("jittor.dataset", Dataset=object)
+
+
+def _imread(path):
+    from PIL import Image
+    return np.asarray(Image.open(path))
+
+
+stub("imageio", imread=_imread, imwrite=None)
+
+
+def load(rel, name, package=None):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel), submodule_search_locations=None)
+    mod = importlib.util.module_from_spec(spec)
+    if package:
+        mod.__package__ = package
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def main():
+    assert os.path.isdir(REF), "run this in the build container: the reference tree is needed"
+    out = {}
+    load("models/position_encoders/freq_encoder/freq_encoder.py", "ref_freq_encoder")
+    net = load("models/networks/neus_network.py", "ref_neus_network")
+    ren = load("models/samplers/neus_render/renderer.py", "ref_neus_renderer")
+
+    # ---------------------------------------------------------------- NeuS
+    enc = pyref_scene.NEUS_ENCODERS
+    CFG.clear()
+    CFG.update(encoder=enc, fp16=False)
+    torch.manual_seed(1234)
+    neus = net.NeuS(**pyref_scene.NEUS_MODEL)
+    params = dict(neus.named_parameters())
+    for k, v in params.items():
+        out["neus.param." + k] = npy(v)
+    # the freshly initialised SDF network is IDR's sphere: keep its statistics too (the consumer checks its own initialisation against them)
+    pts = pyref_scene.neus_points()
+    x = torch.tensor(pts, requires_grad=True)
+    sdf_all = neus.sdf_network(x)
+    out["neus.points"] = pts
+    out["neus.sdf_out"] = npy(sdf_all)
+    out["neus.sdf_gradient"] = npy(neus.sdf_network.gradient(x))
+    dirs = pyref_scene.neus_dirs(len(pts))
+    out["neus.dirs"] = dirs
+    out["neus.color"] = npy(neus.color_network(x, neus.sdf_network.gradient(x), torch.tensor(dirs), sdf_all[:, 1:]))
+    p4 = np.concatenate([pts / 2.0, np.full((len(pts), 1), 0.5, np.float32)], -1).astype(np.float32)
+    a, c = neus.nerf_outside(torch.tensor(p4), torch.tensor(dirs))
+    out["neus.nerf_in"], out["neus.nerf_alpha"], out["neus.nerf_rgb"] = p4, npy(a), npy(c)
+    out["neus.inv_s"] = npy(neus.deviation_network(torch.zeros(1, 3)))
+
+    # sample_pdf
+    rng = np.random.default_rng(5)
+    bins = np.sort(rng.random((5, 9)).astype(np.float32) * 3.0, -1)
+    w = rng.random((5, 8)).astype(np.float32) ** 3
+    out["pdf.bins"], out["pdf.weights"] = bins, w
+    out["pdf.det"] = npy(ren.sample_pdf(torch.tensor(bins), torch.tensor(w), 6, det=True))
+    torch.manual_seed(77)
+    out["pdf.rand"] = npy(ren.sample_pdf(torch.tensor(bins), torch.tensor(w), 6, det=False))
+
+    # render: (perturb, n_outside, cos_anneal_ratio, background)
+    for tag, (perturb, n_outside, anneal, white) in pyref_scene.NEUS_RENDER_CASES.items():
+        # weights as leaves so that parameter gradients through the reference's forward exist
+        for v in params.values():
+            v.requires_grad_(True)
+        r = ren.NeuSRenderer(**dict(pyref_scene.NEUS_RENDERER, n_outside=n_outside, perturb=perturb))
+        r.set_neus_network(neus)
+        rays_o, rays_d, near, far = pyref_scene.neus_rays()
+        ro, rd = torch.tensor(rays_o, requires_grad=True), torch.tensor(rays_d, requires_grad=True)
+        torch.manual_seed(4321)
+        bg = torch.ones(1, 3) if white else None
+        res = r.render(ro, rd, torch.tensor(near), torch.tensor(far), background_rgb=bg, cos_anneal_ratio=anneal)
+        for k, v in res.items():
+            out[f"render.{tag}.{k}"] = npy(v).astype(np.float32) if npy(v).dtype != np.bool_ else npy(v)
+        scalar = (res["color_fine"] * torch.tensor(pyref_scene.NEUS_COLOR_PROBE)).sum() + 0.1 * res["gradient_error"] + 0.05 * res["weight_sum"].sum()
+        names = [k for k in params]
+        grads = torch.autograd.grad(scalar, [params[k] for k in names], allow_unused=True)
+        for k, g in zip(names, grads):
+            out[f"render.{tag}.grad.{k}"] = npy(g) if g is not None else np.zeros(params[k].shape, np.float32)
+        for v in params.values():
+            v.requires_grad_(False)
+
+    # ---------------------------------------------------------------- optimiser wrappers, loss, camera path
+    ema_mod = load("optims/ema.py", "ref_ema")
+    dec_mod = load("optims/expdecay.py", "ref_expdecay")
+    hub_mod = load("models/losses/huber_loss.py", "ref_huber")
+    cam_mod = load("dataset/camera_path.py", "ref_camera_path")
+    rng = np.random.default_rng(11)
+    p0 = [rng.normal(size=(7,)).astype(np.float32), rng.normal(size=(3, 2)).astype(np.float32)]
+    ps = [torch.tensor(p) for p in p0]
+    ema = ema_mod.EMA(ps, decay=0.95)
+    traj = []
+    for step in range(6):
+        for i, p in enumerate(ps):                           # the "optimiser" moves the parameters, then the EMA pulls them back
+            p.update(p + torch.tensor(pyref_scene.ema_delta(step, i, p.shape)))
+        ema.ema_step()
+        traj.append(np.concatenate([npy(p).reshape(-1) for p in ps]))
+    out["ema.p0"] = np.concatenate([p.reshape(-1) for p in p0])
+    out["ema.trajectory"] = np.stack(traj)
+
+    class Nested:
+        lr = 0.1
+
+        def step(self, loss=None):
+            pass
+    dec = dec_mod.ExpDecay(Nested(), decay_start=20, decay_interval=10, decay_base=0.33, decay_end=45)
+    lrs = []
+    for _ in range(70):
+        dec.step()
+        lrs.append(dec._nested_optimizer.lr)
+    out["expdecay.lrs"] = np.asarray(lrs, np.float64)
+    hub = hub_mod.HuberLoss(delta=0.1)
+    a, b = rng.random((64, 3)).astype(np.float32), rng.random((64, 3)).astype(np.float32)
+    b[:8] = a[:8] + np.float32(0.1) * np.sign(rng.normal(size=(8, 3))).astype(np.float32)      # |d| at the switch-over
+    out["huber.x"], out["huber.target"], out["huber.loss"] = a, b, npy(hub(torch.tensor(a), torch.tensor(b)))
+    out["camera_path.poses"] = np.stack([npy(p) for p in cam_mod.path_spherical(7)])
+
+    # ---------------------------------------------------------------- NerfDataset
+    stub("ref_dataset_pkg")
+    load("dataset/dataset_util.py", "ref_dataset_pkg.dataset_util", package="ref_dataset_pkg")
+    ds_mod = load("dataset/dataset.py", "ref_dataset_pkg.dataset", package="ref_dataset_pkg")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        pyref_scene.write_nerf_dataset(d)
+        for mode in ("train", "val", "test"):
+            torch.manual_seed(9)
+            ds = ds_mod.NerfDataset(d, batch_size=32, mode=mode, **pyref_scene.NERF_DATASET_ARGS)
+            pre = f"dataset.{mode}."
+            out[pre + "n_images"] = np.int64(ds.n_images)
+            out[pre + "resolution"] = np.asarray(ds.resolution, np.int64)
+            out[pre + "aabb"] = np.asarray([ds.aabb_scale, ds.aabb_range[0], ds.aabb_range[1]], np.float64)
+            out[pre + "transforms_gpu"] = npy(ds.transforms_gpu)
+            out[pre + "metadata"] = npy(ds.metadata)
+            out[pre + "focal_lengths"] = npy(ds.focal_lengths)
+            out[pre + "image_data"] = npy(ds.image_data).astype(np.float32)
+            if mode == "train":
+                idx = pyref_scene.pixel_indices(ds.n_images, ds.H, ds.W)
+                ids, ro, rd, rgb = ds.generate_random_data(torch.tensor(idx), len(idx))
+                out[pre + "index"], out[pre + "img_id"], out[pre + "rays_o"], out[pre + "rays_d"], out[pre + "rgb"] = idx, npy(ids), npy(ro), npy(rd), npy(rgb)
+                ro, rd = ds.generate_rays_total(1, ds.W, ds.H)              # (W, H) into the parameters named (H, W): how runner.py:207-208,243 call the siblings
+                out[pre + "total.rays_o"], out[pre + "total.rays_d"] = npy(ro), npy(rd)
+                pose = torch.tensor(pyref_scene.NOVEL_POSE)
+                ro, rd = ds.generate_rays_with_pose(pose, ds.W, ds.H)      # runner.py:243
+                out[pre + "pose.rays_o"], out[pre + "pose.rays_d"] = npy(ro), npy(rd)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_pyref_v1.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

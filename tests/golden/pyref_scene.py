@@ -1,0 +1,83 @@
+"""Inputs shared by tests/golden/make_golden_pyref.py (which runs the REFERENCE's Python modules on them) and tests/test_pyref_golden.py (which runs jnerf_amd's): small
+network shapes, fixed points / rays / pixel indices, and a tiny NeRF-synthetic-layout data set on disk.  Everything is a pure function of constants and seeded numpy
+generators, so both sides see identical bits."""
+import json
+import os
+import numpy as np
+
+NEUS_ENCODERS = dict(nerf_pos_encoder=dict(type="FrequencyEncoder", multires=4, input_dims=4), nerf_dir_encoder=dict(type="FrequencyEncoder", multires=2, input_dims=3),
+                     sdf_encoder=dict(type="FrequencyEncoder", multires=4, input_dims=3), rendering_encoder=dict(type="FrequencyEncoder", multires=2, input_dims=3))
+NEUS_MODEL = dict(nerf_network=dict(D=3, W=24, output_ch=4, skips=[1], use_viewdirs=True),
+                  sdf_network=dict(d_out=17, d_hidden=32, n_layers=4, skip_in=[2], bias=0.5, scale=1.0, geometric_init=True, weight_norm=True),
+                  variance_network=dict(init_val=0.3),
+                  rendering_network=dict(d_feature=16, mode="idr", d_out=3, d_hidden=24, n_layers=2, weight_norm=True, squeeze_out=True))
+NEUS_RENDERER = dict(n_samples=8, n_importance=8, n_outside=4, up_sample_steps=2, perturb=1.0)
+# tag -> (perturb, n_outside, cos_anneal_ratio, white background)
+NEUS_RENDER_CASES = {"plain": (0.0, 0, 1.0, False), "perturbed_outside": (1.0, 4, 0.3, False), "white": (0.0, 0, 0.0, True)}
+NEUS_COLOR_PROBE = np.array([[0.7, -0.4, 1.1]], dtype=np.float32)
+
+
+def neus_points(n=24):
+    rng = np.random.default_rng(21)
+    return (rng.normal(size=(n, 3)) * 0.5).astype(np.float32)
+
+
+def neus_dirs(n):
+    rng = np.random.default_rng(22)
+    d = rng.normal(size=(n, 3))
+    return (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def neus_rays(n=6):
+    """rays towards the unit sphere from outside it, with near / far from the sphere as neus_dataset.near_far_from_sphere computes them"""
+    rng = np.random.default_rng(23)
+    o = rng.normal(size=(n, 3))
+    o = 2.5 * o / np.linalg.norm(o, axis=-1, keepdims=True)
+    target = rng.normal(size=(n, 3)) * 0.25
+    d = target - o
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    mid = -(o * d).sum(-1, keepdims=True)
+    return o.astype(np.float32), d.astype(np.float32), (mid - 1.0).astype(np.float32), (mid + 1.0).astype(np.float32)
+
+
+def ema_delta(step, i, shape):
+    return (np.random.default_rng(100 + 10 * step + i).normal(size=tuple(shape)) * 0.1).astype(np.float32)
+
+
+# ------------------------------------------------------------------ a NeRF-synthetic-layout data set (transforms_{train,val,test}.json + RGBA PNGs)
+NERF_DATASET_ARGS = dict(aabb_scale=2)
+NERF_W, NERF_H = 12, 10
+NOVEL_POSE = np.array([[0.6, -0.48, 0.64, 2.1], [0.8, 0.36, -0.48, -1.3], [0.0, 0.8, 0.6, 1.7]], dtype=np.float32)
+
+
+def _pose(rng):
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    m = np.eye(4)
+    m[:3, :3] = q
+    m[:3, 3] = rng.normal(size=3) * 2.0
+    return m
+
+
+def write_nerf_dataset(root):
+    from PIL import Image
+    rng = np.random.default_rng(31)
+    for split, n in (("train", 3), ("val", 11), ("test", 2)):
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        frames = []
+        for i in range(n):
+            img = rng.integers(0, 256, size=(NERF_H, NERF_W, 4), dtype=np.uint8)
+            Image.fromarray(img, "RGBA").save(os.path.join(root, split, "r_%d.png" % i))
+            frames.append({"file_path": "./%s/r_%d" % (split, i), "transform_matrix": _pose(rng).tolist()})
+        meta = {"camera_angle_x": 0.6911112070083618, "frames": frames}
+        if split == "test":
+            meta.update(cx=NERF_W / 2 + 0.75, cy=NERF_H / 2 - 0.5, k1=0.01)
+        with open(os.path.join(root, "transforms_%s.json" % split), "w") as f:
+            json.dump(meta, f)
+
+
+def pixel_indices(n_images, H, W):
+    rng = np.random.default_rng(41)
+    idx = rng.integers(0, n_images * H * W, size=40)
+    idx[:4] = [0, W - 1, H * W - 1, n_images * H * W - 1]
+    return idx.astype(np.int64)
