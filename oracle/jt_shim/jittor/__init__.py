@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 float32, float16, int32, int64 = torch.float32, torch.float16, torch.int32, torch.int64
-flags = type("flags", (), {"use_cuda": 0})()
+flags = type("flags", (), {"use_cuda": 0, "cuda_archs": [80]})()
 
 
 class _VarMeta(type):
@@ -80,12 +80,24 @@ def arange(*a):
     return torch.arange(*a)
 
 
+_DTYPES = {"float32": torch.float32, "float": torch.float32, "float16": torch.float16, "int32": torch.int32, "int": torch.int32, "int64": torch.int64, "uint8": torch.uint8,
+           "bool": torch.bool}
+
+
+def _shape(shape):
+    return [int(shape)] if isinstance(shape, (int, float)) else [int(v) for v in shape]
+
+
+def _dtype(dtype):
+    return _DTYPES[dtype] if isinstance(dtype, str) else dtype
+
+
 def ones(shape, dtype=torch.float32):
-    return torch.ones(list(shape), dtype=dtype)
+    return torch.ones(_shape(shape), dtype=_dtype(dtype))
 
 
 def zeros(shape, dtype=torch.float32):
-    return torch.zeros(list(shape), dtype=dtype)
+    return torch.zeros(_shape(shape), dtype=_dtype(dtype))
 
 
 ones_like, zeros_like = torch.ones_like, torch.zeros_like
@@ -169,6 +181,21 @@ def grad(y, x, retain_graph=True):
 no_grad = torch.no_grad
 
 
+def empty(shape, dtype=torch.float32):
+    return torch.zeros(_shape(shape), dtype=_dtype(dtype))
+
+
+class flag_scope:
+    def __init__(self, **kw):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def gc():
     pass
 
@@ -177,6 +204,6 @@ def sync_all(*a):
     pass
 
 
-from . import nn                                             # noqa: E402
+from . import nn, init                                       # noqa: E402
 from .nn import Module                                       # noqa: E402,F401
 Function = object

@@ -47,6 +47,26 @@ class ModuleList(Module, list):
             yield from m._walk(prefix + str(i) + ".")
 
 
+class Sequential(Module):
+    """jittor: nn.Sequential - indexable, modules applied in order"""
+    def __init__(self, *mods):
+        self.layers = list(mods)
+
+    def __getitem__(self, i):
+        return self.layers[i]
+
+    def __len__(self):
+        return len(self.layers)
+
+    def execute(self, x):
+        for m in self.layers:
+            x = m(x)
+        return x
+
+    def float16(self):
+        return self
+
+
 class Linear(Module):
     """jittor: nn.Linear - weight [out, in] ~ init.invariant_uniform = U(+-sqrt(3 / fan_in)), bias ~ U(+-1 / sqrt(fan_in))"""
     def __init__(self, in_features, out_features, bias=True):

@@ -13,6 +13,12 @@ What runs (reference file -> what the fixture holds):
         term included: a double backward)
   optims/ema.py, optims/expdecay.py, models/losses/huber_loss.py, dataset/camera_path.py
         EMA.ema_step trajectories, ExpDecay's learning-rate sequence on the ngp_base.py schedule, HuberLoss values, path_spherical poses
+  models/networks/ngp_network.py
+        NGPNetworks in the configuration ngp_base.py selects (fp16 unset -> the nn.Linear / ReLU chain), with the CUDA encoders replaced by stubs that return supplied
+        encodings: outputs [n, 4], .density, and autograd gradients w.r.t. the encodings and the five weight matrices; FMLP's flat `con_weights` for the same matrices
+  models/samplers/density_grid_sampler/density_grid_sampler.py
+        DensityGridSampler with its jt.code wrappers replaced by recorders: constructor arguments handed to the ops, the occupancy-refresh call sequence at several
+        training steps (sample counts, thresholds, model.density block sizes, ema step) and update_batch_rays' adaptive ray count - as a JSON trace
   dataset/dataset.py (+ dataset_util.py)
         NerfDataset on a small transforms_*.json data set written by tests/golden/pyref_scene.py: transforms, metadata, focal lengths, aabb, image data,
         generate_random_data on fixed pixel indices, generate_rays_total, generate_rays_with_pose - the latter two called the way runner.py:207-208,243 call this
@@ -120,6 +126,77 @@ def load(rel, name, package=None):
 
 def npy(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def sampler_traces():
+    """models/samplers/density_grid_sampler/density_grid_sampler.py with its eight jt.code wrappers replaced by recorders: which op is called when, with which scalar
+    arguments (occupancy-grid refresh schedule, sample counts, thresholds, block splitting of model.density, the adaptive ray count)."""
+    trace = []
+
+    def op(name, ret):
+        class Op:
+            def __init__(self, header, *a, **kw):
+                trace.append(["ctor", name, [_plain(v) for v in a], {k: _plain(v) for k, v in kw.items()}])
+
+            def execute(self, *a, **kw):
+                trace.append(["call", name, [_plain(v) for v in a]])
+                return ret(*a)
+            __call__ = execute
+        Op.__name__ = name
+        return Op
+
+    def _plain(v):
+        if isinstance(v, torch.Tensor):
+            return ["tensor", list(v.shape)] if v.numel() != 1 else ["scalar", float(v.reshape(-1)[0])]
+        if isinstance(v, (list, tuple)):
+            return [_plain(x) for x in v]
+        return v if isinstance(v, (int, float, str, bool, type(None))) else str(type(v).__name__)
+
+    pkg = "ref_dgs_pkg"
+    stub(pkg)
+    stub(pkg + ".ema_grid_samples_nerf", ema_grid_samples_nerf=op("ema_grid_samples_nerf", lambda tmp, grid, n: grid))
+    stub(pkg + ".generate_grid_samples_nerf_nonuniform",
+         generate_grid_samples_nerf_nonuniform=op("generate_grid_samples_nerf_nonuniform", lambda grid, n, step, casc, thresh: (torch.zeros(n, 3), torch.zeros(n, dtype=torch.int32))))
+    stub(pkg + ".splat_grid_samples_nerf_max_nearest_neighbor",
+         splat_grid_samples_nerf_max_nearest_neighbor=op("splat_grid_samples_nerf_max_nearest_neighbor", lambda idx, mlp, tmp, n: tmp))
+    stub(pkg + ".update_bitfield", update_bitfield=op("update_bitfield", lambda grid, mean, bits: (bits, mean)))
+    stub(pkg + ".mark_untrained_density_grid", mark_untrained_density_grid=op("mark_untrained_density_grid", lambda focal, xf, n: torch.zeros(n)))
+    stub(pkg + ".compacted_coord", CompactedCoord=op("CompactedCoord", lambda *a: None))
+    stub(pkg + ".ray_sampler", RaySampler=op("RaySampler", lambda *a: None))
+    stub(pkg + ".calc_rgb", CalcRgb=op("CalcRgb", lambda *a: None))
+    jt.init.zero_ = lambda x: x.zero_()
+    torch.Tensor.assign = lambda self, other: self.set_(other)
+    mod = load("models/samplers/density_grid_sampler/density_grid_sampler.py", pkg + ".density_grid_sampler", package=pkg)
+
+    class Model:
+        def density(self, pos):
+            trace.append(["call", "model.density", [int(pos.shape[0])]])
+            return torch.zeros(pos.shape[0], 1)
+
+    result = {}
+    for case, args in pyref_scene.SAMPLER_CASES.items():
+        del trace[:]
+
+        class Dataset:
+            n_images, resolution, aabb_scale = 7, [12, 10], args["aabb_scale"]
+            aabb_range = (0.5 - args["aabb_scale"] / 2, 0.5 + args["aabb_scale"] / 2)
+            focal_lengths, transforms_gpu, metadata, batch_size = torch.zeros(7, 2), torch.zeros(7, 4, 3), torch.zeros(7, 11), 4096
+        CFG.clear()
+        CFG.update(model_obj=Model(), dataset_obj=Dataset(), **pyref_scene.SAMPLER_CFG)
+        CFG["const_dt"] = args["const_dt"]
+        smp = mod.DensityGridSampler(update_den_freq=16, update_block_size=args["block"])
+        res = {"ctor": list(trace), "cascades": [smp.NERF_CASCADES, smp.max_cascade], "refresh": {}, "rays": []}
+        for step in pyref_scene.SAMPLER_STEPS:
+            del trace[:]
+            CFG["m_training_step"] = step
+            smp.update_density_grid()
+            res["refresh"][str(step)] = list(trace) + [["state", "density_grid_ema_step", int(smp.density_grid_ema_step.item())]]
+        for measured in pyref_scene.SAMPLER_MEASURED:
+            smp.measured_batch_size = torch.tensor([measured], dtype=torch.int32)
+            smp.update_batch_rays()
+            res["rays"].append([smp.n_rays_per_batch, smp.dataset.batch_size, int(smp.measured_batch_size.item())])
+        result[case] = res
+    return result
 
 
 def main():
@@ -246,6 +323,53 @@ def main():
                 pose = torch.tensor(pyref_scene.NOVEL_POSE)
                 ro, rd = ds.generate_rays_with_pose(pose, ds.W, ds.H)      # runner.py:243
                 out[pre + "pose.rays_o"], out[pre + "pose.rays_d"] = npy(ro), npy(rd)
+    # ---------------------------------------------------------------- NGPNetworks: the nn.Linear chain ngp_base.py runs (fp32), and FMLP's weight packing
+    stub("jnerf.ops.code_ops.fully_fused_mlp", FullyFusedMlp_weight=lambda weights: None)          # the binary tiny-cuda-nn call: never executed here
+
+    class StubEncoder(jt.nn.Module):
+        """stands in for HashEncoder / SHEncoder (CUDA ops): returns the encodings the fixture supplies"""
+        def __init__(self, out_dim):
+            self.out_dim, self.values = out_dim, None
+
+        def execute(self, x):
+            return self.values
+
+    REG["ENCODERS"].m["StubPos"] = lambda: StubEncoder(32)
+    REG["ENCODERS"].m["StubDir"] = lambda: StubEncoder(16)
+    ngp = load("models/networks/ngp_network.py", "ref_ngp_network")
+    CFG.clear()
+    CFG.update(encoder=dict(pos_encoder=dict(type="StubPos"), dir_encoder=dict(type="StubDir")), fp16=False)
+    net = ngp.NGPNetworks(use_fully=True)                         # fp16 unset: falls through to the nn.Linear branch (ngp_network.py:59-67)
+    mats = pyref_scene.ngp_weights()                              # (out, in) matrices, every value exactly representable in fp16
+    lins = [net.density_mlp[0], net.density_mlp[2], net.rgb_mlp[0], net.rgb_mlp[2], net.rgb_mlp[4]]
+    for lin, w in zip(lins, mats):
+        assert tuple(lin.weight.shape) == w.shape and lin.bias is None
+        lin.weight = torch.tensor(w, requires_grad=True)
+    feat, sh, dout = pyref_scene.ngp_inputs()
+    net.pos_encoder.values = torch.tensor(feat, requires_grad=True)
+    net.dir_encoder.values = torch.tensor(sh)
+    dummy = torch.zeros(len(feat), 3)
+    res = net(dummy, dummy)
+    out["ngp.feat"], out["ngp.sh"], out["ngp.dout"] = feat, sh, dout
+    out["ngp.out"] = npy(res)
+    out["ngp.density"] = npy(net.density(dummy))
+    out["ngp.density16"] = npy(net.density_mlp(net.pos_encoder.values))
+    grads = torch.autograd.grad((res * torch.tensor(dout)).sum(), [net.pos_encoder.values] + [l.weight for l in lins])
+    out["ngp.dfeat"] = npy(grads[0])
+    for i, g in enumerate(grads[1:]):
+        out[f"ngp.dW{i}"] = npy(g)
+    for i, w in enumerate(mats):
+        out[f"ngp.W{i}"] = w
+    # FMLP's flat parameter for the same matrices, through the reference's packing code (FMLP takes (in, out) matrices: ngp_network.py:16, 23-30)
+    pack_d = ngp.FMLP(None, weights=[torch.tensor(mats[0].T.copy()), torch.tensor(mats[1].T.copy())])
+    pack_c = ngp.FMLP(None, weights=[torch.tensor(m.T.copy()) for m in mats[2:]])
+    out["ngp.pack_density"], out["ngp.pack_rgb"] = npy(pack_d.con_weights).astype(np.float32), npy(pack_c.con_weights).astype(np.float32)
+    out["ngp.pack_out_dims"] = np.asarray([pack_d.output_shape1, pack_c.output_shape1], np.int64)
+
+    # ---------------------------------------------------------------- DensityGridSampler: the Python orchestration around the CUDA ops (which are stubs that record)
+    import json
+    out["sampler.traces"] = np.frombuffer(json.dumps(sampler_traces()).encode(), dtype=np.uint8)
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_pyref_v1.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

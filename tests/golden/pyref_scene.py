@@ -81,3 +81,28 @@ def pixel_indices(n_images, H, W):
     idx = rng.integers(0, n_images * H * W, size=40)
     idx[:4] = [0, W - 1, H * W - 1, n_images * H * W - 1]
     return idx.astype(np.int64)
+
+
+# ------------------------------------------------------------------ NGPNetworks (ngp_network.py): weights and encodings
+def ngp_weights():
+    """the five nn.Linear weights (out, in) of the density and colour networks; multiples of 2^-9 below 0.4 - exact in fp16, which FMLP's packing casts the last layer to"""
+    rng = np.random.default_rng(51)
+    shapes = [(64, 32), (16, 64), (64, 32), (64, 64), (3, 64)]
+    return [(rng.integers(-200, 201, size=s) / 512.0).astype(np.float32) for s in shapes]
+
+
+def ngp_inputs(n=40):
+    rng = np.random.default_rng(52)
+    feat = (rng.normal(size=(n, 32)) * 0.5).astype(np.float32)
+    sh = (rng.normal(size=(n, 16)) * 0.5).astype(np.float32)
+    dout = rng.normal(size=(n, 4)).astype(np.float32)
+    return feat, sh, dout
+
+
+# ------------------------------------------------------------------ DensityGridSampler orchestration (density_grid_sampler.py)
+SAMPLER_CFG = dict(n_rays_per_batch=4096, cone_angle_constant=0.00390625, fp16=False, near_distance=0.2, n_training_steps=16, target_batch_size=1 << 18,
+                   background_color=[0.0, 0.0, 0.0], m_training_step=0)
+SAMPLER_CASES = {"lego": dict(aabb_scale=1, const_dt=True, block=5000000), "fox": dict(aabb_scale=4, const_dt=False, block=1500000),
+                 "wide": dict(aabb_scale=32, const_dt=False, block=5000000)}
+SAMPLER_STEPS = [0, 16, 240, 256, 272]
+SAMPLER_MEASURED = [16 * 50000, 16 * 262144, 16 * 700000, 0, 16 * 3000, 123457]

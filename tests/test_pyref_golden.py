@@ -205,3 +205,104 @@ def test_nerf_dataset_host_state_and_oracle_ray_generation(mode, tmp_path):
     _, ro, rd = O.generate_rays(np.arange(H * W, dtype=np.int64), W, H, G[pre + "focal_lengths"][:1], np.ascontiguousarray(G[pre + "metadata"][:1, 4:6]), xf)
     np.testing.assert_allclose(ro, G[pre + "pose.rays_o"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(rd, G[pre + "pose.rays_d"][..., 0], rtol=2e-6, atol=2e-7)
+
+
+def test_ngp_network_wiring_and_weight_packing():
+    """models/networks/ngp_network.py executed with stub encoders: (i) FMLP's flat parameter is the (out, in) matrices row-major, the last one zero-padded to 16 rows;
+    (ii) the C oracle's field network - what every HIP field kernel is held to - on that flat parameter reproduces the reference's nn.Linear chain (concat order, the
+    density column that is passed on, no biases), forward and backward (torch autograd through the reference's forward source)."""
+    from oracle import oracle as O
+    W = [G[f"ngp.W{i}"] for i in range(5)]
+    pad = lambda w: np.concatenate([w, np.zeros((16 - w.shape[0], w.shape[1]), np.float32)], 0)
+    wd = np.concatenate([W[0].ravel(), W[1].ravel()])
+    wc = np.concatenate([W[2].ravel(), W[3].ravel(), pad(W[4]).ravel()])
+    np.testing.assert_array_equal(G["ngp.pack_density"], wd)
+    np.testing.assert_array_equal(G["ngp.pack_rgb"], wc)
+    assert wd.size == 3072 and wc.size == 7168 and list(G["ngp.pack_out_dims"]) == [16, 3]
+    feat, sh, dout = G["ngp.feat"], G["ngp.sh"], G["ngp.dout"]
+    np.testing.assert_allclose(O.field_fwd(feat, sh, wd, wc), G["ngp.out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(O.density_fwd(feat, wd), G["ngp.density"][:, 0], rtol=1e-5, atol=1e-6)
+    dfeat, dwd, dwc = O.field_bwd(feat, sh, wd, wc, dout)
+    np.testing.assert_allclose(dfeat, G["ngp.dfeat"], rtol=1e-4, atol=1e-5)
+    want_dwd = np.concatenate([G["ngp.dW0"].ravel(), G["ngp.dW1"].ravel()])
+    want_dwc = np.concatenate([G["ngp.dW2"].ravel(), G["ngp.dW3"].ravel(), pad(G["ngp.dW4"]).ravel()])
+    np.testing.assert_allclose(dwd, want_dwd, rtol=1e-4, atol=1e-4 * np.abs(want_dwd).max())
+    np.testing.assert_allclose(dwc, want_dwc, rtol=1e-4, atol=1e-4 * np.abs(want_dwc).max())
+    # our FMLP module (the fp16 configuration's parameter container): same flat layout, same function on its generic path
+    from jnerf_amd.network import FMLP
+    f = FMLP([32, 64, 16], device="cpu")
+    assert f.con_weights.shape == (3072,)
+    with torch.no_grad():
+        f.con_weights.copy_(torch.tensor(G["ngp.pack_density"]))
+    np.testing.assert_array_equal(f.layers()[0].detach().numpy(), W[0])
+    np.testing.assert_array_equal(f.layers()[1].detach().numpy(), W[1])
+    np.testing.assert_allclose(f(torch.tensor(feat)).detach().numpy(), G["ngp.density16"], rtol=1e-5, atol=1e-6)
+    c = FMLP([32, 64, 64, 3], device="cpu")
+    assert c.con_weights.shape == (7168,) and c.output_shape1 == 3
+    with torch.no_grad():
+        c.con_weights.copy_(torch.tensor(G["ngp.pack_rgb"]))
+    rgb_in = np.concatenate([G["ngp.density16"], sh], -1)
+    np.testing.assert_allclose(c(torch.tensor(rgb_in)).detach().numpy(), G["ngp.out"][:, :3], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", list(S.SAMPLER_CASES))
+def test_sampler_orchestration_follows_the_references_call_trace(case, monkeypatch):
+    """density_grid_sampler.py executed with recording stubs for its CUDA ops, against jnerf_amd.sampler.DensityGridSampler with recording stubs for the HIP ops:
+    cascade count, what the refresh at training steps 0 / 16 / 240 / 256 / 272 launches (sample counts, thresholds, cascades, model.density block sizes, ema step),
+    and the adaptive ray count of update_batch_rays."""
+    import json
+    from jnerf_amd import sampler as smod
+    ref = json.loads(bytes(G["sampler.traces"]).decode())[case]
+    args = S.SAMPLER_CASES[case]
+    trace = []
+
+    class Model(torch.nn.Module):
+        def density(self, pos):
+            trace.append(("model.density", int(pos.shape[0])))
+            return torch.zeros(pos.shape[0], 1)
+
+    class Dataset:
+        n_images, resolution, aabb_scale = 7, [12, 10], args["aabb_scale"]
+        aabb_range = (0.5 - args["aabb_scale"] / 2, 0.5 + args["aabb_scale"] / 2)
+        focal_lengths, transforms_gpu, metadata, batch_size = torch.zeros(7, 2), torch.zeros(7, 4, 3), torch.zeros(7, 11), 4096
+    ds = Dataset()
+    cfg = reset_cfg(device="cpu", model_obj=Model(), dataset_obj=ds, pipeline_buffer_sets=1, **dict(S.SAMPLER_CFG, const_dt=args["const_dt"]))
+    monkeypatch.setattr(smod.ops, "grid_mark_untrained", lambda n, focal, xf, W, H, grid=None: trace.append(("mark", int(n), int(W), int(H))))
+    monkeypatch.setattr(smod.ops, "grid_generate_samples",
+                        lambda n, rng, step, aabb, grid, n_cascades, thresh, pos=None, idx=None, morton_order=False:
+                        trace.append(("generate", int(n), int(step.item()), int(n_cascades), float(thresh), tuple(float(v) for v in aabb))))
+    monkeypatch.setattr(smod.ops, "grid_splat_max", lambda idx, d, tmp: trace.append(("splat", int(idx.shape[0]))))
+    monkeypatch.setattr(smod.ops, "grid_ema", lambda grid, tmp, decay=0.95: trace.append(("ema", int(grid.shape[0]), float(decay))))
+    monkeypatch.setattr(smod.ops, "grid_update_bitfield", lambda grid, cascades, mean=None, bitfield=None: trace.append(("bitfield", int(grid.shape[0]), int(cascades), int(bitfield.shape[0]))))
+    smp = smod.DensityGridSampler(update_den_freq=16, update_block_size=args["block"])
+    assert [smp.NERF_CASCADES, smp.max_cascade] == ref["cascades"]
+    ctor = {e[1]: e for e in ref["ctor"]}
+    # what the reference hands its op wrappers at construction is what ours keeps as attributes and passes per call
+    assert ctor["RaySampler"][2] == [smp.near_distance, smp.cone_angle_constant, list(smp.aabb_range), smp.n_rays_per_batch, smp.MAX_STEP]
+    assert ctor["CompactedCoord"][2][-1] == smp.target_batch_size and ctor["ema_grid_samples_nerf"][3]["decay"] == smp.density_grid_decay
+    assert smp.max_samples == ctor["RaySampler"][2][3] * ctor["RaySampler"][2][4]            # ray_sampler.py:15: 4096 * 1024 whatever the ray count becomes
+    for step in S.SAMPLER_STEPS:
+        del trace[:]
+        cfg.m_training_step = step
+        smp.update_density_grid()
+        want = ref["refresh"][str(step)]
+        w_mark = [e[2][2] for e in want if e[1] == "mark_untrained_density_grid"]
+        assert [t[1] for t in trace if t[0] == "mark"] == w_mark and (len(w_mark) == 1) == (step == 0)
+        assert all(t[2:] == (12, 10) for t in trace if t[0] == "mark")
+        # generate: (n, ema step, cascades, threshold); the reference launches the second call even for n = 0 (ours only advances the generator then)
+        w_gen = [(e[2][1], int(e[2][2][1]), e[2][3] + 1, e[2][4]) for e in want if e[1] == "generate_grid_samples_nerf_nonuniform" and e[2][1] > 0]
+        assert [t[1:5] for t in trace if t[0] == "generate"] == w_gen
+        assert all(t[5] == tuple(ctor["generate_grid_samples_nerf_nonuniform"][3]["aabb_range"]) for t in trace if t[0] == "generate")
+        assert [t[1] for t in trace if t[0] == "model.density"] == [e[2][0] for e in want if e[1] == "model.density"]
+        assert sum(t[1] for t in trace if t[0] == "splat") == sum(e[2][3] for e in want if e[1] == "splat_grid_samples_nerf_max_nearest_neighbor")
+        assert [t[1:3] for t in trace if t[0] == "ema"] == [(e[2][2], 0.95) for e in want if e[1] == "ema_grid_samples_nerf"]
+        w_bits = [(e[2][0][1][0], e[2][2][1][0]) for e in want if e[1] == "update_bitfield"]
+        assert [(t[1], t[3]) for t in trace if t[0] == "bitfield"] == w_bits and all(t[2] == ref["cascades"][0] for t in trace if t[0] == "bitfield")
+        assert int(smp.density_grid_ema_step.item()) == want[-1][2]
+        order = [t[0] for t in trace if t[0] in ("generate", "model.density", "ema", "bitfield")]
+        assert order == sorted(order, key=["generate", "model.density", "ema", "bitfield"].index)          # samples, then queries, then the grid update
+    for measured, want in zip(S.SAMPLER_MEASURED, ref["rays"]):
+        smp.measured_batch_size.fill_(measured)
+        smp.update_batch_rays()
+        smp.finish_batch_rays_update()
+        assert [smp.n_rays_per_batch, smp.dataset.batch_size, int(smp.measured_batch_size.item())] == want
