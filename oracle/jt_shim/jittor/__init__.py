@@ -182,6 +182,7 @@ no_grad = torch.no_grad
 
 
 def empty(shape, dtype=torch.float32):
+    """zeros, so that fixtures never depend on uninitialised memory (GridEncode's gigabyte of scratch stays untouched virtual memory either way)"""
     return torch.zeros(_shape(shape), dtype=_dtype(dtype))
 
 

@@ -16,6 +16,8 @@ What runs (reference file -> what the fixture holds):
   models/networks/ngp_network.py
         NGPNetworks in the configuration ngp_base.py selects (fp16 unset -> the nn.Linear / ReLU chain), with the CUDA encoders replaced by stubs that return supplied
         encodings: outputs [n, 4], .density, and autograd gradients w.r.t. the encodings and the five weight matrices; FMLP's flat `con_weights` for the same matrices
+  models/position_encoders/hash_encoder/grid_encode.py
+        GridEncode.__init__'s level table (offsets, parameter count, per-level scale) for aabb_scale 1 .. 128
   models/samplers/density_grid_sampler/density_grid_sampler.py
         DensityGridSampler with its jt.code wrappers replaced by recorders: constructor arguments handed to the ops, the occupancy-refresh call sequence at several
         training steps (sample counts, thresholds, model.density block sizes, ema step) and update_batch_rays' adaptive ray count - as a JSON trace
@@ -365,6 +367,15 @@ def main():
     pack_c = ngp.FMLP(None, weights=[torch.tensor(m.T.copy()) for m in mats[2:]])
     out["ngp.pack_density"], out["ngp.pack_rgb"] = npy(pack_d.con_weights).astype(np.float32), npy(pack_c.con_weights).astype(np.float32)
     out["ngp.pack_out_dims"] = np.asarray([pack_d.output_shape1, pack_c.output_shape1], np.int64)
+
+    # ---------------------------------------------------------------- GridEncode.__init__: the level table (grid_encode.py:17-40)
+    stub("jnerf.utils.common", enlarge=None)
+    ge = load("models/position_encoders/hash_encoder/grid_encode.py", "ref_grid_encode")
+    for aabb in pyref_scene.LEVEL_TABLE_AABBS:
+        g = ge.GridEncode("", aabb_scale=aabb, n_rays_per_batch=8, MAX_STEP=8)        # tiny scratch buffers; the table does not depend on them
+        out[f"levels.{aabb}.offsets"] = npy(g.m_hashmap_offsets_table).astype(np.int64)
+        out[f"levels.{aabb}.n_params"] = np.int64(g.m_n_params)
+        out[f"levels.{aabb}.per_level_scale"] = np.float64(g.m_per_level_scale)
 
     # ---------------------------------------------------------------- DensityGridSampler: the Python orchestration around the CUDA ops (which are stubs that record)
     import json

@@ -106,3 +106,5 @@ SAMPLER_CASES = {"lego": dict(aabb_scale=1, const_dt=True, block=5000000), "fox"
                  "wide": dict(aabb_scale=32, const_dt=False, block=5000000)}
 SAMPLER_STEPS = [0, 16, 240, 256, 272]
 SAMPLER_MEASURED = [16 * 50000, 16 * 262144, 16 * 700000, 0, 16 * 3000, 123457]
+
+LEVEL_TABLE_AABBS = [1, 2, 4, 8, 16, 32, 128]

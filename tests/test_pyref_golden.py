@@ -306,3 +306,20 @@ def test_sampler_orchestration_follows_the_references_call_trace(case, monkeypat
         smp.update_batch_rays()
         smp.finish_batch_rays_update()
         assert [smp.n_rays_per_batch, smp.dataset.batch_size, int(smp.measured_batch_size.item())] == want
+
+
+@pytest.mark.parametrize("aabb", S.LEVEL_TABLE_AABBS)
+def test_level_table_equals_grid_encode_init(aabb):
+    """grid_encode.py:17-40 executed: offsets and parameter count of the C oracle's and of jnerf_amd.ops' level table"""
+    from oracle import oracle as O
+    from jnerf_amd import ops
+    want = G[f"levels.{aabb}.offsets"]
+    for table, offsets, n_params in (O.level_table(aabb), ops.level_table(aabb)):
+        np.testing.assert_array_equal(offsets.astype(np.int64), want)
+        np.testing.assert_array_equal(table[:, 0].astype(np.int64), want[:16])
+        np.testing.assert_array_equal(table[:, 1].astype(np.int64), np.diff(want))
+        assert n_params == int(G[f"levels.{aabb}.n_params"])
+        # the kernels' fp32 per-level scale (HashEncode.h:149-151) follows the same geometric progression: res = ceil(16 s^l - 1) + 1
+        s = float(G[f"levels.{aabb}.per_level_scale"])
+        res = table[:, 2].astype(np.int64)
+        assert all(abs(int(res[l]) - (int(np.ceil(16.0 * s ** l - 1.0)) + 1)) <= 1 for l in range(16))
