@@ -16,6 +16,9 @@ What runs (reference file -> what the fixture holds):
   models/networks/ngp_network.py
         NGPNetworks in the configuration ngp_base.py selects (fp16 unset -> the nn.Linear / ReLU chain), with the CUDA encoders replaced by stubs that return supplied
         encodings: outputs [n, 4], .density, and autograd gradients w.r.t. the encodings and the five weight matrices; FMLP's flat `con_weights` for the same matrices
+  dataset/neus_dataset.py
+        NeuSDataset on tests/synth_dtu.py's scene (cv2.imread / decomposeProjectionMatrix replaced: see the comment at the stub): images, masks, intrinsics and their
+        inverses, poses, focal, object bounding box, gen_rays_at (two resolution levels), gen_random_rays_at, gen_rays_between, near_far_from_sphere
   models/position_encoders/hash_encoder/grid_encode.py
         GridEncode.__init__'s level table (offsets, parameter count, per-level scale) for aabb_scale 1 .. 128
   models/samplers/density_grid_sampler/density_grid_sampler.py
@@ -29,6 +32,7 @@ What runs (reference file -> what the fixture holds):
 The consumer is tests/test_pyref_golden.py (CPU): jnerf_amd's modules on the same inputs / weights / seeds against these vectors."""
 import importlib.util
 import os
+import tempfile
 import sys
 import types
 import numpy as np
@@ -302,7 +306,6 @@ def main():
     stub("ref_dataset_pkg")
     load("dataset/dataset_util.py", "ref_dataset_pkg.dataset_util", package="ref_dataset_pkg")
     ds_mod = load("dataset/dataset.py", "ref_dataset_pkg.dataset", package="ref_dataset_pkg")
-    import tempfile
     with tempfile.TemporaryDirectory() as d:
         pyref_scene.write_nerf_dataset(d)
         for mode in ("train", "val", "test"):
@@ -367,6 +370,52 @@ def main():
     pack_c = ngp.FMLP(None, weights=[torch.tensor(m.T.copy()) for m in mats[2:]])
     out["ngp.pack_density"], out["ngp.pack_rgb"] = npy(pack_d.con_weights).astype(np.float32), npy(pack_c.con_weights).astype(np.float32)
     out["ngp.pack_out_dims"] = np.asarray([pack_d.output_shape1, pack_c.output_shape1], np.int64)
+
+    # ---------------------------------------------------------------- NeuSDataset (dataset/neus_dataset.py) on the procedural DTU-layout scene of tests/synth_dtu.py
+    from tests import synth_dtu
+    from jnerf_amd.neus_dataset import decompose_projection
+
+    def cv_imread(path):
+        from PIL import Image
+        return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[..., ::-1])          # cv2.imread: BGR, uint8
+
+    # cv2 is not installed: imread through Pillow, decomposeProjectionMatrix through jnerf_amd's own RQ split (which tests/test_neus_cpu.py checks against closed forms) -
+    # for THAT function the fixture is circular; everything the reference computes from K, R, t onwards is its own code
+    stub("cv2", imread=cv_imread, decomposeProjectionMatrix=lambda P: decompose_projection(P))
+    jt.linalg = types.SimpleNamespace(inv=torch.linalg.inv)
+    jt.randint = lambda low, high, shape: torch.randint(low, high, list(shape))
+    _expand = torch.Tensor.expand
+
+    def jt_expand(self, *shape):
+        """jittor: Var.expand broadcasts BOTH ways - a target extent of 1 (or -1) keeps the variable's own extent (neus_dataset.py expands a [3,3] matrix to (bs,1,1))"""
+        shape = list(shape[0]) if len(shape) == 1 and isinstance(shape[0], (list, tuple, torch.Size)) else list(shape)
+        off = len(shape) - self.dim()
+        for i in range(self.dim()):
+            if shape[off + i] in (1, -1):
+                shape[off + i] = self.shape[i]
+        return _expand(self, *shape)
+    torch.Tensor.expand = jt_expand
+    nds = load("dataset/neus_dataset.py", "ref_neus_dataset")
+    with tempfile.TemporaryDirectory() as d:
+        synth_dtu.make_scene(d, **pyref_scene.NEUS_SCENE)
+        ds = nds.NeuSDataset(d, "cameras_sphere.npz", "cameras_sphere.npz")
+        pre = "neusds."
+        out[pre + "shape"] = np.asarray([ds.n_images, ds.H, ds.W], np.int64)
+        out[pre + "images"], out[pre + "masks"] = npy(ds.images).astype(np.float32), npy(ds.masks).astype(np.float32)
+        out[pre + "intrinsics_all"], out[pre + "intrinsics_all_inv"], out[pre + "pose_all"] = npy(ds.intrinsics_all), npy(ds.intrinsics_all_inv), npy(ds.pose_all)
+        out[pre + "focal"] = npy(ds.focal)
+        out[pre + "bbox"] = np.stack([ds.object_bbox_min, ds.object_bbox_max]).astype(np.float64)
+        for lvl in (1, 2):
+            ro, rv = ds.gen_rays_at(1, resolution_level=lvl)
+            out[pre + f"rays_at.{lvl}.o"], out[pre + f"rays_at.{lvl}.v"] = npy(ro), npy(rv)
+        torch.manual_seed(55)
+        out[pre + "random_rays"] = npy(ds.gen_random_rays_at(2, 20))
+        ro, rv = ds.gen_rays_between(0, 1, 0.3, resolution_level=2)
+        out[pre + "between.o"], out[pre + "between.v"] = npy(ro), npy(rv)
+        rays = torch.tensor(out[pre + "random_rays"])
+        near, far = ds.near_far_from_sphere(rays[:, :3], rays[:, 3:6])
+        out[pre + "near"], out[pre + "far"] = npy(near), npy(far)
+    torch.Tensor.expand = _expand
 
     # ---------------------------------------------------------------- GridEncode.__init__: the level table (grid_encode.py:17-40)
     stub("jnerf.utils.common", enlarge=None)

@@ -108,3 +108,4 @@ SAMPLER_STEPS = [0, 16, 240, 256, 272]
 SAMPLER_MEASURED = [16 * 50000, 16 * 262144, 16 * 700000, 0, 16 * 3000, 123457]
 
 LEVEL_TABLE_AABBS = [1, 2, 4, 8, 16, 32, 128]
+NEUS_SCENE = dict(n_images=3, W=16, H=12, seed=3)

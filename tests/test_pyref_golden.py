@@ -323,3 +323,35 @@ def test_level_table_equals_grid_encode_init(aabb):
         s = float(G[f"levels.{aabb}.per_level_scale"])
         res = table[:, 2].astype(np.int64)
         assert all(abs(int(res[l]) - (int(np.ceil(16.0 * s ** l - 1.0)) + 1)) <= 1 for l in range(16))
+
+
+def test_neus_dataset_against_the_references(tmp_path):
+    """dataset/neus_dataset.py executed on tests/synth_dtu.py's scene (cv2 replaced by Pillow and by our own projection split - circular for that one function, see
+    make_golden_pyref.py): what NeuSDataset holds and every ray generator"""
+    from tests import synth_dtu
+    from jnerf_amd.neus_dataset import NeuSDataset
+    synth_dtu.make_scene(str(tmp_path), **S.NEUS_SCENE)
+    reset_cfg(device="cpu")
+    ds = NeuSDataset(str(tmp_path), "cameras_sphere.npz", "cameras_sphere.npz")
+    pre = "neusds."
+    assert [ds.n_images, ds.H, ds.W] == list(G[pre + "shape"])
+    np.testing.assert_array_equal(ds.images.numpy(), G[pre + "images"])
+    np.testing.assert_array_equal(ds.masks.numpy(), G[pre + "masks"])
+    np.testing.assert_allclose(ds.intrinsics_all.numpy(), G[pre + "intrinsics_all"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ds.intrinsics_all_inv.numpy(), G[pre + "intrinsics_all_inv"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ds.pose_all.numpy(), G[pre + "pose_all"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(float(ds.focal), float(G[pre + "focal"]), rtol=1e-6)
+    np.testing.assert_allclose(np.stack([ds.object_bbox_min, ds.object_bbox_max]), G[pre + "bbox"], rtol=1e-6, atol=1e-6)
+    for lvl in (1, 2):
+        o, v = ds.gen_rays_at(1, resolution_level=lvl)
+        np.testing.assert_allclose(o.numpy(), G[pre + f"rays_at.{lvl}.o"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(v.numpy(), G[pre + f"rays_at.{lvl}.v"], rtol=1e-5, atol=1e-6)
+    torch.manual_seed(55)
+    rays = ds.gen_random_rays_at(2, 20)
+    np.testing.assert_allclose(rays.numpy(), G[pre + "random_rays"], rtol=1e-5, atol=1e-6)
+    o, v = ds.gen_rays_between(0, 1, 0.3, resolution_level=2)
+    np.testing.assert_allclose(o.numpy(), G[pre + "between.o"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v.numpy(), G[pre + "between.v"], rtol=1e-5, atol=2e-6)
+    near, far = ds.near_far_from_sphere(rays[:, :3], rays[:, 3:6])
+    np.testing.assert_allclose(near.numpy(), G[pre + "near"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(far.numpy(), G[pre + "far"], rtol=1e-5, atol=1e-6)
