@@ -19,6 +19,9 @@ What runs (reference file -> what the fixture holds):
   dataset/neus_dataset.py
         NeuSDataset on tests/synth_dtu.py's scene (cv2.imread / decomposeProjectionMatrix replaced: see the comment at the stub): images, masks, intrinsics and their
         inverses, poses, focal, object bounding box, gen_rays_at (two resolution levels), gen_random_rays_at, gen_rays_between, near_far_from_sphere
+  runner/neus_runner.py
+        NeuSRunner.train for six iterations end to end (data set -> rays -> renderer -> colour / eikonal / mask losses -> backward -> step, learning-rate and cosine
+        annealing schedules, image permutation) with a plain-SGD stand-in for Adam: loss and learning rate of every iteration, initial and final parameters
   models/position_encoders/hash_encoder/grid_encode.py
         GridEncode.__init__'s level table (offsets, parameter count, per-level scale) for aabb_scale 1 .. 128
   models/samplers/density_grid_sampler/density_grid_sampler.py
@@ -415,6 +418,59 @@ def main():
         rays = torch.tensor(out[pre + "random_rays"])
         near, far = ds.near_far_from_sphere(rays[:, :3], rays[:, 3:6])
         out[pre + "near"], out[pre + "far"] = npy(near), npy(far)
+    torch.Tensor.expand = _expand
+
+    # ---------------------------------------------------------------- NeuSRunner.train (runner/neus_runner.py): six iterations end to end with a plain-SGD optimiser
+    class PlainSGD:
+        """stands in for Adam (which lives inside Jittor): p -= lr * g.  Records loss and learning rate of every iteration."""
+        def __init__(self, params, lr, **kw):
+            self.params = [p.requires_grad_(True) for p in params]
+            self.param_groups = [{"lr": lr, "params": self.params}]
+            self.log = []
+
+        def zero_grad(self):
+            self.grads = None
+
+        def backward(self, loss):
+            self.grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+            self.log.append([float(loss), float(self.param_groups[0]["lr"])])
+
+        def step(self):
+            with torch.no_grad():
+                for p_, g_ in zip(self.params, self.grads):
+                    if g_ is not None:
+                        p_ -= self.param_groups[0]["lr"] * g_
+
+    REG["OPTIMS"].m["PlainSGD"] = PlainSGD
+    jt.nn.binary_cross_entropy_with_logits = lambda output, target: torch.nn.functional.binary_cross_entropy_with_logits(output, target)     # jittor: mean of the stable form
+    stub("trimesh")
+    stub("jnerf.dataset")
+    stub("jnerf.dataset.neus_dataset", NeuSDataset=nds.NeuSDataset)
+    stub("jnerf.models")
+    stub("jnerf.models.networks")
+    stub("jnerf.models.networks.neus_network", NeuS=sys.modules["ref_neus_network"].NeuS)
+    stub("jnerf.models.samplers")
+    stub("jnerf.models.samplers.neus_render")
+    stub("jnerf.models.samplers.neus_render.renderer", NeuSRenderer=ren.NeuSRenderer)
+    sys.modules["jnerf.utils.registry"].SCHEDULERS = Registry()
+    rmod = load("runner/neus_runner.py", "ref_neus_runner")
+    torch.Tensor.expand = jt_expand
+    for tag, over in pyref_scene.NEUS_RUN_CASES.items():
+        with tempfile.TemporaryDirectory() as d:
+            synth_dtu.make_scene(d, **pyref_scene.NEUS_SCENE)
+            CFG.clear()
+            CFG.update(pyref_scene.neus_run_cfg(d, **over))
+            torch.manual_seed(99)
+            run = rmod.NeuSRunner()
+            for k, v in run.neus_network.named_parameters():
+                out[f"neusrun.{tag}.init.{k}"] = npy(v).copy()
+            run.dataset.pose_all.requires_grad_(True)       # jt.grad(sdf, points) differentiates w.r.t. ANY variable; torch needs the points to hang off a leaf that requires a gradient
+            torch.manual_seed(777)
+            run.train()
+            out[f"neusrun.{tag}.log"] = np.asarray(run.optimizer.log, np.float64)
+            for k, v in run.neus_network.named_parameters():
+                out[f"neusrun.{tag}.final.{k}"] = npy(v).copy()
+            out[f"neusrun.{tag}.iter_step"] = np.int64(run.iter_step)
     torch.Tensor.expand = _expand
 
     # ---------------------------------------------------------------- GridEncode.__init__: the level table (grid_encode.py:17-40)

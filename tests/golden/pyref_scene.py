@@ -109,3 +109,15 @@ SAMPLER_MEASURED = [16 * 50000, 16 * 262144, 16 * 700000, 0, 16 * 3000, 123457]
 
 LEVEL_TABLE_AABBS = [1, 2, 4, 8, 16, 32, 128]
 NEUS_SCENE = dict(n_images=3, W=16, H=12, seed=3)
+
+
+# ------------------------------------------------------------------ NeuSRunner.train end to end (runner/neus_runner.py)
+NEUS_RUN_CASES = {"mask": dict(mask_weight=0.1, use_white_bkgd=False, n_outside=0), "womask": dict(mask_weight=0.0, use_white_bkgd=True, n_outside=4)}
+
+
+def neus_run_cfg(root, mask_weight, use_white_bkgd, n_outside):
+    return dict(dataset=dict(type="NeuSDataset", dataset_dir=root, render_cameras_name="cameras_sphere.npz", object_cameras_name="cameras_sphere.npz"),
+                encoder=NEUS_ENCODERS, model=dict(type="NeuS", **NEUS_MODEL), render=dict(type="NeuSRenderer", **dict(NEUS_RENDERER, n_outside=n_outside)),
+                optim=dict(type="PlainSGD", lr=0.02), base_exp_dir=os.path.join(root, "log"), learning_rate_alpha=0.05, end_iter=6, batch_size=16,
+                validate_resolution_level=4, warm_up_end=2, anneal_end=4, use_white_bkgd=use_white_bkgd, save_freq=1000, val_freq=1000, val_mesh_freq=1000,
+                report_freq=1000, igr_weight=0.1, mask_weight=mask_weight, fp16=False)

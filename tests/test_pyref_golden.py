@@ -355,3 +355,55 @@ def test_neus_dataset_against_the_references(tmp_path):
     near, far = ds.near_far_from_sphere(rays[:, :3], rays[:, 3:6])
     np.testing.assert_allclose(near.numpy(), G[pre + "near"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(far.numpy(), G[pre + "far"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", list(S.NEUS_RUN_CASES))
+def test_neus_runner_six_iterations_follow_the_references(tag, tmp_path):
+    """runner/neus_runner.py's train() executed end to end for six iterations (plain SGD standing in for Adam on both sides) against jnerf_amd.neus_runner.NeuSRunner from
+    the same initial parameters and generator seed: loss and learning rate of every iteration, final parameters.  Covers the ray batches (random pixels of a permuted
+    view order), near / far, the colour / eikonal / mask losses incl. the reference's clipped-opacity-as-logits BCE, the warm-up + cosine schedule and the annealing ratio."""
+    from tests import synth_dtu
+    from jnerf_amd.utils.registry import OPTIMS
+    from jnerf_amd.neus_runner import NeuSRunner
+
+    class PlainSGD:
+        def __init__(self, params, lr, **kw):
+            self.params = list(params)
+            self.param_groups = [{"lr": lr, "params": self.params}]
+            self.log = []
+
+        def zero_grad(self):
+            self.grads = None
+
+        def backward(self, loss):
+            self.grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+            self.log.append([float(loss.detach()), float(self.param_groups[0]["lr"])])
+
+        def step(self):
+            with torch.no_grad():
+                for p, g in zip(self.params, self.grads):
+                    if g is not None:
+                        p -= self.param_groups[0]["lr"] * g
+
+    synth_dtu.make_scene(str(tmp_path), **S.NEUS_SCENE)
+    reset_cfg(device="cpu", **S.neus_run_cfg(str(tmp_path), **S.NEUS_RUN_CASES[tag]))
+    OPTIMS._modules["PlainSGD"] = PlainSGD
+    try:
+        run = NeuSRunner()
+    finally:
+        del OPTIMS._modules["PlainSGD"]
+    run.renderer.fused_composite = False
+    init = {k[len(f"neusrun.{tag}.init."):]: torch.tensor(G[k]) for k in G.files if k.startswith(f"neusrun.{tag}.init.")}
+    run.neus_network.load_state_dict(init)
+    torch.manual_seed(777)
+    run.train()
+    log, want = np.asarray(run.optimizer.log), G[f"neusrun.{tag}.log"]
+    assert run.iter_step == int(G[f"neusrun.{tag}.iter_step"]) == 6 and log.shape == want.shape
+    np.testing.assert_allclose(log[:, 1], want[:, 1], rtol=1e-12)                         # learning rates: 0, lr/2, then the cosine
+    np.testing.assert_allclose(log[:, 0], want[:, 0], rtol=2e-5)                          # losses (iterations 2.. already depend on the updated parameters)
+    assert want[0, 1] == 0.0 and want[2, 1] == 0.02 and want[5, 1] < want[3, 1]
+    for k, v in run.neus_network.state_dict().items():
+        ref = G[f"neusrun.{tag}.final.{k}"]
+        np.testing.assert_allclose(v.numpy(), ref, rtol=1e-4, atol=2e-6 + 1e-5 * np.abs(ref).max(), err_msg=k)
+    moved = max(float(np.abs(G[f"neusrun.{tag}.final.{k}"] - G[f"neusrun.{tag}.init.{k}"]).max()) for k in init)
+    assert moved > 1e-3                                                                      # the six steps did change the parameters
