@@ -80,7 +80,7 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libngp_oracle" not in txt, f
-                assert "jt_shim" not in txt and "import jittor" not in txt and "from jittor" not in txt, f          # the Jittor stand-in is for the fixture generator only
+                assert "jt_shim" not in txt and not re.search(r"(import|from) jittor(?![_\w])", txt), f          # the Jittor stand-in is for the fixture generator only
     for f in ("bench.py", "__graft_entry__.py"):
         assert "jt_shim" not in open(os.path.join(ROOT, f)).read(), f
 
