@@ -16,6 +16,8 @@ What runs (reference file -> what the fixture holds):
   models/networks/ngp_network.py
         NGPNetworks in the configuration ngp_base.py selects (fp16 unset -> the nn.Linear / ReLU chain), with the CUDA encoders replaced by stubs that return supplied
         encodings: outputs [n, 4], .density, and autograd gradients w.r.t. the encodings and the five weight matrices; FMLP's flat `con_weights` for the same matrices
+  models/networks/ori_nerf_network.py
+        OriginNeRFNetworks (nerf_base.py's model) on the reference's FrequencyEncoders: parameters, outputs, .density
   dataset/neus_dataset.py
         NeuSDataset on tests/synth_dtu.py's scene (cv2.imread / decomposeProjectionMatrix replaced: see the comment at the stub): images, masks, intrinsics and their
         inverses, poses, focal, object bounding box, gen_rays_at (two resolution levels), gen_random_rays_at, gen_rays_between, near_far_from_sphere
@@ -373,6 +375,18 @@ def main():
     pack_c = ngp.FMLP(None, weights=[torch.tensor(m.T.copy()) for m in mats[2:]])
     out["ngp.pack_density"], out["ngp.pack_rgb"] = npy(pack_d.con_weights).astype(np.float32), npy(pack_c.con_weights).astype(np.float32)
     out["ngp.pack_out_dims"] = np.asarray([pack_d.output_shape1, pack_c.output_shape1], np.int64)
+
+    # ---------------------------------------------------------------- OriginNeRFNetworks (models/networks/ori_nerf_network.py; BASELINE config 0) on real FrequencyEncoders
+    ori = load("models/networks/ori_nerf_network.py", "ref_ori_nerf_network")
+    CFG.clear()
+    CFG.update(encoder=pyref_scene.ORI_ENCODERS, fp16=False)
+    torch.manual_seed(8)
+    onet = ori.OriginNeRFNetworks(**pyref_scene.ORI_MODEL)
+    for k, v in onet.named_parameters():
+        out["ori.param." + k] = npy(v)
+    opos, odir = torch.tensor(pyref_scene.neus_points(30) * 0.5 + 0.5), torch.tensor(pyref_scene.neus_dirs(30))
+    out["ori.pos"], out["ori.dir"] = npy(opos), npy(odir)
+    out["ori.out"], out["ori.density"] = npy(onet(opos, odir)), npy(onet.density(opos))
 
     # ---------------------------------------------------------------- NeuSDataset (dataset/neus_dataset.py) on the procedural DTU-layout scene of tests/synth_dtu.py
     from tests import synth_dtu

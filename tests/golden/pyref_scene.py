@@ -121,3 +121,6 @@ def neus_run_cfg(root, mask_weight, use_white_bkgd, n_outside):
                 optim=dict(type="PlainSGD", lr=0.02), base_exp_dir=os.path.join(root, "log"), learning_rate_alpha=0.05, end_iter=6, batch_size=16,
                 validate_resolution_level=4, warm_up_end=2, anneal_end=4, use_white_bkgd=use_white_bkgd, save_freq=1000, val_freq=1000, val_mesh_freq=1000,
                 report_freq=1000, igr_weight=0.1, mask_weight=mask_weight, fp16=False)
+
+ORI_ENCODERS = dict(pos_encoder=dict(type="FrequencyEncoder", multires=4), dir_encoder=dict(type="FrequencyEncoder", multires=2))
+ORI_MODEL = dict(D=4, W=32, skips=[2])

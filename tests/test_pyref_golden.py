@@ -407,3 +407,16 @@ def test_neus_runner_six_iterations_follow_the_references(tag, tmp_path):
         np.testing.assert_allclose(v.numpy(), ref, rtol=1e-4, atol=2e-6 + 1e-5 * np.abs(ref).max(), err_msg=k)
     moved = max(float(np.abs(G[f"neusrun.{tag}.final.{k}"] - G[f"neusrun.{tag}.init.{k}"]).max()) for k in init)
     assert moved > 1e-3                                                                      # the six steps did change the parameters
+
+
+def test_origin_nerf_network_equals_the_references():
+    """models/networks/ori_nerf_network.py (nerf_base.py's model) executed on the reference's FrequencyEncoders: names, shapes, outputs, .density"""
+    reset_cfg(device="cpu", encoder=S.ORI_ENCODERS)
+    from jnerf_amd.networks_ori import OriginNeRFNetworks
+    m = OriginNeRFNetworks(**S.ORI_MODEL)
+    sd = {k[len("ori.param."):]: torch.tensor(G[k]) for k in G.files if k.startswith("ori.param.")}
+    assert set(sd) == set(m.state_dict()) and all(tuple(sd[k].shape) == tuple(v.shape) for k, v in m.state_dict().items())
+    m.load_state_dict(sd)
+    pos, d = torch.tensor(G["ori.pos"]), torch.tensor(G["ori.dir"])
+    np.testing.assert_allclose(m(pos, d).detach().numpy(), G["ori.out"], **TOL)
+    np.testing.assert_allclose(m.density(pos).detach().numpy(), G["ori.density"], **TOL)
