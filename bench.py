@@ -439,7 +439,8 @@ def main():
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16" if fp16 else "f32",
                 "data": "synthetic", "loss": round(float(last_loss), 6),
                 "config": {"workload": wl + f"procedural scene {n_images}x{res}x{res} RGBA, random-init weights, {args.burn_in}-step burn-in before warm-up",
-                           "samples_per_iter_per_gpu": (1 << 18) // share, "parallelism": f"ray-batch dp{world} ({args.scaling} scaling)" if world > 1 else "single"},
+                           "samples_per_iter_per_gpu": (1 << 18) // share, "parallelism": f"ray-batch dp{world} ({args.scaling} scaling)" if world > 1 else "single",
+                           **({"dp_exchange": getattr(getattr(runner, "_fast", None), "dp_exchange", None)} if use_dist else {})},
                 "roofline": roof, "cpu_baseline": None if (args.no_cpu_baseline or use_dist) else cpu_baseline(aabb_scale, fp16, const_dt), "extra": extra}
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -43,6 +43,34 @@ def library_comm():
     return handle
 
 
+def library_comm_or_fallback():
+    """library_comm(), agreed on by ALL ranks: if creating the library's own communicator fails on any rank (a second RCCL instance beside torch's in one process is the
+    one thing a single-GPU box cannot exercise), every rank drops it and the step runs in two phases with torch.distributed's all-reduce of the gradients (same RCCL
+    backend) in between and a replicated sweep - said loudly on stderr, and visible as `dp_exchange` in bench.py's line.  `dp_require_library_comm = True` in the config turns
+    the fallback into the error it replaces."""
+    import sys
+    from .utils.config import get_cfg
+    err = None
+    try:
+        comm = library_comm()
+    except RuntimeError as e:
+        if get_cfg().dp_require_library_comm:
+            raise
+        comm, err = None, e
+    if dist.get_backend() != "nccl" or not torch.cuda.is_available():
+        return comm
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    if dist.get_world_size() > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if comm is not None:
+            destroy()
+        print(f"[jnerf_amd.dp] WARNING rank {dist.get_rank()}: the in-library RCCL communicator is unavailable ({err or 'failed on another rank'}); "
+              "the exchange step runs through torch.distributed around a phase-split step", file=sys.stderr, flush=True)
+        return None
+    return comm
+
+
 def destroy():
     global _comm
     if _comm is not None:

@@ -103,9 +103,10 @@ class FusedTrainStep:
         a.phase, a.comm, a.dp = L.PHASE_ALL, None, None
         self._dp_host_collective = False
         if dp.active():
-            comm = dp.library_comm()
+            comm = dp.library_comm_or_fallback()
+            self.dp_exchange = "in-library RCCL" if comm is not None else "torch.distributed all-reduce between the two phases of the step"
             if comm is None:
-                self._dp_host_collective = True           # gloo (tests): BACKWARD -> dist.all_reduce -> SWEEP, see _call_native
+                self._dp_host_collective = True           # gloo (tests) or a failed library communicator: BACKWARD -> dist.all_reduce -> SWEEP, see _call_native
                 if r.cfg.dp_host_sharded:
                     # (tests) the SHARDED sweep without RCCL: the sweep phase updates this rank's shard only and the host gathers the shards - the same plan and shard
                     # arithmetic as the in-library exchange, executed with more than one rank on a box that has one GPU
