@@ -55,6 +55,31 @@ torch.Tensor.copy = lambda self: self.detach().clone()
 torch.Tensor.update = _update
 torch.Tensor.stop_grad = lambda self: self.detach()
 torch.Tensor.sync = lambda self: self
+torch.Tensor.assign = lambda self, other: self.set_(other)            # jittor: Var.assign rebinds the variable's data (DensityGridSampler.enlarge)
+# jittor: binary operators promote mixed dtypes (camera_path.py multiplies an integer matrix into a float one)
+_mm = torch.Tensor.__matmul__
+torch.Tensor.__matmul__ = lambda a, b: _mm(*(t.to(torch.promote_types(a.dtype, b.dtype)) for t in (a, b)))
+# jittor: Var.transpose(*axes) / fuse_transpose(axes) permute
+_tr = torch.Tensor.transpose
+torch.Tensor.transpose = lambda self, *a: self.permute(*a) if len(a) > 2 else _tr(self, *a)
+torch.Tensor.fuse_transpose = lambda self, axes: self.permute(*axes)
+# jittor: a Python list operand becomes a Var (dataset.py adds the offset list to a pose column)
+_add = torch.Tensor.__add__
+torch.Tensor.__add__ = lambda a, b: _add(a, torch.tensor(b, dtype=a.dtype) if isinstance(b, (list, tuple)) else b)
+_expand = torch.Tensor.expand
+
+
+def _jt_expand(self, *shape):
+    """jittor: Var.expand broadcasts BOTH ways - a target extent of 1 (or -1) keeps the variable's own extent (neus_dataset.py expands a [3,3] matrix to (bs,1,1))"""
+    shape = list(shape[0]) if len(shape) == 1 and isinstance(shape[0], (list, tuple, torch.Size)) else list(shape)
+    off = len(shape) - self.dim()
+    for i in range(self.dim()):
+        if shape[off + i] in (1, -1):
+            shape[off + i] = self.shape[i]
+    return _expand(self, *shape)
+
+
+torch.Tensor.expand = _jt_expand
 _orig_numpy = torch.Tensor.numpy
 torch.Tensor.numpy = lambda self, *a, **k: _orig_numpy(self.detach(), *a, **k)
 
@@ -205,6 +230,62 @@ def sync_all(*a):
     pass
 
 
+def random(shape, dtype=torch.float32):
+    """jittor: jt.random = uniform [0, 1)"""
+    return torch.rand(_shape(shape), dtype=_dtype(dtype))
+
+
+def randperm(n):
+    return torch.randperm(int(n))
+
+
+def randint(low, high, shape):
+    return torch.randint(low, high, _shape(shape))
+
+
+def normalize(x, p=2, dim=1, eps=1e-30):
+    """jittor: misc.py normalize = x / x.norm(p, dim, keepdim, eps)"""
+    return x / norm(x, p, dim, keepdim=True, eps=eps)
+
+
+pow = torch.pow
+import types as _types                                        # noqa: E402
+linalg = _types.SimpleNamespace(inv=torch.linalg.inv)
+
+
+class Function:
+    """jittor: jt.Function - `execute` is the forward, `grad(*output gradients)` returns one gradient (or None) per argument of execute; calling the object records both"""
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *args):
+        fn = self
+
+        class _Bridge(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, *a):
+                out = fn.execute(*a)
+                ctx.n_args = len(a)
+                return tuple(out) if isinstance(out, (list, tuple)) else out
+
+            @staticmethod
+            def backward(ctx, *grads):
+                res = fn.grad(*grads)
+                res = list(res) if isinstance(res, (list, tuple)) else [res]
+                return tuple(res + [None] * (ctx.n_args - len(res)))
+        return _Bridge.apply(*args)
+
+
+from ._code import code                                      # noqa: E402
+
+
+class _Log:
+    def i(self, *a):
+        pass
+    v = w = e = i
+
+
+LOG = _Log()
+
 from . import nn, init                                       # noqa: E402
 from .nn import Module                                       # noqa: E402,F401
-Function = object

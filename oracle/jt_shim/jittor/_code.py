@@ -1,0 +1,234 @@
+"""jt.code for the stand-in: the reference's op wrappers build CUDA source as Python f-strings and hand it to Jittor's JIT.  Here the call is bound to oracle/_ref - the
+reference's OWN kernel headers compiled for the host (oracle/ref_shim; see oracle/ref.py) - by the name of the kernel the source launches, with the scalar constants the
+wrapper interpolated into the source read back out of it.  The wrappers themselves (ray_sampler.py, compacted_coord.py, calc_rgb.py, grid_encode.py, sh_encoder.py and the
+five density-grid ops) therefore run UNMODIFIED: their buffer allocation, trimming, detaching, saved tensors and return conventions are the reference's own.
+
+The global `jittor::rng` (pcg32{1337}, ops/code_ops/global_vars.py:13-16) lives here; the two launches followed by `rng.advance()` in the CUDA source are bound to
+oracle/_ref entry points that advance the state they are given.  fp32 only (what ngp_base.py runs)."""
+import ctypes as C
+import importlib.util
+import os
+import re
+import numpy as np
+import torch
+
+_REF = None
+RNG = None
+CALLS = []            # (kernel name, n) of every dispatched launch - the fixture generator reads it
+
+
+def _ref():
+    global _REF, RNG
+    if _REF is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "ref.py")
+        spec = importlib.util.spec_from_file_location("_jt_shim_ref", path)
+        _REF = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_REF)
+        _require(_REF.available(), "oracle/_ref is not built (python -c 'import __graft_entry__ as g; g.build()' in the build container)")
+        RNG = _REF.PCG32(1337)
+    return _REF
+
+
+def reset_rng(seed=1337):
+    global RNG
+    RNG = _ref().PCG32(seed)
+
+
+def _require(cond, msg):
+    """(the fixture generator runs under python -O - the reference's `assert var.dtype == 'float32'` compares a torch dtype with a string - so no bare asserts here)"""
+    if not cond:
+        raise RuntimeError("jt.code stand-in: " + msg)
+
+
+def _np(t):
+    return t.detach().contiguous().numpy()
+
+
+def _put(dst, arr):
+    """write a numpy result into the (pre-allocated) output variable, as the kernel would"""
+    src = torch.from_numpy(np.ascontiguousarray(arr))
+    if src.dtype != dst.dtype:
+        src = src.view(dst.dtype) if src.element_size() == dst.element_size() and not src.dtype.is_floating_point else src.to(dst.dtype)
+    with torch.no_grad():
+        dst.reshape(-1)[:src.numel()].copy_(src.reshape(-1))
+    return dst
+
+
+def _aabb(src):
+    v = re.findall(r"Constant\(\s*([-+0-9.eE]+)\s*\)", src)
+    _require(len(v) >= 2, "no bounding box in the source")
+    return float(v[0]), float(v[1])
+
+
+def _num(src, pattern, cast=float):
+    m = re.search(pattern, src)
+    _require(m, f"pattern {pattern!r} not found in the generated source")
+    return cast(m.group(1).rstrip("f"))
+
+
+def _const_dt(header):
+    return "clamp_(" not in header           # density_grid_sampler.py:107-115 injects one of two calc_dt bodies
+
+
+def _hash_scale(src):
+    return _num(src, r"std::log2\(\s*([-+0-9.eE]+)\s*\)")
+
+
+# ---------------------------------------------------------------------------------------------------------------- one handler per jt.code site
+def _kernel_grid(inputs, outputs, header, src):
+    offsets, x, grid = inputs
+    out, m_positions, m_encoded = outputs
+    n = x.shape[0]
+    if n == 0:
+        return
+    _require(grid.dtype == torch.float32, "fp32 only")
+    res = np.zeros((n, 32), np.float32)
+    xs = _np(x).astype(np.float32)
+    lib = _ref()._l("hash")
+    lib.ref_hash_fwd_f32(C.c_uint32(n), xs.ctypes.data_as(C.c_void_p), _np(grid).ctypes.data_as(C.c_void_p), _np(offsets).astype(np.uint32).ctypes.data_as(C.c_void_p),
+                         C.c_double(_hash_scale(src)), res.ctypes.data_as(C.c_void_p))
+    _put(out, res)
+    _put(m_positions, xs.T.copy())           # extract_position: positions as structure of arrays (only the backward launch below reads them back)
+    m_positions._n = n
+
+
+def _kernel_grid_backward(inputs, outputs, header, src):
+    m_positions, offsets, dy = inputs
+    grad, m_encoded = outputs
+    n = dy.shape[0]
+    with torch.no_grad():
+        grad.zero_()                         # cudaMemsetAsync(out0_p, 0, ...)
+    if n == 0:
+        return
+    xs = _np(m_positions)[:3 * n].reshape(3, n).T.copy()
+    g = np.zeros(grad.numel(), np.float32)
+    lib = _ref()._l("hash")
+    lib.ref_hash_bwd_f32(C.c_uint32(n), xs.ctypes.data_as(C.c_void_p), _np(dy).astype(np.float32).ctypes.data_as(C.c_void_p), _np(offsets).astype(np.uint32).ctypes.data_as(C.c_void_p),
+                         C.c_double(_hash_scale(src)), g.ctypes.data_as(C.c_void_p), C.c_uint64(grad.numel()))
+    _put(grad, g)
+
+
+def _kernel_sh(inputs, outputs, header, src):
+    _put(outputs[0], _ref().sh(_np(inputs[0])))
+
+
+def _rays_sampler(inputs, outputs, header, src):
+    rays_o, rays_d, bitfield, metadata, img_ids, xforms = inputs
+    coords, rays_index, numsteps, counter = outputs
+    r = _ref()
+    co, ns, cnt, idx = r.march(_np(rays_o), _np(rays_d), _np(bitfield), _aabb(src), RNG.st, coords.shape[0], _np(metadata), _np(img_ids), _np(xforms),
+                               cone_angle=_num(src, r"cone_angle_constant\s*=\s*([-+0-9.eE]+)"), near=_num(src, r"near_distance\s*=\s*([-+0-9.eE]+)"), const_dt=_const_dt(header))
+    _put(coords, co)
+    _put(rays_index, idx)
+    _put(numsteps, ns.view(np.int32))
+    _put(counter, cnt.view(np.int32))
+
+
+def _compacted_coord(inputs, outputs, header, src):
+    net, coords_in, numsteps = inputs
+    coords_out, numsteps_c, rays_counter, step_counter = outputs
+    co, nsc, cnt = _ref().compact(_np(net), _np(coords_in), _np(numsteps).view(np.uint32), coords_out.shape[0], _aabb(src))
+    _put(coords_out, co)
+    _put(numsteps_c, nsc.view(np.int32))
+    _put(step_counter, cnt.view(np.int32))
+
+
+def _compute_rgbs(inputs, outputs, header, src):
+    net, coords, numsteps, numsteps_c, bg = inputs
+    _put(outputs[0], _ref().rgb_fwd(_np(net), _np(coords), _np(numsteps).view(np.uint32), _np(numsteps_c).view(np.uint32), _np(bg), _aabb(src)))
+
+
+def _compute_rgbs_grad(inputs, outputs, header, src):
+    net, numsteps_c, coords, grad_x, rgb, mean = inputs
+    _put(outputs[0], _ref().rgb_bwd(_np(net), _np(coords), _np(numsteps_c).view(np.uint32), _np(grad_x), _np(rgb), float(mean.reshape(-1)[0]), _aabb(src)))
+
+
+def _compute_rgbs_inference(inputs, outputs, header, src):
+    net, coords, numsteps = inputs
+    rgb, alpha = _ref().rgb_inference(_np(net), _np(coords), _np(numsteps).view(np.uint32), _aabb(src))
+    _put(outputs[0], rgb)
+    _put(outputs[1], alpha)
+
+
+def _mark_untrained(inputs, outputs, header, src):
+    focal, xforms = inputs
+    m = re.search(r"image_resolution\{\s*(\d+)\s*,\s*(\d+)\s*\}", src)
+    _require(m and _num(src, r"int n_images\s*=\s*(\d+)", int) == focal.shape[0], "mark_untrained: image count")
+    _put(outputs[0], _ref().grid_mark(outputs[0].numel(), _np(focal), _np(xforms), int(m.group(1)), int(m.group(2))))
+
+
+def _generate_grid_samples(inputs, outputs, header, src):
+    grid, ema_step = inputs
+    pos, idx = outputs
+    n = pos.shape[0]
+    if n == 0:
+        RNG.advance()                        # the launch covers no element, the host-side rng.advance() behind it still runs
+    else:
+        p, i = _ref().grid_gen(n, RNG.st, int(ema_step.reshape(-1)[0]), _aabb(src), _np(grid), _num(src, r"uint32_t max_cascade\s*=\s*(\d+)", int) + 1,
+                               _num(src, r"float thresh\s*=\s*([-+0-9.eE]+)"))
+        _put(pos, p)
+        _put(idx, i.view(np.int32))
+
+
+def _splat(inputs, outputs, header, src):
+    idx, mlp_out = inputs
+    n = _num(src, r"n_density_grid_samples\s*=\s*(\d+)", int)
+    _require(_num(src, r"padded_output_width\s*=\s*(\d+)", int) == 1 and mlp_out.dtype == torch.float32, "splat: fp32 density column only")
+    if n:
+        tmp = _np(outputs[0])
+        _ref().grid_splat(_np(idx)[:n].view(np.uint32), _np(mlp_out).reshape(-1)[:n], tmp)
+        _put(outputs[0], tmp)
+
+
+def _ema(inputs, outputs, header, src):
+    grid = _np(outputs[0])
+    _ref().grid_ema(grid, _np(inputs[0]), _num(src, r"n_elements,\s*([-+0-9.eE]+)\s*,\s*density_grid"))
+    _put(outputs[0], grid)
+
+
+def _bitfield(inputs, outputs, header, src):
+    _require(_num(header, r"NERF_CASCADES\(\)\s*\{\s*return\s*(\d+)", int) == 5, "oracle/_ref is compiled for five cascades")
+    bits, mean = _ref().grid_bitfield(_np(inputs[0]), 5)
+    with torch.no_grad():
+        outputs[1].zero_()
+    _put(outputs[0], bits)
+    _put(outputs[1], mean)
+
+
+# longest names first: "kernel_grid_backward" contains "kernel_grid", "compute_rgbs_grad" contains "compute_rgbs"
+_HANDLERS = [("kernel_grid_backward", _kernel_grid_backward), ("kernel_grid", _kernel_grid), ("kernel_sh", _kernel_sh), ("rays_sampler", _rays_sampler),
+             ("compacted_coord", _compacted_coord), ("compute_rgbs_inference", _compute_rgbs_inference), ("compute_rgbs_grad", _compute_rgbs_grad), ("compute_rgbs", _compute_rgbs),
+             ("mark_untrained_density_grid", _mark_untrained), ("generate_grid_samples_nerf_nonuniform", _generate_grid_samples),
+             ("splat_grid_samples_nerf_max_nearest_neighbor", _splat), ("ema_grid_samples_nerf", _ema), ("grid_to_bitfield", _bitfield)]
+_DT = {"float32": torch.float32, "float": torch.float32, "float16": torch.float16, "int32": torch.int32, "int": torch.int32, "uint8": torch.uint8, int: torch.int32, float: torch.float32}
+
+
+def code(*args, **kw):
+    """jt.code(shape, dtype, inputs, ...) -> Var | jt.code(shapes=[..], dtypes=[..], inputs=[..], ...) -> [Var] | jt.code(inputs, outputs, ...) -> outputs"""
+    header, src = kw.get("cuda_header", ""), kw.get("cuda_src", "")
+    args = list(args)
+    inputs, outputs, single = kw.get("inputs"), kw.get("outputs"), False
+    is_vars = lambda v: isinstance(v, (list, tuple)) and len(v) > 0 and all(isinstance(t, torch.Tensor) for t in v)
+    if len(args) >= 2 and is_vars(args[0]) and is_vars(args[1]):                     # (inputs, outputs)
+        inputs, outputs = args[0], args[1]
+    elif outputs is None:
+        shapes = kw.get("shapes", args[0] if args else None)
+        dtypes = kw.get("dtypes", args[1] if len(args) > 1 else None)
+        if inputs is None:
+            inputs = args[2] if len(args) > 2 else []
+        single = not (isinstance(shapes, (list, tuple)) and len(shapes) > 0 and isinstance(shapes[0], (list, tuple)))
+        if single:
+            shapes, dtypes = [shapes], [dtypes]
+        outputs = [torch.zeros([int(v) for v in s], dtype=_DT.get(d, d)) for s, d in zip(shapes, dtypes)]
+    inputs, outputs = list(inputs or []), list(outputs)
+    launched = [name for name, _ in _HANDLERS if re.search(r"\b" + name + r"\b", src)]
+    if launched:
+        name = launched[0]
+        CALLS.append((name, int(inputs[0].shape[0]) if inputs and inputs[0].dim() else 0))
+        with torch.no_grad():
+            dict(_HANDLERS)[name]([t.detach() for t in inputs], outputs, header, src)
+        # (the two sources that end in `rng.advance()` - ray_sampler.py:61, generate_grid_samples...py:44 - are bound to oracle/_ref entry points that advance the state
+        #  they are handed, see oracle/ref_shim/ref_march.cpp:18 and ref_grid.cpp:22)
+    else:
+        _require("<<<" not in src and "linear_kernel" not in src, "a kernel the stand-in has no binding for")      # (global_vars.py's empty source defines the globals)
+    return outputs[0] if single else outputs

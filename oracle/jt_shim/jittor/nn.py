@@ -112,14 +112,61 @@ class init:
 
 
 class Optimizer:
-    """jittor: nn.Optimizer(params, lr) - param_groups is a list of dicts with "params"; a bare list of Vars becomes one group"""
+    """jittor: nn.Optimizer(params, lr) - param_groups is a list of dicts with "params"; a bare list of Vars becomes one group.  step(loss) differentiates the SUM of
+    `loss` w.r.t. the parameters (jt.grad of a non-scalar) before the update."""
     def __init__(self, params, lr, param_sync_iter=10000):
         self.lr = lr
         params = list(params)
         if params and not isinstance(params[0], dict):
             params = [{"params": params}]
         self.param_groups = params
+        for pg in self.param_groups:
+            pg["params"] = [p.requires_grad_(True) for p in pg["params"]]
         self.n_step = 0
 
     def zero_grad(self):
         pass
+
+    def pre_step(self, loss, retain_graph=False):
+        if loss is not None:
+            params = [p for pg in self.param_groups for p in pg["params"]]
+            grads = torch.autograd.grad(loss.sum(), params, allow_unused=True, retain_graph=retain_graph)
+            it = iter(grads)
+            for pg in self.param_groups:
+                pg["grads"] = [g if g is not None else torch.zeros_like(p) for p, g in zip(pg["params"], (next(it) for _ in pg["params"]))]
+        self.n_step += 1
+
+    def backward(self, loss, retain_graph=False):
+        self.pre_step(loss, retain_graph)
+        self.n_step -= 1
+
+    def state_dict(self):
+        return {"defaults": getattr(self, "defaults", {})}
+
+    def load_state_dict(self, sd):
+        pass
+
+
+class Adam(Optimizer):
+    """jittor: nn.Adam (restated from Jittor's optim code, NOT pinned - it lives inside Jittor): "values" is the second moment, "m" the first;
+    step_size = lr * sqrt(1 - b1^n) / (1 - b0^n);  p -= m * step_size / (sqrt(values) + eps)"""
+    def __init__(self, params, lr, eps=1e-8, betas=(0.9, 0.999), weight_decay=0):
+        super().__init__(params, lr)
+        self.eps, self.betas, self.weight_decay = eps, betas, weight_decay
+        for pg in self.param_groups:
+            pg["values"] = [torch.zeros_like(p) for p in pg["params"]]
+            pg["m"] = [torch.zeros_like(p) for p in pg["params"]]
+
+    def step(self, loss=None, retain_graph=False):
+        self.pre_step(loss, retain_graph)
+        n = float(self.n_step)
+        b0, b1 = self.betas
+        with torch.no_grad():
+            for pg in self.param_groups:
+                lr = pg.get("lr", self.lr)
+                for p, g, v, m in zip(pg["params"], pg["grads"], pg["values"], pg["m"]):
+                    g = p * self.weight_decay + g
+                    m.copy_(b0 * m + (1 - b0) * g)
+                    v.copy_(b1 * v + (1 - b1) * g * g)
+                    step_size = lr * math.sqrt(1 - b1 ** n) / (1 - b0 ** n)
+                    p.copy_(p - m * step_size / (torch.sqrt(v) + self.eps))

@@ -7,14 +7,20 @@
  * (paths relative to /root/reference/python/jnerf/).  It is pinned against the
  * reference's own kernel source compiled for the host (oracle/_ref, built by
  * oracle/ref_shim/Makefile) and against the committed fixtures in tests/golden/ —
- * see tests/test_oracle_vs_ref.py and tests/test_oracle_golden.py.
+ * see tests/test_oracle_vs_ref.py and tests/test_oracle_golden.py.  End to end it is
+ * pinned by tests/test_refrun_golden.py: 18 iterations of the reference's unmodified Python
+ * package (Runner.train over a Jittor stand-in, every CUDA launch bound to oracle/_ref;
+ * tests/golden/make_golden_refrun.py) are replayed through this file alone - losses to 1e-6
+ * up to the second occupancy refresh, identical sample counts and generator state.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library.  The product path (jnerf_amd/) never does.
  *
  * Parts with NO compilable source in the reference ("parity unpinned"):
  *   - the fully-fused MLP (binary-only tiny-cuda-nn object) -> restated from the
- *     fallback nn.Linear chain models/networks/ngp_network.py:59-67;
+ *     fallback nn.Linear chain models/networks/ngp_network.py:59-67 (that chain itself IS
+ *     executed against this file, forward and backward: tests/test_pyref_golden.py; what
+ *     stays unpinned is the fp16 rounding of the binary kernels);
  *   - Adam (inside Jittor, external)                         -> standard bias-corrected Adam.
  */
 #include <math.h>
@@ -665,8 +671,12 @@ EXPORT void orc_grid_ema(uint32_t n, float decay, float *grid, const float *grid
 /* update_bitfield.py:15-37 + op_header/update_bitfield.h:23-69; mean over cascade 0 only */
 EXPORT void orc_grid_update_bitfield(const float *grid, int cascades, float *mean /*[1]*/, uint8_t *bitfield) {
 	const uint32_t G3 = NERF_GRIDSIZE * NERF_GRIDSIZE * NERF_GRIDSIZE;
-	float s = 0.f;
-	for (uint32_t i = 0; i < G3; ++i) s += fmaxf(grid[i], 0.f) / (G3);
+	/* reduce_sum (update_bitfield.py:25-28) is a block-wise tree reduction on the GPU, accurate to ~1e-7.  A SERIAL fp32 sum of 2 M nearly equal terms is not (measured:
+	   0.7 % high on the first refresh of a training run, when every trained cell holds ~0.0017 - enough to put the threshold above every cell and empty the bitfield),
+	   so the restatement accumulates in double and rounds once. */
+	double acc = 0.0;
+	for (uint32_t i = 0; i < G3; ++i) acc += (double)(fmaxf(grid[i], 0.f) / (G3));
+	const float s = (float)acc;
 	mean[0] = s;
 	float thresh = 0.01f < s ? 0.01f : s;
 	for (uint32_t i = 0; i < G3 / 8 * (uint32_t)cascades; ++i) {

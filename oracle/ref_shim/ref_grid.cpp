@@ -41,9 +41,10 @@ EXP void ref_grid_ema(uint32_t n, float decay, float *grid, const float *tmp) { 
 // launcher, so reduce_sum is restated as what it computes: sum over cascade 0 of max(g,0)/128^3 (update_bitfield.py:25-28).
 EXP void ref_grid_bitfield(const float *grid, float *mean /*[1]*/, uint8_t *bitfield) {
 	const uint32_t n_elements = NERF_GRIDSIZE() * NERF_GRIDSIZE() * NERF_GRIDSIZE();
-	float s = 0.f;
-	for (uint32_t i = 0; i < n_elements; ++i) s += fmaxf(grid[i], 0.f) / (n_elements);
-	mean[0] = s;
+	// (double accumulator: the GPU's tree reduction is accurate to ~1e-7, a serial fp32 sum of 2 M nearly equal terms is off by up to 1 % - see oracle/ngp_oracle.c)
+	double acc = 0.0;
+	for (uint32_t i = 0; i < n_elements; ++i) acc += (double)(fmaxf(grid[i], 0.f) / (n_elements));
+	mean[0] = (float)acc;
 	cpu_linear(grid_to_bitfield, n_elements / 8 * NERF_CASCADES(), grid, bitfield, (const float *)mean);
 	for (uint32_t level = 1; level < NERF_CASCADES(); ++level)
 		cpu_linear(bitfield_max_pool, n_elements / 64, (const uint8_t *)(bitfield + grid_mip_offset(level - 1) / 8), bitfield + grid_mip_offset(level) / 8);

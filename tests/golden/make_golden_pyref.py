@@ -50,19 +50,6 @@ import torch                                                  # noqa: E402
 import jittor as jt                                           # noqa: E402  (the stand-in)
 from tests.golden import pyref_scene                          # noqa: E402
 
-# jittor: binary operators promote mixed dtypes (camera_path.py multiplies an integer matrix into a float one)
-_mm = torch.Tensor.__matmul__
-torch.Tensor.__matmul__ = lambda a, b: _mm(*(t.to(torch.promote_types(a.dtype, b.dtype)) for t in (a, b)))
-# jittor: Var.transpose(*axes) / fuse_transpose(axes) permute
-_tr = torch.Tensor.transpose
-torch.Tensor.transpose = lambda self, *a: self.permute(*a) if len(a) > 2 else _tr(self, *a)
-torch.Tensor.fuse_transpose = lambda self, axes: self.permute(*axes)
-# jittor: a Python list operand becomes a Var (dataset.py adds the offset list to a pose column)
-_add = torch.Tensor.__add__
-torch.Tensor.__add__ = lambda a, b: _add(a, torch.tensor(b, dtype=a.dtype) if isinstance(b, (list, tuple)) else b)
-jt.randperm = lambda n: torch.randperm(int(n))
-jt.normalize = lambda x, p=2, dim=1, eps=1e-30: x / jt.norm(x, p, dim, keepdim=True, eps=eps)       # jittor: misc.py normalize
-jt.pow = torch.pow
 
 
 # ------------------------------------------------------------------ the few jnerf.* names the reference modules import, as stand-ins (none of this is reference code)
@@ -175,8 +162,6 @@ def sampler_traces():
     stub(pkg + ".compacted_coord", CompactedCoord=op("CompactedCoord", lambda *a: None))
     stub(pkg + ".ray_sampler", RaySampler=op("RaySampler", lambda *a: None))
     stub(pkg + ".calc_rgb", CalcRgb=op("CalcRgb", lambda *a: None))
-    jt.init.zero_ = lambda x: x.zero_()
-    torch.Tensor.assign = lambda self, other: self.set_(other)
     mod = load("models/samplers/density_grid_sampler/density_grid_sampler.py", pkg + ".density_grid_sampler", package=pkg)
 
     class Model:
@@ -399,19 +384,6 @@ def main():
     # cv2 is not installed: imread through Pillow, decomposeProjectionMatrix through jnerf_amd's own RQ split (which tests/test_neus_cpu.py checks against closed forms) -
     # for THAT function the fixture is circular; everything the reference computes from K, R, t onwards is its own code
     stub("cv2", imread=cv_imread, decomposeProjectionMatrix=lambda P: decompose_projection(P))
-    jt.linalg = types.SimpleNamespace(inv=torch.linalg.inv)
-    jt.randint = lambda low, high, shape: torch.randint(low, high, list(shape))
-    _expand = torch.Tensor.expand
-
-    def jt_expand(self, *shape):
-        """jittor: Var.expand broadcasts BOTH ways - a target extent of 1 (or -1) keeps the variable's own extent (neus_dataset.py expands a [3,3] matrix to (bs,1,1))"""
-        shape = list(shape[0]) if len(shape) == 1 and isinstance(shape[0], (list, tuple, torch.Size)) else list(shape)
-        off = len(shape) - self.dim()
-        for i in range(self.dim()):
-            if shape[off + i] in (1, -1):
-                shape[off + i] = self.shape[i]
-        return _expand(self, *shape)
-    torch.Tensor.expand = jt_expand
     nds = load("dataset/neus_dataset.py", "ref_neus_dataset")
     with tempfile.TemporaryDirectory() as d:
         synth_dtu.make_scene(d, **pyref_scene.NEUS_SCENE)
@@ -432,7 +404,6 @@ def main():
         rays = torch.tensor(out[pre + "random_rays"])
         near, far = ds.near_far_from_sphere(rays[:, :3], rays[:, 3:6])
         out[pre + "near"], out[pre + "far"] = npy(near), npy(far)
-    torch.Tensor.expand = _expand
 
     # ---------------------------------------------------------------- NeuSRunner.train (runner/neus_runner.py): six iterations end to end with a plain-SGD optimiser
     class PlainSGD:
@@ -468,7 +439,6 @@ def main():
     stub("jnerf.models.samplers.neus_render.renderer", NeuSRenderer=ren.NeuSRenderer)
     sys.modules["jnerf.utils.registry"].SCHEDULERS = Registry()
     rmod = load("runner/neus_runner.py", "ref_neus_runner")
-    torch.Tensor.expand = jt_expand
     for tag, over in pyref_scene.NEUS_RUN_CASES.items():
         with tempfile.TemporaryDirectory() as d:
             synth_dtu.make_scene(d, **pyref_scene.NEUS_SCENE)
@@ -485,7 +455,6 @@ def main():
             for k, v in run.neus_network.named_parameters():
                 out[f"neusrun.{tag}.final.{k}"] = npy(v).copy()
             out[f"neusrun.{tag}.iter_step"] = np.int64(run.iter_step)
-    torch.Tensor.expand = _expand
 
     # ---------------------------------------------------------------- GridEncode.__init__: the level table (grid_encode.py:17-40)
     stub("jnerf.utils.common", enlarge=None)

@@ -124,3 +124,59 @@ def neus_run_cfg(root, mask_weight, use_white_bkgd, n_outside):
 
 ORI_ENCODERS = dict(pos_encoder=dict(type="FrequencyEncoder", multires=4), dir_encoder=dict(type="FrequencyEncoder", multires=2))
 ORI_MODEL = dict(D=4, W=32, skips=[2])
+
+
+# ------------------------------------------------------------------ a small RENDERED NeRF-synthetic-layout scene for the end-to-end run of the reference's Runner
+REFRUN = dict(W=40, H=40, n_train=6, n_val=3, n_test=1, camera_angle_x=0.8, steps=18, n_rays_per_batch=4096, target_batch_size=1 << 14)
+_BALLS = [((0.0, 0.0, 0.0), 0.55, (0.9, 0.25, 0.2)), ((0.55, 0.35, 0.1), 0.3, (0.2, 0.8, 0.3)), ((-0.45, 0.3, -0.35), 0.28, (0.25, 0.35, 0.9))]
+
+
+def _nerf_camera(theta, phi, radius=4.0):
+    """camera-to-world in the NeRF / Blender convention (x right, y up, the camera looks along -z), on a sphere around the origin"""
+    eye = radius * np.array([np.cos(phi) * np.cos(theta), np.cos(phi) * np.sin(theta), np.sin(phi)])
+    back = eye / np.linalg.norm(eye)
+    right = np.cross([0.0, 0.0, 1.0], back)
+    right /= np.linalg.norm(right)
+    up = np.cross(back, right)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, up, back, eye
+    return m
+
+
+def write_rendered_nerf_dataset(root):
+    """three opaque shaded balls in front of a transparent background, RGBA PNGs + transforms_{train,val,test}.json"""
+    from PIL import Image
+    W, H, fov = REFRUN["W"], REFRUN["H"], REFRUN["camera_angle_x"]
+    focal = 0.5 * W / np.tan(0.5 * fov)
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    d_cam = np.stack([(xs + 0.5 - W / 2) / focal, -(ys + 0.5 - H / 2) / focal, -np.ones_like(xs, dtype=np.float64)], -1)
+    light = np.array([0.5, 0.3, 0.8]) / np.linalg.norm([0.5, 0.3, 0.8])
+    k = 0
+    for split, n in (("train", REFRUN["n_train"]), ("val", REFRUN["n_val"]), ("test", REFRUN["n_test"])):
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        frames = []
+        for i in range(n):
+            m = _nerf_camera(2 * np.pi * (k * 0.37 % 1.0), np.deg2rad(15 + 40 * ((k * 0.61) % 1.0)))
+            k += 1
+            d = d_cam @ m[:3, :3].T
+            d /= np.linalg.norm(d, axis=-1, keepdims=True)
+            o = m[:3, 3]
+            best = np.full((H, W), np.inf)
+            rgb = np.zeros((H, W, 3))
+            for c, r, col in _BALLS:
+                oc = o - np.array(c)
+                b = (d * oc).sum(-1)
+                disc = b * b - (oc @ oc - r * r)
+                t = -b - np.sqrt(np.maximum(disc, 0.0))
+                hit = (disc > 0) & (t > 0) & (t < best)
+                nrm = (o + t[..., None] * d - np.array(c)) / r
+                shade = 0.3 + 0.7 * np.clip((nrm * light).sum(-1), 0.0, 1.0)
+                rgb = np.where(hit[..., None], np.array(col) * shade[..., None], rgb)
+                best = np.where(hit, t, best)
+            alpha = np.isfinite(best)
+            img = np.concatenate([rgb * alpha[..., None], alpha[..., None].astype(np.float64)], -1)
+            Image.fromarray((img * 255 + 0.5).astype(np.uint8), "RGBA").save(os.path.join(root, split, "r_%d.png" % i))
+            frames.append({"file_path": "./%s/r_%d" % (split, i), "transform_matrix": m.tolist()})
+        with open(os.path.join(root, "transforms_%s.json" % split), "w") as f:
+            json.dump({"camera_angle_x": fov, "frames": frames}, f)
+REFRUN_SEEDS = dict(perm=4000, bg=5000, grid=31, mlp=5, probe=61)
