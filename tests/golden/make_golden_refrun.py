@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The reference's OWN training loop, end to end, on the CPU of the build container:
 
-    python tests/golden/make_golden_refrun.py          ->  tests/golden/golden_refrun_v1.npz          (about ten minutes)
+    python tests/golden/make_golden_refrun.py [lego|cone]     ->  tests/golden/golden_refrun_v1.npz | golden_refrun_cone_v1.npz          (a few minutes each)
 
 What runs is the reference's unmodified Python package (`import jnerf` from /root/reference/python: Runner, NerfDataset, NGPNetworks, HashEncoder, SHEncoder,
 DensityGridSampler and its eight op wrappers, HuberLoss, Adam / ExpDecay / EMA, utils.config with projects/ngp/configs/ngp_base.py) over
@@ -47,14 +47,14 @@ S = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(S)
 
 
-def main():
+def main(case):
     import jnerf                                               # the reference package itself
     if not jnerf.__file__.startswith("/root/reference/"):
         raise RuntimeError("not the reference package: " + jnerf.__file__)
     from jnerf.utils.config import init_cfg, get_cfg
     from jnerf.runner import Runner
-    R = dict(S.REFRUN)
-    if os.environ.get("REFRUN_STEPS"):                         # (debugging aid; the committed fixture is made without it)
+    R = dict(S.REFRUN, **S.REFRUN_CASES[case])
+    if os.environ.get("REFRUN_STEPS"):                         # (debugging aid; the committed fixtures are made without it)
         R["steps"] = int(os.environ["REFRUN_STEPS"])
     out = {}
     perms, batches, bgs = [], [], []
@@ -78,6 +78,9 @@ def main():
     for mode in ("train", "val", "test"):
         cfg.dataset[mode].root_dir = d
         cfg.dataset[mode].batch_size = R["n_rays_per_batch"]
+        if R["aabb_scale"] is not None:
+            cfg.dataset[mode].aabb_scale = R["aabb_scale"]
+    cfg.const_dt = R["const_dt"]
     cfg.n_rays_per_batch, cfg.target_batch_size, cfg.tot_train_steps = R["n_rays_per_batch"], R["target_batch_size"], R["steps"]
     cfg.log_dir, cfg.exp_name = os.path.join(d, "logs"), "refrun"
     torch.manual_seed(S.REFRUN_SEEDS["mlp"])                   # the stand-in's nn.Linear draws its weights from the global generator
@@ -152,10 +155,10 @@ def main():
     out["final.grid_level_sums"] = np.asarray([[grid[offs[l]:offs[l + 1]].astype(np.float64).sum(), np.abs(grid[offs[l]:offs[l + 1]].astype(np.float64)).sum()] for l in range(16)])
     out["final.rng_state"] = _code.RNG.st.copy()
     out["final.ema_steps"] = np.int64(r.ema_optimizer.steps)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_refrun_v1.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), R["file"])
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "lego")             # one run per process (the reference keeps global state: config, registries, the pcg32 stream)

@@ -180,3 +180,6 @@ def write_rendered_nerf_dataset(root):
         with open(os.path.join(root, "transforms_%s.json" % split), "w") as f:
             json.dump({"camera_angle_x": fov, "frames": frames}, f)
 REFRUN_SEEDS = dict(perm=4000, bg=5000, grid=31, mlp=5, probe=61)
+# the runs of tests/golden/make_golden_refrun.py: name -> (fixture file, configuration on top of ngp_base.py)
+REFRUN_CASES = {"lego": dict(file="golden_refrun_v1.npz", aabb_scale=None, const_dt=True, steps=REFRUN["steps"]),
+                "cone": dict(file="golden_refrun_cone_v1.npz", aabb_scale=2, const_dt=False, steps=6)}          # fox-style sampling: two cascades, cone stepping

@@ -13,18 +13,23 @@ import torch
 
 from tests.golden import pyref_scene as S
 
-G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_refrun_v1.npz"))
+import pytest
 
 
-def test_oracle_replays_the_references_training_run(tmp_path):
+@pytest.mark.parametrize("case", list(S.REFRUN_CASES))
+def test_oracle_replays_the_references_training_run(case, tmp_path):
+    """lego: ngp_base.py as shipped (unit box, constant step), 18 iterations incl. the ray-count update and the second refresh.
+    cone: the same with aabb_scale 2 and const_dt False - two cascades and cone stepping, what ngp_fox.py samples with - 6 iterations."""
     from oracle import oracle as O
+    C = S.REFRUN_CASES[case]
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", C["file"]))
     from jnerf_amd.utils.config import reset_cfg
     from jnerf_amd.dataset import NerfDataset
     R = S.REFRUN
     steps = G["log"].shape[0]
     S.write_rendered_nerf_dataset(str(tmp_path))
     reset_cfg(device="cpu")
-    ds = NerfDataset(str(tmp_path), batch_size=R["n_rays_per_batch"], mode="train")
+    ds = NerfDataset(str(tmp_path), batch_size=R["n_rays_per_batch"], mode="train", **({"aabb_scale": C["aabb_scale"]} if C["aabb_scale"] else {}))
     assert ds.n_images == int(G["dataset.n_images"])
     ours, ref = ds.transforms_gpu.numpy(), G["dataset.transforms_gpu"]
     order = [int(np.argmin(np.abs(ours - ref[i][None]).reshape(len(ours), -1).max(-1))) for i in range(len(ref))]
@@ -33,8 +38,13 @@ def test_oracle_replays_the_references_training_run(tmp_path):
     pp = np.ascontiguousarray(ds.metadata.numpy()[order][:, 4:6])
     pixels = np.ascontiguousarray(ds.image_data.numpy().reshape(ds.n_images, -1, 4)[order]).reshape(-1, 4)
     W, H = ds.resolution
-    aabb, cascades, max_cascade, G3 = (0.0, 1.0), 5, 0, 128 ** 3
-    table, offsets, n_params = O.level_table(1)
+    scale = C["aabb_scale"] or 1
+    aabb, cascades, G3, const_dt = (0.5 - scale / 2, 0.5 + scale / 2), 5, 128 ** 3, C["const_dt"]
+    assert tuple(ds.aabb_range) == aabb
+    max_cascade = 0
+    while (1 << max_cascade) < scale:
+        max_cascade += 1
+    table, offsets, n_params = O.level_table(scale)
     # ---- initial parameters: the hash table redrawn from its seed, the MLP weights from the fixture (FMLP layout: (out, in) row-major, last layer padded to 16 rows)
     grid = (torch.rand([n_params], generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["grid"])) * 2e-4 - 1e-4).numpy()
     Ws = [G[f"init.W{i}"] for i in range(5)]
@@ -73,7 +83,7 @@ def test_oracle_replays_the_references_training_run(tmp_path):
         rgba = pixels[index]
         bg = torch.rand([count, 3], generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["bg"] + i + 1)).numpy()
         target = (rgba[:, :3] * rgba[:, 3:] + bg * (1 - rgba[:, 3:])).astype(np.float32)              # runner.py:66-67
-        co, ns, cnt, _ = O.march_rays(ro, rd, bits, aabb, rng, max_samples, const_dt=True, cascades=cascades)
+        co, ns, cnt, _ = O.march_rays(ro, rd, bits, aabb, rng, max_samples, const_dt=const_dt, cascades=cascades)
         M = int(min(cnt[1], max_samples))
         cc, nsc, counter = O.compact_coords(co[:M], ns, CAP)
         k = int(min(int(nsc[:, 0].sum()), CAP))
@@ -91,8 +101,7 @@ def test_oracle_replays_the_references_training_run(tmp_path):
             mm, vv, ee = state[name]
             O.adam_ema_step(p, g, mm, vv, ee, 0.1, i + 1)       # ngp_base.py:21-37: lr 0.1 (ExpDecay starts at 20 000), betas (0.9, 0.99), eps 1e-15, EMA 0.95
         log.append([float(loss.astype(np.float64).mean()), float(loss.astype(np.float64).sum()), count, k, int(ns[:, 0].sum())])
-        if i == 14:
-            mid_pack = pack.copy()                               # the weights after 15 updates: what the fixture holds as mid.W*
+        mid_pack = pack.copy() if i == 14 else (mid_pack if i > 14 else None)                               # the weights after 15 updates: what the fixture holds as mid.W*
         if i % 16 == 15:                                         # density_grid_sampler.py:266-271
             per_batch = max(measured / 16, 1)
             n_rays = int(min((int(n_rays * CAP / per_batch) + 127) // 128 * 128, CAP))
@@ -107,7 +116,7 @@ def test_oracle_replays_the_references_training_run(tmp_path):
     ref_refresh = G["refresh"]
     assert len(refresh) == len(ref_refresh)
     for a, b in zip(refresh, ref_refresh):
-        assert a[0] == b[0] and a[3] == b[3]                                 # the same cells have been touched
+        assert a[0] == b[0] and abs(a[3] / b[3] - 1) < 1e-3                  # the same cells have been touched (exp() of the two sides may round a splat to 0 differently)
         assert abs(a[1] / b[1] - 1) < 1e-4 and abs(a[4] / b[4] - 1) < 1e-4   # mean / sum of the grid
         assert abs(a[2] / b[2] - 1) < 0.02                                   # occupied bits: cells sitting on the threshold may fall either way
     assert np.array_equal(log[:, 2], want[:, 2])                             # rays per iteration
@@ -119,7 +128,7 @@ def test_oracle_replays_the_references_training_run(tmp_path):
         assert [u[0] for u in ray_updates] == G["ray_updates"][:, 0].tolist()
         assert np.abs(np.asarray(ray_updates)[:, 1:] / G["ray_updates"][:, 1:] - 1).max() < 0.02
     unpack = lambda p: [p[:2048].reshape(64, 32), p[2048:3072].reshape(16, 64), p[3072:5120].reshape(64, 32), p[5120:9216].reshape(64, 64), p[9216:10240].reshape(16, 64)[:3]]
-    for j, w in enumerate(unpack(mid_pack)):
+    for j, w in enumerate(unpack(mid_pack) if steps > 15 else []):
         d = np.abs(w - G[f"mid.W{j}"]).max() / np.abs(G[f"mid.W{j}"]).max()
         print(f"W{j} after 15 updates: largest difference {d:.2e} of the largest weight")
         assert d < 5e-3, (j, d)                                  # measured 1.4e-3 at worst (W0, fed by 1e-4-sized features) (Adam with lr 0.1 and eps 1e-15 turns the sign of a 1e-9 gradient into a 0.1 step: this is the tight point)
@@ -127,6 +136,6 @@ def test_oracle_replays_the_references_training_run(tmp_path):
     for j in range(5):
         d = np.abs(fw[j] - G[f"final.W{j}"]).max() / np.abs(G[f"final.W{j}"]).max()
         print(f"final W{j}: largest difference {d:.2e} of the largest weight")
-        assert d < 0.05, (j, d)
+        assert d < (0.05 if steps > 16 else 5e-3), (j, d)     # (after the second refresh the runs march different cells; a run that ends before it stays together)
     assert np.array_equal(rng.st, G["final.rng_state"])                      # the global pcg32 stream was consumed identically (one advance per generator call)
     assert bytes(G["ckpt_keys"]).decode() == "ema_optimizer,global_step,model,nested_optimizer,optimizer,sampler"
