@@ -1,0 +1,84 @@
+"""-m gpu: the HIP path replays the iterations that the REFERENCE'S OWN training loop ran (tests/golden/golden_refrun_v1.npz - the reference's unmodified Python package
+over the Jittor stand-in with every CUDA launch bound to the reference's kernels compiled for the host; tests/golden/make_golden_refrun.py).  Same pixels, backgrounds,
+initial parameters, pcg32 seed; the HIP side with its own occupancy grid, samples, gradients and optimiser state, through Runner's native step.  The CPU suite already
+holds the C oracle to this fixture (tests/test_refrun_golden.py) and test_trajectory_gpu.py holds the HIP path to the oracle; this closes the triangle directly.
+
+WRITTEN AFTER round 3's GPU minutes were spent: it has not run on an MI355X yet, hence xfail(strict=False) - an XPASS in the driver's round-end run is its first hardware
+evidence, a failure does not stop the suite.  Remove the marker once it has been seen to pass."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import pyref_scene as S
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first GPU run happens outside the authoring session")]
+
+
+def test_hip_path_replays_the_references_training_run(tmp_path):
+    from jnerf_amd import ops
+    from jnerf_amd.presets import ngp_cfg
+    from jnerf_amd.runner import Runner
+    from jnerf_amd.fastpath import FusedTrainStep
+    C = S.REFRUN_CASES["lego"]
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", C["file"]))
+    R = S.REFRUN
+    steps = G["log"].shape[0]
+    S.write_rendered_nerf_dataset(str(tmp_path))
+    cfg = ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_rays_per_batch=R["n_rays_per_batch"], target_batch_size=R["target_batch_size"], pipeline_sampling=False,
+                  log_dir=str(tmp_path / "logs"))
+    one = dict(type="NerfDataset", root_dir=str(tmp_path), batch_size=R["n_rays_per_batch"])
+    cfg.dataset = cfg.dfs(dict(train=dict(one, mode="train"), val=dict(one, mode="val"), test=dict(one, mode="test")))
+    r = Runner()
+    s, enc, ds = r.sampler, r.model.pos_encoder, r.dataset["train"]
+    assert FusedTrainStep.applicable(r)
+    r._fast = FusedTrainStep(r)
+    assert r._fast.native and not r._fast.half and s.max_samples == R["n_rays_per_batch"] * 1024
+    dev = ds.device
+    # ---- the reference's frame order (it walks the directory in file-system order), then the data set's arrays in that order
+    ours, ref = ds.transforms_gpu.cpu().numpy(), G["dataset.transforms_gpu"]
+    order = [int(np.argmin(np.abs(ours - ref[i][None]).reshape(len(ours), -1).max(-1))) for i in range(len(ref))]
+    assert sorted(order) == list(range(ds.n_images))
+    idx_t = torch.as_tensor(order, device=dev)
+    ds.transforms_gpu, ds.focal_lengths, ds.metadata = ds.transforms_gpu[idx_t].contiguous(), ds.focal_lengths[idx_t].contiguous(), ds.metadata[idx_t].contiguous()
+    ds.image_data = ds.image_data.view(ds.n_images, -1, 4)[idx_t].contiguous()
+    W, H = ds.resolution
+    pixels = ds.image_data.view(-1, 4)
+    # ---- initial parameters
+    with torch.no_grad():
+        enc.m_grid.data.copy_((torch.rand([enc.m_grid.numel()], generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["grid"])) * 2e-4 - 1e-4).to(dev))
+        Ws = [G[f"init.W{i}"] for i in range(5)]
+        pad = lambda w: np.concatenate([w, np.zeros((16 - w.shape[0], w.shape[1]), np.float32)], 0)
+        pack = np.concatenate([Ws[0].ravel(), Ws[1].ravel(), Ws[2].ravel(), Ws[3].ravel(), pad(Ws[4]).ravel()]).astype(np.float32)
+        r.model._pack32.copy_(torch.as_tensor(pack, device=dev))
+        r.model._weights_version = getattr(r.model, "_weights_version", 0) + 1
+    perms, log, refresh = {}, [], []
+    for i in range(steps):
+        r.cfg.m_training_step = i
+        s.finish_batch_rays_update()
+        pid, start, count = (int(v) for v in G["batches"][i])
+        assert count == s.n_rays_per_batch, (i, count, s.n_rays_per_batch)          # the adaptive ray count we arrived at is the batch size the reference drew
+        if pid not in perms:
+            perms[pid] = torch.randperm(int(G["perm_sizes"][pid - 1]), generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["perm"] + pid))
+        index = perms[pid][start:start + count].to(dev)
+        img_ids, ro, rd, _ = ops.generate_rays(index, W, H, ds.focal_lengths, ds.metadata, ds.transforms_gpu)
+        rgba = pixels[index]
+        bg = torch.rand([count, 3], generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["bg"] + i + 1)).to(dev)
+        target = (rgba[:, :3] * rgba[:, 3:] + bg * (1 - rgba[:, 3:])).contiguous()
+        pos, dirs = s.sample(img_ids, ro, rd, is_training=True)
+        if i % 16 == 0:
+            refresh.append([i, float(s.density_grid_mean.item()), int(np.unpackbits(s.density_grid_bitfield.cpu().numpy()).sum())])
+        b = {"step": i, "bg": bg, "target": target, "pos": pos, "dirs": dirs, "state": s.export_batch_state(), "keep": (img_ids, ro, rd)}
+        loss = r._fast(b)
+        log.append([float(loss.double().mean().item()), int(s._counters[3].item())])
+    r.drain()
+    log, want = np.asarray(log), G["log"]
+    print("loss HIP      :", np.round(log[:, 0], 6))
+    print("loss reference:", np.round(want[:, 0], 6))
+    print("refresh HIP:", refresh, "reference:", G["refresh"][:, :3].tolist())
+    for a, b in zip(refresh, G["refresh"]):
+        assert abs(a[1] / b[1] - 1) < 1e-3 and abs(a[2] / b[2] - 1) < 0.03          # grid mean; occupied bits (cells on the threshold may fall either way: __expf in the splat)
+    assert np.abs(log[:, 1] / want[:, 3] - 1).max() < 0.03                          # samples trained on
+    rel = np.abs(log[:, 0] / want[:, 0] - 1)
+    assert rel[:16].max() < 5e-3 and rel.max() < 5e-2, rel
+    assert np.array_equal(s.rng_state, G["final.rng_state"])                        # the global pcg32 stream was consumed identically
