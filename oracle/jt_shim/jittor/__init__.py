@@ -80,6 +80,28 @@ def _jt_expand(self, *shape):
 
 
 torch.Tensor.expand = _jt_expand
+
+
+class _Shape(tuple):
+    """jittor: Var.shape is a NanoVector - `[n] + x.shape[1:]` is a list (runner.py:218 pads the last ray chunk that way); a torch.Size refuses"""
+    def __getitem__(self, i):
+        r = tuple.__getitem__(self, i)
+        return _Shape(r) if isinstance(i, slice) else r
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def __add__(self, other):
+        return _Shape(tuple(self) + tuple(other))
+
+    def numel(self):
+        return int(np.prod(self)) if len(self) else 1
+
+
+def enable_jittor_shapes():
+    """(opt-in: replaces the Python-level Tensor.shape attribute for this process)"""
+    get = torch.Tensor.shape.__get__
+    torch.Tensor.shape = property(lambda self: _Shape(get(self)))
 _orig_numpy = torch.Tensor.numpy
 torch.Tensor.numpy = lambda self, *a, **k: _orig_numpy(self.detach(), *a, **k)
 
@@ -176,6 +198,11 @@ def cumprod(x, dim=-1):
 
 
 def gather(x, dim, index):
+    """jittor: gather with an index of the variable's rank is the usual element gather.  dataset.py:205-226 calls it with a 1-D index on 2-D / 3-D variables
+    (`jt.gather(self.focal_lengths, 0, img_ids)`): read as a ROW gather x[index] - the only reading under which those lines make sense (ASSUMED: Jittor's reindex
+    semantics for a lower-rank index are not restated from source)"""
+    if index.dim() < x.dim() and dim == 0:
+        return x[index.long()]
     return torch.gather(x, dim, index.long())
 
 

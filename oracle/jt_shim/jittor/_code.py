@@ -116,6 +116,10 @@ def _rays_sampler(inputs, outputs, header, src):
     rays_o, rays_d, bitfield, metadata, img_ids, xforms = inputs
     coords, rays_index, numsteps, counter = outputs
     r = _ref()
+    if img_ids.shape[0] < rays_o.shape[0]:
+        # runner.py:211-224 pads the last chunk of rays to n_rays_per_batch but hands over the image's H*W ids: for an image of fewer than 4096 pixels the kernel indexes
+        # past the end of that array (on the GPU: whatever follows in memory; the rays concerned are padding and their results are dropped).  Zero ids stand in.
+        img_ids = torch.cat([img_ids, torch.zeros(rays_o.shape[0] - img_ids.shape[0], dtype=img_ids.dtype)])
     co, ns, cnt, idx = r.march(_np(rays_o), _np(rays_d), _np(bitfield), _aabb(src), RNG.st, coords.shape[0], _np(metadata), _np(img_ids), _np(xforms),
                                cone_angle=_num(src, r"cone_angle_constant\s*=\s*([-+0-9.eE]+)"), near=_num(src, r"near_distance\s*=\s*([-+0-9.eE]+)"), const_dt=_const_dt(header))
     _put(coords, co)

@@ -47,6 +47,9 @@ S = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(S)
 
 
+jt.enable_jittor_shapes()
+
+
 def main(case):
     import jnerf                                               # the reference package itself
     if not jnerf.__file__.startswith("/root/reference/"):
@@ -136,6 +139,30 @@ def main(case):
         rays.append([int(cfg.m_training_step), measured, int(r.sampler.n_rays_per_batch)])
     r.sampler.update_batch_rays = recording_rays
 
+    if R["steps"] == 0:
+        # ---- the inference path (runner.py:197-264) on the freshly initialised model: one occupancy refresh (an empty bitfield renders nothing), then a test view and a
+        #      free pose, chunked / padded / assembled by the reference's own render_img and render_img_with_pose
+        from jnerf.utils.registry import build_from_cfg, DATASETS
+        cfg.m_training_step = 0
+        r.sampler.update_density_grid()
+        r.dataset["test"] = build_from_cfg(cfg.dataset.test, DATASETS)
+        out["test.transforms_gpu"] = r.dataset["test"].transforms_gpu.numpy().copy()
+        with jt.no_grad():
+            img, _, tar = r.render_img("test", 0)
+            out["render.img"], out["render.target"] = np.asarray(img, np.float64), np.asarray(tar, np.float64)
+            r.alpha_image = True
+            img_a, alpha, _ = r.render_img("test", 0)
+            out["render.img_alpha"], out["render.alpha"] = np.asarray(img_a, np.float64), np.asarray(alpha, np.float64)
+            r.alpha_image = False
+            out["render.pose"] = np.asarray(S.NOVEL_POSE_NGP, np.float32)
+            out["render.img_pose"] = np.asarray(r.render_img_with_pose(torch.tensor(S.NOVEL_POSE_NGP)), np.float64)
+        out["refresh"] = np.asarray(refresh, np.float64)
+        out["launches"] = np.frombuffer(";".join(f"{n}:{c}" for n, c in _code.CALLS).encode(), np.uint8)
+        out["final.rng_state"] = _code.RNG.st.copy()
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), R["file"])
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+        return
     t0 = time.time()
     r.train()
     print("trained", R["steps"], "iterations in", round(time.time() - t0, 1), "s; losses", np.round([v[0] for v in log], 5))

@@ -182,4 +182,7 @@ def write_rendered_nerf_dataset(root):
 REFRUN_SEEDS = dict(perm=4000, bg=5000, grid=31, mlp=5, probe=61)
 # the runs of tests/golden/make_golden_refrun.py: name -> (fixture file, configuration on top of ngp_base.py)
 REFRUN_CASES = {"lego": dict(file="golden_refrun_v1.npz", aabb_scale=None, const_dt=True, steps=REFRUN["steps"]),
-                "cone": dict(file="golden_refrun_cone_v1.npz", aabb_scale=2, const_dt=False, steps=6)}          # fox-style sampling: two cascades, cone stepping
+                "cone": dict(file="golden_refrun_cone_v1.npz", aabb_scale=2, const_dt=False, steps=6),          # fox-style sampling: two cascades, cone stepping
+                "render": dict(file="golden_refrun_render_v1.npz", aabb_scale=None, const_dt=True, steps=0)}     # no training: one occupancy refresh, then the inference path
+# a camera-to-world pose in the NeRF convention for render_img_with_pose (it goes through matrix_nerf2ngp): on the camera sphere, between the training views
+NOVEL_POSE_NGP = _nerf_camera(1.1, 0.5)[:3, :].astype(np.float32)

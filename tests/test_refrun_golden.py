@@ -139,3 +139,67 @@ def test_oracle_replays_the_references_training_run(case, tmp_path):
         assert d < (0.05 if steps > 16 else 5e-3), (j, d)     # (after the second refresh the runs march different cells; a run that ends before it stays together)
     assert np.array_equal(rng.st, G["final.rng_state"])                      # the global pcg32 stream was consumed identically (one advance per generator call)
     assert bytes(G["ckpt_keys"]).decode() == "ema_optimizer,global_step,model,nested_optimizer,optimizer,sampler"
+
+
+def test_oracle_replays_the_references_inference_path(tmp_path):
+    """the reference's render_img / render_img_with_pose (runner.py:197-264: full-image rays, 4096-ray chunks with the last one padded by dummy rays, sampler.sample ->
+    model -> rays2rgb(inference), assembly, background) on the freshly initialised model after one occupancy refresh, against the C oracle on the same rays"""
+    from oracle import oracle as O
+    from jnerf_amd.utils.config import reset_cfg
+    from jnerf_amd.dataset import NerfDataset
+    R = S.REFRUN
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", S.REFRUN_CASES["render"]["file"]))
+    S.write_rendered_nerf_dataset(str(tmp_path))
+    reset_cfg(device="cpu")
+    train = NerfDataset(str(tmp_path), batch_size=R["n_rays_per_batch"], mode="train")
+    test = NerfDataset(str(tmp_path), batch_size=R["n_rays_per_batch"], mode="test")
+    W, H = train.resolution
+    aabb, cascades, G3 = (0.0, 1.0), 5, 128 ** 3
+    table, _, n_params = O.level_table(1)
+    grid = (torch.rand([n_params], generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["grid"])) * 2e-4 - 1e-4).numpy()
+    Ws = [G[f"init.W{i}"] for i in range(5)]
+    pad = lambda w: np.concatenate([w, np.zeros((16 - w.shape[0], w.shape[1]), np.float32)], 0)
+    pack = np.concatenate([Ws[0].ravel(), Ws[1].ravel(), Ws[2].ravel(), Ws[3].ravel(), pad(Ws[4]).ravel()]).astype(np.float32)
+    rng = O.PCG32(1337)
+    # ---- the one refresh (density_grid_sampler.py:204-264 at step 0); mark_untrained works on the TRAIN set's cameras (any frame order gives the same grid)
+    density_grid = O.grid_mark_untrained(cascades * G3, train.focal_lengths.numpy(), train.transforms_gpu.numpy(), W, H)
+    pos, idx = O.grid_generate_samples(G3, rng, 0, aabb, density_grid, 1, -0.01)
+    rng.advance()
+    dens = O.density_fwd(O.hash_encode_fwd(pos, grid, table), pack[:3072])
+    density_grid = O.grid_ema(density_grid, O.grid_splat_max(idx, dens, np.zeros(cascades * G3, np.float32)))
+    bits, mean = O.grid_update_bitfield(density_grid, cascades)
+    assert int(np.unpackbits(bits).sum()) == int(G["refresh"][0, 2]) and abs(float(mean[0]) / G["refresh"][0, 1] - 1) < 1e-6
+
+    def render(ro, rd):
+        n, chunk = ro.shape[0], R["n_rays_per_batch"]
+        img, alpha = np.zeros((n, 3)), np.zeros((n, 1))
+        for p0 in range(0, n, chunk):
+            o, d = ro[p0:p0 + chunk], rd[p0:p0 + chunk]
+            if o.shape[0] < chunk:                               # runner.py:214-219: the last chunk is filled up with rays (1,1,1) -> (1,1,1)
+                o, d = (np.concatenate([a, np.ones((chunk - a.shape[0], 3), np.float32)]) for a in (o, d))
+            co, ns, cnt, _ = O.march_rays(o, d, bits, aabb, rng, chunk * 1024, const_dt=True, cascades=cascades)
+            M = int(min(cnt[1], chunk * 1024))
+            x, dirs = np.ascontiguousarray(co[:M, :3]), np.ascontiguousarray(co[:M, 4:])
+            out = O.field_fwd(O.hash_encode_fwd(x, grid, table), O.sh_encode(dirs, np.float32), pack[:3072], pack[3072:])
+            rgb, a = O.composite_inference(out, co[:M], ns, cascades)
+            img[p0:p0 + chunk], alpha[p0:p0 + chunk] = rgb[:n - p0], a[:n - p0]
+        return img.reshape(H, W, 3), alpha.reshape(H, W, 1)
+    assert test.n_images == 1 and np.allclose(test.transforms_gpu.numpy(), G["test.transforms_gpu"])
+    every = np.arange(H * W, dtype=np.int64)
+    pp = np.ascontiguousarray(test.metadata.numpy()[:, 4:6])
+    _, ro, rd = O.generate_rays(every, W, H, test.focal_lengths.numpy(), pp, test.transforms_gpu.numpy())
+    bg = np.zeros(3)                                             # ngp_base.py: background_color = [0, 0, 0]
+    img, alpha = render(ro, rd)
+    np.testing.assert_allclose(img + bg * (1 - alpha), G["render.img"], rtol=1e-4, atol=2e-6)
+    rgba = test.image_data.numpy().reshape(H, W, 4)
+    np.testing.assert_allclose(rgba[..., :3] * rgba[..., 3:] + bg * (1 - rgba[..., 3:]), G["render.target"], atol=1e-7)
+    img2, alpha2 = render(ro, rd)                                # alpha_image = True: the colour without the background, and the opacity
+    np.testing.assert_allclose(img2, G["render.img_alpha"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(alpha2, G["render.alpha"], rtol=1e-4, atol=2e-6)
+    assert alpha2.max() > 0.05 and alpha2.std() > 1e-3           # not an empty render: the untrained field is a thin fog, denser along longer chords
+    m = train.matrix_nerf2ngp(G["render.pose"].copy(), train.scale, train.offset)
+    tp = np.ascontiguousarray(train.metadata.numpy()[:1, 4:6])
+    _, ro, rd = O.generate_rays(every, W, H, train.focal_lengths.numpy()[:1], tp, np.ascontiguousarray(m.T)[None])
+    img3, alpha3 = render(ro, rd)
+    np.testing.assert_allclose(img3 + bg * (1 - alpha3), G["render.img_pose"], rtol=1e-4, atol=2e-6)
+    assert np.array_equal(rng.st, G["final.rng_state"])
