@@ -16,7 +16,7 @@ from tests.golden import pyref_scene as S
 import pytest
 
 
-@pytest.mark.parametrize("case", list(S.REFRUN_CASES))
+@pytest.mark.parametrize("case", [c for c, v in S.REFRUN_CASES.items() if v["steps"] > 0])
 def test_oracle_replays_the_references_training_run(case, tmp_path):
     """lego: ngp_base.py as shipped (unit box, constant step), 18 iterations incl. the ray-count update and the second refresh.
     cone: the same with aabb_scale 2 and const_dt False - two cascades and cone stepping, what ngp_fox.py samples with - 6 iterations."""
