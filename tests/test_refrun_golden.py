@@ -203,3 +203,78 @@ def test_oracle_replays_the_references_inference_path(tmp_path):
     img3, alpha3 = render(ro, rd)
     np.testing.assert_allclose(img3 + bg * (1 - alpha3), G["render.img_pose"], rtol=1e-4, atol=2e-6)
     assert np.array_equal(rng.st, G["final.rng_state"])
+
+
+def test_host_stack_replays_the_references_training_run(tmp_path):
+    """THIS build's host side - NerfDataset, DensityGridSampler.sample (refresh schedule, marching + compaction state, adaptive ray count), NGPNetworks on HashEncoder /
+    SHEncoder with their autograd bridges, the compositing bridge, HuberLoss, Adam + ExpDecay + EMA, in Runner's module-path order - executed on the CPU with
+    jnerf_amd.ops re-bound to the C oracle (tests/cpu_ops.py; the product itself binds libngp_hip.so only), on the batches of the reference's own training run."""
+    from tests.cpu_ops import oracle_backed_ops
+    from jnerf_amd.presets import ngp_cfg
+    from jnerf_amd.runner import Runner
+    from jnerf_amd import ops
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", S.REFRUN_CASES["lego"]["file"]))
+    R = S.REFRUN
+    steps = G["log"].shape[0]
+    S.write_rendered_nerf_dataset(str(tmp_path))
+    cfg = ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_rays_per_batch=R["n_rays_per_batch"], target_batch_size=R["target_batch_size"], pipeline_sampling=False,
+                  device="cpu", log_dir=str(tmp_path / "logs"))
+    one = dict(type="NerfDataset", root_dir=str(tmp_path), batch_size=R["n_rays_per_batch"])
+    cfg.dataset = cfg.dfs(dict(train=dict(one, mode="train"), val=dict(one, mode="val"), test=dict(one, mode="test")))
+    with oracle_backed_ops():
+        r = Runner()
+        s, enc, ds = r.sampler, r.model.pos_encoder, r.dataset["train"]
+        assert not getattr(r.model, "fused", False) and s.max_samples == R["n_rays_per_batch"] * 1024
+        ours, ref = ds.transforms_gpu.numpy(), G["dataset.transforms_gpu"]
+        order = torch.as_tensor([int(np.argmin(np.abs(ours - ref[i][None]).reshape(len(ours), -1).max(-1))) for i in range(len(ref))])
+        assert sorted(order.tolist()) == list(range(ds.n_images))
+        ds.transforms_gpu, ds.focal_lengths, ds.metadata = ds.transforms_gpu[order].contiguous(), ds.focal_lengths[order].contiguous(), ds.metadata[order].contiguous()
+        ds.image_data = ds.image_data.view(ds.n_images, -1, 4)[order].contiguous()
+        W, H = ds.resolution
+        pixels = ds.image_data.view(-1, 4)
+        Ws = [G[f"init.W{i}"] for i in range(5)]
+        with torch.no_grad():
+            enc.m_grid.data.copy_(torch.rand([enc.m_grid.numel()], generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["grid"])) * 2e-4 - 1e-4)
+            for lin, w in zip(r.model._linears(), Ws):          # (on the CPU the network is the plain nn.Linear chain: five separate weights)
+                lin.weight.copy_(torch.as_tensor(w))
+        r.ema_optimizer.param_groups[0]["values"] = [p.detach().clone() for p in r.ema_optimizer.param_groups[0]["params"]]        # the EMA starts from the parameters just loaded
+        perms, log, refresh, rays = {}, [], [], []
+        for i in range(steps):
+            cfg.m_training_step = i
+            s.finish_batch_rays_update()
+            pid, start, count = (int(v) for v in G["batches"][i])
+            assert count == s.n_rays_per_batch == ds.batch_size, (i, count, s.n_rays_per_batch, ds.batch_size)
+            if pid not in perms:
+                perms[pid] = torch.randperm(int(G["perm_sizes"][pid - 1]), generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["perm"] + pid))
+            index = perms[pid][start:start + count]
+            img_ids, ro, rd, _ = ops.generate_rays(index, W, H, ds.focal_lengths, ds.metadata, ds.transforms_gpu)
+            rgba = pixels[index]
+            bg = torch.rand([count, 3], generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["bg"] + i + 1))
+            target = (rgba[:, :3] * rgba[:, 3:] + bg * (1 - rgba[:, 3:])).contiguous()
+            pos, dirs = s.sample(img_ids, ro, rd, is_training=True)
+            if s.grid_updated_in_last_sample:
+                refresh.append([i, float(s.density_grid_mean.item()), int(np.unpackbits(s.density_grid_bitfield.numpy()).sum())])
+            out = r.model(pos, dirs)                              # Runner.train_step's module path (runner.py:70-76 of the reference)
+            rgb = s.rays2rgb(out, bg)
+            loss = r.loss_func(rgb, target)
+            r.optimizer.step(loss)
+            r.ema_optimizer.ema_step()
+            log.append([float(loss.detach().double().mean()), int(s._counters[3]), int(s._counters[2])])
+            rays.append(int(s.n_rays_per_batch))
+    log, want = np.asarray(log), G["log"]
+    print("loss host stack:", np.round(log[:, 0], 6))
+    print("loss reference :", np.round(want[:, 0], 6))
+    print("refresh host stack:", refresh, "reference:", G["refresh"][:, :3].tolist())
+    for a, b in zip(refresh, G["refresh"]):
+        assert a[0] == b[0] and abs(a[1] / b[1] - 1) < 1e-4 and abs(a[2] / b[2] - 1) < 0.02
+    assert len(refresh) == len(G["refresh"])
+    assert np.abs(log[:, 1] / want[:, 3] - 1).max() < 0.02
+    rel = np.abs(log[:, 0] / want[:, 0] - 1)
+    assert rel[:16].max() < 1e-4 and rel.max() < 2e-2, rel
+    assert np.array_equal(s.rng_state, G["final.rng_state"])
+    assert int(r.ema_optimizer.steps) == int(G["final.ema_steps"]) == steps
+    fin = [lin.weight.detach().numpy() for lin in r.model._linears()]
+    for j in range(5):
+        d = np.abs(fin[j] - G[f"final.W{j}"]).max() / np.abs(G[f"final.W{j}"]).max()
+        print(f"final W{j}: largest difference {d:.2e} of the largest weight")
+        assert d < 0.05, (j, d)
