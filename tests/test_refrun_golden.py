@@ -278,3 +278,40 @@ def test_host_stack_replays_the_references_training_run(tmp_path):
         d = np.abs(fin[j] - G[f"final.W{j}"]).max() / np.abs(G[f"final.W{j}"]).max()
         print(f"final W{j}: largest difference {d:.2e} of the largest weight")
         assert d < 0.05, (j, d)
+
+
+def test_host_stack_replays_the_references_inference_path(tmp_path):
+    """Runner.render_img / render_img_with_pose of THIS build on the CPU (module path over oracle-backed ops: full-image ray generation, chunk loop with device-side
+    sample counts, sampler.sample(inference) -> model -> rays2rgb(inference), assembly, background) against the images the reference's own methods produced"""
+    from tests.cpu_ops import oracle_backed_ops
+    from jnerf_amd.presets import ngp_cfg
+    from jnerf_amd.runner import Runner
+    from jnerf_amd.utils.registry import build_from_cfg, DATASETS
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", S.REFRUN_CASES["render"]["file"]))
+    R = S.REFRUN
+    S.write_rendered_nerf_dataset(str(tmp_path))
+    cfg = ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_rays_per_batch=R["n_rays_per_batch"], target_batch_size=R["target_batch_size"], pipeline_sampling=False,
+                  device="cpu", log_dir=str(tmp_path / "logs"))
+    one = dict(type="NerfDataset", root_dir=str(tmp_path), batch_size=R["n_rays_per_batch"])
+    cfg.dataset = cfg.dfs(dict(train=dict(one, mode="train"), val=dict(one, mode="val"), test=dict(one, mode="test")))
+    with oracle_backed_ops():
+        r = Runner()
+        s, enc = r.sampler, r.model.pos_encoder
+        with torch.no_grad():
+            enc.m_grid.data.copy_(torch.rand([enc.m_grid.numel()], generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["grid"])) * 2e-4 - 1e-4)
+            for lin, w in zip(r.model._linears(), [G[f"init.W{i}"] for i in range(5)]):
+                lin.weight.copy_(torch.as_tensor(w))
+        cfg.m_training_step = 0
+        s.update_density_grid()
+        assert int(np.unpackbits(s.density_grid_bitfield.numpy()).sum()) == int(G["refresh"][0, 2])
+        r.dataset["test"] = build_from_cfg(cfg.dataset.test, DATASETS)
+        img, _, tar = r.render_img("test", 0)
+        np.testing.assert_allclose(img, G["render.img"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(tar, G["render.target"], atol=1e-7)
+        r.alpha_image = True
+        img_a, alpha, _ = r.render_img("test", 0)
+        np.testing.assert_allclose(img_a, G["render.img_alpha"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(alpha, G["render.alpha"], rtol=1e-4, atol=2e-6)
+        r.alpha_image = False
+        np.testing.assert_allclose(r.render_img_with_pose(G["render.pose"]), G["render.img_pose"], rtol=1e-4, atol=2e-6)
+        assert np.array_equal(s.rng_state, G["final.rng_state"])             # three marches and one refresh: the global pcg32 stream ends where the reference's did
