@@ -205,7 +205,8 @@ def test_oracle_replays_the_references_inference_path(tmp_path):
     assert np.array_equal(rng.st, G["final.rng_state"])
 
 
-def test_host_stack_replays_the_references_training_run(tmp_path):
+@pytest.mark.parametrize("case", [c for c, v in S.REFRUN_CASES.items() if v["steps"] > 0])
+def test_host_stack_replays_the_references_training_run(case, tmp_path):
     """THIS build's host side - NerfDataset, DensityGridSampler.sample (refresh schedule, marching + compaction state, adaptive ray count), NGPNetworks on HashEncoder /
     SHEncoder with their autograd bridges, the compositing bridge, HuberLoss, Adam + ExpDecay + EMA, in Runner's module-path order - executed on the CPU with
     jnerf_amd.ops re-bound to the C oracle (tests/cpu_ops.py; the product itself binds libngp_hip.so only), on the batches of the reference's own training run."""
@@ -213,18 +214,19 @@ def test_host_stack_replays_the_references_training_run(tmp_path):
     from jnerf_amd.presets import ngp_cfg
     from jnerf_amd.runner import Runner
     from jnerf_amd import ops
-    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", S.REFRUN_CASES["lego"]["file"]))
+    C = S.REFRUN_CASES[case]
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", C["file"]))
     R = S.REFRUN
     steps = G["log"].shape[0]
     S.write_rendered_nerf_dataset(str(tmp_path))
-    cfg = ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_rays_per_batch=R["n_rays_per_batch"], target_batch_size=R["target_batch_size"], pipeline_sampling=False,
-                  device="cpu", log_dir=str(tmp_path / "logs"))
-    one = dict(type="NerfDataset", root_dir=str(tmp_path), batch_size=R["n_rays_per_batch"])
+    cfg = ngp_cfg(fp16=False, aabb_scale=C["aabb_scale"] or 1, const_dt=C["const_dt"], n_rays_per_batch=R["n_rays_per_batch"], target_batch_size=R["target_batch_size"],
+                  pipeline_sampling=False, device="cpu", log_dir=str(tmp_path / "logs"))
+    one = dict(type="NerfDataset", root_dir=str(tmp_path), batch_size=R["n_rays_per_batch"], **({"aabb_scale": C["aabb_scale"]} if C["aabb_scale"] else {}))
     cfg.dataset = cfg.dfs(dict(train=dict(one, mode="train"), val=dict(one, mode="val"), test=dict(one, mode="test")))
     with oracle_backed_ops():
         r = Runner()
         s, enc, ds = r.sampler, r.model.pos_encoder, r.dataset["train"]
-        assert not getattr(r.model, "fused", False) and s.max_samples == R["n_rays_per_batch"] * 1024
+        assert not getattr(r.model, "fused", False) and s.max_samples == R["n_rays_per_batch"] * 1024 and s.const_dt == C["const_dt"] and ds.aabb_scale == (C["aabb_scale"] or 1)
         ours, ref = ds.transforms_gpu.numpy(), G["dataset.transforms_gpu"]
         order = torch.as_tensor([int(np.argmin(np.abs(ours - ref[i][None]).reshape(len(ours), -1).max(-1))) for i in range(len(ref))])
         assert sorted(order.tolist()) == list(range(ds.n_images))
