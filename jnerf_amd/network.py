@@ -15,9 +15,16 @@ from .utils.config import get_cfg
 from .utils.registry import build_from_cfg, NETWORKS, ENCODERS
 
 
+def invariant_uniform_bound(in_f):
+    """Jittor's init.invariant_uniform lives inside Jittor (external, not installable here): U(+-sqrt(g / fan_in)).  g = 3 (variance 1 / fan_in) is SURVEY.md's reading and
+    the default of rounds 1-3; a second reading of Jittor's init.py has bound = sqrt(1 / fan) - PyTorch's nn.Linear default - i.e. g = 1.  Nothing in /root/reference
+    decides it (DESIGN.md 'parity unpinned'); `invariant_uniform_gain = 1.0` in the config selects the other reading so that the two can be trained side by side."""
+    g = get_cfg().invariant_uniform_gain
+    return math.sqrt((3.0 if g is None else float(g)) / in_f)
+
+
 def invariant_uniform(out_f, in_f, device):
-    """Jittor's init.invariant_uniform (external): U(+-sqrt(3/fan_in)) — documented assumption, see DESIGN.md 'parity unpinned'."""
-    b = math.sqrt(3.0 / in_f)
+    b = invariant_uniform_bound(in_f)
     return torch.empty((out_f, in_f), dtype=torch.float32, device=device).uniform_(-b, b)
 
 

@@ -28,12 +28,14 @@ def jt_norm(x, dim=-1, keepdim=False, eps=1e-6):
 
 
 def jt_linear(in_features, out_features):
-    """nn.Linear with Jittor's default initialisation (jittor.nn.Linear: weight = init.invariant_uniform -> U(+-sqrt(3 / fan_in)), bias = U(+-1 / sqrt(fan_in))) instead of
+    """nn.Linear with Jittor's default initialisation (jittor.nn.Linear: weight = init.invariant_uniform -> U(+-sqrt(g / fan_in)), g = 3 unless the config says otherwise - network.invariant_uniform_bound; bias = U(+-1 / sqrt(fan_in))) instead of
     torch's kaiming-uniform default, which is sqrt(3) times narrower in the weights.  Jittor is an external dependency of the reference: restated from its published
     source, parity unpinned (same note as network.py:invariant_uniform)."""
     lin = nn.Linear(in_features, out_features)
     with torch.no_grad():
-        lin.weight.uniform_(-math.sqrt(3.0 / in_features), math.sqrt(3.0 / in_features))
+        from .network import invariant_uniform_bound
+        b = invariant_uniform_bound(in_features)
+        lin.weight.uniform_(-b, b)
         lin.bias.uniform_(-1.0 / math.sqrt(in_features), 1.0 / math.sqrt(in_features))
     return lin
 
