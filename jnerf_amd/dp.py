@@ -11,6 +11,7 @@ import torch.distributed as dist
 from . import _lib as L
 
 _comm = None          # (handle, rank, world)
+_comm_unavailable = False          # set by library_comm_or_fallback when the ranks agreed to do without it: every later caller gets None (the torch.distributed route)
 
 
 def active():
@@ -25,7 +26,7 @@ def active():
 def library_comm():
     """handle of the library's RCCL communicator over the default process group, created on first use; None when the group's backend is not nccl (= RCCL)"""
     global _comm
-    if not active() or dist.get_backend() != "nccl" or not torch.cuda.is_available():
+    if _comm_unavailable or not active() or dist.get_backend() != "nccl" or not torch.cuda.is_available():
         return None
     rank, world = dist.get_rank(), dist.get_world_size()
     if _comm is not None and _comm[1:] == (rank, world):
@@ -63,8 +64,10 @@ def library_comm_or_fallback():
     if dist.get_world_size() > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
+        global _comm_unavailable
         if comm is not None:
             destroy()
+        _comm_unavailable = True
         print(f"[jnerf_amd.dp] WARNING rank {dist.get_rank()}: the in-library RCCL communicator is unavailable ({err or 'failed on another rank'}); "
               "the exchange step runs through torch.distributed around a phase-split step", file=sys.stderr, flush=True)
         return None
