@@ -75,7 +75,7 @@ def main(case):
     jt.save = lambda obj, path: out.setdefault("ckpt_keys", np.frombuffer(",".join(sorted(obj)).encode(), np.uint8))       # runner.py:123-131's dictionary, not written
 
     d = tempfile.mkdtemp(prefix="refrun_")
-    S.write_rendered_nerf_dataset(d)
+    S.write_rendered_nerf_dataset(d, R.get("res"))
     init_cfg("/root/reference/projects/ngp/configs/ngp_base.py")
     cfg = get_cfg()
     for mode in ("train", "val", "test"):

@@ -143,10 +143,10 @@ def _nerf_camera(theta, phi, radius=4.0):
     return m
 
 
-def write_rendered_nerf_dataset(root):
-    """three opaque shaded balls in front of a transparent background, RGBA PNGs + transforms_{train,val,test}.json"""
+def write_rendered_nerf_dataset(root, res=None):
+    """three opaque shaded balls in front of a transparent background, RGBA PNGs + transforms_{train,val,test}.json (`res`: square images of that size instead of W x H)"""
     from PIL import Image
-    W, H, fov = REFRUN["W"], REFRUN["H"], REFRUN["camera_angle_x"]
+    W, H, fov = res or REFRUN["W"], res or REFRUN["H"], REFRUN["camera_angle_x"]
     focal = 0.5 * W / np.tan(0.5 * fov)
     ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
     d_cam = np.stack([(xs + 0.5 - W / 2) / focal, -(ys + 0.5 - H / 2) / focal, -np.ones_like(xs, dtype=np.float64)], -1)
@@ -183,6 +183,6 @@ REFRUN_SEEDS = dict(perm=4000, bg=5000, grid=31, mlp=5, probe=61)
 # the runs of tests/golden/make_golden_refrun.py: name -> (fixture file, configuration on top of ngp_base.py)
 REFRUN_CASES = {"lego": dict(file="golden_refrun_v1.npz", aabb_scale=None, const_dt=True, steps=REFRUN["steps"]),
                 "cone": dict(file="golden_refrun_cone_v1.npz", aabb_scale=2, const_dt=False, steps=6),          # fox-style sampling: two cascades, cone stepping
-                "render": dict(file="golden_refrun_render_v1.npz", aabb_scale=None, const_dt=True, steps=0)}     # no training: one occupancy refresh, then the inference path
+                "render": dict(file="golden_refrun_render_v1.npz", aabb_scale=None, const_dt=True, steps=0, res=20)}     # no training: one occupancy refresh, then the inference path
 # a camera-to-world pose in the NeRF convention for render_img_with_pose (it goes through matrix_nerf2ngp): on the camera sphere, between the training views
 NOVEL_POSE_NGP = _nerf_camera(1.1, 0.5)[:3, :].astype(np.float32)

@@ -149,7 +149,7 @@ def test_oracle_replays_the_references_inference_path(tmp_path):
     from jnerf_amd.dataset import NerfDataset
     R = S.REFRUN
     G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", S.REFRUN_CASES["render"]["file"]))
-    S.write_rendered_nerf_dataset(str(tmp_path))
+    S.write_rendered_nerf_dataset(str(tmp_path), S.REFRUN_CASES["render"]["res"])
     reset_cfg(device="cpu")
     train = NerfDataset(str(tmp_path), batch_size=R["n_rays_per_batch"], mode="train")
     test = NerfDataset(str(tmp_path), batch_size=R["n_rays_per_batch"], mode="test")
@@ -291,7 +291,7 @@ def test_host_stack_replays_the_references_inference_path(tmp_path):
     from jnerf_amd.utils.registry import build_from_cfg, DATASETS
     G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", S.REFRUN_CASES["render"]["file"]))
     R = S.REFRUN
-    S.write_rendered_nerf_dataset(str(tmp_path))
+    S.write_rendered_nerf_dataset(str(tmp_path), S.REFRUN_CASES["render"]["res"])
     cfg = ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_rays_per_batch=R["n_rays_per_batch"], target_batch_size=R["target_batch_size"], pipeline_sampling=False,
                   device="cpu", log_dir=str(tmp_path / "logs"))
     one = dict(type="NerfDataset", root_dir=str(tmp_path), batch_size=R["n_rays_per_batch"])
