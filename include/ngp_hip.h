@@ -122,6 +122,14 @@ int ngp_density32_fwd(void *stream, uint32_t n, const float *feat, int feat_layo
 int ngp_field32_bwd(void *stream, uint32_t n, const float *feat, int feat_layout, const float *dir, uint32_t dir_stride_floats,
                     const float *wd, const float *wc, const float *dLdout, float *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid);
 int ngp_field32_bwd_slabs(uint32_t n);
+/* The default kernels behind the three calls above compute every fp32 product from split fp16 operands (csrc/field_split.hip); operands are lifted into fp16's range by
+ * fixed powers of two, so features beyond ~255 or activations beyond ~4094 would overflow - the reference's fp32 nn.Linear chain (ngp_network.py:59-67) has no such limit.
+ * The kernels therefore track the largest operand they split and raise a device-side flag: bit 0 = an operand came within 4x of the limit (nothing has overflowed yet),
+ * bit 1 = one left the range (that launch's results contain infinities) or a backward stored a non-finite feature gradient.
+ * ngp_field32_range_check returns the flag bits (>= 0; reset != 0 clears them) or NGP_E_ARG; it reads 4 bytes back - call it where the host synchronises anyway.
+ * ngp_field32_select(1) switches this process to the exact-product kernels (v_mfma_f32_16x16x4_f32: no operand range), (0) back to the split ones; returns the previous choice. */
+int ngp_field32_range_check(int reset);
+int ngp_field32_select(int exact);
 
 /* ---- sampler ------------------------------------------------------------------------------------------------------
  * rng_state_host: u64[2] = {state, inc} of the reference's global pcg32{1337} (ops/code_ops/global_vars.py:13-16); it is advanced

@@ -79,6 +79,8 @@ SIGNATURES = {
     "ngp_density32_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp]),
     "ngp_field32_bwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "ngp_field32_bwd_slabs": (C.c_int, [_u32]),
+    "ngp_field32_range_check": (C.c_int, [_i32]),
+    "ngp_field32_select": (C.c_int, [_i32]),
     "ngp_reduce_slabs": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _i32]),
     "ngp_march_rays": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _i32]),
     "ngp_compact_coords": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),

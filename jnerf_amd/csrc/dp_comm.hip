@@ -54,6 +54,20 @@ int nccl_dtype(int dtype) { return dtype == NGP_F16 ? 6 : 7; }
 struct NgpComm { void *nccl; int rank, world; };
 
 #define RCCL_CALL(call, what) do { int r_ = (call); if (r_ != 0) { ngp_set_error("%s: RCCL error %d (%s)", what, r_, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); return 1000 + r_; } } while (0)
+// Inside an open group an error must not return past ncclGroupEnd: the thread's group would stay open and the next RCCL call of this process - the library's or
+// torch's - would be queued into it silently.  RcclGroup opens a group and closes it on every path out of the scope; GROUP_CALL records the first
+// failure, stops issuing, and the function returns it after the group was closed.
+namespace {
+struct RcclGroup {
+	int rc = 0; bool open = false;
+	RcclGroup() { rc = g_rccl.GroupStart(); open = rc == 0; }
+	int close() { if (open) { open = false; const int r = g_rccl.GroupEnd(); if (!rc) rc = r; } return rc; }
+	~RcclGroup() { close(); }
+};
+int rccl_fail(int r, const char *what) { ngp_set_error("%s: RCCL error %d (%s)", what, r, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return 1000 + r; }
+}  // namespace
+#define GROUP_CALL(grp, call, what) do { if (!(grp).rc) { const int r_ = (call); if (r_ != 0) { (grp).rc = r_; rccl_fail(r_, what); } } } while (0)
+#define GROUP_FINISH(grp, what) do { const bool failed_inside_ = (grp).rc != 0; const int r_ = (grp).close(); if (r_ != 0) { if (!failed_inside_) rccl_fail(r_, what); return 1000 + r_; } } while (0)
 
 NGP_API int ngp_comm_unique_id(void *id_out_host) {
 	NGP_REQUIRE(id_out_host, NGP_E_ARG, "ngp_comm_unique_id: null output");
@@ -127,10 +141,10 @@ NGP_API int ngp_allreduce_grads(void *comm, void *stream, int n_bufs, void *cons
 	NgpComm *c = (NgpComm *)comm;
 	if (n_bufs == 0) return 0;
 	for (int i = 0; i < n_bufs; ++i) NGP_REQUIRE(dtypes_host[i] == NGP_F32 || dtypes_host[i] == NGP_F16, NGP_E_DTYPE, "ngp_allreduce_grads: bad dtype %d", dtypes_host[i]);
-	RCCL_CALL(g_rccl.GroupStart(), "ncclGroupStart");
+	RcclGroup grp;
 	for (int i = 0; i < n_bufs; ++i)
-		if (counts_host[i]) RCCL_CALL(g_rccl.AllReduce(bufs_host[i], bufs_host[i], (size_t)counts_host[i], nccl_dtype(dtypes_host[i]), 0, c->nccl, (hipStream_t)stream), "ncclAllReduce");
-	RCCL_CALL(g_rccl.GroupEnd(), "ncclGroupEnd");
+		if (counts_host[i]) GROUP_CALL(grp, g_rccl.AllReduce(bufs_host[i], bufs_host[i], (size_t)counts_host[i], nccl_dtype(dtypes_host[i]), 0, c->nccl, (hipStream_t)stream), "ncclAllReduce");
+	GROUP_FINISH(grp, "ncclGroupStart/End(ngp_allreduce_grads)");
 	return 0;
 }
 
@@ -139,16 +153,16 @@ NGP_API int ngp_allreduce_grads(void *comm, void *stream, int n_bufs, void *cons
 int ngp_dp_reduce(void *comm, hipStream_t s, const NgpDpPlan *plan, void *grad, int dtype, uint32_t first_bucket, uint32_t last_bucket, float *tail_f32, float *extra_f32, uint64_t extra_count) {
 	NgpComm *c = (NgpComm *)comm;
 	const size_t es = dtype == NGP_F16 ? 2 : 4;
-	RCCL_CALL(g_rccl.GroupStart(), "ncclGroupStart");
+	RcclGroup grp;
 	for (uint32_t b = first_bucket; b <= last_bucket && b < plan->n_buckets; ++b) {
 		if (!plan->shard_count[b]) continue;
 		char *base = (char *)grad + plan->cut[b] * es;
-		RCCL_CALL(g_rccl.ReduceScatter(base, base + (size_t)plan->rank * plan->shard_count[b] * es, (size_t)plan->shard_count[b], nccl_dtype(dtype), 0, c->nccl, s), "ncclReduceScatter");
+		GROUP_CALL(grp, g_rccl.ReduceScatter(base, base + (size_t)plan->rank * plan->shard_count[b] * es, (size_t)plan->shard_count[b], nccl_dtype(dtype), 0, c->nccl, s), "ncclReduceScatter");
 	}
 	if (tail_f32 && plan->tail_count && last_bucket + 1 >= plan->n_buckets)
-		RCCL_CALL(g_rccl.AllReduce(tail_f32 + plan->tail_begin, tail_f32 + plan->tail_begin, (size_t)plan->tail_count, 7, 0, c->nccl, s), "ncclAllReduce(tail)");
-	if (extra_f32 && extra_count) RCCL_CALL(g_rccl.AllReduce(extra_f32, extra_f32, (size_t)extra_count, 7, 0, c->nccl, s), "ncclAllReduce(mlp)");
-	RCCL_CALL(g_rccl.GroupEnd(), "ncclGroupEnd");
+		GROUP_CALL(grp, g_rccl.AllReduce(tail_f32 + plan->tail_begin, tail_f32 + plan->tail_begin, (size_t)plan->tail_count, 7, 0, c->nccl, s), "ncclAllReduce(tail)");
+	if (extra_f32 && extra_count) GROUP_CALL(grp, g_rccl.AllReduce(extra_f32, extra_f32, (size_t)extra_count, 7, 0, c->nccl, s), "ncclAllReduce(mlp)");
+	GROUP_FINISH(grp, "ncclGroupStart/End(ngp_dp_reduce)");
 	return 0;
 }
 
@@ -159,15 +173,15 @@ NGP_API int ngp_dp_allgather(void *comm, void *stream, const NgpDpPlan *plan, in
 	NGP_REQUIRE(plan->world == c->world && plan->rank == c->rank, NGP_E_ARG, "ngp_dp_allgather: plan is for rank %d of %d, communicator is rank %d of %d", plan->rank, plan->world, c->rank, c->world);
 	if (n_bufs == 0) return 0;
 	for (int i = 0; i < n_bufs; ++i) NGP_REQUIRE(dtypes_host[i] == NGP_F32 || dtypes_host[i] == NGP_F16, NGP_E_DTYPE, "ngp_dp_allgather: bad dtype %d", dtypes_host[i]);   // (before the group opens: an early return must not leave it open)
-	RCCL_CALL(g_rccl.GroupStart(), "ncclGroupStart");
+	RcclGroup grp;
 	for (int i = 0; i < n_bufs; ++i) {
 		const size_t es = dtypes_host[i] == NGP_F16 ? 2 : 4;
 		for (uint32_t b = 0; b < plan->n_buckets; ++b) {
 			if (!plan->shard_count[b]) continue;
 			char *base = (char *)bufs_host[i] + plan->cut[b] * es;
-			RCCL_CALL(g_rccl.AllGather(base + (size_t)plan->rank * plan->shard_count[b] * es, base, (size_t)plan->shard_count[b], nccl_dtype(dtypes_host[i]), c->nccl, (hipStream_t)stream), "ncclAllGather");
+			GROUP_CALL(grp, g_rccl.AllGather(base + (size_t)plan->rank * plan->shard_count[b] * es, base, (size_t)plan->shard_count[b], nccl_dtype(dtypes_host[i]), c->nccl, (hipStream_t)stream), "ncclAllGather");
 		}
 	}
-	RCCL_CALL(g_rccl.GroupEnd(), "ncclGroupEnd");
+	GROUP_FINISH(grp, "ncclGroupStart/End(ngp_dp_allgather)");
 	return 0;
 }

@@ -1071,15 +1071,26 @@ static int check_field32(const char *fn, const void *feat, const void *wd, const
 	return 0;
 }
 // forward kernel: split fp16 operands on v_mfma_f32_16x16x32_f16 (field_split.hip, default) | exact fp32 products on v_mfma_f32_16x16x4_f32 (NGP_FIELD32_FWD=mfma32)
+static int g_fwd_split = -1, g_bwd_variant = -1;     // -1: not decided yet (environment, then the default); set by ngp_field32_select
 static bool fwd_split() {
-	static int v = -1;
-	if (v < 0) { const char *e = getenv("NGP_FIELD32_FWD"); v = (e && (e[0] == 'm' || e[0] == '0')) ? 0 : 1; }
-	return v == 1;
+	if (g_fwd_split < 0) { const char *e = getenv("NGP_FIELD32_FWD"); g_fwd_split = (e && (e[0] == 'm' || e[0] == '0')) ? 0 : 1; }
+	return g_fwd_split == 1;
 }
 static bool dens_split() {       // (probe hook: NGP_DENSITY32_FWD=mfma32|split selects the density-only forward independently)
 	static int v = -1;
-	if (v < 0) { const char *e = getenv("NGP_DENSITY32_FWD"); v = !e ? (fwd_split() ? 1 : 0) : ((e[0] == 'm' || e[0] == '0') ? 0 : 1); }
-	return v == 1;
+	if (v < 0) { const char *e = getenv("NGP_DENSITY32_FWD"); v = !e ? -2 : ((e[0] == 'm' || e[0] == '0') ? 0 : 1); }
+	return v == -2 ? fwd_split() : v == 1;
+}
+static int bwd_variant() {
+	if (g_bwd_variant < 0) { const char *e = getenv("NGP_FIELD32_BWD"); g_bwd_variant = e ? atoi(e) : NGP_FIELD32_BWD_DEFAULT; }
+	return g_bwd_variant;
+}
+// Which kernels ngp_field32_fwd / ngp_density32_fwd / ngp_field32_bwd launch from now on in this process: exact = 1 -> the exact-product fp32-MFMA kernels (no operand
+// range), exact = 0 -> the split-operand kernels (default).  Both fragment sets are always present in a packed weight buffer.  Returns the previous setting.
+NGP_API int ngp_field32_select(int exact) {
+	const int was = (fwd_split() ? 0 : 1);
+	g_fwd_split = exact ? 0 : 1; g_bwd_variant = exact ? 2 : 3;
+	return was;
 }
 // n_frags fp32 fragments (n_frags < 0: the first -n_frags split fp16 fragments of the forward instead) of raw weight packs in a per-(device, stream) scratch, or the caller's packed buffer
 static const float *pack_weights32(const char *fn, hipStream_t s, const void *wd, const void *wc, int n_frags, int layout_flags) {
@@ -1154,7 +1165,7 @@ int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, 
 	const dim3 grid(n_slabs), block(512);
 	hipStream_t s = (hipStream_t)stream;
 	// 3 = split fp16 operands on the fp16 matrix cores (field_split.hip, r3), 2 = two free-running groups on fp32 MFMAs, 0 / 1: see below
-	static const int variant = [] { const char *e = getenv("NGP_FIELD32_BWD"); return e ? atoi(e) : NGP_FIELD32_BWD_DEFAULT; }();
+	const int variant = bwd_variant();
 	const float *packed = pack_weights32("ngp_field32_bwd", s, wd, wc, variant == 3 ? -NSPLIT_FRAGS : NF32_ALL, layout_flags); if (!packed) return NGP_E_ARG;
 	if (variant == 3) return ngp_field32_bwd_split(stream, n, feat, layout, dir, dir_stride, packed + NF32_ALL * 256, dLdout, dLdfeat, wgrad_slabs, n_slabs, n_valid, am_in);
 	// 2 = two free-running groups (r3, default: 138 us, +1 % it/s), 0 = lock-step phases (r2: 145 us), 1 = ping-pong roles sharing barriers (r3 experiment: 151 us - ten

@@ -13,9 +13,22 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 // fp16 spans 6e-5 .. 65504 (normal range): B operands are multiplied by a power of two before the split and the factor is taken out of the fp32 accumulator again (both
 // exact).  Hash features start at ~1e-4 and stay below ~10: x 256 (safe up to 255); hidden activations / density logits / SH: x 16 (safe up to 4094; accurate down to a
-// tensor scale of ~4e-6).  Values beyond the safe maxima overflow to infinity - NGP_FIELD32_FWD=mfma32 is the kernel without such a range.
+// tensor scale of ~4e-6).  Values beyond the safe maxima would overflow to infinity - the exact-product kernels of field32.hip (NGP_FIELD32_FWD=mfma32) have no such
+// range.  (r4) No silent infinity: the forward kernels keep the largest prescaled operand they split (four v_max3 per eight operands) and raise a device-side flag -
+// bit 0 once an operand comes within a factor four of fp16's largest finite value (features > 63.9, activations > 1023: nothing has overflowed yet), bit 1 when one
+// exceeded it (the results of that launch contain infinities); the backward raises bit 1 when a feature gradient it stores is not finite.  ngp_field32_range_check
+// reads (and optionally clears) the flag; Runner polls it where it synchronises anyway (every 16th step, after every rendered image): bit 0 switches the process to
+// the exact-product kernels through ngp_field32_select before anything overflowed, bit 1 is an error.
 #define FEAT_PRESCALE 256.0f
 #define HID_PRESCALE 16.0f
+#define SPLIT_RANGE_MAX 65504.0f
+#define SPLIT_RANGE_NEAR (SPLIT_RANGE_MAX / 4.0f)
+__device__ uint32_t g_split_range_flag = 0u;
+// rmax: two packed 16-bit maxima of |h| bit patterns (fp16: 0x7bff = 65504, 0x7c00 = infinity, above = NaN; 0x73ff = 16376 = a quarter of the range)
+__device__ __forceinline__ void range_report(uint32_t rmax) {
+	const uint32_t m = max(rmax & 0xffffu, rmax >> 16);
+	if (m > 0x73ffu) atomicOr(&g_split_range_flag, m > 0x7bffu ? 3u : 1u);
+}
 
 __global__ __launch_bounds__(256) void k_pack_split(const float *__restrict__ wd, const float *__restrict__ wc, _Float16 *__restrict__ out, int n_frags) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -40,6 +53,25 @@ __device__ __forceinline__ B2 split_relu(floatx4 a, floatx4 b) {
 #pragma unroll
 	for (int k = 0; k < 4; ++k) { v[k] = fmaxf(a[k], 0.f) * HID_PRESCALE; v[4 + k] = fmaxf(b[k], 0.f) * HID_PRESCALE; }
 	return split8(v);
+}
+// split8 that also folds the operands' magnitudes into rmax: the h part converted back (it is needed for the residual anyway; an overflowed operand reads as infinity)
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ B2 split8(const float v[8], uint32_t &rmax) {
+	const B2 r = split8(v);
+	// |h| as bit patterns order like the magnitudes (an overflowed operand reads 0x7c00): a packed unsigned 16-bit maximum over the four registers of the h part
+	const uint4v q = __builtin_bit_cast(uint4v, r.h) & 0x7fff7fffu;
+	ushort2v m = __builtin_bit_cast(ushort2v, rmax);
+#pragma unroll
+	for (int k = 0; k < 4; ++k) m = __builtin_elementwise_max(m, __builtin_bit_cast(ushort2v, q[k]));
+	rmax = __builtin_bit_cast(uint32_t, m);
+	return r;
+}
+__device__ __forceinline__ B2 split_relu(floatx4 a, floatx4 b, uint32_t &rmax) {
+	float v[8];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { v[k] = fmaxf(a[k], 0.f) * HID_PRESCALE; v[4 + k] = fmaxf(b[k], 0.f) * HID_PRESCALE; }
+	return split8(v, rmax);
 }
 struct Acc { floatx4 main, corr; };
 __device__ __forceinline__ half8 ld_half8(const _Float16 *lds, int f, int lane) { return *reinterpret_cast<const half8 *>(lds + f * 512 + lane * 8); }
@@ -84,30 +116,30 @@ __device__ __forceinline__ void load_feat_split(const float *__restrict__ feat, 
 }
 
 template <bool DENSITY_ONLY, int MSTRIDE>
-__device__ __forceinline__ void forward_split(const _Float16 *wl, int lane, const float feat[8], const float sh[4], floatx4 &den, floatx4 &rgb) {
+__device__ __forceinline__ void forward_split(const _Float16 *wl, int lane, const float feat[8], const float sh[4], floatx4 &den, floatx4 &rgb, uint32_t &rmax) {
 	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
 	float fs[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) fs[k] = feat[k] * FEAT_PRESCALE;
-	const B2 b0 = split8(fs);
+	const B2 b0 = split8(fs, rmax);
 	floatx4 c0[4];
 #pragma unroll
 	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, t, lane, b0, a); c0[t] = combine(a, 1.0f / FEAT_PRESCALE); }        // L0: 32 -> 64
-	const B2 h0 = split_relu(c0[0], c0[1]), h1 = split_relu(c0[2], c0[3]);
+	const B2 h0 = split_relu(c0[0], c0[1], rmax), h1 = split_relu(c0[2], c0[3], rmax);
 	{ Acc a = {z, z}; mma3<MSTRIDE>(wl, 4, lane, h0, a); mma3<MSTRIDE>(wl, 5, lane, h1, a); den = combine(a, 1.0f / HID_PRESCALE); }               // L1: 64 -> 16
 	if (DENSITY_ONLY) return;
 	float in2[8];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) { in2[k] = den[k] * HID_PRESCALE; in2[4 + k] = sh[k] * HID_PRESCALE; }
-	const B2 b2 = split8(in2);
+	const B2 b2 = split8(in2, rmax);
 	floatx4 c2[4];
 #pragma unroll
 	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, 6 + t, lane, b2, a); c2[t] = combine(a, 1.0f / HID_PRESCALE); }                       // L2: [density(16) | SH(16)] -> 64
-	const B2 g00 = split_relu(c2[0], c2[1]), g01 = split_relu(c2[2], c2[3]);
+	const B2 g00 = split_relu(c2[0], c2[1], rmax), g01 = split_relu(c2[2], c2[3], rmax);
 	floatx4 c3[4];
 #pragma unroll
 	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, 10 + 2 * t, lane, g00, a); mma3<MSTRIDE>(wl, 11 + 2 * t, lane, g01, a); c3[t] = combine(a, 1.0f / HID_PRESCALE); }   // L3: 64 -> 64
-	const B2 g10 = split_relu(c3[0], c3[1]), g11 = split_relu(c3[2], c3[3]);
+	const B2 g10 = split_relu(c3[0], c3[1], rmax), g11 = split_relu(c3[2], c3[3], rmax);
 	{ Acc a = {z, z}; mma3<MSTRIDE>(wl, 18, lane, g10, a); mma3<MSTRIDE>(wl, 19, lane, g11, a); rgb = combine(a, 1.0f / HID_PRESCALE); }                          // L4: 64 -> 16 (3 used)
 }
 
@@ -133,6 +165,7 @@ __global__ __launch_bounds__(256) void k_field32_fwd_split(uint32_t n, const flo
 		if (!DENSITY_ONLY) { d[0] = dir[(size_t)ic * dir_stride]; d[1] = dir[(size_t)ic * dir_stride + 1]; d[2] = dir[(size_t)ic * dir_stride + 2]; }
 	};
 	float f[8], fn[8], d[3] = {0.f, 0.f, 0.f}, dn[3] = {0.f, 0.f, 0.f};
+	uint32_t rmax = 0u;                                             // largest prescaled operand this lane split, as packed fp16 bit patterns (range_report)
 	if (wave < n_tiles) fetch(wave, f, d);
 	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
 		const uint32_t i = tile * 16u + s;
@@ -141,7 +174,7 @@ __global__ __launch_bounds__(256) void k_field32_fwd_split(uint32_t n, const flo
 		float sh[4] = {0.f, 0.f, 0.f, 0.f};
 		if (!DENSITY_ONLY) sh4_split(d, g, sh);
 		floatx4 den, rgb;
-		forward_split<DENSITY_ONLY, NSPLIT_FWD * 512>(wl, lane, f, sh, den, rgb);
+		forward_split<DENSITY_ONLY, NSPLIT_FWD * 512>(wl, lane, f, sh, den, rgb, rmax);
 		if (g == 0 && i < lim) {
 			if (DENSITY_ONLY) out[i] = den[0];
 			else *reinterpret_cast<float4 *>(out + (size_t)i * 4) = make_float4(rgb[0], rgb[1], rgb[2], den[0]);
@@ -152,6 +185,7 @@ __global__ __launch_bounds__(256) void k_field32_fwd_split(uint32_t n, const flo
 			d[0] = dn[0]; d[1] = dn[1]; d[2] = dn[2];
 		}
 	}
+	range_report(rmax);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- backward
@@ -229,6 +263,7 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 	extern __shared__ __attribute__((aligned(16))) _Float16 smem_split[];
 	__shared__ float smax[8];
 	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // running max |dL/dfeature| of levels 8t + 2g + pr over this lane's samples (absmax_epilogue)
+	bool bad = false;                                      // a feature gradient that is not finite: an operand of the chain left fp16's range (g_split_range_flag bit 1)
 	_Float16 *wl = smem_split;                             // [2 parts][42 fragments][512]
 	_Float16 *stage = smem_split + NSPLIT_HALVES;          // [2 planes][SROWS][SRS]
 	{
@@ -370,6 +405,7 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 					const float2 v = make_float2(dF[t][2 * pr], dF[t][2 * pr + 1]);
 					const uint32_t level = 8 * t + 2 * g + pr;
 					lmax[t][pr] = fmaxf(lmax[t][pr], fmaxf(fabsf(v.x), fabsf(v.y)));
+					bad |= !(fabsf(v.x) <= 3.0e38f) || !(fabsf(v.y) <= 3.0e38f);
 					if (LAYOUT == NGP_LAYOUT_SOA) reinterpret_cast<float2 *>(dfeat)[(size_t)level * n + i] = v;
 					else *reinterpret_cast<float2 *>(dfeat + (size_t)i * 32 + 2 * level) = v;
 				}
@@ -398,7 +434,19 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 			slab[3072 + 6144 + ro * 64 + 16 * tx + ci] = aV2[r] + xch[((tx * 2 + 1) * 64 + lane) * 4 + r];
 		}
 	}
+	if (bad) atomicOr(&g_split_range_flag, 2u);
 	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, reinterpret_cast<float *>(stage), 8); }
+}
+
+// bit 0: an operand of a split forward came within 4x of fp16's largest finite value since the last reset; bit 1: one left the range (infinities in that launch's
+// results) or a split backward stored a non-finite feature gradient.  Synchronises the device (a 4-byte read-back): call it where the host waits anyway.
+NGP_API int ngp_field32_range_check(int reset) {
+	uint32_t v = 0u;
+	hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_range_flag), sizeof(v), 0, hipMemcpyDeviceToHost);
+	if (e != hipSuccess) { ngp_set_error("ngp_field32_range_check: %s", hipGetErrorString(e)); return NGP_E_ARG; }
+	if (reset && v) { const uint32_t zero = 0u; e = hipMemcpyToSymbol(HIP_SYMBOL(g_split_range_flag), &zero, sizeof(zero), 0, hipMemcpyHostToDevice);
+		if (e != hipSuccess) { ngp_set_error("ngp_field32_range_check: %s", hipGetErrorString(e)); return NGP_E_ARG; } }
+	return (int)v;
 }
 
 static uint32_t split_grid(uint32_t n) { uint32_t b = div_up(div_up(n, 16), 4); return b < 1024 ? (b ? b : 1) : 1024; }

@@ -804,6 +804,8 @@ static int hash_bwd_method() {
 #define BIN_LEVEL_MAX (BIN_ENTRIES * BINS_PER_LEVEL)                  // 2^19 entries: the largest level the bins cover
 #define RUN_RES_MAX 300u                                              // levels up to this resolution go through k_bin_records_runs
 static_assert(RUN_RES_MAX == NGP_DP_COARSE_RES_MAX, "the data-parallel bucket boundary (ngp_dp_plan) is the boundary between the run-combined and the fine levels");
+#define PAIR_CURSORS_PER_LEVEL 128u                                       // (= PAIR_BINS, defined with the edge-record kernels below)
+#define N_CURSORS (16u * BINS_PER_LEVEL + 16u * PAIR_CURSORS_PER_LEVEL)    // u32 cursors of a workspace: [16][64] per-corner bins, then [16][128] edge-record bins
 struct BinPlan { uint32_t level[16]; uint32_t n_levels; uint32_t cap; uint32_t spill_cap; };   // binned levels, records per bin, entries of the spill list
 struct LevelSel { uint32_t hl[16]; };                                  // the binned-level ordinals one launch works on (blockIdx.y, or blockIdx.x / 64)
 struct SpillEntry { uint32_t key /* binned-level ordinal << 19 | entry */; float x, y; };       // value in record units (fp16 records: scaled)
@@ -840,6 +842,7 @@ __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__res
 	const uint32_t level = blockIdx.y;
 	if (blockIdx.x == 0) {                                               // cursors u32[16][BINS_PER_LEVEL], spill count
 		if (threadIdx.x < BINS_PER_LEVEL) cursors[level * BINS_PER_LEVEL + threadIdx.x] = 0u;
+		if (threadIdx.x < PAIR_CURSORS_PER_LEVEL) cursors[16u * BINS_PER_LEVEL + level * PAIR_CURSORS_PER_LEVEL + threadIdx.x] = 0u;   // the edge-record cursors live behind them
 		if (level == 0 && threadIdx.x == BINS_PER_LEVEL) *spill_count = 0u;
 	}
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
@@ -979,8 +982,8 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float 
 #define RUN_STAGE 3072u
 static uint32_t run_stage_bytes(uint32_t stage) { return stage * 12u + 4u * BINS_PER_LEVEL * 4u; }
 
-template <typename T, int LAYOUT>
-__global__ __launch_bounds__(RUN_WG) void k_bin_records_runs(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
+template <typename T, int LAYOUT, int OCC /* waves per SIMD the register budget is held to: 4 = natural (114 VGPRs), 5 = all 1280 workgroups of a 2^18-sample batch resident at once (probe) */>
+__global__ __launch_bounds__(RUN_WG, OCC) void k_bin_records_runs(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
                                                            const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ cursors, void *__restrict__ rec_val,
                                                            uint16_t *__restrict__ rec_idx, uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill,
                                                            const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */) {
@@ -1199,6 +1202,196 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------- pair records (r4): the fine hashed levels, fp32
+// Round 3's fine levels wrote eight 10-byte records per (sample, level) - 124 MB out and back in for the six fine levels of the ngp_base.py table, the largest
+// block of the stage's traffic.  What the eight contributions of a cell share makes half of that unnecessary:
+//   * the hash is x ^ y*P1 ^ z*P2 masked to 19 bits and x + 1 <= res <= 2048 touches bits 0..11 only, so the two x-neighbours of a cell edge ALWAYS fall into the
+//     same 4096-entry slice of the level: bins of 4096 entries (128 per level) receive both, and ONE record can carry the edge;
+//   * their two contributions are (g * wy*wz) * (1 - fx) and (g * wy*wz) * fx: the record carries a = g.x*(wy*wz), b = g.y*(wy*wz) and fx, the accumulate kernel
+//     multiplies.  Three roundings per contribution like the reference's ((wx*wy)*wz)*g, in another order: within 2 ulp of it per contribution, far inside what
+//     the reference's float atomics (one rounding per add, arrival order) scatter around the exact sum; the accumulation itself stays exact (64-bit integers).
+// 16 bytes per EDGE {a, b, fx, slot0 | slot1 << 12 | bin << 24} = 8 bytes per contribution instead of 10, one 16-byte store / load per two contributions instead
+// of four narrow ones, half the LDS histogram and staging traffic in the record kernel - and the 64 KiB accumulator of a 4096-entry bin lets TWO accumulate
+// workgroups share a CU, so one's write-out and start-up hide behind the other's record stream (round 2 measured that gain but paid for it with half-length
+// record runs; the edge records are twice as large, so a 1024-sample workgroup writes the same 512-byte runs as before).
+// Levels: hashed, 2^19 entries, run-combining limit < res <= 2048, fp32 dL/dy and gradient.  Everything else keeps the per-corner records above.
+#define PAIR_BIN_BITS 12u
+#define PAIR_BIN_ENTRIES (1u << PAIR_BIN_BITS)
+#define PAIR_BINS 128u
+static_assert(PAIR_BINS == PAIR_CURSORS_PER_LEVEL, "cursor layout");
+#define PAIR_RES_MAX 2048u
+#define PAIR_PAD_MAX 8u
+static_assert(PAIR_BIN_ENTRIES * PAIR_BINS == BIN_LEVEL_MAX, "the pair path covers the full 2^19-entry levels");
+struct alignas(16) PairRec { float a, b, fx; uint32_t loc; };
+static uint32_t pair_stage_bytes(uint32_t wg, uint32_t pad) { return (wg * 4u + PAIR_BINS * (pad - 1u)) * 16u + (3u * PAIR_BINS + 4u) * 4u; }
+
+// S samples per workgroup.  `pad`: every (workgroup, bin) run is rounded up to a multiple of `pad` records with null records (a = b = 0), so that no 64- / 128-byte
+// line of a bin's stream is shared by two workgroups (= two XCDs' L2s holding partial dirty lines of it).
+template <int LAYOUT, uint32_t S>
+__global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__restrict__ pos, uint32_t stride, const float *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
+                                                 const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ pcursors, PairRec *__restrict__ prec, uint32_t pcap, uint32_t pad,
+                                                 uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill, const uint32_t *__restrict__ n_valid) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
+	const uint32_t stage_cap = S * 4u + PAIR_BINS * (pad - 1u);
+	PairRec *stage = reinterpret_cast<PairRec *>(bin_smem);
+	uint32_t *cnt = bin_smem + stage_cap * 4u, *base = cnt + PAIR_BINS, *loff = base + PAIR_BINS;      // loff[PAIR_BINS] = staged total
+	const uint32_t po = blockIdx.y, hl = sel.hl[po], level = bp.level[hl];
+	const uint32_t mask = lt.v[4 * level + 1] - 1u;
+	const float scale = __uint_as_float(lt.v[4 * level + 3]);
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	if (level_absmax(absmax_bits, level) == 0u || blockIdx.x * S >= lim) return;                          // uniform exit
+	if (threadIdx.x < PAIR_BINS) cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t i = blockIdx.x * S + threadIdx.x;
+	const float2 *dy = reinterpret_cast<const float2 *>(dLdy);
+	float2 g2 = make_float2(0.f, 0.f);
+	Corner c;
+	uint32_t h[4], rank[4];
+	bool live = false;
+	if (i < lim) {
+		g2 = LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level];
+		live = (g2.x != 0.f || g2.y != 0.f);
+		if (live) {
+			c = locate(pos, stride, i, scale);
+			const uint32_t ty0 = c.g[1] * 19349663u, tz0 = c.g[2] * 83492791u;
+#pragma unroll
+			for (uint32_t q = 0; q < 4; ++q) {                                // q = (y corner, z corner), HashEncode.h:68-94
+				h[q] = (ty0 + ((q & 1u) ? 19349663u : 0u)) ^ (tz0 + ((q & 2u) ? 83492791u : 0u));
+				const uint32_t i0 = (c.g[0] ^ h[q]) & mask, i1 = ((c.g[0] + 1u) ^ h[q]) & mask;
+				// (positions outside the unit cube can carry x + 1 into the bin bits: that edge goes to the spill list as two contributions, rank = ~0)
+				rank[q] = ((i0 ^ i1) >> PAIR_BIN_BITS) ? ~0u : atomicAdd(&cnt[i0 >> PAIR_BIN_BITS], 1u);
+			}
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 64u) {                                                    // wave 0, two bins per lane: global reservation, exclusive prefix, padding records
+		const uint32_t b0 = 2u * threadIdx.x, c0 = cnt[b0], c1 = cnt[b0 + 1u];
+		const uint32_t p0 = (c0 + pad - 1u) / pad * pad, p1 = (c1 + pad - 1u) / pad * pad;
+		base[b0] = p0 ? atomicAdd(&pcursors[po * PAIR_BINS + b0], p0) : 0u;
+		base[b0 + 1u] = p1 ? atomicAdd(&pcursors[po * PAIR_BINS + b0 + 1u], p1) : 0u;
+		uint32_t x = p0 + p1;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)threadIdx.x >= o) x += y; }
+		const uint32_t e0 = x - (p0 + p1);
+		loff[b0] = e0; loff[b0 + 1u] = e0 + p0;
+		if (threadIdx.x == 63u) loff[PAIR_BINS] = x;
+		for (uint32_t k = c0; k < p0; ++k) stage[e0 + k] = PairRec{0.f, 0.f, 0.f, b0 << 24};
+		for (uint32_t k = c1; k < p1; ++k) stage[e0 + p0 + k] = PairRec{0.f, 0.f, 0.f, (b0 + 1u) << 24};
+	}
+	__syncthreads();
+	if (live) {
+#pragma unroll
+		for (uint32_t q = 0; q < 4; ++q) {
+			const float wy = (q & 1u) ? c.w[1] : 1 - c.w[1], wz = (q & 2u) ? c.w[2] : 1 - c.w[2], wyz = wy * wz;
+			const uint32_t i0 = (c.g[0] ^ h[q]) & mask, i1 = ((c.g[0] + 1u) ^ h[q]) & mask;
+			const float a = g2.x * wyz, b = g2.y * wyz;
+			if (rank[q] != ~0u) {
+				const uint32_t bin = i0 >> PAIR_BIN_BITS;
+				stage[loff[bin] + rank[q]] = PairRec{a, b, c.w[0], (i0 & (PAIR_BIN_ENTRIES - 1u)) | ((i1 & (PAIR_BIN_ENTRIES - 1u)) << PAIR_BIN_BITS) | (bin << 24)};
+			} else {
+				const uint32_t k = atomicAdd(spill_count, 2u);
+				const float w0 = 1 - c.w[0];
+				if (k + 1u < bp.spill_cap) { spill[k] = SpillEntry{(hl << 19) | i0, a * w0, b * w0}; spill[k + 1u] = SpillEntry{(hl << 19) | i1, a * c.w[0], b * c.w[0]}; }
+			}
+		}
+	}
+	__syncthreads();
+	const uint32_t total = loff[PAIR_BINS];
+	for (uint32_t p = threadIdx.x; p < total; p += S) {
+		const PairRec r = stage[p];
+		const uint32_t bin = r.loc >> 24, slot = base[bin] + (p - loff[bin]);
+		if (slot < pcap) prec[(size_t)(po * PAIR_BINS + bin) * pcap + slot] = r;
+		else if (r.a != 0.f || r.b != 0.f) {                            // bin full (pathological clustering): the shared spill list, as two contributions
+			const uint32_t k = atomicAdd(spill_count, 2u);
+			const float w0 = 1 - r.fx;
+			const uint32_t e0 = (bin << PAIR_BIN_BITS) | (r.loc & (PAIR_BIN_ENTRIES - 1u)), e1 = (bin << PAIR_BIN_BITS) | ((r.loc >> PAIR_BIN_BITS) & (PAIR_BIN_ENTRIES - 1u));
+			if (k + 1u < bp.spill_cap) { spill[k] = SpillEntry{(hl << 19) | e0, r.a * w0, r.b * w0}; spill[k + 1u] = SpillEntry{(hl << 19) | e1, r.a * r.fx, r.b * r.fx}; }
+		}
+	}
+}
+
+// One workgroup per (pair level, 4096-entry bin): 64 KiB of 64-bit accumulators, two workgroups per CU.  Every thread takes FOUR consecutive edge records (64 bytes,
+// two trips in flight), sums neighbours that name the same edge in registers (consecutive records of a bin come from consecutive samples of a ray: a level-10 cell
+// is two steps long) and issues four LDS atomics per distinct edge.  The spill list is scanned whenever it is not empty (out-of-cube edges land there directly).
+#define PACC_WG 512u
+template <typename G>
+__global__ __launch_bounds__(PACC_WG) void k_bin_accumulate_pairs(LevelTable lt, BinPlan bp, LevelSel sel, const uint32_t *__restrict__ absmax_bits, const uint32_t *__restrict__ pcursors,
+                                                                  const PairRec *__restrict__ prec, uint32_t pcap, const uint32_t *__restrict__ spill_count,
+                                                                  const SpillEntry *__restrict__ spill, G *__restrict__ grad, int overwrite) {
+	extern __shared__ __attribute__((aligned(16))) unsigned long long iacc[];   // [PAIR_BIN_ENTRIES][2] 64-bit fixed point
+	using GP = typename Pair<G>::type;
+	const uint32_t po = blockIdx.x / PAIR_BINS, bin = blockIdx.x % PAIR_BINS, hl = sel.hl[po], level = bp.level[hl];
+	const uint32_t amax = level_absmax(absmax_bits, level);
+	float s32 = 0.f;
+	{ const float m = __uint_as_float(amax); if (m > 0.f && m < 3.0e38f) { int ex; frexpf(m, &ex); s32 = ldexpf(1.0f, 38 - ex); } }
+	const float inv = s32 > 0.f ? 1.0f / s32 : 0.f;
+	const uint32_t raw = pcursors[po * PAIR_BINS + bin], count = min(raw, pcap);
+	const uint32_t ns = min(*spill_count, bp.spill_cap);
+	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level] + (bin << PAIR_BIN_BITS);
+	if (s32 == 0.f || (count == 0 && ns == 0)) {                         // nothing to add: an accumulating destination is left alone, an overwritten one gets its zeros
+		if (overwrite) {
+			GP zv; from_f2(zv, make_float2(0.f, 0.f));
+			for (uint32_t e = threadIdx.x; e < PAIR_BIN_ENTRIES; e += PACC_WG) dst[e] = zv;
+		}
+		return;
+	}
+	for (uint32_t e = threadIdx.x; e < PAIR_BIN_ENTRIES; e += PACC_WG) { iacc[2 * e] = 0ull; iacc[2 * e + 1] = 0ull; }
+	__syncthreads();
+	auto add_fixed = [&](uint32_t local, long long ix, long long iy) {
+		if ((ix | iy) == 0) return;
+		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add(&iacc[2 * local + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+	auto to_fixed = [&](const PairRec &r, long long v[4]) {
+		const float w0 = 1 - r.fx;
+		v[0] = __float2ll_rn((r.a * w0) * s32); v[1] = __float2ll_rn((r.b * w0) * s32);
+		v[2] = __float2ll_rn((r.a * r.fx) * s32); v[3] = __float2ll_rn((r.b * r.fx) * s32);
+	};
+	auto flush = [&](uint32_t edge, const long long s[4]) {
+		add_fixed(edge & (PAIR_BIN_ENTRIES - 1u), s[0], s[1]);
+		add_fixed((edge >> PAIR_BIN_BITS) & (PAIR_BIN_ENTRIES - 1u), s[2], s[3]);
+	};
+	constexpr uint32_t K = 4;
+	struct alignas(16) RK { PairRec r[K]; };
+	const PairRec *recs = prec + (size_t)(po * PAIR_BINS + bin) * pcap;
+	const RK *pk = reinterpret_cast<const RK *>(recs);
+	auto run_add = [&](const RK &x) {
+		uint32_t cur = x.r[0].loc & 0xffffffu; long long s[4]; to_fixed(x.r[0], s);
+#pragma unroll
+		for (uint32_t q = 1; q < K; ++q) {
+			long long v[4]; to_fixed(x.r[q], v);
+			const uint32_t e = x.r[q].loc & 0xffffffu;
+			if (e == cur) { s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+			else { flush(cur, s); cur = e; s[0] = v[0]; s[1] = v[1]; s[2] = v[2]; s[3] = v[3]; }
+		}
+		flush(cur, s);
+	};
+	const uint32_t groups = count / K;
+	uint32_t r = threadIdx.x;
+	for (; r + PACC_WG < groups; r += 2 * PACC_WG) { const RK x0 = pk[r], x1 = pk[r + PACC_WG]; run_add(x0); run_add(x1); }
+	for (; r < groups; r += PACC_WG) { const RK x = pk[r]; run_add(x); }
+	if (threadIdx.x < count - groups * K) { const PairRec x = recs[groups * K + threadIdx.x]; long long v[4]; to_fixed(x, v); flush(x.loc & 0xffffffu, v); }
+	for (uint32_t t = threadIdx.x; t < ns; t += PACC_WG) {                 // out-of-cube edges and overflowed bins (normally ns == 0)
+		const SpillEntry se = spill[t];
+		const uint32_t e = se.key & (BIN_LEVEL_MAX - 1u);
+		if ((se.key >> 19) == hl && (e >> PAIR_BIN_BITS) == bin) add_fixed(e & (PAIR_BIN_ENTRIES - 1u), __float2ll_rn(se.x * s32), __float2ll_rn(se.y * s32));
+	}
+	__syncthreads();
+	// write-out: two entries (16 bytes of fp32 gradient) per thread and trip
+	for (uint32_t e = 2u * threadIdx.x; e < PAIR_BIN_ENTRIES; e += 2u * PACC_WG) {
+		const long long s0 = (long long)iacc[2 * e], s1 = (long long)iacc[2 * e + 1], s2 = (long long)iacc[2 * e + 2], s3 = (long long)iacc[2 * e + 3];
+		float2 v0 = make_float2((float)s0 * inv, (float)s1 * inv), v1 = make_float2((float)s2 * inv, (float)s3 * inv);
+		if (!overwrite) {
+			if ((s0 | s1 | s2 | s3) == 0) continue;
+			const float2 o0 = to_f2(dst[e]), o1 = to_f2(dst[e + 1]);
+			v0.x += o0.x; v0.y += o0.y; v1.x += o1.x; v1.y += o1.y;
+		}
+		GP w0, w1; from_f2(w0, v0); from_f2(w1, v1);
+		if (sizeof(GP) == 8) *reinterpret_cast<float4 *>(dst + e) = make_float4(v0.x, v0.y, v1.x, v1.y);
+		else { dst[e] = w0; dst[e + 1] = w1; }
+	}
+}
+
 // Which levels can take the binned path: up to 2^19 entries, and indexed the way the record kernels index (dense, or the XOR hash masked by a power of two).
 // (aabb_scale 23.4 has a DENSE level with res 80 = 512000 entries - round 1 binned it with the XOR hash by looking at the size alone.)
 static bool level_dense_host(uint32_t size, uint32_t res) { uint32_t stride = 1; for (int d = 0; d < 3; ++d) if (stride <= size) stride *= res; return !(size < stride); }
@@ -1217,8 +1410,14 @@ static uint64_t hash_bwd_workspace_bytes(const LevelTable &lt) {           // pa
 	return (entries * sizeof(float2) + 255) & ~(uint64_t)255;
 }
 static uint32_t bin_capacity(uint32_t n) { uint32_t c = (n / 2 + 7u) & ~7u; return c < 4096u ? 4096u : c; }   // 4x the expected n*8/64 records per bin; % 8: 16-byte aligned streams
-// workspace = slabs | cursors u32[16*64] | absmax partials u32[16*64], spill count u32 | record values | record indices | spill list
-struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, total; uint32_t cap, spill_cap, n_binned; };
+static uint32_t pair_capacity(uint32_t n) { uint32_t c = (n / 8 + 7u) & ~7u; return c < 2048u ? 2048u : c; }    // 4x the expected n*4/128 edge records per bin (padding included)
+// the levels whose cell edges never leave a 4096-entry bin (k_bin_pairs): full 2^19-entry hashed tables up to res 2048
+static bool level_pair_capable(const LevelTable &lt, int l) {
+	const uint32_t size = lt.v[4 * l + 1], res = lt.v[4 * l + 2];
+	return size == BIN_LEVEL_MAX && !level_dense_host(size, res) && res <= PAIR_RES_MAX;
+}
+// workspace = slabs | cursors u32[N_CURSORS] | absmax partials u32[16*NGP_ABSMAX_PARTS], spill count u32 | record values | record indices | spill list | edge records
+struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, pair_rec, total; uint32_t cap, spill_cap, n_binned, pcap, n_pair; };
 static WsLayout ws_layout(const LevelTable &lt, uint32_t n) {
 	WsLayout w;
 	w.n_binned = 0;
@@ -1226,11 +1425,15 @@ static WsLayout ws_layout(const LevelTable &lt, uint32_t n) {
 	w.cap = bin_capacity(n);
 	w.spill_cap = w.n_binned * 8u * (n < (1u << 25) / (w.n_binned ? w.n_binned : 1u) ? n : (1u << 25) / (w.n_binned ? w.n_binned : 1u));   // worst case: every record of every binned level overflows (12 B each)
 	w.cursors = hash_bwd_workspace_bytes(lt);
-	w.absmax = w.cursors + 4096;
+	w.absmax = w.cursors + N_CURSORS * 4u;
 	w.rec_val = w.absmax + 16u * ABSMAX_PARTS * 4u + 256;
 	w.rec_idx = w.rec_val + (uint64_t)w.n_binned * BINS_PER_LEVEL * w.cap * sizeof(float2);       // every level owns 64 * cap * 8 bytes (rec_val_at)
 	w.spill = (w.rec_idx + (uint64_t)w.n_binned * BINS_PER_LEVEL * w.cap * sizeof(uint16_t) + 255) & ~(uint64_t)255;
-	w.total = w.spill + (uint64_t)w.spill_cap * sizeof(SpillEntry);
+	w.pair_rec = (w.spill + (uint64_t)w.spill_cap * sizeof(SpillEntry) + 255) & ~(uint64_t)255;
+	w.n_pair = 0;
+	for (int l = 0; l < 16; ++l) if (level_binned(lt, l) && level_pair_capable(lt, l)) ++w.n_pair;
+	w.pcap = pair_capacity(n);
+	w.total = w.pair_rec + (uint64_t)w.n_pair * PAIR_BINS * w.pcap * sizeof(PairRec);
 	return w;
 }
 static uint64_t hash_bwd_workspace_bytes_binned(const LevelTable &lt, uint32_t n) { return ws_layout(lt, n).total; }
@@ -1290,16 +1493,24 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	const bool use_bins = use_slabs && !level_scratch && (dtype == NGP_F16 || grad_dtype == NGP_F32) && workspace_bytes >= wl.total && getenv("NGP_HASH_BWD_NO_BINS") == nullptr;
 	bool in_bins[16];
 	BinPlan bp; bp.n_levels = 0; bp.cap = wl.cap; bp.spill_cap = wl.spill_cap;
-	LevelSel sel_fine, sel_runs, sel_all;
-	uint32_t n_fine = 0, n_runs = 0;
+	LevelSel sel_fine, sel_runs, sel_all, sel_pair;                      // sel_all: every level with per-corner records (runs + fine); sel_pair: the edge-record levels
+	uint32_t n_fine = 0, n_runs = 0, n_pair = 0, n_all = 0;
+	// edge records (k_bin_pairs): fp32 in, fp32 out, 16-byte aligned gradient.  NGP_HASH_BWD_PAIRS=0 keeps round 3's per-corner records (A/B), _PAIR_WG / _PAIR_PAD are probe hooks
+	const bool pairs_on = [] { const char *e = getenv("NGP_HASH_BWD_PAIRS"); return !(e && e[0] == '0'); }();
+	const uint32_t pair_wg = [] { const char *e = getenv("NGP_HASH_BWD_PAIR_WG"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : 1024u; return v == 512u ? 512u : 1024u; }();
+	const uint32_t pair_pad = [] { const char *e = getenv("NGP_HASH_BWD_PAIR_PAD"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : 1u; return v == 2u || v == 4u || v == 8u ? v : 1u; }();
+	const bool use_pairs = use_bins && pairs_on && dtype == NGP_F32 && grad_dtype == NGP_F32 && ((uintptr_t)grad & 15u) == 0;
 	const uint32_t run_res_max = [] { const char *e = getenv("NGP_HASH_BWD_RUN_RES"); return e ? (uint32_t)strtoul(e, nullptr, 0) : RUN_RES_MAX; }();   // probe hook
+	const int run_occ = [] { const char *e = getenv("NGP_HASH_BWD_RUN_OCC"); return e && e[0] == '5' ? 5 : 4; }();   // probe hook
 	const uint32_t run_stage = [] { const char *e = getenv("NGP_HASH_BWD_RUN_STAGE"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : RUN_STAGE; return v > 8192u ? 8192u : v; }();   // probe hook
 	for (int l = 0; l < 16; ++l) {                                       // (coarsest level first measured 1 % faster than finest first on both samplings)
 		in_bins[l] = use_bins && level_binned(lt, l);
 		if (!in_bins[l]) continue;
 		const uint32_t hl = bp.n_levels++;
-		bp.level[hl] = (uint32_t)l; sel_all.hl[hl] = hl;
-		if (lt.v[4 * l + 2] <= run_res_max) sel_runs.hl[n_runs++] = hl; else sel_fine.hl[n_fine++] = hl;
+		bp.level[hl] = (uint32_t)l;
+		if (lt.v[4 * l + 2] <= run_res_max) { sel_runs.hl[n_runs++] = hl; sel_all.hl[n_all++] = hl; }
+		else if (use_pairs && level_pair_capable(lt, l)) sel_pair.hl[n_pair++] = hl;
+		else { sel_fine.hl[n_fine++] = hl; sel_all.hl[n_all++] = hl; }
 	}
 	uint64_t slab_cursor = 0;
 	for (int l = 0; l < 16; ++l) {
@@ -1330,6 +1541,8 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	void *rec_val = use_bins ? (void *)(ws + wl.rec_val) : nullptr;
 	uint16_t *rec_idx = use_bins ? (uint16_t *)(ws + wl.rec_idx) : nullptr;
 	SpillEntry *spill = use_bins ? (SpillEntry *)(ws + wl.spill) : nullptr;
+	uint32_t *pcursors = use_bins ? cursors + 16u * BINS_PER_LEVEL : nullptr;
+	PairRec *pair_rec = use_bins ? (PairRec *)(ws + wl.pair_rec) : nullptr;
 	{ const char *e = getenv("NGP_PROBE_LEVEL_MASK"); plan.level_mask = e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffu; }
 	{ const char *e = getenv("NGP_PROBE_COARSE_RES"); plan.coarse_res = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }
 	for (int l = 0; l < 16; ++l) {                                       // chunked levels without slabs are flushed with atomics -> need a zeroed destination
@@ -1345,6 +1558,23 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	const bool probe_skip_bins = getenv("NGP_PROBE_SKIP_BINS") != nullptr;      // tools/probe_scatter.py: time the scan kernel alone
 	const int ow = zero_first ? 1 : 0;
 	bool coarse_marked = false;
+	int pair_err = 0;
+	auto pair_set_lds = [&](const void *k, size_t bytes) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); pair_err = (int)e; } };
+	auto pair_records = [&]() {                                          // (fp32 only: outside the dtype macro)
+		const uint32_t lds = pair_stage_bytes(pair_wg, pair_pad);
+		static bool once = false;
+		if (!once) { pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_SOA, 512u>, pair_stage_bytes(512u, PAIR_PAD_MAX)); pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_AOS, 512u>, pair_stage_bytes(512u, PAIR_PAD_MAX));
+			pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_SOA, 1024u>, pair_stage_bytes(1024u, PAIR_PAD_MAX)); pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_AOS, 1024u>, pair_stage_bytes(1024u, PAIR_PAD_MAX));
+			pair_set_lds((const void *)k_bin_accumulate_pairs<float>, PAIR_BIN_ENTRIES * 16u); once = true; }
+#define PGO(L, S) NGP_LAUNCH((k_bin_pairs<L, S>), dim3(div_up(n, S), n_pair), dim3(S), lds, s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_pair, (const uint32_t *)absmax, pcursors, pair_rec, wl.pcap, pair_pad, spill_count, spill, n_valid)
+		if (in_layout == NGP_LAYOUT_SOA) { if (pair_wg == 512u) PGO(NGP_LAYOUT_SOA, 512u); else PGO(NGP_LAYOUT_SOA, 1024u); }
+		else { if (pair_wg == 512u) PGO(NGP_LAYOUT_AOS, 512u); else PGO(NGP_LAYOUT_AOS, 1024u); }
+#undef PGO
+	};
+	auto pair_accumulate = [&]() {
+		NGP_LAUNCH((k_bin_accumulate_pairs<float>), dim3(n_pair * PAIR_BINS), dim3(PACC_WG), PAIR_BIN_ENTRIES * 16u, s, lt, bp, sel_pair, (const uint32_t *)absmax, (const uint32_t *)pcursors, (const PairRec *)pair_rec, wl.pcap,
+		           (const uint32_t *)spill_count, (const SpillEntry *)spill, (float *)grad, ow);
+	};
 #define SET_LDS(K, BYTES) do { static bool done_ = false; if (!done_) { hipError_t e = hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
 	if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } done_ = true; } } while (0)
 #define GO(T, G, L) do { \
@@ -1356,20 +1586,25 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		if (!absmax_done) NGP_LAUNCH((k_level_absmax<T, L>), dim3(ABSMAX_OWN_PARTS, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid, cursors, spill_count);   /* also zeroes the cursors and the spill count */ \
 		if (units && side.ok) { hipEventRecord(side.fork, s); sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* the scan of the remaining levels runs beside the binning kernels */ \
 		if (!probe_skip_bins) { \
-		if (n_runs) { SET_LDS((k_bin_records_runs<T, L>), run_stage_bytes(8192u)); \
-			NGP_LAUNCH((k_bin_records_runs<T, L>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(run_stage), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, run_stage); } \
+		if (n_runs && run_occ == 5) { SET_LDS((k_bin_records_runs<T, L, 5>), run_stage_bytes(8192u)); \
+			NGP_LAUNCH((k_bin_records_runs<T, L, 5>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(run_stage), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, run_stage); } \
+		else if (n_runs) { SET_LDS((k_bin_records_runs<T, L, 4>), run_stage_bytes(8192u)); \
+			NGP_LAUNCH((k_bin_records_runs<T, L, 4>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(run_stage), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, run_stage); } \
 		if (n_fine) { SET_LDS((k_bin_records<T, L>), bin_stage_bytes<T>()); \
 			NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, BIN_WG), n_fine), dim3(BIN_WG), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_fine, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid); } \
-		if (sizeof(RV_) == 8 && !(after_coarse && n_runs && n_fine)) {   /* fp32: run records and fine records have the same type - one accumulate launch over all levels */ \
-			SET_LDS((k_bin_accumulate<G, float2>), BIN_ENTRIES * 16); \
-			NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(bp.n_levels * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
+		if (n_pair) pair_records(); \
+		if (sizeof(RV_) == 8 && !(after_coarse && n_runs && n_fine)) {   /* fp32: run records and fine records have the same type - one accumulate launch over all their levels */ \
+			if (n_all) { SET_LDS((k_bin_accumulate<G, float2>), BIN_ENTRIES * 16); \
+				NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_all * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
+				if (after_coarse && n_runs && n_pair) { hipEventRecord(after_coarse, s); coarse_marked = true; } }   /* (no per-corner fine level here: this launch IS the coarse levels) */ \
 		} else { \
 			if (n_runs) { SET_LDS((k_bin_accumulate<G, float2>), BIN_ENTRIES * 16); \
 				NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_runs * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_runs, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
-				if (after_coarse && n_fine) { hipEventRecord(after_coarse, s); coarse_marked = true; } } \
+				if (after_coarse && (n_fine || n_pair)) { hipEventRecord(after_coarse, s); coarse_marked = true; } } \
 			if (n_fine) { SET_LDS((k_bin_accumulate<G, RV_>), BIN_ENTRIES * 16); \
 				NGP_LAUNCH((k_bin_accumulate<G, RV_>), dim3(n_fine * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_fine, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); } \
-		} } \
+		} \
+		if (n_pair) pair_accumulate(); } \
 	} \
 	if (units) NGP_LAUNCH((k_hash_bwd_owner<T, G, L>), grid, block, shmem, sd, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr); \
 	if (units && use_slabs && slab_cursor) NGP_LAUNCH((k_reduce_dense<G>), dim3(1024, 16), dim3(256), 0, sd, lt, plan, (const float2 *)workspace, (G *)grad, accumulate & 1); \
@@ -1379,6 +1614,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	else { if (in_layout == NGP_LAYOUT_SOA) GO(__half, __half, NGP_LAYOUT_SOA); else GO(__half, __half, NGP_LAYOUT_AOS); }
 #undef GO
 #undef SET_LDS
+	if (pair_err) return pair_err;
 	NGP_LAUNCH_CHECK("ngp_hash_encode_bwd");
 	if (after_coarse && !coarse_marked) hipEventRecord(after_coarse, s);      // no separate coarse launch on this path: the marker follows the whole scatter
 	return 0;
@@ -1402,7 +1638,7 @@ AbsmaxOut ngp_hash_bwd_absmax_slots(const uint32_t *level_table_host, uint32_t n
 	const WsLayout wl = ws_layout(lt, n);
 	if (!(dtype == NGP_F16 || grad_dtype == NGP_F32) || workspace_bytes < wl.total) return am;
 	char *ws = (char *)workspace;
-	am.parts = (uint32_t *)(ws + wl.absmax); am.cursors = (uint32_t *)(ws + wl.cursors); am.n_cursors = 16u * BINS_PER_LEVEL; am.spill_count = am.parts + 16u * ABSMAX_PARTS;
+	am.parts = (uint32_t *)(ws + wl.absmax); am.cursors = (uint32_t *)(ws + wl.cursors); am.n_cursors = N_CURSORS; am.spill_count = am.parts + 16u * ABSMAX_PARTS;
 	return am;
 }
 

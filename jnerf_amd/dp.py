@@ -23,6 +23,64 @@ def active():
     return dist.get_world_size() > 1 or get_cfg().dp_force_collectives is True
 
 
+def _create_comm(rank, world):
+    """One attempt at the library's communicator with a SYMMETRIC collective sequence: rank 0 always broadcasts - the RCCL unique id, or None when drawing it
+    failed - so no rank is ever left waiting in a broadcast that its peer skipped; every rank then runs the same ngp_comm_init or none.  -> (handle | None, error | None)"""
+    lib = L.lib()
+    uid = (C.c_char * L.COMM_ID_BYTES)()
+    box, err = [None], None
+    if rank == 0:
+        try:
+            L.check(lib.ngp_comm_unique_id(uid), "ngp_comm_unique_id")
+            box = [bytes(uid.raw)]
+        except RuntimeError as e:
+            err = e
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", torch.cuda.current_device()))
+    if box[0] is None:
+        return None, err or RuntimeError("rank 0 could not draw an RCCL unique id")
+    handle = C.c_void_p()
+    try:
+        L.check(lib.ngp_comm_init(C.byref(handle), rank, world, C.create_string_buffer(box[0], L.COMM_ID_BYTES)), "ngp_comm_init")
+    except RuntimeError as e:
+        return None, e
+    return handle, None
+
+
+def _selftest(handle, rank, world, dev, timeout_s):
+    """SUM all-reduce of (rank + 1) over 1024 floats through the library's communicator on a private stream; -> None | the error (TimeoutError: never completed)"""
+    import time
+    from . import ops
+    st = torch.cuda.Stream(device=dev)
+    try:
+        with torch.cuda.stream(st):
+            buf = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=dev)
+            bufs, counts, dts = (C.c_void_p * 1)(buf.data_ptr()), (C.c_uint64 * 1)(buf.numel()), (C.c_int * 1)(ops._dt(buf))
+            L.check(L.lib().ngp_allreduce_grads(handle, st.cuda_stream, 1, bufs, counts, dts), "ngp_allreduce_grads(self-test)")
+            done = torch.cuda.Event()
+            done.record(st)
+        t0 = time.time()
+        while not done.query():
+            if time.time() - t0 > timeout_s:
+                return TimeoutError(f"the self-test collective of the in-library communicator did not complete within {timeout_s:.0f} s")
+            time.sleep(0.002)
+        want = world * (world + 1) / 2.0
+        if not bool((buf == want).all().item()):
+            return RuntimeError(f"the self-test collective of the in-library communicator returned {buf[0].item()} instead of {want}")
+    except RuntimeError as e:
+        return e
+    return None
+
+
+def n_ranks_seen():
+    """world size as the library's communicator reports it (ngp_comm_rank_world), None without one - bench.py prints it so that a multi-GPU run diagnoses itself"""
+    if _comm is None:
+        return None
+    r, w = C.c_int(-1), C.c_int(-1)
+    L.check(L.lib().ngp_comm_rank_world(_comm[0], C.byref(r), C.byref(w)), "ngp_comm_rank_world")
+    return int(w.value)
+
+
 def library_comm():
     """handle of the library's RCCL communicator over the default process group, created on first use; None when the group's backend is not nccl (= RCCL)"""
     global _comm
@@ -31,15 +89,9 @@ def library_comm():
     rank, world = dist.get_rank(), dist.get_world_size()
     if _comm is not None and _comm[1:] == (rank, world):
         return _comm[0]
-    lib = L.lib()
-    uid = (C.c_char * L.COMM_ID_BYTES)()
-    if rank == 0:
-        L.check(lib.ngp_comm_unique_id(uid), "ngp_comm_unique_id")
-    box = [bytes(uid.raw)]
-    if world > 1:
-        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", torch.cuda.current_device()))
-    handle = C.c_void_p()
-    L.check(lib.ngp_comm_init(C.byref(handle), rank, world, C.create_string_buffer(box[0], L.COMM_ID_BYTES)), "ngp_comm_init")
+    handle, err = _create_comm(rank, world)
+    if handle is None:
+        raise err
     _comm = (handle, rank, world)
     return handle
 
@@ -48,30 +100,43 @@ def library_comm_or_fallback():
     """library_comm(), agreed on by ALL ranks: if creating the library's own communicator fails on any rank (a second RCCL instance beside torch's in one process is the
     one thing a single-GPU box cannot exercise), every rank drops it and the step runs in two phases with torch.distributed's all-reduce of the gradients (same RCCL
     backend) in between and a replicated sweep - said loudly on stderr, and visible as `dp_exchange` in bench.py's line.  `dp_require_library_comm = True` in the config turns
-    the fallback into the error it replaces."""
+    the fallback into the error it replaces.  Every rank walks through the same collectives whatever fails where: broadcast of the id (or of None), then the MIN agreement."""
     import sys
     from .utils.config import get_cfg
-    err = None
-    try:
-        comm = library_comm()
-    except RuntimeError as e:
-        if get_cfg().dp_require_library_comm:
-            raise
-        comm, err = None, e
-    if dist.get_backend() != "nccl" or not torch.cuda.is_available():
-        return comm
-    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-    if dist.get_world_size() > 1:
+    global _comm, _comm_unavailable
+    if _comm_unavailable or not active() or dist.get_backend() != "nccl" or not torch.cuda.is_available():
+        return None
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if _comm is not None and _comm[1:] == (rank, world):
+        return _comm[0]
+    handle, err = _create_comm(rank, world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ok = torch.tensor([0 if handle is None else 1], dtype=torch.int32, device=dev)
+    if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    hung = False
+    if int(ok.item()) == 1:
+        # every rank holds a communicator: one small collective through it BEFORE the training step depends on it (a second RCCL instance beside torch's in one process
+        # has never run at world > 1 on the authoring side - no multi-GPU box).  On a stream of its own and polled with a deadline, so a collective that never
+        # completes costs `dp_selftest_timeout` seconds (default 30) and that stream - not the run.
+        err = _selftest(handle, rank, world, dev, float(get_cfg().dp_selftest_timeout or 30.0))
+        hung = isinstance(err, TimeoutError)
+        ok.fill_(0 if err is not None else 1)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
-        global _comm_unavailable
-        if comm is not None:
-            destroy()
+        if handle is not None and not hung:                             # (a communicator with a collective still in flight is abandoned, not destroyed: destroy would wait for it)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            L.lib().ngp_comm_destroy(handle)
+        if get_cfg().dp_require_library_comm:
+            raise err or RuntimeError("the in-library RCCL communicator failed on another rank (dp_require_library_comm)")
         _comm_unavailable = True
-        print(f"[jnerf_amd.dp] WARNING rank {dist.get_rank()}: the in-library RCCL communicator is unavailable ({err or 'failed on another rank'}); "
+        print(f"[jnerf_amd.dp] WARNING rank {rank}: the in-library RCCL communicator is unavailable ({err or 'failed on another rank'}); "
               "the exchange step runs through torch.distributed around a phase-split step", file=sys.stderr, flush=True)
         return None
-    return comm
+    _comm = (handle, rank, world)
+    return handle
 
 
 def destroy():

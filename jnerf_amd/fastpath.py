@@ -124,7 +124,11 @@ class FusedTrainStep:
                 a.dp_overlap = 1 if cfg.dp_overlap else 0
                 self._dp_plan = dp.plan(enc.level_table, enc.n_params, n_buckets=2 if cfg.dp_overlap else 1)
                 a.comm, a.dp = comm, C.addressof(self._dp_plan)
-                if self.half and cfg.dp_grad_dtype != "fp32":      # fp16 mode: the table gradient travels as scaled fp16 (the reference's gradients are fp16 to begin with)
+                # fp16 mode: the table gradient travels as scaled fp16 by default (the reference's gradients are fp16 to begin with).  fp32 mode (r4): opt-in,
+                # `dp_grad_dtype = "fp16"` - halves the 48.8 MB reduce-scatter; every rank's gradient element is rounded once to 11 significant bits (values scaled by
+                # 2^14 into fp16's normal range), i.e. 2^-12 relative per addend instead of fp32's 2^-24: the same wire the fp16 configuration always uses, NOT bit-identical
+                # to the single-GPU fp32 run (the default fp32 wire is, tests/test_train_gpu.py::test_rccl_exchange_step_adds_no_arithmetic)
+                if (self.half and cfg.dp_grad_dtype != "fp32") or (not self.half and cfg.dp_grad_dtype == "fp16"):
                     if self._grad_wire is None:
                         self._grad_wire = torch.empty(enc.n_params, dtype=torch.float16, device=dev)
                     a.grad_wire, a.wire_scale = self._grad_wire.data_ptr(), adam.DP_HALF_SCALE

@@ -268,6 +268,22 @@ def density32_fwd(feat, wd, n, layout=LAYOUT_AOS, packed=None):
     return out
 
 
+def field32_range_check(reset=True, synchronize=True):
+    """flag bits of the split-operand fp32 field kernels (include/ngp_hip.h): 1 = an operand came within 4x of fp16's range, 2 = one left it.
+    synchronize: wait for the device first, so that every launch issued so far has reported (the read-back itself only orders against the null stream)."""
+    if synchronize and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    v = int(L.lib().ngp_field32_range_check(int(reset)))
+    if v < 0:
+        check(v, "ngp_field32_range_check")
+    return v
+
+
+def field32_select(exact):
+    """exact=True: the exact-product fp32-MFMA kernels from now on in this process; False: the split-operand kernels (default).  Returns the previous choice."""
+    return bool(L.lib().ngp_field32_select(int(bool(exact))))
+
+
 def field32_bwd_slabs(n):
     return int(L.lib().ngp_field32_bwd_slabs(n))
 

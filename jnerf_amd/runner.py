@@ -147,6 +147,24 @@ class Runner:
         return {"step": step, "bg": bg, "target": rgb_target, "pos": pos, "dirs": dirs, "state": self.sampler.export_batch_state(),
                 "keep": (img_ids, rays_o, rays_d)}
 
+    def _poll_field32_range(self):
+        """(r4) The fp32 configuration's default field kernels work on split fp16 operands with fixed prescales (csrc/field_split.hip): features beyond ~255 or
+        activations beyond ~4094 do not fit.  The kernels flag operands that come within a factor four of that (ngp_field32_range_check); polled where the host waits
+        anyway - every 16th step, after every rendered image.  Near the limit: this process continues on the exact-product fp32-MFMA kernels (nothing has overflowed
+        yet, results unchanged up to fp32 rounding).  Beyond it: the launches since the last poll produced infinities - an error, never a silent one."""
+        m = self.model
+        if not (torch.cuda.is_available() and getattr(m, "fused", False) and getattr(m, "fused_dtype", None) == torch.float32) or getattr(self, "_field32_exact", False):
+            return
+        from . import ops
+        flag = ops.field32_range_check(reset=True, synchronize=False)
+        if flag & 2:
+            raise RuntimeError("fp32 field network: an operand left the range of the split-operand kernels (|feature| > 255 or |activation| > 4094) - the results since the "
+                               "last check contain infinities.  Re-run with NGP_FIELD32_FWD=mfma32 NGP_FIELD32_BWD=2 (exact-product kernels, no operand range).")
+        if flag & 1:
+            print("[jnerf_amd] fp32 field network: operands within 4x of the split-operand kernels' range; continuing on the exact-product fp32-MFMA kernels", flush=True)
+            ops.field32_select(True)
+            self._field32_exact = True
+
     def train_step(self, i):
         """Software-pipelined: the ray generation + marching of batches i+1 .. i+depth only read the dataset and the occupancy bitfield, so they are
         issued on side streams while batch i goes through the network / backward / optimiser.  The marcher is a dependent-latency kernel (its
@@ -176,6 +194,8 @@ class Runner:
                 self._grid_event.record(main)            # side streams must not read the bitfield before this refresh has finished
                 self._grid_valid = True
         cfg.m_training_step = i
+        if i % 16 == 0 and i:
+            self._poll_field32_range()
         if self._fast:
             loss = self._fast(b)                         # same kernels, same order, no autograd / nn.Module overhead (fastpath.py)
         else:
@@ -403,6 +423,7 @@ class Runner:
         if self._native_render_ok():
             self._render_rays_native(rays_o_total, rays_d_total, chunk, imgs, alphas, counts)
             host = counts.tolist()
+            self._poll_field32_range()
             self.n_samples_rendered = int(host[0])
             if host[1] and chunk > self.sampler.max_samples // self.sampler.MAX_STEP:
                 return self._render_rays(img_ids, rays_o_total, rays_d_total, self.sampler.max_samples // self.sampler.MAX_STEP)

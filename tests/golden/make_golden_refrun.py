@@ -119,12 +119,13 @@ def main(case):
         log.append([float(loss.detach().double().mean()), float(loss.detach().double().sum()), x.shape[0], k, int(s._rays_numsteps[:, 0].sum())])
         return loss
     r.loss_func.execute = recording_loss
-    refresh = []
+    refresh, bitfields = [], []
     upd = r.sampler.update_density_grid
 
     def recording_refresh():
         upd()
         s = r.sampler
+        bitfields.append(s.density_grid_bitfield.numpy().astype(np.uint8).copy())     # (r4) what the reference marches through until the next refresh: lets a replay teacher-force it
         refresh.append([int(cfg.m_training_step), float(s.density_grid_mean.reshape(-1)[0]), int(np.unpackbits(s.density_grid_bitfield.numpy()).sum()),
                         float((s.density_grid > 0).sum()), float(s.density_grid.double().clamp_min(0).sum())])
     r.sampler.update_density_grid = recording_refresh
@@ -171,6 +172,7 @@ def main(case):
     out["perm_sizes"] = np.asarray(perms, np.int64)
     out["bg_shapes"] = np.asarray(bgs, np.int64)
     out["refresh"] = np.asarray(refresh, np.float64)            # per refresh: step, grid mean, bits set, cells > 0, sum of max(grid, 0)
+    out["refresh.bitfield"] = np.stack(bitfields)               # per refresh: the occupancy bitfield (5 * 128^3 / 8 bytes, morton order)
     out["ray_updates"] = np.asarray(rays, np.int64)             # per update: step, measured samples over 16 iterations, new ray count
     out["launches"] = np.frombuffer(";".join(f"{n}:{c}" for n, c in _code.CALLS).encode(), np.uint8)
     for i, lin in enumerate(lins):

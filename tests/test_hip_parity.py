@@ -317,6 +317,43 @@ def test_field32_split_forward_accuracy_over_magnitudes(H, mag):
         assert np.abs(exact - ref).max() <= 2e-6 * scale and np.abs(exact - out).max() <= 2e-6 * scale and not np.array_equal(exact, out)
 
 
+@pytest.mark.parametrize("what,value,want", [("feat", 40.0, 0), ("feat", 100.0, 1), ("feat", 200.0, 1), ("feat", 255.0, 1), ("feat", 300.0, 3),
+                                             ("hidden", 500.0, 0), ("hidden", 2000.0, 1), ("hidden", 4000.0, 1), ("hidden", 5000.0, 3)])
+def test_field32_split_operand_range_is_flagged_never_silent(H, what, value, want):
+    """(r4) the split kernels lift their operands into fp16 by fixed powers of two: features x 256 (finite up to 255.9), activations x 16 (up to 4094).
+    Operands near / beyond that must raise the device-side flag - bit 0 within a factor four of the limit (results still exact), bit 1 beyond it - and the exact-product
+    kernels selected through ngp_field32_select must then give the fp32 result with nothing flagged."""
+    from jnerf_amd import ops
+    n = 2000
+    feat, d, wd, wc = _field32_inputs(n, seed=5)
+    feat, wd = feat.copy(), wd.copy()
+    if what == "feat":
+        feat *= np.float32(value / np.abs(feat).max())                      # largest |feature| == value
+    else:
+        h = np.maximum(feat.astype(np.float64) @ wd[:2048].reshape(64, 32).astype(np.float64).T, 0)
+        wd[:2048] *= np.float32(value / h.max())                            # largest first-layer activation == value ...
+        wd[2048:] *= np.float32(0.01)                                       # ... and a small density head, so that nothing downstream comes near the range
+    ref, _ = _field32_chain_fp64(feat, d, wd, wc)
+    scale = np.abs(ref).max()
+    ops.field32_range_check(reset=True)
+    try:
+        out = H.N(ops.field32_fwd(H.T(feat), H.T(d), H.T(wd), H.T(wc))).astype(np.float64)
+        flag = ops.field32_range_check(reset=True)
+        if what == "feat" or want < 3:
+            assert flag == want, (what, value, flag)
+        else:
+            assert flag == 3, (what, value, flag)
+        if want < 3:                                                        # inside the range (however close): fp32 accuracy
+            assert np.isfinite(out).all() and np.abs(out - ref).max() <= 2e-6 * scale, (what, value, np.abs(out - ref).max() / scale)
+        assert ops.field32_select(True) is False                            # the process was on the split kernels
+        exact = H.N(ops.field32_fwd(H.T(feat), H.T(d), H.T(wd), H.T(wc))).astype(np.float64)
+        assert ops.field32_range_check(reset=True) == 0
+        assert np.isfinite(exact).all() and np.abs(exact - ref).max() <= 4e-6 * scale, (what, value, np.abs(exact - ref).max() / scale)
+    finally:
+        ops.field32_select(False)
+        ops.field32_range_check(reset=True)
+
+
 def _field32_chain_fp64(feat, d, wd, wc):
     """ngp_network.py:59-84 without biases, in fp64: (out [n,4] = rgb(3) | density logit, density head [n,16])"""
     sh = O.sh_encode(d, np.float32).astype(np.float64)

@@ -1,12 +1,11 @@
-"""tools/extract_mesh.py's pipeline on a field trained on the GPU.  WRITTEN AFTER round 3's GPU minutes were spent: the host logic is covered on the CPU
-(tests/test_mesh_cpu.py) but this file has not run on an MI355X yet, so it is marked xfail(strict=False) - an XPASS in the driver's round-end run is its first
-hardware evidence, a failure does not stop the suite.  Remove the marker once it has been seen to pass."""
+"""tools/extract_mesh.py's pipeline on a field trained on the GPU.  The host logic is covered on the CPU (tests/test_mesh_cpu.py); first seen to pass
+on an MI355X in the driver's round-3 run (XPASS), a plain gpu test since round 4."""
 import os
 import numpy as np
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first GPU run of the mesh path happens outside the authoring session")]
+pytestmark = [pytest.mark.gpu]
 
 
 def _distance_to_scene(p):

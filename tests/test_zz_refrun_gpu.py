@@ -3,8 +3,10 @@ over the Jittor stand-in with every CUDA launch bound to the reference's kernels
 initial parameters, pcg32 seed; the HIP side with its own occupancy grid, samples, gradients and optimiser state, through Runner's native step.  The CPU suite already
 holds the C oracle to this fixture (tests/test_refrun_golden.py) and test_trajectory_gpu.py holds the HIP path to the oracle; this closes the triangle directly.
 
-WRITTEN AFTER round 3's GPU minutes were spent: it has not run on an MI355X yet, hence xfail(strict=False) - an XPASS in the driver's round-end run is its first hardware
-evidence, a failure does not stop the suite.  Remove the marker once it has been seen to pass."""
+(r4) First run on an MI355X by the driver at the end of round 3 (XPASS, loss within 3 %, sample counts within 3 %: ~0.5 % of the occupancy cells sit on the threshold
+after the first refresh and the __expf of the splat decides them differently).  Now the reference's own bitfields travel with the fixture (`refresh.bitfield`) and are
+teacher-forced after each of the HIP side's refreshes - exactly what tests/test_trajectory_gpu.py does against the oracle - so the remaining edge of the triangle
+reference -> HIP is tight: identical sample counts, losses to 1e-4; the HIP side's own bitfield may differ from the reference's only in cells that sit on the threshold."""
 import os
 import numpy as np
 import pytest
@@ -12,7 +14,7 @@ import torch
 
 from tests.golden import pyref_scene as S
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first GPU run happens outside the authoring session")]
+pytestmark = [pytest.mark.gpu]
 
 
 def test_hip_path_replays_the_references_training_run(tmp_path):
@@ -53,6 +55,30 @@ def test_hip_path_replays_the_references_training_run(tmp_path):
         r.model._pack32.copy_(torch.as_tensor(pack, device=dev))
         r.model._weights_version = getattr(r.model, "_weights_version", 0) + 1
     perms, log, refresh = {}, [], []
+    # ---- teacher-forced occupancy: the HIP side runs its own refresh (grid, mean, bitfield), is compared with the reference's, and then marches through the reference's bits
+    ref_bits = G["refresh.bitfield"]
+    own_refresh = s.update_density_grid
+    G3 = s.NERF_GRIDSIZE ** 3
+
+    def forced_refresh():
+        own_refresh()
+        k = len(refresh)
+        mine = s.density_grid_bitfield.cpu().numpy()
+        mean = float(s.density_grid_mean.item())
+        refresh.append([int(r.cfg.m_training_step), mean, int(np.unpackbits(mine).sum())])
+        a, b = np.unpackbits(mine[:G3 // 8], bitorder="little"), np.unpackbits(ref_bits[k][:G3 // 8], bitorder="little")
+        differ = np.nonzero(a != b)[0]
+        grid0 = s.density_grid[:G3].cpu().numpy()
+        thresh = min(s.NERF_MIN_OPTICAL_THICKNESS, mean)
+        print(f"refresh {k}: cascade-0 cells set {int(a.sum())} (reference {int(b.sum())}), {differ.size} differ; threshold {thresh:.6e}")
+        if differ.size:
+            off = np.abs(grid0[differ] / thresh - 1)
+            assert off.max() < 2e-3, ("a cell whose occupancy bit differs from the reference's is not on the threshold", float(off.max()))
+        assert differ.size <= 0.02 * max(int(b.sum()), 1)
+        s.density_grid_bitfield.copy_(torch.as_tensor(ref_bits[k], device=s.density_grid_bitfield.device))
+        if s._occ_bounds is not None and r.cfg.march_occupancy_bounds is not False:
+            ops.grid_occupied_bounds(s.density_grid_bitfield, s.NERF_CASCADES, out=s._occ_bounds)
+    s.update_density_grid = forced_refresh
     for i in range(steps):
         r.cfg.m_training_step = i
         s.finish_batch_rays_update()
@@ -66,8 +92,6 @@ def test_hip_path_replays_the_references_training_run(tmp_path):
         bg = torch.rand([count, 3], generator=torch.Generator().manual_seed(S.REFRUN_SEEDS["bg"] + i + 1)).to(dev)
         target = (rgba[:, :3] * rgba[:, 3:] + bg * (1 - rgba[:, 3:])).contiguous()
         pos, dirs = s.sample(img_ids, ro, rd, is_training=True)
-        if i % 16 == 0:
-            refresh.append([i, float(s.density_grid_mean.item()), int(np.unpackbits(s.density_grid_bitfield.cpu().numpy()).sum())])
         b = {"step": i, "bg": bg, "target": target, "pos": pos, "dirs": dirs, "state": s.export_batch_state(), "keep": (img_ids, ro, rd)}
         loss = r._fast(b)
         log.append([float(loss.double().mean().item()), int(s._counters[3].item())])
@@ -76,11 +100,12 @@ def test_hip_path_replays_the_references_training_run(tmp_path):
     print("loss HIP      :", np.round(log[:, 0], 6))
     print("loss reference:", np.round(want[:, 0], 6))
     print("refresh HIP:", refresh, "reference:", G["refresh"][:, :3].tolist())
+    assert len(refresh) == len(G["refresh"])
     for a, b in zip(refresh, G["refresh"]):
-        assert abs(a[1] / b[1] - 1) < 1e-3 and abs(a[2] / b[2] - 1) < 0.03          # grid mean; occupied bits (cells on the threshold may fall either way: __expf in the splat)
-    assert np.abs(log[:, 1] / want[:, 3] - 1).max() < 0.03                          # samples trained on
+        assert a[0] == int(b[0]) and abs(a[1] / b[1] - 1) < 1e-3 and abs(a[2] / b[2] - 1) < 0.03   # step; grid mean; occupied bits of the HIP side's OWN refresh (before forcing)
+    assert np.array_equal(log[:, 1].astype(np.int64), want[:, 3].astype(np.int64)), (log[:, 1], want[:, 3])        # samples trained on: identical, every iteration
     rel = np.abs(log[:, 0] / want[:, 0] - 1)
-    # on the first refresh every trained cell sits within ~1e-3 of the threshold (their mean): the 1e-6 of __expf flips a fraction of a percent of the cells, the marcher then
-    # keeps slightly different samples - the losses agree to that, not to rounding
-    assert rel.max() < 3e-2, rel
+    print("relative loss difference:", np.round(rel, 7))
+    # same samples, same pixels, same backgrounds: what is left is fp32 rounding of two implementations of the network / scatter / Adam over 18 iterations
+    assert rel.max() < 1e-4, rel
     assert np.array_equal(s.rng_state, G["final.rng_state"])                        # the global pcg32 stream was consumed identically

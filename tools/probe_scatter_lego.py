@@ -1,0 +1,81 @@
+"""Hash-grid backward of the ngp_base.py (lego, fp32) configuration on a REAL training batch, under the probe switches of csrc/hash_encode.hip: per-kernel
+HIP-event times (csrc/prof.hip) and the gradient of every variant against round 3's per-corner records (NGP_HASH_BWD_PAIRS=0).  Run through gpurun.
+usage: python tools/probe_scatter_lego.py [steps] [scene]"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jnerf_amd import ops
+from jnerf_amd.presets import ngp_cfg
+from jnerf_amd.runner import Runner
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    scene = sys.argv[2] if len(sys.argv) > 2 else "bricks"
+    ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=100, W=800, H=800, device="cuda:0", scene=scene)
+    r = Runner()
+    with r.training_stream():
+        for i in range(steps):
+            r.train_step(i)
+        r.drain()
+    torch.cuda.synchronize()
+    f = r._fast
+    enc = f.enc
+    n = f.n
+    dfeat, _ = r.model._bwd_buffers(n)
+    n_valid = f.s._n_valid
+    nv = int(n_valid.item())
+    print("scene", scene, "n", n, "n_valid", nv, flush=True)
+    pos = f.s._pos_train
+    table = enc.level_table
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n), dtype=torch.uint8, device="cuda")
+    print("workspace MB", ws.numel() / 2 ** 20)
+
+    def run_once(g):
+        ops.hash_encode_bwd(pos, dfeat, table, enc.n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws, n_valid=n_valid)
+
+    def variant(name, env, ref=None, reps=20):
+        for k, v in env.items():
+            os.environ[k] = v
+        g = torch.full((enc.n_params,), float("nan"), dtype=torch.float32, device="cuda")
+        run_once(g); torch.cuda.synchronize()
+        g2 = torch.full((enc.n_params,), float("nan"), dtype=torch.float32, device="cuda")
+        run_once(g2); torch.cuda.synchronize()
+        repro = bool(torch.equal(g, g2))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            run_once(g2)
+        b.record(); torch.cuda.synchronize()
+        total = a.elapsed_time(b) / reps * 1e3
+        ops.prof_enable("*")
+        for _ in range(reps):
+            run_once(g2)
+        torch.cuda.synchronize()
+        ops.prof_enable("")
+        pk = {k.split("<")[0].strip("( "): sum(v) / len(v) * 1e3 for k, v in ops.prof_read().items() if v}
+        for k in env:
+            os.environ.pop(k, None)
+        diff = ""
+        if ref is not None:
+            d = (g - ref).abs()
+            rel = d / (ref.abs() + 1e-7 * ref.abs().max())
+            diff = f" | vs ref: max abs {d.max().item():.3e} (max |ref| {ref.abs().max().item():.3e}), max rel {rel.max().item():.3e}, nan {int(torch.isnan(g).sum())}"
+        print(f"{name:58s} {total:7.1f} us  repro={repro} " + " ".join(f"{k}={v:.1f}" for k, v in sorted(pk.items())) + diff, flush=True)
+        return g
+
+    ref = variant("r3 per-corner records (PAIRS=0)", {"NGP_HASH_BWD_PAIRS": "0"})
+    # fp64 ground truth on the GPU for the fine levels is expensive; the per-corner path is itself held to the oracle by tests/test_hip_parity.py
+    for wg in ("1024", "512"):
+        for pad in ("1", "4", "8"):
+            variant(f"edge records WG={wg} PAD={pad}", {"NGP_HASH_BWD_PAIR_WG": wg, "NGP_HASH_BWD_PAIR_PAD": pad}, ref)
+    variant("edge records + runs OCC=5 STAGE=2560", {"NGP_HASH_BWD_RUN_OCC": "5", "NGP_HASH_BWD_RUN_STAGE": "2560"}, ref)
+    variant("edge records + runs STAGE=2560 (OCC 4)", {"NGP_HASH_BWD_RUN_STAGE": "2560"}, ref)
+    for res in ("200", "450", "600"):
+        variant(f"edge records, run combining up to res {res}", {"NGP_HASH_BWD_RUN_RES": res}, ref)
+    variant("r3 + runs OCC=5 STAGE=2560", {"NGP_HASH_BWD_PAIRS": "0", "NGP_HASH_BWD_RUN_OCC": "5", "NGP_HASH_BWD_RUN_STAGE": "2560"}, ref)
+
+
+if __name__ == "__main__":
+    main()
