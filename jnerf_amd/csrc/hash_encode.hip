@@ -804,8 +804,11 @@ static int hash_bwd_method() {
 #define BIN_LEVEL_MAX (BIN_ENTRIES * BINS_PER_LEVEL)                  // 2^19 entries: the largest level the bins cover
 #define RUN_RES_MAX 300u                                              // levels up to this resolution go through k_bin_records_runs
 static_assert(RUN_RES_MAX == NGP_DP_COARSE_RES_MAX, "the data-parallel bucket boundary (ngp_dp_plan) is the boundary between the run-combined and the fine levels");
-#define PAIR_CURSORS_PER_LEVEL 128u                                       // (= PAIR_BINS, defined with the edge-record kernels below)
-#define N_CURSORS (16u * BINS_PER_LEVEL + 16u * PAIR_CURSORS_PER_LEVEL)    // u32 cursors of a workspace: [16][64] per-corner bins, then [16][128] edge-record bins
+// One cursor per bin.  (r4 tried eight sub-lists with a cursor each, on the theory that same-address atomics queue behind each other: no change for the record kernels,
+// +5 us for the accumulate's eight-way gather - the cost of these reservations is their NUMBER, see the edge records below.  CUR_SUBS is kept as the switch.)
+#define CUR_SUBS 1u
+#define N_CURSORS (16u * BINS_PER_LEVEL * CUR_SUBS)                       // u32 cursors of a workspace: [16][64][CUR_SUBS]
+#define N_ZEROED (N_CURSORS + 16u)                                        // ... followed by the unit queue head of k_bin_accumulate2 (+ spare words): zeroed together with the cursors every step
 struct BinPlan { uint32_t level[16]; uint32_t n_levels; uint32_t cap; uint32_t spill_cap; };   // binned levels, records per bin, entries of the spill list
 struct LevelSel { uint32_t hl[16]; };                                  // the binned-level ordinals one launch works on (blockIdx.y, or blockIdx.x / 64)
 struct SpillEntry { uint32_t key /* binned-level ordinal << 19 | entry */; float x, y; };       // value in record units (fp16 records: scaled)
@@ -817,10 +820,39 @@ __device__ __forceinline__ uint32_t bin_of(uint32_t e, bool il) { return il ? (e
 __device__ __forceinline__ uint32_t local_of(uint32_t e, bool il) { return il ? ((e >> 9) << 3) | (e & 7u) : e & (BIN_ENTRIES - 1u); }
 __device__ __forceinline__ uint32_t entry_of(uint32_t bin, uint32_t local, bool il) { return il ? ((local >> 3) << 9) | (bin << 3) | (local & 7u) : (bin << BIN_BITS) | local; }
 // record streams of (binned level hl, bin): every level owns 64 * cap * 8 bytes of the value area whatever its record type
-template <typename RV> __device__ __forceinline__ RV *rec_val_at(void *base, uint32_t hl, uint32_t bin, uint32_t cap) {
-	return reinterpret_cast<RV *>(reinterpret_cast<char *>(base) + (size_t)hl * BINS_PER_LEVEL * cap * 8u) + (size_t)bin * cap;
+// (cap = capacity of ONE sub-list; list = bin * CUR_SUBS + sub)
+template <typename RV> __device__ __forceinline__ RV *rec_val_at(void *base, uint32_t hl, uint32_t list, uint32_t cap) {
+	return reinterpret_cast<RV *>(reinterpret_cast<char *>(base) + (size_t)hl * BINS_PER_LEVEL * CUR_SUBS * cap * 8u) + (size_t)list * cap;
 }
-__device__ __forceinline__ uint16_t *rec_idx_at(uint16_t *base, uint32_t hl, uint32_t bin, uint32_t cap) { return base + ((size_t)hl * BINS_PER_LEVEL + bin) * cap; }
+__device__ __forceinline__ uint16_t *rec_idx_at(uint16_t *base, uint32_t hl, uint32_t list, uint32_t cap) { return base + ((size_t)hl * BINS_PER_LEVEL * CUR_SUBS + list) * cap; }
+// Reading a bin back: its eight sub-lists laid end to end in units of K records (`groups`) plus the < K leftover records of every sub-list (`tails`).
+struct SubLists { uint32_t cnt[CUR_SUBS], gstart[CUR_SUBS + 1], tstart[CUR_SUBS + 1]; bool over; };
+__device__ __forceinline__ SubLists sub_lists(const uint32_t *__restrict__ cur /* the bin's CUR_SUBS cursors */, uint32_t cap, uint32_t K) {
+	SubLists m; m.over = false; m.gstart[0] = 0u; m.tstart[0] = 0u;
+#pragma unroll
+	for (uint32_t k = 0; k < CUR_SUBS; ++k) {
+		const uint32_t raw = cur[k];
+		m.over |= raw > cap;
+		m.cnt[k] = min(raw, cap);
+		m.gstart[k + 1] = m.gstart[k] + m.cnt[k] / K;
+		m.tstart[k + 1] = m.tstart[k] + m.cnt[k] % K;
+	}
+	return m;
+}
+// flat group index r -> index into the bin's sub-list layout in units of K records (sub-list k begins k * gcap groups in); static indexing only (the tables stay in registers)
+__device__ __forceinline__ uint32_t sub_group(const SubLists &m, uint32_t r, uint32_t gcap) {
+	uint32_t k = 0, s0 = 0;
+#pragma unroll
+	for (uint32_t j = 1; j < CUR_SUBS; ++j) if (r >= m.gstart[j]) { k = j; s0 = m.gstart[j]; }
+	return k * gcap + (r - s0);
+}
+// flat leftover index t -> record index in the bin's sub-list layout (sub-list k begins k * cap records in, its leftovers follow its cnt / K * K grouped records)
+__device__ __forceinline__ uint32_t sub_tail(const SubLists &m, uint32_t t, uint32_t cap, uint32_t K) {
+	uint32_t k = 0, s0 = 0, full = m.cnt[0] / K * K;
+#pragma unroll
+	for (uint32_t j = 1; j < CUR_SUBS; ++j) if (t >= m.tstart[j]) { k = j; s0 = m.tstart[j]; full = m.cnt[j] / K * K; }
+	return k * cap + full + (t - s0);
+}
 
 // Largest |dL/dy| of every level (the scale of the fixed-point accumulation).  Every workgroup writes the maximum of its share of the samples to ABSMAX_PARTS
 // partial slots per level - no atomics (same-address global atomics retire one at a time at the L2: 8192 of them on 16 addresses took ~90 us), nothing to zero
@@ -840,9 +872,9 @@ __global__ __launch_bounds__(256) void k_level_absmax(uint32_t n, const T *__res
                                                       uint32_t *__restrict__ cursors, uint32_t *__restrict__ spill_count) {
 	using P = typename Pair<T>::type;
 	const uint32_t level = blockIdx.y;
-	if (blockIdx.x == 0) {                                               // cursors u32[16][BINS_PER_LEVEL], spill count
-		if (threadIdx.x < BINS_PER_LEVEL) cursors[level * BINS_PER_LEVEL + threadIdx.x] = 0u;
-		if (threadIdx.x < PAIR_CURSORS_PER_LEVEL) cursors[16u * BINS_PER_LEVEL + level * PAIR_CURSORS_PER_LEVEL + threadIdx.x] = 0u;   // the edge-record cursors live behind them
+	if (blockIdx.x == 0) {                                               // this level's sixteenth of the cursors, spill count
+		for (uint32_t j = threadIdx.x; j < N_CURSORS / 16u; j += 256u) cursors[level * (N_CURSORS / 16u) + j] = 0u;
+		if (level == 0 && threadIdx.x < N_ZEROED - N_CURSORS) cursors[N_CURSORS + threadIdx.x] = 0u;
 		if (level == 0 && threadIdx.x == BINS_PER_LEVEL) *spill_count = 0u;
 	}
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
@@ -912,7 +944,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float 
 	RV *stage_val = reinterpret_cast<RV *>(bin_smem);                                   // [4096] contributions, grouped by bin
 	uint32_t *stage_idx = bin_smem + BIN_WG * 8u * (sizeof(RV) / 4u);                     // [4096] level-wide entry indices
 	uint32_t *cnt = stage_idx + BIN_WG * 8u, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL;
-	const uint32_t hl = sel.hl[blockIdx.y], level = bp.level[hl];
+	const uint32_t hl = sel.hl[blockIdx.y], level = bp.level[hl], sub = blockIdx.x % CUR_SUBS;
 	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const bool dense = level_is_dense(size, res), il = size < BIN_LEVEL_MAX;
@@ -944,7 +976,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float 
 	__syncthreads();
 	if (threadIdx.x < BINS_PER_LEVEL) {                                    // wave 0: global run reservation + exclusive prefix of the counts (LDS offsets of the runs)
 		const uint32_t c = cnt[threadIdx.x];
-		base[threadIdx.x] = c ? atomicAdd(&cursors[hl * BINS_PER_LEVEL + threadIdx.x], c) : 0u;
+		base[threadIdx.x] = c ? atomicAdd(&cursors[(hl * BINS_PER_LEVEL + threadIdx.x) * CUR_SUBS + sub], c) : 0u;
 		uint32_t x = c;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)threadIdx.x >= o) x += y; }
@@ -965,7 +997,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_records(uint32_t n, const float 
 		const RV v = stage_val[p];
 		const uint32_t bin = bin_of(e, il), slot = base[bin] + (p - loff[bin]);
 		if (slot < bp.cap) {
-			rec_val_at<RV>(rec_val, hl, bin, bp.cap)[slot] = v; rec_idx_at(rec_idx, hl, bin, bp.cap)[slot] = (uint16_t)local_of(e, il);
+			rec_val_at<RV>(rec_val, hl, bin * CUR_SUBS + sub, bp.cap)[slot] = v; rec_idx_at(rec_idx, hl, bin * CUR_SUBS + sub, bp.cap)[slot] = (uint16_t)local_of(e, il);
 		} else {                                                        // bin full (pathological clustering): the shared spill list, scanned by the bin's owner
 			const uint32_t k = atomicAdd(spill_count, 1u);
 			if (k < bp.spill_cap) { const float2 f = to_f2(v); spill[k] = SpillEntry{(hl << 19) | e, f.x, f.y}; }
@@ -992,7 +1024,7 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_records_runs(uint32_t n, co
 	float2 *stage_val = reinterpret_cast<float2 *>(bin_smem);                             // [stage]
 	uint32_t *stage_idx = bin_smem + stage * 2u;                                          // [stage] level-wide entry indices
 	uint32_t *cnt = stage_idx + stage, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL, *cnt2 = loff + BINS_PER_LEVEL;
-	const uint32_t hl = sel.hl[blockIdx.y], level = bp.level[hl];
+	const uint32_t hl = sel.hl[blockIdx.y], level = bp.level[hl], sub = blockIdx.x % CUR_SUBS;
 	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const bool dense = level_is_dense(size, res), il = size < BIN_LEVEL_MAX;
@@ -1063,7 +1095,7 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_records_runs(uint32_t n, co
 	__syncthreads();
 	if (threadIdx.x < BINS_PER_LEVEL) {                                    // wave 0: global reservation + exclusive prefix of the counts
 		const uint32_t c = cnt[threadIdx.x];
-		base[threadIdx.x] = c ? atomicAdd(&cursors[hl * BINS_PER_LEVEL + threadIdx.x], c) : 0u;
+		base[threadIdx.x] = c ? atomicAdd(&cursors[(hl * BINS_PER_LEVEL + threadIdx.x) * CUR_SUBS + sub], c) : 0u;
 		uint32_t x = c;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)threadIdx.x >= o) x += y; }
@@ -1072,7 +1104,7 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_records_runs(uint32_t n, co
 	__syncthreads();
 	const uint32_t cap = bp.cap;
 	auto store = [&](uint32_t e, uint32_t bin, uint32_t slot, float2 v) {
-		if (slot < cap) { rec_val_at<float2>(rec_val, hl, bin, cap)[slot] = v; rec_idx_at(rec_idx, hl, bin, cap)[slot] = (uint16_t)local_of(e, il); }
+		if (slot < cap) { rec_val_at<float2>(rec_val, hl, bin * CUR_SUBS + sub, cap)[slot] = v; rec_idx_at(rec_idx, hl, bin * CUR_SUBS + sub, cap)[slot] = (uint16_t)local_of(e, il); }
 		else { const uint32_t k = atomicAdd(spill_count, 1u); if (k < bp.spill_cap) spill[k] = SpillEntry{(hl << 19) | e, v.x, v.y}; }
 	};
 	sweep([&](uint32_t e, float x, float y) {
@@ -1121,8 +1153,9 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 		s32 = vs;                                                            // (only its zero-ness is used on this path)
 		inv = vs > 0.f ? 1.0f / (vs * 16777216.0f) : 0.f;
 	}
-	const uint32_t raw = cursors[hl * BINS_PER_LEVEL + bin];
-	const uint32_t count = min(raw, bp.cap);
+	constexpr uint32_t K = 8;
+	const SubLists sl = sub_lists(cursors + (hl * BINS_PER_LEVEL + bin) * CUR_SUBS, bp.cap, K);
+	const uint32_t count = sl.gstart[CUR_SUBS] * K + sl.tstart[CUR_SUBS];
 	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level];
 	if (s32 == 0.f || count == 0) {                                      // nothing to add: an accumulating destination is left alone, an overwritten one gets its zeros
 		if (overwrite) {
@@ -1133,8 +1166,8 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	}
 	for (uint32_t e = threadIdx.x; e < n_local * 2; e += 1024) iacc[e] = 0ull;
 	__syncthreads();
-	const RV *rec_val = rec_val_at<RV>(rec_val_base, hl, bin, bp.cap);             // cap % 8 == 0: both streams of a bin start 16-byte aligned
-	const uint16_t *rec_idx = rec_idx_at(rec_idx_base, hl, bin, bp.cap);
+	const RV *rec_val = rec_val_at<RV>(rec_val_base, hl, bin * CUR_SUBS, bp.cap);  // cap % 8 == 0: both streams of every sub-list start 16-byte aligned; sub-list k begins k * cap records further
+	const uint16_t *rec_idx = rec_idx_at(rec_idx_base, hl, bin * CUR_SUBS, bp.cap);
 	auto add = [&](uint32_t local, RV v) {
 		long long ix, iy; rec_to_fixed(v, s32, ix, iy);
 		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1144,12 +1177,12 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	// record pass; a fine level's cell that is two steps long): a wavefront's 64 lanes would hit a handful of entries, and same-address ds_add_u64 serialise.  So
 	// every thread takes K = 8 CONSECUTIVE records, sums runs of equal entries in registers (exact: the sums are integers) and issues one pair of LDS atomics per
 	// run; neighbouring lanes are then 8 records apart.  Two trips (64 / 32 + 16 bytes per thread each) are in flight.
-	constexpr uint32_t K = 8;
 	struct alignas(16) VK { RV v[K]; };
 	struct alignas(16) IK { uint16_t i[K]; };
 	const VK *pv = reinterpret_cast<const VK *>(rec_val);
 	const IK *pi = reinterpret_cast<const IK *>(rec_idx);
-	const uint32_t groups = count / K;
+	const uint32_t groups = sl.gstart[CUR_SUBS], gcap = bp.cap / K;
+	auto grp = [&](uint32_t r) { return sub_group(sl, r, gcap); };     // group r of the bin -> its place in the sub-list layout
 	auto add_fixed = [&](uint32_t local, long long ix, long long iy) {
 		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		__hip_atomic_fetch_add(&iacc[2 * local + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1166,12 +1199,16 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	};
 	uint32_t r = threadIdx.x;
 	for (; r + 1024 < groups; r += 2 * 1024) {
-		const VK x0 = pv[r], x1 = pv[r + 1024]; const IK k0 = pi[r], k1 = pi[r + 1024];
+		const uint32_t a0 = grp(r), a1 = grp(r + 1024);
+		const VK x0 = pv[a0], x1 = pv[a1]; const IK k0 = pi[a0], k1 = pi[a1];
 		run_add(x0, k0); run_add(x1, k1);
 	}
-	for (; r < groups; r += 1024) { const VK x = pv[r]; const IK k = pi[r]; run_add(x, k); }
-	if (threadIdx.x < count - groups * K) { const uint32_t t = groups * K + threadIdx.x; add(rec_idx[t], rec_val[t]); }
-	if (raw > bp.cap) {                                                   // this bin overflowed: its surplus records are somewhere in the shared spill list
+	for (; r < groups; r += 1024) { const uint32_t a0 = grp(r); const VK x = pv[a0]; const IK k = pi[a0]; run_add(x, k); }
+	if (threadIdx.x < sl.tstart[CUR_SUBS]) {                             // the < K leftover records of every sub-list
+		const uint32_t t = sub_tail(sl, threadIdx.x, bp.cap, K);
+		add(rec_idx[t], rec_val[t]);
+	}
+	if (sl.over) {                                                        // a sub-list of this bin overflowed: its surplus records are somewhere in the shared spill list
 		const uint32_t ns = min(*spill_count, bp.spill_cap);
 		for (uint32_t t = threadIdx.x; t < ns; t += 1024) {
 			const SpillEntry se = spill[t];
@@ -1202,44 +1239,55 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	}
 }
 
-// ---------------------------------------------------------------------------------------------------------------- pair records (r4): the fine hashed levels, fp32
-// Round 3's fine levels wrote eight 10-byte records per (sample, level) - 124 MB out and back in for the six fine levels of the ngp_base.py table, the largest
-// block of the stage's traffic.  What the eight contributions of a cell share makes half of that unnecessary:
-//   * the hash is x ^ y*P1 ^ z*P2 masked to 19 bits and x + 1 <= res <= 2048 touches bits 0..11 only, so the two x-neighbours of a cell edge ALWAYS fall into the
-//     same 4096-entry slice of the level: bins of 4096 entries (128 per level) receive both, and ONE record can carry the edge;
-//   * their two contributions are (g * wy*wz) * (1 - fx) and (g * wy*wz) * fx: the record carries a = g.x*(wy*wz), b = g.y*(wy*wz) and fx, the accumulate kernel
-//     multiplies.  Three roundings per contribution like the reference's ((wx*wy)*wz)*g, in another order: within 2 ulp of it per contribution, far inside what
-//     the reference's float atomics (one rounding per add, arrival order) scatter around the exact sum; the accumulation itself stays exact (64-bit integers).
-// 16 bytes per EDGE {a, b, fx, slot0 | slot1 << 12 | bin << 24} = 8 bytes per contribution instead of 10, one 16-byte store / load per two contributions instead
-// of four narrow ones, half the LDS histogram and staging traffic in the record kernel - and the 64 KiB accumulator of a 4096-entry bin lets TWO accumulate
-// workgroups share a CU, so one's write-out and start-up hide behind the other's record stream (round 2 measured that gain but paid for it with half-length
-// record runs; the edge records are twice as large, so a 1024-sample workgroup writes the same 512-byte runs as before).
+// ---------------------------------------------------------------------------------------------------------------- edge records (r4): the fine hashed levels, fp32
+// Round 3's fine levels wrote eight 10-byte records per (sample, level) - 124 MB out and back in for the six fine levels of the ngp_base.py table - through lists whose
+// slots were handed out by one returning global atomic per (workgroup, bin).  Two things were wrong with that, both measured this round (profiles/r04_scatter_probes.md):
+//   * the ATOMICS, not the bytes, set the record kernels' duration: returning device-scope atomics retire at ~8 G/s chip-wide whatever their addresses (eight cursors
+//     per bin changed nothing), so the 196 k / 393 k reservations of a 2^18-sample batch cost 25 / 50 us of k_bin_pairs' 52 / 78 us (1024- / 512-sample workgroups);
+//     the stores themselves cost 9 us, and the plain append pattern without atomics runs at 5-6 TB/s (tools/microbench_stream.py);
+//   * the eight contributions of a cell share most of their bits.
+// So: NO global atomics and half the bytes.
+//   * The hash is x ^ y*P1 ^ z*P2 masked to 19 bits and x + 1 <= res <= 2048 touches bits 0..11 only: the two x-neighbours of a cell edge ALWAYS fall into the same
+//     4096-entry slice of the level.  Bins are 4096 entries (128 per level) and ONE record carries the edge: {a = g.x*(wy*wz), b = g.y*(wy*wz), fx, slot0 | slot1 << 12},
+//     16 bytes for two contributions (a*(1-fx), b*(1-fx) -> slot0; a*fx, b*fx -> slot1; the accumulate kernel multiplies: three roundings per contribution like the
+//     reference's ((wx*wy)*wz)*g, in another order - within 2 ulp of it per contribution, far inside what the reference's float atomics scatter around the exact sum;
+//     the accumulation itself stays exact, 64-bit integers).
+//   * Every record workgroup owns a REGION of the record area (4 x its samples records): it sorts its edge records by bin in LDS (histogram, prefix, staging - as before)
+//     and writes the staged block out as it is - one contiguous, fully coalesced 64 KiB store stream - plus the 129 bin offsets inside its region (u16).  Nothing is
+//     reserved, nothing can overflow, the layout is deterministic.
+//   * The accumulate workgroup of (level, bin) walks the W regions: eight lanes per region read that region's segment of the bin (offset table -> start, length;
+//     32 records on average = one 64-byte quad of records per lane), neighbours that name the same edge are summed in registers, four LDS atomics per distinct edge.
+//     64 KiB of accumulators: two workgroups per CU, one's write-out and start-up hide behind the other's record stream.
 // Levels: hashed, 2^19 entries, run-combining limit < res <= 2048, fp32 dL/dy and gradient.  Everything else keeps the per-corner records above.
 #define PAIR_BIN_BITS 12u
 #define PAIR_BIN_ENTRIES (1u << PAIR_BIN_BITS)
 #define PAIR_BINS 128u
-static_assert(PAIR_BINS == PAIR_CURSORS_PER_LEVEL, "cursor layout");
 #define PAIR_RES_MAX 2048u
-#define PAIR_PAD_MAX 8u
-static_assert(PAIR_BIN_ENTRIES * PAIR_BINS == BIN_LEVEL_MAX, "the pair path covers the full 2^19-entry levels");
+#define PAIR_OFFS (PAIR_BINS + 2u)                                     // u16 offsets per region: 128 bin starts, the total, one pad (rows stay 4-byte aligned)
+static_assert(PAIR_BIN_ENTRIES * PAIR_BINS == BIN_LEVEL_MAX, "the edge-record path covers the full 2^19-entry levels");
 struct alignas(16) PairRec { float a, b, fx; uint32_t loc; };
-static uint32_t pair_stage_bytes(uint32_t wg, uint32_t pad) { return (wg * 4u + PAIR_BINS * (pad - 1u)) * 16u + (3u * PAIR_BINS + 4u) * 4u; }
+static uint32_t pair_stage_bytes(uint32_t wg) { return wg * 4u * 16u + (2u * PAIR_BINS + 4u) * 4u; }
+__host__ __device__ static inline uint32_t pair_region_records(uint32_t wg) { return wg * 4u + 4u; }     // + 4: the last segment's quad may be read past its end
 
-// S samples per workgroup.  `pad`: every (workgroup, bin) run is rounded up to a multiple of `pad` records with null records (a = b = 0), so that no 64- / 128-byte
-// line of a bin's stream is shared by two workgroups (= two XCDs' L2s holding partial dirty lines of it).
+// S samples per workgroup = one region
 template <int LAYOUT, uint32_t S>
 __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__restrict__ pos, uint32_t stride, const float *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
-                                                 const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ pcursors, PairRec *__restrict__ prec, uint32_t pcap, uint32_t pad,
-                                                 uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill, const uint32_t *__restrict__ n_valid) {
+                                                 const uint32_t *__restrict__ absmax_bits, PairRec *__restrict__ prec, uint16_t *__restrict__ poff,
+                                                 uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill, const uint32_t *__restrict__ n_valid,
+                                                 uint32_t probe /* timing experiment (NGP_PAIR_PROBE; results wrong unless 0): 1 = no record stores */) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
-	const uint32_t stage_cap = S * 4u + PAIR_BINS * (pad - 1u);
-	PairRec *stage = reinterpret_cast<PairRec *>(bin_smem);
-	uint32_t *cnt = bin_smem + stage_cap * 4u, *base = cnt + PAIR_BINS, *loff = base + PAIR_BINS;      // loff[PAIR_BINS] = staged total
+	PairRec *stage = reinterpret_cast<PairRec *>(bin_smem);                                   // [4 S] edge records, grouped by bin
+	uint32_t *cnt = bin_smem + S * 4u * 4u, *loff = cnt + PAIR_BINS;                          // loff[PAIR_BINS] = total
 	const uint32_t po = blockIdx.y, hl = sel.hl[po], level = bp.level[hl];
 	const uint32_t mask = lt.v[4 * level + 1] - 1u;
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
+	const size_t region = (size_t)po * gridDim.x + blockIdx.x;
+	uint16_t *my_off = poff + region * PAIR_OFFS;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	if (level_absmax(absmax_bits, level) == 0u || blockIdx.x * S >= lim) return;                          // uniform exit
+	if (level_absmax(absmax_bits, level) == 0u || blockIdx.x * S >= lim) {                   // uniform exit: an empty region
+		if (threadIdx.x < PAIR_OFFS) my_off[threadIdx.x] = 0;
+		return;
+	}
 	if (threadIdx.x < PAIR_BINS) cnt[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t i = blockIdx.x * S + threadIdx.x;
@@ -1264,19 +1312,15 @@ __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__rest
 		}
 	}
 	__syncthreads();
-	if (threadIdx.x < 64u) {                                                    // wave 0, two bins per lane: global reservation, exclusive prefix, padding records
+	if (threadIdx.x < 64u) {                                                    // wave 0, two bins per lane: exclusive prefix = the region's bin offsets
 		const uint32_t b0 = 2u * threadIdx.x, c0 = cnt[b0], c1 = cnt[b0 + 1u];
-		const uint32_t p0 = (c0 + pad - 1u) / pad * pad, p1 = (c1 + pad - 1u) / pad * pad;
-		base[b0] = p0 ? atomicAdd(&pcursors[po * PAIR_BINS + b0], p0) : 0u;
-		base[b0 + 1u] = p1 ? atomicAdd(&pcursors[po * PAIR_BINS + b0 + 1u], p1) : 0u;
-		uint32_t x = p0 + p1;
+		uint32_t x = c0 + c1;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)threadIdx.x >= o) x += y; }
-		const uint32_t e0 = x - (p0 + p1);
-		loff[b0] = e0; loff[b0 + 1u] = e0 + p0;
-		if (threadIdx.x == 63u) loff[PAIR_BINS] = x;
-		for (uint32_t k = c0; k < p0; ++k) stage[e0 + k] = PairRec{0.f, 0.f, 0.f, b0 << 24};
-		for (uint32_t k = c1; k < p1; ++k) stage[e0 + p0 + k] = PairRec{0.f, 0.f, 0.f, (b0 + 1u) << 24};
+		const uint32_t e0 = x - (c0 + c1);
+		loff[b0] = e0; loff[b0 + 1u] = e0 + c0;
+		reinterpret_cast<uint32_t *>(my_off)[threadIdx.x] = e0 | ((e0 + c0) << 16);          // (4 S <= 4096 < 2^16)
+		if (threadIdx.x == 63u) { loff[PAIR_BINS] = x; reinterpret_cast<uint32_t *>(my_off)[64] = x; }
 	}
 	__syncthreads();
 	if (live) {
@@ -1286,8 +1330,7 @@ __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__rest
 			const uint32_t i0 = (c.g[0] ^ h[q]) & mask, i1 = ((c.g[0] + 1u) ^ h[q]) & mask;
 			const float a = g2.x * wyz, b = g2.y * wyz;
 			if (rank[q] != ~0u) {
-				const uint32_t bin = i0 >> PAIR_BIN_BITS;
-				stage[loff[bin] + rank[q]] = PairRec{a, b, c.w[0], (i0 & (PAIR_BIN_ENTRIES - 1u)) | ((i1 & (PAIR_BIN_ENTRIES - 1u)) << PAIR_BIN_BITS) | (bin << 24)};
+				stage[loff[i0 >> PAIR_BIN_BITS] + rank[q]] = PairRec{a, b, c.w[0], (i0 & (PAIR_BIN_ENTRIES - 1u)) | ((i1 & (PAIR_BIN_ENTRIES - 1u)) << PAIR_BIN_BITS)};
 			} else {
 				const uint32_t k = atomicAdd(spill_count, 2u);
 				const float w0 = 1 - c.w[0];
@@ -1297,98 +1340,316 @@ __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__rest
 	}
 	__syncthreads();
 	const uint32_t total = loff[PAIR_BINS];
-	for (uint32_t p = threadIdx.x; p < total; p += S) {
-		const PairRec r = stage[p];
-		const uint32_t bin = r.loc >> 24, slot = base[bin] + (p - loff[bin]);
-		if (slot < pcap) prec[(size_t)(po * PAIR_BINS + bin) * pcap + slot] = r;
-		else if (r.a != 0.f || r.b != 0.f) {                            // bin full (pathological clustering): the shared spill list, as two contributions
-			const uint32_t k = atomicAdd(spill_count, 2u);
-			const float w0 = 1 - r.fx;
-			const uint32_t e0 = (bin << PAIR_BIN_BITS) | (r.loc & (PAIR_BIN_ENTRIES - 1u)), e1 = (bin << PAIR_BIN_BITS) | ((r.loc >> PAIR_BIN_BITS) & (PAIR_BIN_ENTRIES - 1u));
-			if (k + 1u < bp.spill_cap) { spill[k] = SpillEntry{(hl << 19) | e0, r.a * w0, r.b * w0}; spill[k + 1u] = SpillEntry{(hl << 19) | e1, r.a * r.fx, r.b * r.fx}; }
-		}
-	}
+	PairRec *out = prec + region * pair_region_records(S);
+	if (probe & 1u) { if (total == 0x7fffffffu) out[0] = stage[0]; return; }
+	for (uint32_t p = threadIdx.x; p < total; p += S) out[p] = stage[p];
 }
 
-// One workgroup per (pair level, 4096-entry bin): 64 KiB of 64-bit accumulators, two workgroups per CU.  Every thread takes FOUR consecutive edge records (64 bytes,
-// two trips in flight), sums neighbours that name the same edge in registers (consecutive records of a bin come from consecutive samples of a ray: a level-10 cell
-// is two steps long) and issues four LDS atomics per distinct edge.  The spill list is scanned whenever it is not empty (out-of-cube edges land there directly).
-#define PACC_WG 512u
-template <typename G>
-__global__ __launch_bounds__(PACC_WG) void k_bin_accumulate_pairs(LevelTable lt, BinPlan bp, LevelSel sel, const uint32_t *__restrict__ absmax_bits, const uint32_t *__restrict__ pcursors,
-                                                                  const PairRec *__restrict__ prec, uint32_t pcap, const uint32_t *__restrict__ spill_count,
-                                                                  const SpillEntry *__restrict__ spill, G *__restrict__ grad, int overwrite) {
+// ---- run records without atomics (r4): the coarse levels of the fp32 path.  k_bin_records_runs above with the edge kernel's layout: a region per record workgroup
+// (its run records sorted by bin, 12 bytes each {x, y, slot}; the bin offsets beside them), 128 bins of 4096 entries like the edge levels - so that ONE accumulate
+// kernel serves every level.  Entries of a level smaller than 2^19 are dealt to the bins in interleaved groups of eight (the spatially coherent dense indices
+// spread evenly), as before with 64 bins.
+struct RunRec { float x, y; uint32_t loc; };
+#define RUN2_OFFS (PAIR_BINS + 2u)
+__host__ __device__ static inline uint32_t run2_region_records() { return RUN_WG * RUN_K * 8u + 4u; }
+static uint32_t run2_stage_bytes(uint32_t stage) { return stage * 12u + (3u * PAIR_BINS + 4u) * 4u; }
+__device__ __forceinline__ uint32_t bin2_of(uint32_t e, bool il) { return il ? (e >> 3) & (PAIR_BINS - 1u) : e >> PAIR_BIN_BITS; }
+__device__ __forceinline__ uint32_t local2_of(uint32_t e, bool il) { return il ? ((e >> 10) << 3) | (e & 7u) : e & (PAIR_BIN_ENTRIES - 1u); }
+__device__ __forceinline__ uint32_t entry2_of(uint32_t bin, uint32_t local, bool il) { return il ? ((local >> 3) << 10) | (bin << 3) | (local & 7u) : (bin << PAIR_BIN_BITS) | local; }
+
+template <int LAYOUT, int OCC>
+__global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const float *__restrict__ pos, uint32_t stride, const float *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
+                                                         const uint32_t *__restrict__ absmax_bits, RunRec *__restrict__ rrec, uint16_t *__restrict__ roff,
+                                                         const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */,
+                                                         uint32_t probe /* timing experiments (results wrong): 1 = the histogram atomics spread over lane-distinct addresses, 2 = no global record stores */) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
+	RunRec *stage_rec = reinterpret_cast<RunRec *>(bin_smem);                              // [stage]
+	uint32_t *cnt = bin_smem + stage * 3u, *loff = cnt + PAIR_BINS, *cnt2 = loff + PAIR_BINS + 2u;   // loff[PAIR_BINS] = total
+	const uint32_t ro = blockIdx.y, hl = sel.hl[ro], level = bp.level[hl];
+	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
+	const float scale = __uint_as_float(lt.v[4 * level + 3]);
+	const bool dense = level_is_dense(size, res), il = size < BIN_LEVEL_MAX;
+	const size_t region = (size_t)ro * gridDim.x + blockIdx.x;
+	uint16_t *my_off = roff + region * RUN2_OFFS;
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	if (level_absmax(absmax_bits, level) == 0u || blockIdx.x * RUN_WG * RUN_K >= lim) {        // uniform exit: an empty region
+		if (threadIdx.x < RUN2_OFFS) my_off[threadIdx.x] = 0;
+		return;
+	}
+	if (threadIdx.x < PAIR_BINS) { cnt[threadIdx.x] = 0; cnt2[threadIdx.x] = 0; }
+	__syncthreads();
+	const uint32_t first = (blockIdx.x * RUN_WG + threadIdx.x) * RUN_K;
+	const float2 *dy = reinterpret_cast<const float2 *>(dLdy);
+	uint32_t cell[RUN_K][3]; float frac[RUN_K][3]; float2 gk[RUN_K];
+	{
+		float px[RUN_K][3];
+		if (first + RUN_K <= lim && stride == 3) {
+			const float4 *p4 = reinterpret_cast<const float4 *>(pos + (size_t)first * 3);   // 24 floats, 16-byte aligned (first % 8 == 0)
+			float4 v[6];
+#pragma unroll
+			for (int r = 0; r < 6; ++r) v[r] = p4[r];
+			const float *f = reinterpret_cast<const float *>(v);
+#pragma unroll
+			for (uint32_t k = 0; k < RUN_K; ++k) { px[k][0] = f[3 * k]; px[k][1] = f[3 * k + 1]; px[k][2] = f[3 * k + 2]; }
+#pragma unroll
+			for (uint32_t k = 0; k < RUN_K; ++k) gk[k] = LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + first + k] : dy[(size_t)(first + k) * 16 + level];
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < RUN_K; ++k) {
+				const uint32_t i = first + k;
+				if (i < lim) {
+					px[k][0] = pos[(size_t)i * stride]; px[k][1] = pos[(size_t)i * stride + 1]; px[k][2] = pos[(size_t)i * stride + 2];
+					gk[k] = LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level];
+				} else { px[k][0] = px[k][1] = px[k][2] = 0.f; gk[k] = make_float2(0.f, 0.f); }
+			}
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < RUN_K; ++k)
+#pragma unroll
+			for (int d = 0; d < 3; ++d) { const float p = px[k][d] * scale + 0.5f; const float fl = floorf(p); cell[k][d] = (uint32_t)(int)fl; frac[k][d] = p - fl; }   // pos_fract, HashEncode.h:106-115
+	}
+	// one sweep over the thread's samples; emit(entry, x, y) is called for the eight corners of every finished run (k_bin_records_runs' sweep)
+	auto sweep = [&](auto emit) {
+		bool open = false;
+		uint32_t key[3] = {0u, 0u, 0u};
+		float ax[8], ay[8];
+		auto flush = [&]() {
+			uint32_t idx[8];
+			cell_entries(size, res, dense, key[0], key[1], key[2], idx);
+#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q) emit(idx[q], ax[q], ay[q]);
+		};
+#pragma unroll
+		for (uint32_t k = 0; k < RUN_K; ++k) {
+			if (gk[k].x == 0.f && gk[k].y == 0.f) continue;        // zero rows (padding) add exact zeros in the reference: skipped, they do not end a run either
+			if (open && !(cell[k][0] == key[0] && cell[k][1] == key[1] && cell[k][2] == key[2])) { flush(); open = false; }
+			if (!open) {
+				open = true; key[0] = cell[k][0]; key[1] = cell[k][1]; key[2] = cell[k][2];
+#pragma unroll
+				for (uint32_t q = 0; q < 8; ++q) { ax[q] = 0.f; ay[q] = 0.f; }
+			}
+			const float x1 = frac[k][0], x0 = 1 - x1, y1 = frac[k][1], y0 = 1 - y1, z1 = frac[k][2], z0 = 1 - z1;
+#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q) {
+				const float w = ((q & 1u) ? x1 : x0) * ((q & 2u) ? y1 : y0) * ((q & 4u) ? z1 : z0);                 // the reference's x, y, z multiplication order
+				ax[q] += gk[k].x * w; ay[q] += gk[k].y * w;
+			}
+		}
+		if (open) flush();
+	};
+	const uint32_t spread = (probe & 1u) ? threadIdx.x : 0u;
+	sweep([&](uint32_t e, float, float) { atomicAdd(&cnt[(bin2_of(e, il) + spread) & (PAIR_BINS - 1u)], 1u); });
+	__syncthreads();
+	if (threadIdx.x < 64u) {                                                    // wave 0, two bins per lane: exclusive prefix = the region's bin offsets
+		const uint32_t b0 = 2u * threadIdx.x, c0 = cnt[b0], c1 = cnt[b0 + 1u];
+		uint32_t x = c0 + c1;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)threadIdx.x >= o) x += y; }
+		const uint32_t e0 = x - (c0 + c1);
+		loff[b0] = e0; loff[b0 + 1u] = e0 + c0;
+		reinterpret_cast<uint32_t *>(my_off)[threadIdx.x] = e0 | ((e0 + c0) << 16);          // (<= 16384 records per region < 2^16)
+		if (threadIdx.x == 63u) { loff[PAIR_BINS] = x; reinterpret_cast<uint32_t *>(my_off)[64] = x; }
+	}
+	__syncthreads();
+	RunRec *out = rrec + region * run2_region_records();
+	sweep([&](uint32_t e, float x, float y) {
+		const uint32_t bin = (bin2_of(e, il) + spread) & (PAIR_BINS - 1u), p = loff[bin] + atomicAdd(&cnt2[bin], 1u);
+		const RunRec r{x, y, local2_of(e, il)};
+		if (p < stage) stage_rec[p] = r; else if (!(probe & 2u)) out[p] = r;     // beyond the staging area (scattered positions only): straight to its place in the region
+	});
+	__syncthreads();
+	const uint32_t total = min(loff[PAIR_BINS], stage);
+	if (probe & 2u) return;
+	for (uint32_t p = threadIdx.x; p < total; p += RUN_WG) out[p] = stage_rec[p];
+}
+
+// ---- ONE accumulate kernel for every level of the fp32 path: a workgroup per (level, 4096-entry bin), 64 KiB of 64-bit accumulators (two workgroups per CU).  It walks
+// the record regions of its level: LANES lanes per region read the region's segment of the bin (offset table -> start, length) with consecutive lanes on consecutive
+// records (full lines), I records per lane in flight, U regions per thread.  Unit order: edge levels first (the heavier units), then the run levels.
+#define ACC2_WG 512u
+#define ACC2_RB 512u                                                     // regions per block of the gather (= threads: one region per thread when the segment table is built)
+#define ACC2_MAPN 1024u
+#define ACC2_LDS_EXTRA ((2u * (ACC2_RB + 1u) + 16u) * 4u + ACC2_MAPN * 8u)
+struct Acc2Plan { uint32_t n_pair, n_run, pair_regions, pair_region_records, run_regions, run_region_records, probe; };
+// c * s (s a power of two) rounded to the nearest integer (ties to even), as a 64-bit integer: __float2ll_rn without the generic expansion.  t = c * s is exact, rint(t) is
+// an integer-valued float with <= 24 significant bits, so its split into hi * 2^32 + lo is exact too.  |t| < 2^62 by construction of the scale.
+__device__ __forceinline__ long long fixed_rn(float c, float s) {
+	const float r = rintf(c * s), m = fabsf(r);
+	const float hi = floorf(m * 2.3283064365386963e-10f);               // floor(|r| / 2^32)
+	const float lo = fmaf(hi, -4294967296.0f, m);                        // |r| - hi * 2^32, in [0, 2^32): exact (a multiple of ulp(|r|) below 2^32)
+	const long long v = (long long)(((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo);
+	return r < 0.f ? -v : v;
+}
+static_assert(ACC2_RB == ACC2_WG, "gather_flat builds one segment-table row per thread");
+// The records of one (level, bin) lie in n_regions segments (one per record workgroup).  Per block of ACC2_RB regions: segment table (start, length) -> exclusive prefix P in LDS ->
+// the segments laid end to end as ONE flat list that the threads walk densely (thread t takes flat records t, t + 512, ...; eight loads in flight): consecutive lanes read
+// consecutive records of a segment (full lines) and every lane has work - eight lanes per segment with a fixed number of slots left half of them idle, and the kernel was
+// bound by exactly that (k_bin_accumulate2 90 us).  flat index -> segment: a map with one entry per 2^shift flat records (the segment holding the first of them), then a
+// short forward walk over P.
+// this thread's row of the segment table of (level, bin): region w0 + threadIdx.x -> {length, index of the segment's first record}
+__device__ __forceinline__ uint2 segment_row(const uint16_t *__restrict__ offs, uint32_t level_ord, uint32_t n_regions, uint32_t region_records, uint32_t offs_per_region, uint32_t bin, uint32_t w0) {
+	if (w0 + threadIdx.x >= n_regions) return make_uint2(0u, 0u);
+	const size_t region = (size_t)level_ord * n_regions + w0 + threadIdx.x;
+	const uint32_t o = *reinterpret_cast<const uint32_t *>(offs + region * offs_per_region + (bin & ~1u));        // offsets of bins 2k, 2k+1 in one word
+	const uint32_t o2 = *reinterpret_cast<const uint32_t *>(offs + region * offs_per_region + (bin & ~1u) + 2u);  // ... of 2k+2 (or the total)
+	const uint32_t q0 = (bin & 1u) ? o >> 16 : o & 0xffffu, q1 = (bin & 1u) ? o2 & 0xffffu : o >> 16;
+	return make_uint2(q1 - q0, (uint32_t)(region * region_records) + q0);
+}
+template <typename Rec, typename F>
+__device__ __forceinline__ void gather_flat(const Rec *__restrict__ recs, const uint16_t *__restrict__ offs, uint32_t level_ord, uint32_t n_regions, uint32_t region_records,
+                                            uint32_t offs_per_region, uint32_t bin, uint32_t *__restrict__ lds, uint32_t probe /* timing experiments: 1 = records loaded, not processed; 2 = not loaded */,
+                                            uint2 row0 /* segment_row(..., 0), loaded by the caller ahead of time */, F process) {
+	uint32_t sink = 0;
+	uint2 *seg = reinterpret_cast<uint2 *>(lds);                           // [RB + 1] per segment: {flat index of its END, start - flat index of its beginning}: one 8-byte read answers "is f mine" and "where is it"
+	uint32_t *wsum = lds + 2u * (ACC2_RB + 1u);                            // per-wave totals[8 (+8 spare)]
+	uint2 *map = reinterpret_cast<uint2 *>(wsum + 16u);                    // [ACC2_MAPN] per 2^shift flat records: the seg entry of the segment holding the first of them, its index in the top 9 bits of .x
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	for (uint32_t w0 = 0; w0 < n_regions; w0 += ACC2_RB) {
+		const uint2 row = w0 == 0 ? row0 : segment_row(offs, level_ord, n_regions, region_records, offs_per_region, bin, w0);
+		const uint32_t len = row.x, st = row.y;
+		uint32_t inc = len;                                                 // inclusive prefix over the workgroup's 512 lengths
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+		if (lane == 63u) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t base = 0, T = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < ACC2_WG / 64u; ++k) { const uint32_t v = wsum[k]; base += k < wave ? v : 0u; T += v; }
+		const uint32_t p0 = base + inc - len;
+		seg[threadIdx.x] = make_uint2(p0 + len, st - p0);
+		if (threadIdx.x == ACC2_RB - 1u) seg[ACC2_RB] = make_uint2(0xffffffffu, 0u);     // sentinel: the forward walk stops here
+		uint32_t shift = 3;
+		while ((T >> shift) >= ACC2_MAPN) ++shift;
+		if (T >> 23) { T = (1u << 23) - 1u; }                               // (cannot happen below 8 M records per bin; keeps the packed entries well-formed)
+		if (len) { const uint32_t G = 1u << shift; for (uint32_t g = (p0 + G - 1u) >> shift; (g << shift) < p0 + len; ++g) map[g] = make_uint2((p0 + len) | (threadIdx.x << 23), st - p0); }   // (T < 2^23: 8 M records of one bin)
+		__syncthreads();
+		constexpr uint32_t B = 8;
+		for (uint32_t f0 = threadIdx.x; f0 < T; f0 += ACC2_WG * B) {
+			Rec x[B];
+#pragma unroll
+			for (uint32_t b = 0; b < B; ++b) {
+				const uint32_t f = f0 + b * ACC2_WG;
+				if (f < T) {
+					uint2 e = map[f >> shift];
+					uint32_t w = e.x >> 23; e.x &= 0x7fffffu;
+					while (f >= e.x) e = seg[++w];                          // (rarely: f lies up to 2^shift - 1 records behind the mapped one; empty segments end where they begin: skipped)
+					if (!(probe & 2u)) x[b] = recs[e.y + f];
+				}
+			}
+#pragma unroll
+			for (uint32_t b = 0; b < B; ++b) if (f0 + b * ACC2_WG < T) { if (probe & 1u) sink ^= reinterpret_cast<const uint32_t *>(&x[b])[0]; else process(x[b]); }
+		}
+		__syncthreads();                                                    // the tables are rebuilt for the next block of regions
+	}
+	if (sink == 0x9e3779b9u) lds[0] = sink;                                 // (keeps the probe's loads alive)
+}
+
+template <typename G, bool QUEUE /* units drawn from a queue by resident workgroups | one unit per workgroup */>
+__global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, BinPlan bp, LevelSel sel_pair, LevelSel sel_run, Acc2Plan ap, const uint32_t *__restrict__ absmax_bits,
+                                                               const PairRec *__restrict__ prec, const uint16_t *__restrict__ poff, const RunRec *__restrict__ rrec, const uint16_t *__restrict__ roff,
+                                                               const uint32_t *__restrict__ spill_count, const SpillEntry *__restrict__ spill, G *__restrict__ grad, int overwrite,
+                                                               uint32_t *__restrict__ queue_head /* zero at launch (hash_bwd_impl launches the kernel at most twice per step: two words) */) {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long iacc[];   // [PAIR_BIN_ENTRIES][2] 64-bit fixed point
+	__shared__ uint32_t s_next;
 	using GP = typename Pair<G>::type;
-	const uint32_t po = blockIdx.x / PAIR_BINS, bin = blockIdx.x % PAIR_BINS, hl = sel.hl[po], level = bp.level[hl];
+	uint32_t *tables = reinterpret_cast<uint32_t *>(iacc + 2u * PAIR_BIN_ENTRIES);        // gather_flat's segment tables, behind the accumulators
+	// Persistent: two workgroups per CU take the units round-robin.  A unit's critical path held two memory round trips (its row of the segment table, then the records);
+	// the row of the NEXT unit is now requested before this unit's records are, so only one of them is exposed (fixed cost of the 2048 units of a 2^18-sample batch: 30 of 74 us).
+	const uint32_t n_units = (ap.n_pair + ap.n_run) * PAIR_BINS;
+	auto unit_row = [&](uint32_t u) {
+		const bool pr = u < ap.n_pair * PAIR_BINS;
+		const uint32_t v = pr ? u : u - ap.n_pair * PAIR_BINS;
+		return pr ? segment_row(poff, v / PAIR_BINS, ap.pair_regions, ap.pair_region_records, PAIR_OFFS, v % PAIR_BINS, 0u)
+		          : segment_row(roff, v / PAIR_BINS, ap.run_regions, ap.run_region_records, RUN2_OFFS, v % PAIR_BINS, 0u);
+	};
+	// Units differ in weight (an edge unit carries ~3x the records of a run unit), so after its first unit - the launch order: the heaviest first - a workgroup draws the next
+	// from a queue (one returning atomic per unit, issued a whole unit ahead of its use).
+	uint2 row_next = blockIdx.x < n_units ? unit_row(blockIdx.x) : make_uint2(0u, 0u);
+	if (QUEUE && threadIdx.x == 0) s_next = gridDim.x + atomicAdd(queue_head, 1u);
+	uint32_t u = blockIdx.x;
+	while (u < n_units) {
+	const uint2 row0 = row_next;
+	uint32_t u_next = ~0u;
+	if (QUEUE) {
+		__syncthreads();
+		u_next = s_next;
+		if (u_next < n_units) row_next = unit_row(u_next);
+		__syncthreads();                                                  // everyone has read s_next
+		if (threadIdx.x == 0) s_next = gridDim.x + atomicAdd(queue_head, 1u);
+	}
+	const uint32_t u_this = u;
+	u = u_next;
+	const bool is_pair = u_this < ap.n_pair * PAIR_BINS;
+	const uint32_t unit = is_pair ? u_this : u_this - ap.n_pair * PAIR_BINS;
+	const uint32_t ord = unit / PAIR_BINS, bin = unit % PAIR_BINS, hl = is_pair ? sel_pair.hl[ord] : sel_run.hl[ord], level = bp.level[hl];
+	const uint32_t size = lt.v[4 * level + 1];
+	const bool il = size < BIN_LEVEL_MAX;
+	// slots of this bin that are entries of the level (interleaved: groups bin, bin + 128, ... of the level's ceil(size / 8) groups)
+	const uint32_t groups_all = (size + 7u) >> 3;
+	const uint32_t n_local = il ? (groups_all > bin ? ((groups_all - bin + PAIR_BINS - 1u) / PAIR_BINS) << 3 : 0u) : PAIR_BIN_ENTRIES;
 	const uint32_t amax = level_absmax(absmax_bits, level);
 	float s32 = 0.f;
 	{ const float m = __uint_as_float(amax); if (m > 0.f && m < 3.0e38f) { int ex; frexpf(m, &ex); s32 = ldexpf(1.0f, 38 - ex); } }
 	const float inv = s32 > 0.f ? 1.0f / s32 : 0.f;
-	const uint32_t raw = pcursors[po * PAIR_BINS + bin], count = min(raw, pcap);
-	const uint32_t ns = min(*spill_count, bp.spill_cap);
-	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level] + (bin << PAIR_BIN_BITS);
-	if (s32 == 0.f || (count == 0 && ns == 0)) {                         // nothing to add: an accumulating destination is left alone, an overwritten one gets its zeros
+	const uint32_t ns = is_pair ? min(*spill_count, bp.spill_cap) : 0u;
+	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level];
+	if (s32 == 0.f) {                                                     // the level has no gradient: an accumulating destination is left alone, an overwritten one gets its zeros
 		if (overwrite) {
 			GP zv; from_f2(zv, make_float2(0.f, 0.f));
-			for (uint32_t e = threadIdx.x; e < PAIR_BIN_ENTRIES; e += PACC_WG) dst[e] = zv;
+			for (uint32_t e = threadIdx.x; e < n_local; e += ACC2_WG) { const uint32_t t = entry2_of(bin, e, il); if (t < size) dst[t] = zv; }
 		}
-		return;
+		continue;                                                           // (uniform)
 	}
-	for (uint32_t e = threadIdx.x; e < PAIR_BIN_ENTRIES; e += PACC_WG) { iacc[2 * e] = 0ull; iacc[2 * e + 1] = 0ull; }
+	for (uint32_t e = threadIdx.x; e < n_local; e += ACC2_WG) { iacc[2 * e] = 0ull; iacc[2 * e + 1] = 0ull; }
 	__syncthreads();
 	auto add_fixed = [&](uint32_t local, long long ix, long long iy) {
 		if ((ix | iy) == 0) return;
 		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		__hip_atomic_fetch_add(&iacc[2 * local + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	};
-	auto to_fixed = [&](const PairRec &r, long long v[4]) {
-		const float w0 = 1 - r.fx;
-		v[0] = __float2ll_rn((r.a * w0) * s32); v[1] = __float2ll_rn((r.b * w0) * s32);
-		v[2] = __float2ll_rn((r.a * r.fx) * s32); v[3] = __float2ll_rn((r.b * r.fx) * s32);
-	};
-	auto flush = [&](uint32_t edge, const long long s[4]) {
-		add_fixed(edge & (PAIR_BIN_ENTRIES - 1u), s[0], s[1]);
-		add_fixed((edge >> PAIR_BIN_BITS) & (PAIR_BIN_ENTRIES - 1u), s[2], s[3]);
-	};
-	constexpr uint32_t K = 4;
-	struct alignas(16) RK { PairRec r[K]; };
-	const PairRec *recs = prec + (size_t)(po * PAIR_BINS + bin) * pcap;
-	const RK *pk = reinterpret_cast<const RK *>(recs);
-	auto run_add = [&](const RK &x) {
-		uint32_t cur = x.r[0].loc & 0xffffffu; long long s[4]; to_fixed(x.r[0], s);
-#pragma unroll
-		for (uint32_t q = 1; q < K; ++q) {
-			long long v[4]; to_fixed(x.r[q], v);
-			const uint32_t e = x.r[q].loc & 0xffffffu;
-			if (e == cur) { s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
-			else { flush(cur, s); cur = e; s[0] = v[0]; s[1] = v[1]; s[2] = v[2]; s[3] = v[3]; }
+	if (is_pair) {
+		gather_flat(prec, poff, ord, ap.pair_regions, ap.pair_region_records, PAIR_OFFS, bin, tables, ap.probe, row0, [&](const PairRec &r) {
+			const float w0 = 1 - r.fx;
+			add_fixed(r.loc & (PAIR_BIN_ENTRIES - 1u), fixed_rn(r.a * w0, s32), fixed_rn(r.b * w0, s32));
+			add_fixed((r.loc >> PAIR_BIN_BITS) & (PAIR_BIN_ENTRIES - 1u), fixed_rn(r.a * r.fx, s32), fixed_rn(r.b * r.fx, s32));
+		});
+		for (uint32_t t = threadIdx.x; t < ns; t += ACC2_WG) {             // out-of-cube edges (normally ns == 0)
+			const SpillEntry se = spill[t];
+			const uint32_t e = se.key & (BIN_LEVEL_MAX - 1u);
+			if ((se.key >> 19) == hl && (e >> PAIR_BIN_BITS) == bin) add_fixed(e & (PAIR_BIN_ENTRIES - 1u), __float2ll_rn(se.x * s32), __float2ll_rn(se.y * s32));
 		}
-		flush(cur, s);
-	};
-	const uint32_t groups = count / K;
-	uint32_t r = threadIdx.x;
-	for (; r + PACC_WG < groups; r += 2 * PACC_WG) { const RK x0 = pk[r], x1 = pk[r + PACC_WG]; run_add(x0); run_add(x1); }
-	for (; r < groups; r += PACC_WG) { const RK x = pk[r]; run_add(x); }
-	if (threadIdx.x < count - groups * K) { const PairRec x = recs[groups * K + threadIdx.x]; long long v[4]; to_fixed(x, v); flush(x.loc & 0xffffffu, v); }
-	for (uint32_t t = threadIdx.x; t < ns; t += PACC_WG) {                 // out-of-cube edges and overflowed bins (normally ns == 0)
-		const SpillEntry se = spill[t];
-		const uint32_t e = se.key & (BIN_LEVEL_MAX - 1u);
-		if ((se.key >> 19) == hl && (e >> PAIR_BIN_BITS) == bin) add_fixed(e & (PAIR_BIN_ENTRIES - 1u), __float2ll_rn(se.x * s32), __float2ll_rn(se.y * s32));
+	} else {
+		gather_flat(rrec, roff, ord, ap.run_regions, ap.run_region_records, RUN2_OFFS, bin, tables, ap.probe, row0, [&](const RunRec &r) {
+			add_fixed(r.loc, fixed_rn(r.x, s32), fixed_rn(r.y, s32));
+		});
 	}
 	__syncthreads();
-	// write-out: two entries (16 bytes of fp32 gradient) per thread and trip
-	for (uint32_t e = 2u * threadIdx.x; e < PAIR_BIN_ENTRIES; e += 2u * PACC_WG) {
-		const long long s0 = (long long)iacc[2 * e], s1 = (long long)iacc[2 * e + 1], s2 = (long long)iacc[2 * e + 2], s3 = (long long)iacc[2 * e + 3];
-		float2 v0 = make_float2((float)s0 * inv, (float)s1 * inv), v1 = make_float2((float)s2 * inv, (float)s3 * inv);
-		if (!overwrite) {
-			if ((s0 | s1 | s2 | s3) == 0) continue;
-			const float2 o0 = to_f2(dst[e]), o1 = to_f2(dst[e + 1]);
-			v0.x += o0.x; v0.y += o0.y; v1.x += o1.x; v1.y += o1.y;
+	if (!il) {                                                            // a full bin: contiguous, two entries (16 bytes of fp32 gradient) per thread and trip
+		GP *d = dst + (bin << PAIR_BIN_BITS);
+		for (uint32_t e = 2u * threadIdx.x; e < PAIR_BIN_ENTRIES; e += 2u * ACC2_WG) {
+			const long long s0 = (long long)iacc[2 * e], s1 = (long long)iacc[2 * e + 1], s2 = (long long)iacc[2 * e + 2], s3 = (long long)iacc[2 * e + 3];
+			float2 v0 = make_float2((float)s0 * inv, (float)s1 * inv), v1 = make_float2((float)s2 * inv, (float)s3 * inv);
+			if (!overwrite) {
+				if ((s0 | s1 | s2 | s3) == 0) continue;
+				const float2 o0 = to_f2(d[e]), o1 = to_f2(d[e + 1]);
+				v0.x += o0.x; v0.y += o0.y; v1.x += o1.x; v1.y += o1.y;
+			}
+			GP w0, w1; from_f2(w0, v0); from_f2(w1, v1);
+			if (sizeof(GP) == 8) *reinterpret_cast<float4 *>(d + e) = make_float4(v0.x, v0.y, v1.x, v1.y);
+			else { d[e] = w0; d[e + 1] = w1; }
 		}
-		GP w0, w1; from_f2(w0, v0); from_f2(w1, v1);
-		if (sizeof(GP) == 8) *reinterpret_cast<float4 *>(dst + e) = make_float4(v0.x, v0.y, v1.x, v1.y);
-		else { dst[e] = w0; dst[e + 1] = w1; }
+	} else {
+		for (uint32_t e = threadIdx.x; e < n_local; e += ACC2_WG) {
+			const uint32_t t = entry2_of(bin, e, il);
+			if (t >= size) continue;
+			const long long sx = (long long)iacc[2 * e], sy = (long long)iacc[2 * e + 1];
+			float2 v = make_float2((float)sx * inv, (float)sy * inv);
+			if (!overwrite) { if (sx == 0 && sy == 0) continue; const float2 old = to_f2(dst[t]); v.x += old.x; v.y += old.y; }
+			GP o; from_f2(o, v);
+			dst[t] = o;
+		}
+	}
+	if (QUEUE) __syncthreads();                                           // the accumulators are cleared again for the next unit
 	}
 }
 
@@ -1409,15 +1670,15 @@ static uint64_t hash_bwd_workspace_bytes(const LevelTable &lt) {           // pa
 	for (int l = 0; l < 16; ++l) if (!level_exclusive(lt, l)) entries += (uint64_t)32u * lt.v[4 * l + 1];
 	return (entries * sizeof(float2) + 255) & ~(uint64_t)255;
 }
-static uint32_t bin_capacity(uint32_t n) { uint32_t c = (n / 2 + 7u) & ~7u; return c < 4096u ? 4096u : c; }   // 4x the expected n*8/64 records per bin; % 8: 16-byte aligned streams
-static uint32_t pair_capacity(uint32_t n) { uint32_t c = (n / 8 + 7u) & ~7u; return c < 2048u ? 2048u : c; }    // 4x the expected n*4/128 edge records per bin (padding included)
+// capacity of one record list: 4x the expected n*8/64 records per bin; % 8: 16-byte aligned streams
+static uint32_t bin_capacity(uint32_t n) { uint32_t c = ((n / 2) / CUR_SUBS + 7u) & ~7u; const uint32_t lo = 4096u / CUR_SUBS; return c < lo ? lo : c; }
 // the levels whose cell edges never leave a 4096-entry bin (k_bin_pairs): full 2^19-entry hashed tables up to res 2048
 static bool level_pair_capable(const LevelTable &lt, int l) {
 	const uint32_t size = lt.v[4 * l + 1], res = lt.v[4 * l + 2];
 	return size == BIN_LEVEL_MAX && !level_dense_host(size, res) && res <= PAIR_RES_MAX;
 }
 // workspace = slabs | cursors u32[N_CURSORS] | absmax partials u32[16*NGP_ABSMAX_PARTS], spill count u32 | record values | record indices | spill list | edge records
-struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, pair_rec, total; uint32_t cap, spill_cap, n_binned, pcap, n_pair; };
+struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, pair_rec, pair_off, run_rec, run_off, total; uint32_t cap, spill_cap, n_binned, n_pair; };
 static WsLayout ws_layout(const LevelTable &lt, uint32_t n) {
 	WsLayout w;
 	w.n_binned = 0;
@@ -1425,15 +1686,21 @@ static WsLayout ws_layout(const LevelTable &lt, uint32_t n) {
 	w.cap = bin_capacity(n);
 	w.spill_cap = w.n_binned * 8u * (n < (1u << 25) / (w.n_binned ? w.n_binned : 1u) ? n : (1u << 25) / (w.n_binned ? w.n_binned : 1u));   // worst case: every record of every binned level overflows (12 B each)
 	w.cursors = hash_bwd_workspace_bytes(lt);
-	w.absmax = w.cursors + N_CURSORS * 4u;
+	w.absmax = w.cursors + N_ZEROED * 4u;
 	w.rec_val = w.absmax + 16u * ABSMAX_PARTS * 4u + 256;
-	w.rec_idx = w.rec_val + (uint64_t)w.n_binned * BINS_PER_LEVEL * w.cap * sizeof(float2);       // every level owns 64 * cap * 8 bytes (rec_val_at)
-	w.spill = (w.rec_idx + (uint64_t)w.n_binned * BINS_PER_LEVEL * w.cap * sizeof(uint16_t) + 255) & ~(uint64_t)255;
+	w.rec_idx = w.rec_val + (uint64_t)w.n_binned * BINS_PER_LEVEL * CUR_SUBS * w.cap * sizeof(float2);       // every level owns 64 * 8 * cap * 8 bytes (rec_val_at)
+	w.spill = (w.rec_idx + (uint64_t)w.n_binned * BINS_PER_LEVEL * CUR_SUBS * w.cap * sizeof(uint16_t) + 255) & ~(uint64_t)255;
 	w.pair_rec = (w.spill + (uint64_t)w.spill_cap * sizeof(SpillEntry) + 255) & ~(uint64_t)255;
 	w.n_pair = 0;
 	for (int l = 0; l < 16; ++l) if (level_binned(lt, l) && level_pair_capable(lt, l)) ++w.n_pair;
-	w.pcap = pair_capacity(n);
-	w.total = w.pair_rec + (uint64_t)w.n_pair * PAIR_BINS * w.pcap * sizeof(PairRec);
+	// edge records: one region per record workgroup (sized for the smaller workgroup choice: more regions, more slack records), then the regions' bin offsets
+	const uint64_t regions512 = div_up(n, 512u);
+	w.pair_off = (w.pair_rec + (uint64_t)w.n_pair * regions512 * pair_region_records(512u) * sizeof(PairRec) + 255) & ~(uint64_t)255;
+	w.run_rec = w.pair_off + (((uint64_t)w.n_pair * regions512 * PAIR_OFFS * sizeof(uint16_t) + 255) & ~(uint64_t)255);
+	// run records of the fp32 path: a region per 2048-sample workgroup, worst case eight records per sample (scattered positions); any binned level can be a run level
+	const uint64_t regions_run = div_up(n, RUN_WG * RUN_K);
+	w.run_off = (w.run_rec + (uint64_t)w.n_binned * regions_run * run2_region_records() * sizeof(RunRec) + 255) & ~(uint64_t)255;
+	w.total = w.run_off + (((uint64_t)w.n_binned * regions_run * RUN2_OFFS * sizeof(uint16_t) + 255) & ~(uint64_t)255);
 	return w;
 }
 static uint64_t hash_bwd_workspace_bytes_binned(const LevelTable &lt, uint32_t n) { return ws_layout(lt, n).total; }
@@ -1495,20 +1762,23 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	BinPlan bp; bp.n_levels = 0; bp.cap = wl.cap; bp.spill_cap = wl.spill_cap;
 	LevelSel sel_fine, sel_runs, sel_all, sel_pair;                      // sel_all: every level with per-corner records (runs + fine); sel_pair: the edge-record levels
 	uint32_t n_fine = 0, n_runs = 0, n_pair = 0, n_all = 0;
-	// edge records (k_bin_pairs): fp32 in, fp32 out, 16-byte aligned gradient.  NGP_HASH_BWD_PAIRS=0 keeps round 3's per-corner records (A/B), _PAIR_WG / _PAIR_PAD are probe hooks
+	// edge records (k_bin_pairs): fp32 in, fp32 out, 16-byte aligned gradient.  NGP_HASH_BWD_PAIRS=0 keeps round 3's per-corner records (A/B), _PAIR_WG is a probe hook
 	const bool pairs_on = [] { const char *e = getenv("NGP_HASH_BWD_PAIRS"); return !(e && e[0] == '0'); }();
 	const uint32_t pair_wg = [] { const char *e = getenv("NGP_HASH_BWD_PAIR_WG"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : 1024u; return v == 512u ? 512u : 1024u; }();
-	const uint32_t pair_pad = [] { const char *e = getenv("NGP_HASH_BWD_PAIR_PAD"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : 1u; return v == 2u || v == 4u || v == 8u ? v : 1u; }();
 	const bool use_pairs = use_bins && pairs_on && dtype == NGP_F32 && grad_dtype == NGP_F32 && ((uintptr_t)grad & 15u) == 0;
 	const uint32_t run_res_max = [] { const char *e = getenv("NGP_HASH_BWD_RUN_RES"); return e ? (uint32_t)strtoul(e, nullptr, 0) : RUN_RES_MAX; }();   // probe hook
-	const int run_occ = [] { const char *e = getenv("NGP_HASH_BWD_RUN_OCC"); return e && e[0] == '5' ? 5 : 4; }();   // probe hook
-	const uint32_t run_stage = [] { const char *e = getenv("NGP_HASH_BWD_RUN_STAGE"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : RUN_STAGE; return v > 8192u ? 8192u : v; }();   // probe hook
+	// (probe hooks) staging records / register budget of the run kernels.  fp32 path: 2560 records and five waves per SIMD - all 1280 workgroups of a 2^18-sample batch resident
+	// at once (measured: 54 -> 43 us); per-corner path: round 2's 3072 / natural register count
+	const int run_occ = [&] { const char *e = getenv("NGP_HASH_BWD_RUN_OCC"); return e ? (e[0] == '5' ? 5 : 4) : 0; }();
+	const uint32_t run_stage_env = [] { const char *e = getenv("NGP_HASH_BWD_RUN_STAGE"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; return v > 8192u ? 8192u : v; }();
+	const int run_occ_v = run_occ ? run_occ : (use_pairs ? 5 : 4);
+	const uint32_t run_stage = run_stage_env ? run_stage_env : (use_pairs ? 2048u : RUN_STAGE);   // (2048 x 12 B + tables = 26 KiB: five workgroups per CU with room to spare)
 	for (int l = 0; l < 16; ++l) {                                       // (coarsest level first measured 1 % faster than finest first on both samplings)
 		in_bins[l] = use_bins && level_binned(lt, l);
 		if (!in_bins[l]) continue;
 		const uint32_t hl = bp.n_levels++;
 		bp.level[hl] = (uint32_t)l;
-		if (lt.v[4 * l + 2] <= run_res_max) { sel_runs.hl[n_runs++] = hl; sel_all.hl[n_all++] = hl; }
+		if (lt.v[4 * l + 2] <= run_res_max) { sel_runs.hl[n_runs++] = hl; if (!use_pairs) sel_all.hl[n_all++] = hl; }
 		else if (use_pairs && level_pair_capable(lt, l)) sel_pair.hl[n_pair++] = hl;
 		else { sel_fine.hl[n_fine++] = hl; sel_all.hl[n_all++] = hl; }
 	}
@@ -1541,8 +1811,10 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	void *rec_val = use_bins ? (void *)(ws + wl.rec_val) : nullptr;
 	uint16_t *rec_idx = use_bins ? (uint16_t *)(ws + wl.rec_idx) : nullptr;
 	SpillEntry *spill = use_bins ? (SpillEntry *)(ws + wl.spill) : nullptr;
-	uint32_t *pcursors = use_bins ? cursors + 16u * BINS_PER_LEVEL : nullptr;
 	PairRec *pair_rec = use_bins ? (PairRec *)(ws + wl.pair_rec) : nullptr;
+	uint16_t *pair_off = use_bins ? (uint16_t *)(ws + wl.pair_off) : nullptr;
+	RunRec *run_rec = use_bins ? (RunRec *)(ws + wl.run_rec) : nullptr;
+	uint16_t *run_off = use_bins ? (uint16_t *)(ws + wl.run_off) : nullptr;
 	{ const char *e = getenv("NGP_PROBE_LEVEL_MASK"); plan.level_mask = e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffu; }
 	{ const char *e = getenv("NGP_PROBE_COARSE_RES"); plan.coarse_res = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }
 	for (int l = 0; l < 16; ++l) {                                       // chunked levels without slabs are flushed with atomics -> need a zeroed destination
@@ -1560,20 +1832,45 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	bool coarse_marked = false;
 	int pair_err = 0;
 	auto pair_set_lds = [&](const void *k, size_t bytes) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); pair_err = (int)e; } };
-	auto pair_records = [&]() {                                          // (fp32 only: outside the dtype macro)
-		const uint32_t lds = pair_stage_bytes(pair_wg, pair_pad);
+	// ---- the fp32 path (use_pairs): run records + edge records in regions, no global atomics, one accumulate kernel.  (Levels it cannot take - hashed tables that are
+	// neither run levels nor edge-capable - stay on the per-corner kernels below, with their own accumulate launch.)
+	auto v2_records = [&]() {
 		static bool once = false;
-		if (!once) { pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_SOA, 512u>, pair_stage_bytes(512u, PAIR_PAD_MAX)); pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_AOS, 512u>, pair_stage_bytes(512u, PAIR_PAD_MAX));
-			pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_SOA, 1024u>, pair_stage_bytes(1024u, PAIR_PAD_MAX)); pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_AOS, 1024u>, pair_stage_bytes(1024u, PAIR_PAD_MAX));
-			pair_set_lds((const void *)k_bin_accumulate_pairs<float>, PAIR_BIN_ENTRIES * 16u); once = true; }
-#define PGO(L, S) NGP_LAUNCH((k_bin_pairs<L, S>), dim3(div_up(n, S), n_pair), dim3(S), lds, s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_pair, (const uint32_t *)absmax, pcursors, pair_rec, wl.pcap, pair_pad, spill_count, spill, n_valid)
-		if (in_layout == NGP_LAYOUT_SOA) { if (pair_wg == 512u) PGO(NGP_LAYOUT_SOA, 512u); else PGO(NGP_LAYOUT_SOA, 1024u); }
-		else { if (pair_wg == 512u) PGO(NGP_LAYOUT_AOS, 512u); else PGO(NGP_LAYOUT_AOS, 1024u); }
+		if (!once) { pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_SOA, 512u>, pair_stage_bytes(512u)); pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_AOS, 512u>, pair_stage_bytes(512u));
+			pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_SOA, 1024u>, pair_stage_bytes(1024u)); pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_AOS, 1024u>, pair_stage_bytes(1024u));
+			pair_set_lds((const void *)k_bin_runs2<NGP_LAYOUT_SOA, 4>, run2_stage_bytes(8192u)); pair_set_lds((const void *)k_bin_runs2<NGP_LAYOUT_AOS, 4>, run2_stage_bytes(8192u));
+			pair_set_lds((const void *)k_bin_runs2<NGP_LAYOUT_SOA, 5>, run2_stage_bytes(8192u)); pair_set_lds((const void *)k_bin_runs2<NGP_LAYOUT_AOS, 5>, run2_stage_bytes(8192u));
+			pair_set_lds((const void *)k_bin_accumulate2<float, true>, PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA); pair_set_lds((const void *)k_bin_accumulate2<float, false>, PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA); once = true; }
+		if (n_runs) {
+			const uint32_t run_probe = [] { const char *e = getenv("NGP_RUN_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
+#define RGO(L, O) NGP_LAUNCH((k_bin_runs2<L, O>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run2_stage_bytes(run_stage), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, run_rec, run_off, n_valid, run_stage, run_probe)
+			if (in_layout == NGP_LAYOUT_SOA) { if (run_occ_v == 5) RGO(NGP_LAYOUT_SOA, 5); else RGO(NGP_LAYOUT_SOA, 4); }
+			else { if (run_occ_v == 5) RGO(NGP_LAYOUT_AOS, 5); else RGO(NGP_LAYOUT_AOS, 4); }
+#undef RGO
+		}
+		if (n_pair) {
+			const uint32_t pair_probe = [] { const char *e = getenv("NGP_PAIR_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
+#define PGO(L, S) NGP_LAUNCH_INDEPENDENT((k_bin_pairs<L, S>), dim3(div_up(n, S), n_pair), dim3(S), pair_stage_bytes(S), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_pair, (const uint32_t *)absmax, pair_rec, pair_off, spill_count, spill, n_valid, pair_probe)
+			if (in_layout == NGP_LAYOUT_SOA) { if (pair_wg == 512u) PGO(NGP_LAYOUT_SOA, 512u); else PGO(NGP_LAYOUT_SOA, 1024u); }
+			else { if (pair_wg == 512u) PGO(NGP_LAYOUT_AOS, 512u); else PGO(NGP_LAYOUT_AOS, 1024u); }
 #undef PGO
+		}
 	};
-	auto pair_accumulate = [&]() {
-		NGP_LAUNCH((k_bin_accumulate_pairs<float>), dim3(n_pair * PAIR_BINS), dim3(PACC_WG), PAIR_BIN_ENTRIES * 16u, s, lt, bp, sel_pair, (const uint32_t *)absmax, (const uint32_t *)pcursors, (const PairRec *)pair_rec, wl.pcap,
-		           (const uint32_t *)spill_count, (const SpillEntry *)spill, (float *)grad, ow);
+	uint32_t acc2_launches = 0;
+	auto v2_accumulate = [&](bool runs, bool pairs) {
+		Acc2Plan ap;
+		ap.n_pair = pairs ? n_pair : 0u; ap.n_run = runs ? n_runs : 0u;
+		ap.pair_regions = div_up(n, pair_wg); ap.pair_region_records = pair_region_records(pair_wg);
+		ap.run_regions = div_up(n, RUN_WG * RUN_K); ap.run_region_records = run2_region_records();
+		ap.probe = [] { const char *e = getenv("NGP_ACC_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
+		if (ap.n_pair + ap.n_run == 0) return;
+		const uint32_t acc2_grid = [] { const char *e = getenv("NGP_ACC_GRID"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();   // probe hook: > 0 = that many resident workgroups drawing units from a queue
+		const uint32_t n_units = (ap.n_pair + ap.n_run) * PAIR_BINS;
+		uint32_t *qh = cursors + N_CURSORS + (acc2_launches++);
+#define AGO(Q, GRID) NGP_LAUNCH((k_bin_accumulate2<float, Q>), dim3(GRID), dim3(ACC2_WG), PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA, s, lt, bp, sel_pair, sel_runs, ap, (const uint32_t *)absmax, (const PairRec *)pair_rec, \
+		           (const uint16_t *)pair_off, (const RunRec *)run_rec, (const uint16_t *)run_off, (const uint32_t *)spill_count, (const SpillEntry *)spill, (float *)grad, ow, qh)
+		if (acc2_grid) AGO(true, min(n_units, acc2_grid)); else AGO(false, n_units);
+#undef AGO
 	};
 #define SET_LDS(K, BYTES) do { static bool done_ = false; if (!done_) { hipError_t e = hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
 	if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } done_ = true; } } while (0)
@@ -1586,25 +1883,28 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		if (!absmax_done) NGP_LAUNCH((k_level_absmax<T, L>), dim3(ABSMAX_OWN_PARTS, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid, cursors, spill_count);   /* also zeroes the cursors and the spill count */ \
 		if (units && side.ok) { hipEventRecord(side.fork, s); sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* the scan of the remaining levels runs beside the binning kernels */ \
 		if (!probe_skip_bins) { \
-		if (n_runs && run_occ == 5) { SET_LDS((k_bin_records_runs<T, L, 5>), run_stage_bytes(8192u)); \
+		if (use_pairs) v2_records(); \
+		else if (n_runs && run_occ_v == 5) { SET_LDS((k_bin_records_runs<T, L, 5>), run_stage_bytes(8192u)); \
 			NGP_LAUNCH((k_bin_records_runs<T, L, 5>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(run_stage), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, run_stage); } \
 		else if (n_runs) { SET_LDS((k_bin_records_runs<T, L, 4>), run_stage_bytes(8192u)); \
 			NGP_LAUNCH((k_bin_records_runs<T, L, 4>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(run_stage), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, run_stage); } \
 		if (n_fine) { SET_LDS((k_bin_records<T, L>), bin_stage_bytes<T>()); \
 			NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, BIN_WG), n_fine), dim3(BIN_WG), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_fine, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid); } \
-		if (n_pair) pair_records(); \
-		if (sizeof(RV_) == 8 && !(after_coarse && n_runs && n_fine)) {   /* fp32: run records and fine records have the same type - one accumulate launch over all their levels */ \
+		if (use_pairs) {   /* fp32 path: ONE accumulate launch over run + edge levels - two when the data-parallel exchange wants the coarse levels first */ \
+			if (after_coarse && n_runs && (n_pair || n_fine)) { v2_accumulate(true, false); hipEventRecord(after_coarse, s); coarse_marked = true; v2_accumulate(false, true); } \
+			else v2_accumulate(true, true); \
+			if (n_fine) { SET_LDS((k_bin_accumulate<G, RV_>), BIN_ENTRIES * 16); \
+				NGP_LAUNCH((k_bin_accumulate<G, RV_>), dim3(n_fine * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_fine, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); } \
+		} else if (sizeof(RV_) == 8 && !(after_coarse && n_runs && n_fine)) {   /* fp32 records, one type: one accumulate launch over all their levels */ \
 			if (n_all) { SET_LDS((k_bin_accumulate<G, float2>), BIN_ENTRIES * 16); \
-				NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_all * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
-				if (after_coarse && n_runs && n_pair) { hipEventRecord(after_coarse, s); coarse_marked = true; } }   /* (no per-corner fine level here: this launch IS the coarse levels) */ \
+				NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_all * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); } \
 		} else { \
 			if (n_runs) { SET_LDS((k_bin_accumulate<G, float2>), BIN_ENTRIES * 16); \
 				NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_runs * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_runs, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
-				if (after_coarse && (n_fine || n_pair)) { hipEventRecord(after_coarse, s); coarse_marked = true; } } \
+				if (after_coarse && n_fine) { hipEventRecord(after_coarse, s); coarse_marked = true; } } \
 			if (n_fine) { SET_LDS((k_bin_accumulate<G, RV_>), BIN_ENTRIES * 16); \
 				NGP_LAUNCH((k_bin_accumulate<G, RV_>), dim3(n_fine * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_fine, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); } \
-		} \
-		if (n_pair) pair_accumulate(); } \
+		} } \
 	} \
 	if (units) NGP_LAUNCH((k_hash_bwd_owner<T, G, L>), grid, block, shmem, sd, n, pos, pos_stride, (const T *)dLdy, lt, plan, (G *)grad, accumulate, n_valid, (const float *)level_scratch, use_slabs ? (float2 *)workspace : (float2 *)nullptr); \
 	if (units && use_slabs && slab_cursor) NGP_LAUNCH((k_reduce_dense<G>), dim3(1024, 16), dim3(256), 0, sd, lt, plan, (const float2 *)workspace, (G *)grad, accumulate & 1); \
@@ -1638,7 +1938,7 @@ AbsmaxOut ngp_hash_bwd_absmax_slots(const uint32_t *level_table_host, uint32_t n
 	const WsLayout wl = ws_layout(lt, n);
 	if (!(dtype == NGP_F16 || grad_dtype == NGP_F32) || workspace_bytes < wl.total) return am;
 	char *ws = (char *)workspace;
-	am.parts = (uint32_t *)(ws + wl.absmax); am.cursors = (uint32_t *)(ws + wl.cursors); am.n_cursors = N_CURSORS; am.spill_count = am.parts + 16u * ABSMAX_PARTS;
+	am.parts = (uint32_t *)(ws + wl.absmax); am.cursors = (uint32_t *)(ws + wl.cursors); am.n_cursors = N_ZEROED; am.spill_count = am.parts + 16u * ABSMAX_PARTS;
 	return am;
 }
 

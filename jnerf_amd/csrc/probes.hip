@@ -27,3 +27,35 @@ NGP_API int ngp_x_probe_lds_atomic(void *stream, uint32_t blocks, uint32_t iters
 	NGP_LAUNCH_CHECK("ngp_x_probe_lds_atomic");
 	return 0;
 }
+
+// ---- memory-stream probes (tools/microbench_stream.py): what the chip sustains for the access patterns of the hash-backward record lists
+//   mode 0  read    every thread sums 16-byte loads, grid-stride              (read roofline)
+//   mode 1  write   every thread stores 16-byte values, grid-stride            (write roofline)
+//   mode 2  copy    b[i] = a[i]
+//   mode 3  append  the record kernels' pattern without their arithmetic: `streams` lists `spacing` bytes apart, workgroup w writes a fragment of `frag` bytes
+//                   at offset w * frag of EVERY list (consecutive threads -> consecutive 16 bytes of a fragment, then the next list)
+__global__ __launch_bounds__(1024) void k_probe_stream(int mode, uint64_t n16, const uint4 *__restrict__ a, uint4 *__restrict__ b, uint32_t streams, uint32_t frag, uint64_t spacing, float *__restrict__ sink) {
+	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+	if (mode == 0) {
+		uint32_t acc = 0;
+		for (uint64_t i = tid; i < n16; i += nth) { const uint4 v = a[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+		if (acc == 0x12345u) sink[0] = 1.f;
+	} else if (mode == 1) {
+		const uint4 v = make_uint4((uint32_t)tid, 1u, 2u, 3u);
+		for (uint64_t i = tid; i < n16; i += nth) b[i] = v;
+	} else if (mode == 2) {
+		for (uint64_t i = tid; i < n16; i += nth) b[i] = a[i];
+	} else {
+		const uint32_t per = frag / 16u, total = streams * per;                 // 16-byte units this workgroup writes
+		const uint4 v = make_uint4(blockIdx.x, threadIdx.x, 2u, 3u);
+		for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
+			const uint32_t s = p / per, j = p - s * per;
+			b[((uint64_t)s * spacing + (uint64_t)blockIdx.x * frag) / 16u + j] = v;
+		}
+	}
+}
+NGP_API int ngp_x_probe_stream(void *stream, int mode, uint32_t blocks, uint32_t threads, uint64_t n16, const void *a, void *b, uint32_t streams, uint32_t frag, uint64_t spacing, float *sink) {
+	hipLaunchKernelGGL(k_probe_stream, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, mode, n16, (const uint4 *)a, (uint4 *)b, streams, frag, spacing, sink);
+	NGP_LAUNCH_CHECK("ngp_x_probe_stream");
+	return 0;
+}

@@ -13,6 +13,7 @@ from jnerf_amd.runner import Runner
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     scene = sys.argv[2] if len(sys.argv) > 2 else "bricks"
+    torch.manual_seed(0)
     ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=100, W=800, H=800, device="cuda:0", scene=scene)
     r = Runner()
     with r.training_stream():
@@ -65,16 +66,12 @@ def main():
         print(f"{name:58s} {total:7.1f} us  repro={repro} " + " ".join(f"{k}={v:.1f}" for k, v in sorted(pk.items())) + diff, flush=True)
         return g
 
-    ref = variant("r3 per-corner records (PAIRS=0)", {"NGP_HASH_BWD_PAIRS": "0"})
-    # fp64 ground truth on the GPU for the fine levels is expensive; the per-corner path is itself held to the oracle by tests/test_hip_parity.py
-    for wg in ("1024", "512"):
-        for pad in ("1", "4", "8"):
-            variant(f"edge records WG={wg} PAD={pad}", {"NGP_HASH_BWD_PAIR_WG": wg, "NGP_HASH_BWD_PAIR_PAD": pad}, ref)
-    variant("edge records + runs OCC=5 STAGE=2560", {"NGP_HASH_BWD_RUN_OCC": "5", "NGP_HASH_BWD_RUN_STAGE": "2560"}, ref)
-    variant("edge records + runs STAGE=2560 (OCC 4)", {"NGP_HASH_BWD_RUN_STAGE": "2560"}, ref)
-    for res in ("200", "450", "600"):
-        variant(f"edge records, run combining up to res {res}", {"NGP_HASH_BWD_RUN_RES": res}, ref)
-    variant("r3 + runs OCC=5 STAGE=2560", {"NGP_HASH_BWD_PAIRS": "0", "NGP_HASH_BWD_RUN_OCC": "5", "NGP_HASH_BWD_RUN_STAGE": "2560"}, ref)
+    ref = variant("round-3 path: per-corner records, cursor atomics (PAIRS=0)", {"NGP_HASH_BWD_PAIRS": "0"})
+    variant("r4 path (regions, no atomics; edge WG=1024, runs OCC 5 STAGE 2048, one unit per accumulate workgroup)", {}, ref)
+    variant("r4 path, 512 resident accumulate workgroups drawing units from a queue", {"NGP_ACC_GRID": "512"}, ref)
+    variant("r4 path, ACC_PROBE 1: records loaded, not processed (results wrong)", {"NGP_ACC_PROBE": "1"}, None)
+    variant("r4 path, ACC_PROBE 3: tables, look-ups, zeroing, write-out only (results wrong)", {"NGP_ACC_PROBE": "3"}, None)
+    variant("r4 path, run combining up to res 600", {"NGP_HASH_BWD_RUN_RES": "600"}, ref)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@ set -u
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pq && mkdir -p /tmp/pq
-rocprofv3 --pmc $1 --kernel-trace -d /tmp/pq -o sq -- python $R/bench.py --no-cpu-baseline --no-psnr --steps 20 --warmup 60 > /tmp/pq/log 2>&1
+rocprofv3 --pmc $1 --kernel-trace -d /tmp/pq -o sq -- python $R/bench.py --no-cpu-baseline --no-psnr --no-fox --no-neus --no-spheres --steps 20 --warmup 60 > /tmp/pq/log 2>&1
 cd $R
 DB=$(find /tmp/pq -name "*.db" | head -1)
 python - "$DB" "$2" "$1" <<'PY'
