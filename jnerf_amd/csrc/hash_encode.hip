@@ -1266,38 +1266,44 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 #define PAIR_OFFS (PAIR_BINS + 2u)                                     // u16 offsets per region: 128 bin starts, the total, one pad (rows stay 4-byte aligned)
 static_assert(PAIR_BIN_ENTRIES * PAIR_BINS == BIN_LEVEL_MAX, "the edge-record path covers the full 2^19-entry levels");
 struct alignas(16) PairRec { float a, b, fx; uint32_t loc; };
-static uint32_t pair_stage_bytes(uint32_t wg) { return wg * 4u * 16u + (2u * PAIR_BINS + 4u) * 4u; }
-__host__ __device__ static inline uint32_t pair_region_records(uint32_t wg) { return wg * 4u + 4u; }     // + 4: the last segment's quad may be read past its end
+#define PAIR_STAGE_RECORDS 4096u                                       // LDS staging of a record workgroup = its region: 1024 samples x 4 edge records | 512 samples x 8 single records
+static uint32_t pair_stage_bytes() { return PAIR_STAGE_RECORDS * 16u + (2u * PAIR_BINS + 4u) * 4u; }
+__host__ __device__ static inline uint32_t pair_region_records() { return PAIR_STAGE_RECORDS + 4u; }     // + 4: slack behind the last segment
 
-// S samples per workgroup = one region
-template <int LAYOUT, uint32_t S>
-__global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__restrict__ pos, uint32_t stride, const float *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
+// S samples per workgroup = one region.  Levels beyond res 2048 (aabb_scale > 1: ngp_fox.py's 2353 .. 8192) cannot pair their x-neighbours - x + 1 reaches into the
+// bin bits - so they emit eight SINGLE records per sample in the same format (fx = 0, both slots the same entry: the second contribution is an exact zero and is
+// skipped); S = 512 then.  T = type of dL/dy (fp16 configuration: the contributions are formed in fp32 from the fp16 gradient - at least as accurate as the fp16
+// records of the per-corner path).
+template <typename T, int LAYOUT, uint32_t S>
+__global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
                                                  const uint32_t *__restrict__ absmax_bits, PairRec *__restrict__ prec, uint16_t *__restrict__ poff,
                                                  uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill, const uint32_t *__restrict__ n_valid,
                                                  uint32_t probe /* timing experiment (NGP_PAIR_PROBE; results wrong unless 0): 1 = no record stores */) {
+	using P = typename Pair<T>::type;
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
-	PairRec *stage = reinterpret_cast<PairRec *>(bin_smem);                                   // [4 S] edge records, grouped by bin
-	uint32_t *cnt = bin_smem + S * 4u * 4u, *loff = cnt + PAIR_BINS;                          // loff[PAIR_BINS] = total
+	PairRec *stage = reinterpret_cast<PairRec *>(bin_smem);                                   // [PAIR_STAGE_RECORDS] records, grouped by bin
+	uint32_t *cnt = bin_smem + PAIR_STAGE_RECORDS * 4u, *loff = cnt + PAIR_BINS;             // loff[PAIR_BINS] = total
 	const uint32_t po = blockIdx.y, hl = sel.hl[po], level = bp.level[hl];
 	const uint32_t mask = lt.v[4 * level + 1] - 1u;
+	const bool split = lt.v[4 * level + 2] > PAIR_RES_MAX;                                    // (uniform; the host launches S = 512 when any level of the launch is split)
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const size_t region = (size_t)po * gridDim.x + blockIdx.x;
 	uint16_t *my_off = poff + region * PAIR_OFFS;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	if (level_absmax(absmax_bits, level) == 0u || blockIdx.x * S >= lim) {                   // uniform exit: an empty region
+	if (level_absmax(absmax_bits, level) == 0u || blockIdx.x * S >= lim || (split && S * 8u > PAIR_STAGE_RECORDS)) {   // uniform exit: an empty region
 		if (threadIdx.x < PAIR_OFFS) my_off[threadIdx.x] = 0;
 		return;
 	}
 	if (threadIdx.x < PAIR_BINS) cnt[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t i = blockIdx.x * S + threadIdx.x;
-	const float2 *dy = reinterpret_cast<const float2 *>(dLdy);
+	const P *dy = reinterpret_cast<const P *>(dLdy);
 	float2 g2 = make_float2(0.f, 0.f);
 	Corner c;
-	uint32_t h[4], rank[4];
+	uint32_t h[4], rank[8];
 	bool live = false;
 	if (i < lim) {
-		g2 = LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level];
+		g2 = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level]);
 		live = (g2.x != 0.f || g2.y != 0.f);
 		if (live) {
 			c = locate(pos, stride, i, scale);
@@ -1306,8 +1312,9 @@ __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__rest
 			for (uint32_t q = 0; q < 4; ++q) {                                // q = (y corner, z corner), HashEncode.h:68-94
 				h[q] = (ty0 + ((q & 1u) ? 19349663u : 0u)) ^ (tz0 + ((q & 2u) ? 83492791u : 0u));
 				const uint32_t i0 = (c.g[0] ^ h[q]) & mask, i1 = ((c.g[0] + 1u) ^ h[q]) & mask;
-				// (positions outside the unit cube can carry x + 1 into the bin bits: that edge goes to the spill list as two contributions, rank = ~0)
-				rank[q] = ((i0 ^ i1) >> PAIR_BIN_BITS) ? ~0u : atomicAdd(&cnt[i0 >> PAIR_BIN_BITS], 1u);
+				if (split) { rank[2 * q] = atomicAdd(&cnt[i0 >> PAIR_BIN_BITS], 1u); rank[2 * q + 1] = atomicAdd(&cnt[i1 >> PAIR_BIN_BITS], 1u); }
+				// (edge levels: positions outside the unit cube can carry x + 1 into the bin bits: that edge goes to the spill list as two contributions, rank = ~0)
+				else rank[2 * q] = ((i0 ^ i1) >> PAIR_BIN_BITS) ? ~0u : atomicAdd(&cnt[i0 >> PAIR_BIN_BITS], 1u);
 			}
 		}
 	}
@@ -1319,18 +1326,26 @@ __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__rest
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)threadIdx.x >= o) x += y; }
 		const uint32_t e0 = x - (c0 + c1);
 		loff[b0] = e0; loff[b0 + 1u] = e0 + c0;
-		reinterpret_cast<uint32_t *>(my_off)[threadIdx.x] = e0 | ((e0 + c0) << 16);          // (4 S <= 4096 < 2^16)
+		reinterpret_cast<uint32_t *>(my_off)[threadIdx.x] = e0 | ((e0 + c0) << 16);          // (<= 4096 records per region < 2^16)
 		if (threadIdx.x == 63u) { loff[PAIR_BINS] = x; reinterpret_cast<uint32_t *>(my_off)[64] = x; }
 	}
 	__syncthreads();
 	if (live) {
 #pragma unroll
 		for (uint32_t q = 0; q < 4; ++q) {
-			const float wy = (q & 1u) ? c.w[1] : 1 - c.w[1], wz = (q & 2u) ? c.w[2] : 1 - c.w[2], wyz = wy * wz;
+			const float wy = (q & 1u) ? c.w[1] : 1 - c.w[1], wz = (q & 2u) ? c.w[2] : 1 - c.w[2];
 			const uint32_t i0 = (c.g[0] ^ h[q]) & mask, i1 = ((c.g[0] + 1u) ^ h[q]) & mask;
+			if (split) {
+				const float w0 = ((1 - c.w[0]) * wy) * wz, w1 = (c.w[0] * wy) * wz;             // the reference's x, y, z multiplication order
+				const uint32_t l0 = i0 & (PAIR_BIN_ENTRIES - 1u), l1 = i1 & (PAIR_BIN_ENTRIES - 1u);
+				stage[loff[i0 >> PAIR_BIN_BITS] + rank[2 * q]] = PairRec{g2.x * w0, g2.y * w0, 0.f, l0 | (l0 << PAIR_BIN_BITS)};
+				stage[loff[i1 >> PAIR_BIN_BITS] + rank[2 * q + 1]] = PairRec{g2.x * w1, g2.y * w1, 0.f, l1 | (l1 << PAIR_BIN_BITS)};
+				continue;
+			}
+			const float wyz = wy * wz;
 			const float a = g2.x * wyz, b = g2.y * wyz;
-			if (rank[q] != ~0u) {
-				stage[loff[i0 >> PAIR_BIN_BITS] + rank[q]] = PairRec{a, b, c.w[0], (i0 & (PAIR_BIN_ENTRIES - 1u)) | ((i1 & (PAIR_BIN_ENTRIES - 1u)) << PAIR_BIN_BITS)};
+			if (rank[2 * q] != ~0u) {
+				stage[loff[i0 >> PAIR_BIN_BITS] + rank[2 * q]] = PairRec{a, b, c.w[0], (i0 & (PAIR_BIN_ENTRIES - 1u)) | ((i1 & (PAIR_BIN_ENTRIES - 1u)) << PAIR_BIN_BITS)};
 			} else {
 				const uint32_t k = atomicAdd(spill_count, 2u);
 				const float w0 = 1 - c.w[0];
@@ -1340,7 +1355,7 @@ __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__rest
 	}
 	__syncthreads();
 	const uint32_t total = loff[PAIR_BINS];
-	PairRec *out = prec + region * pair_region_records(S);
+	PairRec *out = prec + region * pair_region_records();
 	if (probe & 1u) { if (total == 0x7fffffffu) out[0] = stage[0]; return; }
 	for (uint32_t p = threadIdx.x; p < total; p += S) out[p] = stage[p];
 }
@@ -1357,8 +1372,8 @@ __device__ __forceinline__ uint32_t bin2_of(uint32_t e, bool il) { return il ? (
 __device__ __forceinline__ uint32_t local2_of(uint32_t e, bool il) { return il ? ((e >> 10) << 3) | (e & 7u) : e & (PAIR_BIN_ENTRIES - 1u); }
 __device__ __forceinline__ uint32_t entry2_of(uint32_t bin, uint32_t local, bool il) { return il ? ((local >> 3) << 10) | (bin << 3) | (local & 7u) : (bin << PAIR_BIN_BITS) | local; }
 
-template <int LAYOUT, int OCC>
-__global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const float *__restrict__ pos, uint32_t stride, const float *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
+template <typename T, int LAYOUT, int OCC>
+__global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
                                                          const uint32_t *__restrict__ absmax_bits, RunRec *__restrict__ rrec, uint16_t *__restrict__ roff,
                                                          const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */,
                                                          uint32_t probe /* timing experiments (results wrong): 1 = the histogram atomics spread over lane-distinct addresses, 2 = no global record stores */) {
@@ -1379,7 +1394,8 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const flo
 	if (threadIdx.x < PAIR_BINS) { cnt[threadIdx.x] = 0; cnt2[threadIdx.x] = 0; }
 	__syncthreads();
 	const uint32_t first = (blockIdx.x * RUN_WG + threadIdx.x) * RUN_K;
-	const float2 *dy = reinterpret_cast<const float2 *>(dLdy);
+	using P = typename Pair<T>::type;
+	const P *dy = reinterpret_cast<const P *>(dLdy);
 	uint32_t cell[RUN_K][3]; float frac[RUN_K][3]; float2 gk[RUN_K];
 	{
 		float px[RUN_K][3];
@@ -1392,14 +1408,14 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const flo
 #pragma unroll
 			for (uint32_t k = 0; k < RUN_K; ++k) { px[k][0] = f[3 * k]; px[k][1] = f[3 * k + 1]; px[k][2] = f[3 * k + 2]; }
 #pragma unroll
-			for (uint32_t k = 0; k < RUN_K; ++k) gk[k] = LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + first + k] : dy[(size_t)(first + k) * 16 + level];
+			for (uint32_t k = 0; k < RUN_K; ++k) gk[k] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + first + k] : dy[(size_t)(first + k) * 16 + level]);
 		} else {
 #pragma unroll
 			for (uint32_t k = 0; k < RUN_K; ++k) {
 				const uint32_t i = first + k;
 				if (i < lim) {
 					px[k][0] = pos[(size_t)i * stride]; px[k][1] = pos[(size_t)i * stride + 1]; px[k][2] = pos[(size_t)i * stride + 2];
-					gk[k] = LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level];
+					gk[k] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + i] : dy[(size_t)i * 16 + level]);
 				} else { px[k][0] = px[k][1] = px[k][2] = 0.f; gk[k] = make_float2(0.f, 0.f); }
 			}
 		}
@@ -1673,9 +1689,9 @@ static uint64_t hash_bwd_workspace_bytes(const LevelTable &lt) {           // pa
 // capacity of one record list: 4x the expected n*8/64 records per bin; % 8: 16-byte aligned streams
 static uint32_t bin_capacity(uint32_t n) { uint32_t c = ((n / 2) / CUR_SUBS + 7u) & ~7u; const uint32_t lo = 4096u / CUR_SUBS; return c < lo ? lo : c; }
 // the levels whose cell edges never leave a 4096-entry bin (k_bin_pairs): full 2^19-entry hashed tables up to res 2048
-static bool level_pair_capable(const LevelTable &lt, int l) {
+static bool level_pair_capable(const LevelTable &lt, int l) {            // (beyond res 2048: as eight single records per sample)
 	const uint32_t size = lt.v[4 * l + 1], res = lt.v[4 * l + 2];
-	return size == BIN_LEVEL_MAX && !level_dense_host(size, res) && res <= PAIR_RES_MAX;
+	return size == BIN_LEVEL_MAX && !level_dense_host(size, res);
 }
 // workspace = slabs | cursors u32[N_CURSORS] | absmax partials u32[16*NGP_ABSMAX_PARTS], spill count u32 | record values | record indices | spill list | edge records
 struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, pair_rec, pair_off, run_rec, run_off, total; uint32_t cap, spill_cap, n_binned, n_pair; };
@@ -1695,7 +1711,7 @@ static WsLayout ws_layout(const LevelTable &lt, uint32_t n) {
 	for (int l = 0; l < 16; ++l) if (level_binned(lt, l) && level_pair_capable(lt, l)) ++w.n_pair;
 	// edge records: one region per record workgroup (sized for the smaller workgroup choice: more regions, more slack records), then the regions' bin offsets
 	const uint64_t regions512 = div_up(n, 512u);
-	w.pair_off = (w.pair_rec + (uint64_t)w.n_pair * regions512 * pair_region_records(512u) * sizeof(PairRec) + 255) & ~(uint64_t)255;
+	w.pair_off = (w.pair_rec + (uint64_t)w.n_pair * regions512 * pair_region_records() * sizeof(PairRec) + 255) & ~(uint64_t)255;
 	w.run_rec = w.pair_off + (((uint64_t)w.n_pair * regions512 * PAIR_OFFS * sizeof(uint16_t) + 255) & ~(uint64_t)255);
 	// run records of the fp32 path: a region per 2048-sample workgroup, worst case eight records per sample (scattered positions); any binned level can be a run level
 	const uint64_t regions_run = div_up(n, RUN_WG * RUN_K);
@@ -1765,7 +1781,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	// edge records (k_bin_pairs): fp32 in, fp32 out, 16-byte aligned gradient.  NGP_HASH_BWD_PAIRS=0 keeps round 3's per-corner records (A/B), _PAIR_WG is a probe hook
 	const bool pairs_on = [] { const char *e = getenv("NGP_HASH_BWD_PAIRS"); return !(e && e[0] == '0'); }();
 	const uint32_t pair_wg = [] { const char *e = getenv("NGP_HASH_BWD_PAIR_WG"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : 1024u; return v == 512u ? 512u : 1024u; }();
-	const bool use_pairs = use_bins && pairs_on && dtype == NGP_F32 && grad_dtype == NGP_F32 && ((uintptr_t)grad & 15u) == 0;
+	const bool use_pairs = use_bins && pairs_on && grad_dtype == NGP_F32 && ((uintptr_t)grad & 15u) == 0;      // (either dL/dy precision; the fp16-gradient table of the module path keeps the per-corner records)
 	const uint32_t run_res_max = [] { const char *e = getenv("NGP_HASH_BWD_RUN_RES"); return e ? (uint32_t)strtoul(e, nullptr, 0) : RUN_RES_MAX; }();   // probe hook
 	// (probe hooks) staging records / register budget of the run kernels.  fp32 path: 2560 records and five waves per SIMD - all 1280 workgroups of a 2^18-sample batch resident
 	// at once (measured: 54 -> 43 us); per-corner path: round 2's 3072 / natural register count
@@ -1834,33 +1850,39 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	auto pair_set_lds = [&](const void *k, size_t bytes) { hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) { ngp_set_error("ngp_hash_encode_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); pair_err = (int)e; } };
 	// ---- the fp32 path (use_pairs): run records + edge records in regions, no global atomics, one accumulate kernel.  (Levels it cannot take - hashed tables that are
 	// neither run levels nor edge-capable - stay on the per-corner kernels below, with their own accumulate launch.)
-	auto v2_records = [&]() {
+	bool any_split = false;                                              // an edge level beyond res 2048 in this call: 512-sample record workgroups (eight single records per sample)
+	for (uint32_t k = 0; k < n_pair; ++k) any_split |= lt.v[4 * bp.level[sel_pair.hl[k]] + 2] > PAIR_RES_MAX;
+	const uint32_t pair_s = any_split ? 512u : pair_wg;
+	auto v2_set_lds = [&]() {
 		static bool once = false;
-		if (!once) { pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_SOA, 512u>, pair_stage_bytes(512u)); pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_AOS, 512u>, pair_stage_bytes(512u));
-			pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_SOA, 1024u>, pair_stage_bytes(1024u)); pair_set_lds((const void *)k_bin_pairs<NGP_LAYOUT_AOS, 1024u>, pair_stage_bytes(1024u));
-			pair_set_lds((const void *)k_bin_runs2<NGP_LAYOUT_SOA, 4>, run2_stage_bytes(8192u)); pair_set_lds((const void *)k_bin_runs2<NGP_LAYOUT_AOS, 4>, run2_stage_bytes(8192u));
-			pair_set_lds((const void *)k_bin_runs2<NGP_LAYOUT_SOA, 5>, run2_stage_bytes(8192u)); pair_set_lds((const void *)k_bin_runs2<NGP_LAYOUT_AOS, 5>, run2_stage_bytes(8192u));
-			pair_set_lds((const void *)k_bin_accumulate2<float, true>, PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA); pair_set_lds((const void *)k_bin_accumulate2<float, false>, PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA); once = true; }
-		if (n_runs) {
-			const uint32_t run_probe = [] { const char *e = getenv("NGP_RUN_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
-#define RGO(L, O) NGP_LAUNCH((k_bin_runs2<L, O>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run2_stage_bytes(run_stage), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, run_rec, run_off, n_valid, run_stage, run_probe)
-			if (in_layout == NGP_LAYOUT_SOA) { if (run_occ_v == 5) RGO(NGP_LAYOUT_SOA, 5); else RGO(NGP_LAYOUT_SOA, 4); }
-			else { if (run_occ_v == 5) RGO(NGP_LAYOUT_AOS, 5); else RGO(NGP_LAYOUT_AOS, 4); }
-#undef RGO
-		}
-		if (n_pair) {
-			const uint32_t pair_probe = [] { const char *e = getenv("NGP_PAIR_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
-#define PGO(L, S) NGP_LAUNCH_INDEPENDENT((k_bin_pairs<L, S>), dim3(div_up(n, S), n_pair), dim3(S), pair_stage_bytes(S), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_pair, (const uint32_t *)absmax, pair_rec, pair_off, spill_count, spill, n_valid, pair_probe)
-			if (in_layout == NGP_LAYOUT_SOA) { if (pair_wg == 512u) PGO(NGP_LAYOUT_SOA, 512u); else PGO(NGP_LAYOUT_SOA, 1024u); }
-			else { if (pair_wg == 512u) PGO(NGP_LAYOUT_AOS, 512u); else PGO(NGP_LAYOUT_AOS, 1024u); }
-#undef PGO
-		}
+		if (once) return;
+#define PSET(T) pair_set_lds((const void *)k_bin_pairs<T, NGP_LAYOUT_SOA, 512u>, pair_stage_bytes()); pair_set_lds((const void *)k_bin_pairs<T, NGP_LAYOUT_AOS, 512u>, pair_stage_bytes()); \
+		pair_set_lds((const void *)k_bin_pairs<T, NGP_LAYOUT_SOA, 1024u>, pair_stage_bytes()); pair_set_lds((const void *)k_bin_pairs<T, NGP_LAYOUT_AOS, 1024u>, pair_stage_bytes()); \
+		pair_set_lds((const void *)k_bin_runs2<T, NGP_LAYOUT_SOA, 4>, run2_stage_bytes(8192u)); pair_set_lds((const void *)k_bin_runs2<T, NGP_LAYOUT_AOS, 4>, run2_stage_bytes(8192u)); \
+		pair_set_lds((const void *)k_bin_runs2<T, NGP_LAYOUT_SOA, 5>, run2_stage_bytes(8192u)); pair_set_lds((const void *)k_bin_runs2<T, NGP_LAYOUT_AOS, 5>, run2_stage_bytes(8192u));
+		PSET(float) PSET(__half)
+#undef PSET
+		pair_set_lds((const void *)k_bin_accumulate2<float, true>, PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA); pair_set_lds((const void *)k_bin_accumulate2<float, false>, PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA);
+		once = true;
 	};
+	const uint32_t run_probe = [] { const char *e = getenv("NGP_RUN_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
+	const uint32_t pair_probe = [] { const char *e = getenv("NGP_PAIR_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
+	// ---- the region path (use_pairs): run records + edge records in regions, no global atomics, one accumulate kernel.  (Levels it cannot take - small hashed tables
+	// that are not run levels - stay on the per-corner kernels below, with their own accumulate launch.)
+#define V2_RECORDS(T) do { v2_set_lds(); \
+	if (n_runs) { \
+		if (in_layout == NGP_LAYOUT_SOA) { if (run_occ_v == 5) V2_RGO(T, NGP_LAYOUT_SOA, 5); else V2_RGO(T, NGP_LAYOUT_SOA, 4); } \
+		else { if (run_occ_v == 5) V2_RGO(T, NGP_LAYOUT_AOS, 5); else V2_RGO(T, NGP_LAYOUT_AOS, 4); } } \
+	if (n_pair) { \
+		if (in_layout == NGP_LAYOUT_SOA) { if (pair_s == 512u) V2_PGO(T, NGP_LAYOUT_SOA, 512u); else V2_PGO(T, NGP_LAYOUT_SOA, 1024u); } \
+		else { if (pair_s == 512u) V2_PGO(T, NGP_LAYOUT_AOS, 512u); else V2_PGO(T, NGP_LAYOUT_AOS, 1024u); } } } while (0)
+#define V2_RGO(T, L, O) NGP_LAUNCH((k_bin_runs2<T, L, O>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run2_stage_bytes(run_stage), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, run_rec, run_off, n_valid, run_stage, run_probe)
+#define V2_PGO(T, L, S) NGP_LAUNCH_INDEPENDENT((k_bin_pairs<T, L, S>), dim3(div_up(n, S), n_pair), dim3(S), pair_stage_bytes(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_pair, (const uint32_t *)absmax, pair_rec, pair_off, spill_count, spill, n_valid, pair_probe)
 	uint32_t acc2_launches = 0;
 	auto v2_accumulate = [&](bool runs, bool pairs) {
 		Acc2Plan ap;
 		ap.n_pair = pairs ? n_pair : 0u; ap.n_run = runs ? n_runs : 0u;
-		ap.pair_regions = div_up(n, pair_wg); ap.pair_region_records = pair_region_records(pair_wg);
+		ap.pair_regions = div_up(n, pair_s); ap.pair_region_records = pair_region_records();
 		ap.run_regions = div_up(n, RUN_WG * RUN_K); ap.run_region_records = run2_region_records();
 		ap.probe = [] { const char *e = getenv("NGP_ACC_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
 		if (ap.n_pair + ap.n_run == 0) return;
@@ -1883,7 +1905,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		if (!absmax_done) NGP_LAUNCH((k_level_absmax<T, L>), dim3(ABSMAX_OWN_PARTS, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid, cursors, spill_count);   /* also zeroes the cursors and the spill count */ \
 		if (units && side.ok) { hipEventRecord(side.fork, s); sd = side.stream; hipStreamWaitEvent(sd, side.fork, 0); }   /* the scan of the remaining levels runs beside the binning kernels */ \
 		if (!probe_skip_bins) { \
-		if (use_pairs) v2_records(); \
+		if (use_pairs) V2_RECORDS(T); \
 		else if (n_runs && run_occ_v == 5) { SET_LDS((k_bin_records_runs<T, L, 5>), run_stage_bytes(8192u)); \
 			NGP_LAUNCH((k_bin_records_runs<T, L, 5>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(run_stage), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, run_stage); } \
 		else if (n_runs) { SET_LDS((k_bin_records_runs<T, L, 4>), run_stage_bytes(8192u)); \

@@ -1,4 +1,6 @@
 set -u
 mkdir -p gpurun_out
-bash tools/rocprof_pmc_sq.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" gpurun_out/r4j_sq.md > gpurun_out/r4j_sq.log 2>&1
-cat gpurun_out/r4j_sq.md | cut -c1-220
+bash tools/repro_two_process.sh 3 > gpurun_out/r4k_repro_two_process.txt 2>&1; cat gpurun_out/r4k_repro_two_process.txt
+python tools/probe_scatter.py 400 spheres fox > gpurun_out/r4k_probe_scatter_fox.txt 2>&1; tail -5 gpurun_out/r4k_probe_scatter_fox.txt
+bash tools/gpu.sh tests > /dev/null 2>&1; tail -30 gpurun_out/tests_gpu.log
+bash tools/gpu.sh ab fox "NGP_HASH_BWD_PAIRS=0"

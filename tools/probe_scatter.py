@@ -1,5 +1,6 @@
-"""Times the hash-grid backward (ngp_hash_encode_bwd_ws) on a REAL training batch: trains the bench configuration for a few hundred steps, then replays the
-last batch's positions and dL/dfeatures through the encoder's accumulate_grad under the probe switches of csrc/hash_encode.hip.  Run through gpurun."""
+"""Hash-grid backward of the ngp_base.py (lego, fp32) configuration on a REAL training batch, under the probe switches of csrc/hash_encode.hip: per-kernel
+HIP-event times (csrc/prof.hip) and the gradient of every variant against round 3's per-corner records (NGP_HASH_BWD_PAIRS=0).  Run through gpurun.
+usage: python tools/probe_scatter.py [steps] [scene] [lego|fox]      (fox: the fp16 / aabb_scale 4 / cone-stepping configuration)"""
 import os
 import sys
 import torch
@@ -9,45 +10,72 @@ from jnerf_amd.presets import ngp_cfg
 from jnerf_amd.runner import Runner
 
 
-def timeit(fn, reps=10):
-    fn(); torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps * 1e3
-
-
 def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0")
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    scene = sys.argv[2] if len(sys.argv) > 2 else "bricks"
+    fox = len(sys.argv) > 3 and sys.argv[3] == "fox"
+    torch.manual_seed(0)
+    if fox:
+        ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0", scene=scene)
+    else:
+        ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=100, W=800, H=800, device="cuda:0", scene=scene)
     r = Runner()
-    for i in range(steps):
-        r.train_step(i)
-    r.drain(); torch.cuda.synchronize()
+    with r.training_stream():
+        for i in range(steps):
+            r.train_step(i)
+        r.drain()
+    torch.cuda.synchronize()
     f = r._fast
     enc = f.enc
     n = f.n
-    dfeat, _, _ = r.model._bwd_buffers(n)
+    dfeat, _ = r.model._bwd_buffers(n)
     n_valid = f.s._n_valid
-    print("n_valid", int(n_valid.item()) if n_valid.numel() == 1 else n_valid)
-    fn = lambda: enc.accumulate_grad(f.s._pos_train, dfeat, ops.LAYOUT_SOA, n_valid=n_valid)
-    rows = []
-    def run(name, **env):
+    nv = int(n_valid.item())
+    print("config", "fox" if fox else "lego", "scene", scene, "n", n, "n_valid", nv, flush=True)
+    pos = f.s._pos_train
+    table = enc.level_table
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n), dtype=torch.uint8, device="cuda")
+    print("workspace MB", ws.numel() / 2 ** 20)
+
+    def run_once(g):
+        ops.hash_encode_bwd(pos, dfeat, table, enc.n_params, grad=g, layout=ops.LAYOUT_SOA, zero_first=True, workspace=ws, n_valid=n_valid)
+
+    def variant(name, env, ref=None, reps=20):
         for k, v in env.items():
             os.environ[k] = v
-        rows.append((name, timeit(fn)))
+        g = torch.full((enc.n_params,), float("nan"), dtype=torch.float32, device="cuda")
+        run_once(g); torch.cuda.synchronize()
+        g2 = torch.full((enc.n_params,), float("nan"), dtype=torch.float32, device="cuda")
+        run_once(g2); torch.cuda.synchronize()
+        repro = bool(torch.equal(g, g2))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            run_once(g2)
+        b.record(); torch.cuda.synchronize()
+        total = a.elapsed_time(b) / reps * 1e3
+        ops.prof_enable("*")
+        for _ in range(reps):
+            run_once(g2)
+        torch.cuda.synchronize()
+        ops.prof_enable("")
+        pk = {k.split("<")[0].strip("( "): sum(v) / len(v) * 1e3 for k, v in ops.prof_read().items() if v}
         for k in env:
             os.environ.pop(k, None)
-        print(f"{rows[-1][0]:60s} {rows[-1][1]:8.1f} us", flush=True)
-    run("full backward (production: every level through the bins, res <= 300 with run combining)")
-    run("abs-max pass only", NGP_PROBE_SKIP_BINS="1")
-    for res in (0, 64, 128, 200, 450, 4096):
-        run(f"run combining for levels with res <= {res}", NGP_HASH_BWD_RUN_RES=str(res))
-    for st in (1024, 2048, 4096, 6144, 8192):
-        run(f"LDS staging of {st} run records per workgroup", NGP_HASH_BWD_RUN_STAGE=str(st))
-    run("owner-computes scan for everything (no bins)", NGP_HASH_BWD_NO_BINS="1")
+        diff = ""
+        if ref is not None:
+            d = (g - ref).abs()
+            rel = d / (ref.abs() + 1e-7 * ref.abs().max())
+            diff = f" | vs ref: max abs {d.max().item():.3e} (max |ref| {ref.abs().max().item():.3e}), max rel {rel.max().item():.3e}, nan {int(torch.isnan(g).sum())}"
+        print(f"{name:58s} {total:7.1f} us  repro={repro} " + " ".join(f"{k}={v:.1f}" for k, v in sorted(pk.items())) + diff, flush=True)
+        return g
+
+    ref = variant("round-3 path: per-corner records, cursor atomics (PAIRS=0)", {"NGP_HASH_BWD_PAIRS": "0"})
+    variant("r4 path: record regions, no global atomics, one accumulate kernel", {}, ref)
+    if not fox:
+        variant("r4 path, edge WG=512", {"NGP_HASH_BWD_PAIR_WG": "512"}, ref)
+    variant("r4 path, run combining up to res 600", {"NGP_HASH_BWD_RUN_RES": "600"}, ref)
+    variant("r4 path, run combining up to res 200", {"NGP_HASH_BWD_RUN_RES": "200"}, ref)
 
 
 if __name__ == "__main__":

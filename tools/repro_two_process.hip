@@ -1,0 +1,78 @@
+// Minimal reproducer for VERDICT r3 "weak #3" (profiles/r03_two_process_probe.md): does ngp_hash_encode_fwd return different outputs for identical inputs when a
+// SECOND PROCESS shares the GPU?  No torch, no gloo, no Python: plain HIP + the C ABI of libngp_hip.so.  Build + run (tools/repro_two_process.sh):
+//   hipcc --offload-arch=gfx950 -O2 tools/repro_two_process.hip -Iinclude -Ljnerf_amd/csrc -lngp_hip -o /tmp/repro2p
+//   /tmp/repro2p <seconds> <mode> [tag]         mode: 0 = back-to-back launches on one stream
+//                                                      1 = hipDeviceSynchronize before every launch
+//                                                      2 = every launch reads PRIVATE copies of positions and table (copied right before it, same stream)
+//                                                      3 = a second stream runs an unrelated streaming kernel all the time (the marcher's role in training)
+// Every repetition writes the 16 x n x 2 fp32 features into the same output buffer and a device-side comparison counts the values that differ from the first
+// repetition's.  Run one copy alone and two copies concurrently; a non-zero count in either says the kernel (or the platform under it) is not a function of its inputs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <chrono>
+#include "ngp_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+
+__global__ void k_fill(float *p, size_t n, uint32_t seed, float lo, float hi) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		uint32_t x = (uint32_t)i * 747796405u + seed; x ^= x >> 16; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+		p[i] = lo + (hi - lo) * (float)(x >> 8) * (1.0f / 16777216.0f);
+	}
+}
+__global__ void k_diff(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *count) {
+	unsigned long long c = 0;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+	if (c) atomicAdd(count, c);
+}
+__global__ void k_noise(float *p, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = p[i] * 1.0001f + 1.0f;
+}
+
+int main(int argc, char **argv) {
+	const double seconds = argc > 1 ? atof(argv[1]) : 5.0;
+	const int mode = argc > 2 ? atoi(argv[2]) : 0;
+	const char *tag = argc > 3 ? argv[3] : "solo";
+	const uint32_t n = 1u << 21;                                   // the occupancy refresh's query size
+	uint32_t table_host[64];
+	const uint32_t n_params = ngp_level_table(1.0, table_host);
+	float *pos, *pos2, *table, *table2, *out, *ref, *noise;
+	unsigned long long *count;
+	CK(hipMalloc(&pos, (size_t)n * 3 * 4)); CK(hipMalloc(&pos2, (size_t)n * 3 * 4));
+	CK(hipMalloc(&table, (size_t)n_params * 4)); CK(hipMalloc(&table2, (size_t)n_params * 4));
+	CK(hipMalloc(&out, (size_t)n * 32 * 4)); CK(hipMalloc(&ref, (size_t)n * 32 * 4));
+	CK(hipMalloc(&noise, (size_t)64 << 20)); CK(hipMalloc(&count, 8));
+	hipStream_t s, s2;
+	CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+	hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, pos, (size_t)n * 3, 1u, 0.0f, 1.0f);
+	hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, table, (size_t)n_params, 2u, -1e-4f, 1e-4f);
+	CK(hipMemsetAsync(noise, 0, (size_t)64 << 20, s));
+	CK(hipStreamSynchronize(s));
+	auto run = [&](float *dst) -> int {
+		const float *p = pos, *t = table;
+		if (mode == 2) { if (hipMemcpyAsync(pos2, pos, (size_t)n * 3 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess || hipMemcpyAsync(table2, table, (size_t)n_params * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1; p = pos2; t = table2; }
+		if (mode == 1 && hipDeviceSynchronize() != hipSuccess) return 1;
+		return ngp_hash_encode_fwd(s, n, p, 3, t, table_host, dst, NGP_F32, NGP_LAYOUT_SOA, nullptr);
+	};
+	if (run(ref)) { fprintf(stderr, "hash fwd: %s\n", ngp_last_error()); return 2; }
+	CK(hipStreamSynchronize(s));
+	unsigned long long bad_reps = 0, worst = 0, reps = 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+		if (mode == 3) for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_noise, dim3(512), dim3(256), 0, s2, noise, (size_t)16 << 20);
+		CK(hipMemsetAsync(count, 0, 8, s));
+		if (run(out)) { fprintf(stderr, "hash fwd: %s\n", ngp_last_error()); return 2; }
+		hipLaunchKernelGGL(k_diff, dim3(2048), dim3(256), 0, s, (const uint32_t *)out, (const uint32_t *)ref, (size_t)n * 32, count);
+		unsigned long long c = 0;
+		CK(hipMemcpyAsync(&c, count, 8, hipMemcpyDeviceToHost, s));
+		CK(hipStreamSynchronize(s));
+		++reps;
+		if (c) { ++bad_reps; if (c > worst) worst = c; }
+	}
+	CK(hipDeviceSynchronize());
+	printf("[%s] mode %d: %llu of %llu repetitions differ from the first result (worst: %llu of %llu values)\n", tag, mode, bad_reps, reps, worst, (unsigned long long)n * 32ull);
+	return 0;
+}
