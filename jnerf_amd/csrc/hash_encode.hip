@@ -1781,7 +1781,10 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	// edge records (k_bin_pairs): fp32 in, fp32 out, 16-byte aligned gradient.  NGP_HASH_BWD_PAIRS=0 keeps round 3's per-corner records (A/B), _PAIR_WG is a probe hook
 	const bool pairs_on = [] { const char *e = getenv("NGP_HASH_BWD_PAIRS"); return !(e && e[0] == '0'); }();
 	const uint32_t pair_wg = [] { const char *e = getenv("NGP_HASH_BWD_PAIR_WG"); const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : 1024u; return v == 512u ? 512u : 1024u; }();
-	const bool use_pairs = use_bins && pairs_on && grad_dtype == NGP_F32 && ((uintptr_t)grad & 15u) == 0;      // (either dL/dy precision; the fp16-gradient table of the module path keeps the per-corner records)
+	// fp32 dL/dy only by default.  The kernels take fp16 dL/dy as well (NGP_HASH_BWD_PAIRS=2), but the fp16 configuration is better off with its 6-byte per-corner records:
+	// measured on the ngp_fox.py shape, stage alone 103 vs 99 us, in the step (beside the cone-stepping marcher on the side streams) 1777 vs 1818 it/s
+	const bool pairs_f16 = [] { const char *e = getenv("NGP_HASH_BWD_PAIRS"); return e && e[0] == '2'; }();
+	const bool use_pairs = use_bins && pairs_on && (dtype == NGP_F32 || pairs_f16) && grad_dtype == NGP_F32 && ((uintptr_t)grad & 15u) == 0;
 	const uint32_t run_res_max = [] { const char *e = getenv("NGP_HASH_BWD_RUN_RES"); return e ? (uint32_t)strtoul(e, nullptr, 0) : RUN_RES_MAX; }();   // probe hook
 	// (probe hooks) staging records / register budget of the run kernels.  fp32 path: 2560 records and five waves per SIMD - all 1280 workgroups of a 2^18-sample batch resident
 	// at once (measured: 54 -> 43 us); per-corner path: round 2's 3072 / natural register count

@@ -76,6 +76,10 @@ class Runner:
         with torch.no_grad():
             for p in params:
                 dist.broadcast(p.data, src=0)
+        if torch.cuda.is_available():
+            # (r4) once, before the first kernel reads a parameter: host-staged backends (gloo) land the broadcast through copy streams of their own, and the training
+            # loop runs on yet another stream (training_stream) - nothing is left to stream-ordering subtleties here
+            torch.cuda.synchronize()
         for m in self.model.modules():
             if hasattr(m, "shadow_dirty"):
                 m.shadow_dirty = True                       # fp16 shadows are rebuilt from the synchronised masters at the next read

@@ -1,6 +1,10 @@
 set -u
 mkdir -p gpurun_out
-bash tools/repro_two_process.sh 3 > gpurun_out/r4k_repro_two_process.txt 2>&1; cat gpurun_out/r4k_repro_two_process.txt
-python tools/probe_scatter.py 400 spheres fox > gpurun_out/r4k_probe_scatter_fox.txt 2>&1; tail -5 gpurun_out/r4k_probe_scatter_fox.txt
-bash tools/gpu.sh tests > /dev/null 2>&1; tail -30 gpurun_out/tests_gpu.log
-bash tools/gpu.sh ab fox "NGP_HASH_BWD_PAIRS=0"
+timeout 900 python -m pytest tests/test_hip_parity.py tests/test_zz_refrun_gpu.py -q -x -k "field or refrun or replays" 2>&1 | tail -12 | tee gpurun_out/r4l_tests.log
+bash tools/probe_two_rank_repro.sh 4 2>&1 | tee gpurun_out/r4l_two_rank.txt
+bash tools/gpu.sh ab lego
+bash tools/gpu.sh ab fox
+cd jnerf_amd/csrc && touch field_split.hip field_mlp.hip && EXTRA=-DNGP_FIELD_STAGE16 bash build.sh > /dev/null 2>&1; cd ../..
+echo "--- rebuilt with -DNGP_FIELD_STAGE16 (2-byte staging stores)"
+bash tools/gpu.sh ab lego
+bash tools/gpu.sh ab fox
