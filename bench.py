@@ -47,9 +47,13 @@ def _cpu_inputs(n_samples, n_rays, m_rays, seed, aabb):
     return dict(x=x, d=d, coords=coords, ns=ns, bg=bg, ro=ro, rd=rd, aabb=aabb)
 
 
-def _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar, fp16, const_dt, stages=None):
-    """every hot-path stage of one iteration through the plain-C oracle (ctypes releases the GIL inside each call)"""
+def _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar, fp16, const_dt, stages=None, R=None, offsets=None, aabb_scale=1):
+    """every hot-path stage of one iteration on the host (ctypes releases the GIL inside each call).  R = oracle/_ref (the reference's own kernel headers compiled for the
+    host): used for the stages it has - marcher, hash encode forward / backward, compositing forward / backward; the port (oracle/ngp_oracle.c) does the rest - SH, the
+    two MLPs (binary-only in the reference), Adam + EMA (Jittor's) - and everything when R is None."""
     import numpy as np
+    if R is not None:
+        return _cpu_iteration_ref(O, R, inp, table, offsets, aabb_scale, n_params, grid, wd, wc, bits, npar, fp16, const_dt, stages)
 
     def timed(name, fn):
         ts = time.perf_counter()
@@ -70,6 +74,33 @@ def _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar, fp16, cons
     g = timed("hash_bwd", lambda: O.hash_encode_bwd(x, dfeat.astype(np.float16 if fp16 else np.float32), table, n_params))
     p = np.zeros(npar, np.float32); m = np.zeros_like(p); v = np.zeros_like(p); e = np.zeros_like(p)
     timed("adam_ema", lambda: O.adam_ema_step(p, g[:npar].astype(np.float32), m, v, e, 0.1, 1))
+
+
+def _cpu_iteration_ref(O, R, inp, table, offsets, aabb_scale, n_params, grid, wd, wc, bits, npar, fp16, const_dt, stages):
+    import numpy as np
+
+    def timed(name, fn):
+        ts = time.perf_counter()
+        r = fn()
+        if stages is not None:
+            stages[name] = round((time.perf_counter() - ts) * 1e3, 1)
+        return r
+
+    x, d, coords, ns, bg, aabb = inp["x"], inp["d"], inp["coords"], inp["ns"], inp["bg"], inp["aabb"]
+    n_rays = inp["ro"].shape[0]
+    meta = np.zeros((1, 11), np.float32); ids = np.zeros(n_rays, np.uint32); xf = np.zeros((1, 4, 3), np.float32)
+    timed("march", lambda: R.march(inp["ro"], inp["rd"], bits, aabb, R.PCG32(1337).st, n_rays * 1024, meta, ids, xf, const_dt=const_dt))
+    feat = timed("hash_fwd", lambda: R.hash_fwd(x, grid, offsets, aabb_scale))
+    sh = timed("sh", lambda: O.sh_encode(d, np.float32))
+    out = timed("field_fwd", lambda: O.field_fwd(np.asarray(feat, np.float32), sh, wd, wc))
+    T = np.float16 if fp16 else np.float32
+    rgb = timed("composite_fwd", lambda: R.rgb_fwd(out.astype(T), coords, ns, ns, bg, aabb))
+    _, G = O.huber(rgb, bg)
+    dout = timed("composite_bwd", lambda: R.rgb_bwd(out.astype(T), coords, ns, G, rgb, 0.001, aabb))
+    dfeat, dwd, dwc = timed("field_bwd", lambda: O.field_bwd(np.asarray(feat, np.float32), sh, wd, wc, np.asarray(dout, np.float32)))
+    g = timed("hash_bwd", lambda: R.hash_bwd(x, dfeat.astype(T), offsets, aabb_scale, n_params))
+    p = np.zeros(npar, np.float32); m = np.zeros_like(p); v = np.zeros_like(p); e = np.zeros_like(p)
+    timed("adam_ema", lambda: O.adam_ema_step(p, np.asarray(g[:npar], np.float32), m, v, e, 0.1, 1))
 
 
 def _ref_stage_times(O, table, offsets, n_params, grid, bits, aabb, aabb_scale, fp16, const_dt, n=1 << 15, n_rays=512):
@@ -126,17 +157,28 @@ def cpu_baseline(aabb_scale, fp16, const_dt, n_samples=1 << 18, n_rays=4096, n_m
     m_rays = int(n_march_rays * frac)
     npar = int(n_params * frac) // 4 * 4
     cores = max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    # (r4) the reference's own kernels wherever they exist as source: the port was 2.2x slower than them on the hash forward
+    R = None
+    try:
+        from oracle import ref as _R
+        if _R.available():
+            R = _R
+    except Exception:
+        R = None
     parts = [_cpu_inputs(n_samples // cores, max(n_rays // cores, 1), max(m_rays // cores, 1), seed=k, aabb=aabb) for k in range(cores)]
     with ThreadPoolExecutor(cores) as ex:
         t0 = time.perf_counter()
-        list(ex.map(lambda inp: _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar // cores // 4 * 4, fp16, const_dt), parts))
+        list(ex.map(lambda inp: _cpu_iteration(O, inp, table, n_params, grid, wd, wc, bits, npar // cores // 4 * 4, fp16, const_dt, None, R, offsets, aabb_scale), parts))
         t_par = time.perf_counter() - t0
     stages = {}
     whole = _cpu_inputs(n_samples, n_rays, m_rays, seed=0, aabb=aabb)
     t0 = time.perf_counter()
-    _cpu_iteration(O, whole, table, n_params, grid, wd, wc, bits, npar, fp16, const_dt, stages)
+    _cpu_iteration(O, whole, table, n_params, grid, wd, wc, bits, npar, fp16, const_dt, stages, R, offsets, aabb_scale)
     t_one = time.perf_counter() - t0
-    return {"value": round(frac / t_par, 4), "unit": "iters/s", "cores": cores, "kind": "port", "single_core_value": round(frac / t_one, 4), "single_core_stage_ms": stages,
+    return {"value": round(frac / t_par, 4), "unit": "iters/s", "cores": cores, "kind": "reference+port" if R is not None else "port",
+            "kind_detail": ("marcher, hash encode fwd/bwd, compositing fwd/bwd: the reference's own kernel headers compiled for the host (oracle/_ref); SH, both MLPs, Huber, Adam+EMA: "
+                            "the plain-C port (oracle/ngp_oracle.c) - the reference has no source for them" if R is not None else "plain-C port (oracle/ngp_oracle.c): oracle/_ref is not built on this host"),
+            "single_core_value": round(frac / t_one, 4), "single_core_stage_ms": stages,
             "reference_kernels": _ref_stage_times(O, table, offsets, n_params, grid, bits, aabb, aabb_scale, fp16, const_dt),
             "sample": f"one training iteration of the bench workload's shape ({'fp16' if fp16 else 'fp32'} table, aabb_scale {aabb_scale}, const_dt {const_dt}): {m_rays} rays marched through a "
                       f"shell bitfield, {n_samples} samples through hash fwd/bwd, SH, both MLPs fwd/bwd, compositing fwd/bwd, Huber; Adam+EMA on {npar} of {n_params} parameters "
@@ -158,6 +200,7 @@ def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
         "k_adam_ema": P * (30 if fp16 else 28),                # read p, g, m, v; write p, m, v (+ the fp16 shadow); the gradient is overwritten by the next backward, not zeroed here
         # hash backward: the stage's necessary traffic is pos 12 + dL/dy 32*T + 128 scattered fp32 updates (4 B each as one write); attributed to the kernels that do each part
         "k_level_absmax": n * 32 * T, "k_bin_records": n * (12 + 32 * T) * (16 - n_runs) / 16, "k_bin_records_runs": n * (12 + 32 * T) * n_runs / 16, "k_bin_accumulate": n * 16 * 8 * 2 * 4,
+        "k_bin_pairs": n * (12 + 32 * T) * (16 - n_runs) / 16, "k_bin_runs2": n * (12 + 32 * T) * n_runs / 16, "k_bin_accumulate2": n * 16 * 8 * 2 * 4,
         "k_reduce_slabs": 10240 * 4, "k_pack_frags": 21504 * 2 * 2,
         # sampling: ray in (24 B) + one 28-byte record and one 12-byte position out per sample
         "k_march_count": R * 24 + n * 4, "k_march_wave": R * 24 + n * 4, "k_mscan_totals": R * 4, "k_mscan_ok": R * 4, "k_mscan_final": R * 20, "k_march_write_cached": n * (4 + 40),
@@ -186,7 +229,9 @@ SPLIT_FP16_KERNELS = ("k_field32_fwd_split", "k_field32_bwd_split")
 # FLOP per sample the kernels EXECUTE: the backward kernels recompute the forward (their choice, not algorithmic work); the r3 fp32 variants skip the rgb layer the backward never reads
 EXECUTED_FLOPS_PER_SAMPLE = {"k_field_fwd": 20480.0, "k_field_bwd": 61440.0, "k_field32_fwd": 20480.0, "k_field32_bwd": 61440.0, "k_field32_bwd_2g": 59392.0, "k_field32_bwd_pp": 59392.0,
                              "k_field_bwd_g": 61440.0, "k_field32_fwd_split": 3 * 20480.0, "k_field32_bwd_split": 3 * 59392.0}
-HASH_BWD_STAGE = ("k_level_absmax", "k_bin_records_runs", "k_bin_records", "k_bin_accumulate")
+# the hash-backward stage's kernels: round 3's per-corner records (the fp16 configuration still) | round 4's region records of the fp32 configuration
+HASH_BWD_STAGE = ("k_level_absmax", "k_bin_records_runs", "k_bin_records", "k_bin_accumulate", "k_bin_runs2", "k_bin_pairs", "k_bin_accumulate2")
+HASH_BWD_ACC = ("k_bin_accumulate", "k_bin_accumulate2")
 
 
 def main():
@@ -338,7 +383,7 @@ def main():
         # HBM bytes per launch: rocprofv3 cannot run inside this process, so this is a LOOK-UP in the committed --pmc FETCH_SIZE / WRITE_SIZE passes of this same
         # command (tools/collect_profiles.sh), newest round first; `traffic_source` says which file (null = no such pass committed)
         traffic, traffic_source, counters = None, None, {}
-        for tag in ("r03", "r02"):
+        for tag in ("r04", "r03", "r02"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
                 ent = pm.get(args.config, {}).get(dom, {})
@@ -363,14 +408,16 @@ def main():
                     "issued_frac": counters.get("mfma_issued_frac"), "pipe_util": counters.get("mfma_pipe_util")}   # from the committed MFMA-counter pass (same source file as `traffic`), null if absent
             if split:
                 roof["fp16_pipe"] = {"note": "split operands: every fp32-accurate product is three v_mfma_f32_16x16x32_f16 products; the kernel is LDS- and VALU-bound, not MFMA-bound",
-                                     "issued_TFLOPs": round(3.0 * tf_exec, 1), "peak": 2500.0, "frac": round(3.0 * tf_exec / 2500.0, 4)}
+                                     "issued_TFLOPs": round(3.0 * tf_exec, 1), "peak": 2500.0, "frac": round(3.0 * tf_exec / 2500.0, 4),
+                                     # the ceiling the technique itself allows: a third of the fp16 pipe, in fp32-equivalent products
+                                     "frac_of_split_ceiling": round(tf / (2500.0 / 3.0), 4), "executed_frac_of_split_ceiling": round(tf_exec / (2500.0 / 3.0), 4)}
         else:
             roof = dict(bound="hbm", **hbm)
         # the hash-backward STAGE is four launches under four kernel names (abs-max, two record passes, accumulate): one roofline for the stage, from the probe steps
         stage = None
         st_kernels = [k for k in HASH_BWD_STAGE if k in probe_ms]      # (k_level_absmax is absent when the field backward kernel's epilogue computes the maxima)
-        if "k_bin_accumulate" in st_kernels:
-            st_ms = sum(max(sum(batch_class(probe_ms[k])) / len(batch_class(probe_ms[k])) - ev_overhead, 0.0) * (len(probe_ms[k]) / probe if k == "k_bin_accumulate" else 1.0) for k in st_kernels)
+        if any(k in st_kernels for k in HASH_BWD_ACC):
+            st_ms = sum(max(sum(batch_class(probe_ms[k])) / len(batch_class(probe_ms[k])) - ev_overhead, 0.0) * (len(probe_ms[k]) / probe if k in HASH_BWD_ACC else 1.0) for k in st_kernels)
             T_ = 2 if fp16 else 4
             st_bytes = mean_valid * (12 + 32 * T_ + 16 * 8 * 2 * 4)                 # §8(d): pos + dL/dy + 128 scattered fp32 updates per sample
             stage = {"name": "hash_backward", "kernels": st_kernels, "ms": round(st_ms, 4), "alg_bytes": int(st_bytes), "achieved": round(st_bytes / (st_ms * 1e-3) / 1e9, 1),

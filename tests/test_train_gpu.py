@@ -281,6 +281,23 @@ def test_rccl_exchange_step_adds_no_arithmetic(overlap):
     assert a["loss"] == b["loss"]
 
 
+def test_rccl_fp16_gradient_wire_in_the_fp32_configuration():
+    """(r4) `dp_grad_dtype = "fp16"` in the fp32 configuration: the table gradient travels as fp16 x 2^14 (half the reduce-scatter bytes) - opt-in, NOT bit-identical to the
+    plain run (every element rounded to 11 significant bits once); the world-size-1 run must train like the plain one and say which wire it used"""
+    import os, socket
+    common = ["--gpus", "1", "--config", "lego", "--steps", "24", "--warmup", "4", "--burn-in", "36", "--images", "8", "--res", "96", "--no-psnr", "--no-fox", "--no-neus", "--no-spheres",
+              "--no-cpu-baseline", "--no-kernel-events"]
+    a = _run_bench(common)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_EXTRA_CFG='{"dp_grad_dtype": "fp16"}')
+    b = _run_bench(common + ["--force-dist"], env=env)
+    assert b["extra"]["native_step"] is True and b["extra"]["dp"]["grad_wire"].startswith("fp16") and b["extra"]["dp"]["n_ranks_seen"] == 1
+    assert b["extra"]["dp"]["exchange"].startswith("rccl in-library") and b["extra"]["replicas_identical"] is True
+    assert np.isfinite(b["loss"]) and abs(b["loss"] - a["loss"]) < 0.05 * a["loss"], (a["loss"], b["loss"])
+    for x, y in zip(a["extra"]["param_signature"], b["extra"]["param_signature"]):
+        assert abs(x - y) <= 0.05 * max(abs(x), abs(y), 1.0), (a["extra"]["param_signature"], b["extra"]["param_signature"])
+
+
 def test_bench_contract_small():
     """the bench line's contract on a tiny workload: metric / value / roofline (dominant kernel chosen over ALL kernels, live durations) / per-kernel table"""
     d = _run_bench(["--steps", "16", "--warmup", "4", "--burn-in", "64", "--images", "8", "--res", "96", "--no-fox", "--no-cpu-baseline"])

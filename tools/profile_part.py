@@ -1,0 +1,78 @@
+"""One part of the system under `rocprofv3 --kernel-trace --stats`, behind a marker kernel (torch.arange: `elementwise_kernel_with_index`), so that tools/rocprof_summary.py
+can cut the trace there (VERDICT r3 'missing' #5: the render path and the NeuS iteration had no rocprof evidence).
+  python tools/profile_part.py render [train_steps]     ONE 800 x 800 view of Runner.render_img (lego configuration, `bricks`), after a warm-up view
+  python tools/profile_part.py neus [iterations]        50 NeuS iterations (projects/neus/configs/neus_hash.py on the procedural DTU-layout scene), after 20 warm-up iterations"""
+import os
+import sys
+import time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def marker():
+    torch.cuda.synchronize()
+    torch.arange(7777, device="cuda")
+    torch.cuda.synchronize()
+
+
+def render(steps):
+    from jnerf_amd.presets import ngp_cfg
+    from jnerf_amd.runner import Runner
+    from jnerf_amd.utils.registry import build_from_cfg, DATASETS
+    torch.manual_seed(0)
+    ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=100, W=800, H=800, device="cuda:0", scene="bricks")
+    r = Runner()
+    with r.training_stream():
+        for i in range(steps):
+            r.train_step(i)
+        r.drain()
+    r.dataset["test"] = build_from_cfg(r.cfg.dataset.test, DATASETS)
+    r.render_img("test", 0)
+    marker()
+    t0 = time.perf_counter()
+    r.render_img("test", 1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"render: one 800x800 view after {steps} training steps: {dt * 1e3:.2f} ms wall (under the profiler), {r.n_samples_rendered} samples -> {r.n_samples_rendered / dt / 1e6:.0f} Msamples/s", flush=True)
+
+
+def neus(iters):
+    import tempfile
+    import numpy as np
+    import synth_dtu
+    from jnerf_amd.utils.config import init_cfg, get_cfg
+    from jnerf_amd.neus_runner import NeuSRunner
+    root = tempfile.mkdtemp(prefix="neus_prof_")
+    synth_dtu.make_scene(root, n_images=16, W=128, H=96)
+    init_cfg(os.path.join(ROOT, "projects", "neus", "configs", "neus_hash.py"))
+    cfg = get_cfg()
+    cfg.device = "cuda"
+    cfg.dataset.dataset_dir = root
+    cfg.base_exp_dir = os.path.join(root, "log")
+    cfg.end_iter, cfg.warm_up_end = 2000, 50
+    torch.manual_seed(3)
+    np.random.seed(3)
+    r = NeuSRunner()
+    perm = r.get_image_perm()
+    r.update_learning_rate()
+    for i in range(20):
+        r.train_step(perm[i % len(perm)])
+        r.update_learning_rate()
+    marker()
+    t0 = time.perf_counter()
+    for i in range(20, 20 + iters):
+        r.train_step(perm[i % len(perm)])
+        r.update_learning_rate()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"neus: {iters} iterations of {r.batch_size} rays x {r.renderer.n_samples + r.renderer.n_importance} sections: {dt / iters * 1e3:.2f} ms per iteration (under the profiler)", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1]
+    if what == "render":
+        render(int(sys.argv[2]) if len(sys.argv) > 2 else 1024)
+    else:
+        neus(int(sys.argv[2]) if len(sys.argv) > 2 else 50)

@@ -4,9 +4,14 @@ import sqlite3
 import sys
 
 
-def main(db, out, title, last_steps=0):
+def main(db, out, title, last_steps=0, after_marker=None):
+    """after_marker: only dispatches after the LAST launch of a kernel whose name contains this string (tools/profile_part.py launches torch.arange as the marker)"""
     c = sqlite3.connect(db)
     cutoff = 0
+    if after_marker:
+        marks = [r[0] for r in c.execute("select d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id where s.kernel_name like ? order by d.start", (f"%{after_marker}%",))]
+        if marks:
+            cutoff = marks[-1]
     if last_steps:      # restrict to the last N training steps: cut at the start of the N-th from last batch launch of the field network
         marks = [r[0] for r in c.execute("""select d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
                                             where s.kernel_name like '%k_field32_fwdILi1ELb0%' or s.kernel_name like '%k_field32_fwd_splitILi1ELb0%' or s.kernel_name like '%k_field_fwdI6__halfLi1ELb0%' order by d.start""")]      # one per training step
@@ -43,4 +48,4 @@ def main(db, out, title, last_steps=0):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 kernel summary", int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 kernel summary", int(sys.argv[4]) if len(sys.argv) > 4 else 0, sys.argv[5] if len(sys.argv) > 5 else None)

@@ -1,0 +1,33 @@
+#!/bin/bash
+# End-of-round runs (round 4 as committed: the r04_ prefixes) on the GPU box (through gpurun): full GPU suite, bench lines, rocprofv3 passes, render / NeuS traces, the initialisation A/B.  Everything -> gpurun_out/.
+set -u
+R=$PWD
+mkdir -p gpurun_out
+WHAT=${1:-all}
+if [ $WHAT = all ] || [ $WHAT = tests ]; then
+bash tools/gpu.sh tests > /dev/null 2>&1; tail -6 gpurun_out/tests_gpu.log; cp gpurun_out/tests_gpu.log gpurun_out/r04_tests_gpu.log
+fi
+if [ $WHAT = all ] || [ $WHAT = bench ]; then
+bash tools/gpu.sh bench r04_bench_lego
+bash tools/gpu.sh bench r04_bench_fox --config fox --no-fox --no-neus
+bash tools/gpu.sh bench r04_bench_driver_style --gpus 1 --steps 20 --warmup 5
+fi
+if [ $WHAT = all ] || [ $WHAT = profiles ]; then
+bash tools/collect_profiles_r04.sh all > gpurun_out/r04_collect.log 2>&1; tail -25 gpurun_out/r04_collect.log
+fi
+if [ $WHAT = all ] || [ $WHAT = parts ]; then
+cd /tmp && export TMPDIR=/tmp
+for part in render neus; do
+  rm -rf /tmp/pp_$part && mkdir -p /tmp/pp_$part
+  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pp_$part -o kt -- python $R/tools/profile_part.py $part > /tmp/pp_$part/log 2>&1
+  grep "^render:\|^neus:" /tmp/pp_$part/log | tee $R/gpurun_out/r04_${part}_wall.txt
+  KT=$(find /tmp/pp_$part -name "*.db" | head -1)
+  (cd $R && python tools/rocprof_summary.py "$KT" gpurun_out/r04_${part}_kernel_trace.md "python tools/profile_part.py $part, rocprofv3 --kernel-trace --stats - dispatches after the marker kernel only" 0 elementwise_kernel_with_index)
+done
+cd $R
+fi
+if [ $WHAT = all ] || [ $WHAT = curve ]; then
+INVARIANT_UNIFORM_GAIN=3.0 timeout 600 python tools/train_curve.py gpurun_out/r04_train_curve_bricks_gain3.md 40000 bricks > gpurun_out/r04_curve.log 2>&1
+INVARIANT_UNIFORM_GAIN=1.0 timeout 600 python tools/train_curve.py gpurun_out/r04_train_curve_bricks_gain1.md 40000 bricks >> gpurun_out/r04_curve.log 2>&1
+tail -4 gpurun_out/r04_train_curve_bricks_gain3.md gpurun_out/r04_train_curve_bricks_gain1.md
+fi

@@ -15,9 +15,10 @@ from jnerf_amd.utils.registry import build_from_cfg, DATASETS
 out = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 which = sys.argv[3] if len(sys.argv) > 3 else "lego"
+extra = {"invariant_uniform_gain": float(os.environ["INVARIANT_UNIFORM_GAIN"])} if os.environ.get("INVARIANT_UNIFORM_GAIN") else {}     # (r4) A/B of the two readings of Jittor's init (network.py)
 torch.manual_seed(1234)
 if which in ("lego", "bricks"):
-    ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=100, W=800, H=800, device="cuda:0", tot_train_steps=steps, scene="bricks" if which == "bricks" else "spheres")
+    ngp_cfg(fp16=False, aabb_scale=1, const_dt=True, n_images=100, W=800, H=800, device="cuda:0", tot_train_steps=steps, scene="bricks" if which == "bricks" else "spheres", **extra)
     title = ("lego-difficulty stand-in `bricks`" if which == "bricks" else "procedural") + " 100 x 800 x 800 RGBA, ngp_base.py (lego) hyper-parameters, fp32"
 else:
     ngp_cfg(fp16=True, aabb_scale=4, const_dt=False, n_images=50, W=400, H=400, device="cuda:0", tot_train_steps=steps)
@@ -55,7 +56,7 @@ with r.training_stream():                                   # as Runner.train do
             torch.cuda.synchronize()
             t0 = time.perf_counter()
 with open(out, "w") as f:
-    f.write(f"# Full training schedule on one MI355X (bench scene: {title})\n\n")
+    f.write(f"# Full training schedule on one MI355X (bench scene: {title}" + (f"; invariant_uniform_gain = {extra['invariant_uniform_gain']}" if extra else "") + ")\n\n")
     f.write(f"`python tools/train_curve.py out.md {steps} {which}` - {steps} iterations of 2^18 samples, ExpDecay x0.33 at 20 k and 30 k (ngp_base.py:31-37); PSNR = mean over the held-out test views;\n")
     f.write("training time excludes the evaluation renders.\n\n| iteration | training seconds | it/s so far | test PSNR (dB) | lr | rays / batch |\n|---|---|---|---|---|---|\n")
     for it, s, p, lr, nr in rows:
