@@ -1,4 +1,4 @@
-"""One part of the system under `rocprofv3 --kernel-trace --stats`, behind a marker kernel (torch.arange: `elementwise_kernel_with_index`), so that tools/rocprof_summary.py
+"""One part of the system under `rocprofv3 --kernel-trace --stats`, behind a marker kernel (torch.tril: `triu_tril_kernel`), so that tools/rocprof_summary.py
 can cut the trace there (VERDICT r3 'missing' #5: the render path and the NeuS iteration had no rocprof evidence).
   python tools/profile_part.py render [train_steps]     ONE 800 x 800 view of Runner.render_img (lego configuration, `bricks`), after a warm-up view
   python tools/profile_part.py neus [iterations]        50 NeuS iterations (projects/neus/configs/neus_hash.py on the procedural DTU-layout scene), after 20 warm-up iterations"""
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def marker():
     torch.cuda.synchronize()
-    torch.arange(7777, device="cuda")
+    torch.tril(torch.ones(8, 8, device="cuda"))          # `triu_tril_kernel`: nothing in the package launches it
     torch.cuda.synchronize()
 
 

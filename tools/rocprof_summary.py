@@ -5,7 +5,7 @@ import sys
 
 
 def main(db, out, title, last_steps=0, after_marker=None):
-    """after_marker: only dispatches after the LAST launch of a kernel whose name contains this string (tools/profile_part.py launches torch.arange as the marker)"""
+    """after_marker: only dispatches after the LAST launch of a kernel whose name contains this string (tools/profile_part.py launches torch.tril as the marker)"""
     c = sqlite3.connect(db)
     cutoff = 0
     if after_marker:

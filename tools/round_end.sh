@@ -17,12 +17,12 @@ bash tools/collect_profiles_r04.sh all > gpurun_out/r04_collect.log 2>&1; tail -
 fi
 if [ $WHAT = all ] || [ $WHAT = parts ]; then
 cd /tmp && export TMPDIR=/tmp
-for part in render neus; do
+for part in ${PARTS:-render neus}; do
   rm -rf /tmp/pp_$part && mkdir -p /tmp/pp_$part
   timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pp_$part -o kt -- python $R/tools/profile_part.py $part > /tmp/pp_$part/log 2>&1
   grep "^render:\|^neus:" /tmp/pp_$part/log | tee $R/gpurun_out/r04_${part}_wall.txt
   KT=$(find /tmp/pp_$part -name "*.db" | head -1)
-  (cd $R && python tools/rocprof_summary.py "$KT" gpurun_out/r04_${part}_kernel_trace.md "python tools/profile_part.py $part, rocprofv3 --kernel-trace --stats - dispatches after the marker kernel only" 0 elementwise_kernel_with_index)
+  (cd $R && python tools/rocprof_summary.py "$KT" gpurun_out/r04_${part}_kernel_trace.md "python tools/profile_part.py $part, rocprofv3 --kernel-trace --stats - dispatches after the marker kernel only" 0 triu_tril_kernel)
 done
 cd $R
 fi
