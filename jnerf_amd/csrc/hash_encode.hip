@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const flo
 struct Acc2Plan { uint32_t n_pair, n_run, pair_regions, pair_region_records, run_regions, run_region_records, probe; };
 // c * s (s a power of two) rounded to the nearest integer (ties to even), as a 64-bit integer: __float2ll_rn without the generic expansion.  t = c * s is exact, rint(t) is
 // an integer-valued float with <= 24 significant bits, so its split into hi * 2^32 + lo is exact too.  |t| < 2^62 by construction of the scale.
-__device__ __forceinline__ long long fixed_rn(float c, float s) {
+__host__ __device__ __forceinline__ long long fixed_rn(float c, float s) {
 	const float r = rintf(c * s), m = fabsf(r);
 	const float hi = floorf(m * 2.3283064365386963e-10f);               // floor(|r| / 2^32)
 	const float lo = fmaf(hi, -4294967296.0f, m);                        // |r| - hi * 2^32, in [0, 2^32): exact (a multiple of ulp(|r|) below 2^32)
@@ -1497,6 +1497,8 @@ __device__ __forceinline__ long long fixed_rn(float c, float s) {
 	return r < 0.f ? -v : v;
 }
 static_assert(ACC2_RB == ACC2_WG, "gather_flat builds one segment-table row per thread");
+// test hook (tests/test_host_cpu.py): the same function on the host, against round-half-even of the exact product
+NGP_API long long ngp_x_fixed_rn(float c, float s) { return fixed_rn(c, s); }
 // The records of one (level, bin) lie in n_regions segments (one per record workgroup).  Per block of ACC2_RB regions: segment table (start, length) -> exclusive prefix P in LDS ->
 // the segments laid end to end as ONE flat list that the threads walk densely (thread t takes flat records t, t + 512, ...; eight loads in flight): consecutive lanes read
 // consecutive records of a segment (full lines) and every lane has work - eight lanes per segment with a fixed number of slots left half of them idle, and the kernel was

@@ -23,10 +23,11 @@ def active():
     return dist.get_world_size() > 1 or get_cfg().dp_force_collectives is True
 
 
-def _create_comm(rank, world):
+def _create_comm(rank, world, lib=None, device="cuda"):
     """One attempt at the library's communicator with a SYMMETRIC collective sequence: rank 0 always broadcasts - the RCCL unique id, or None when drawing it
-    failed - so no rank is ever left waiting in a broadcast that its peer skipped; every rank then runs the same ngp_comm_init or none.  -> (handle | None, error | None)"""
-    lib = L.lib()
+    failed - so no rank is ever left waiting in a broadcast that its peer skipped; every rank then runs the same ngp_comm_init or none.  -> (handle | None, error | None)
+    (lib / device: the CPU test drives this sequence over gloo with a stand-in library whose rank 0 fails - tests/test_dist_cpu.py)"""
+    lib = lib or L.lib()
     uid = (C.c_char * L.COMM_ID_BYTES)()
     box, err = [None], None
     if rank == 0:
@@ -36,7 +37,7 @@ def _create_comm(rank, world):
         except RuntimeError as e:
             err = e
     if world > 1:
-        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", torch.cuda.current_device()) if device == "cuda" else None)
     if box[0] is None:
         return None, err or RuntimeError("rank 0 could not draw an RCCL unique id")
     handle = C.c_void_p()

@@ -348,13 +348,17 @@ class Runner:
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             from .optim import sync_all_sharded
             sync_all_sharded()      # (multi-rank runs: train() has done it on every rank - it is a collective, and save_ckpt runs on rank 0 only)
+        elif getattr(self.optimizer._nested_optimizer, "_sharded_dirty", False):
+            #  Adam.state_dict() would all-gather the sharded moments - a collective - from this one rank and hang.  Every rank has to sync first.
+            raise RuntimeError("save_ckpt on a multi-rank run while the sharded optimiser state is stale: call optim.sync_all_sharded() on EVERY rank first (Runner.train does), "
+                               "then save on rank 0")
         os.makedirs(os.path.dirname(path), exist_ok=True)
         ck = {"global_step": self.cfg.m_training_step, "model": self.model.state_dict(), "sampler": self.sampler.state_dict(),
               "optimizer": self.optimizer.state_dict(), "nested_optimizer": self.optimizer._nested_optimizer.state_dict(),
               "ema_optimizer": self.ema_optimizer.state_dict(),
               "extra": {"rng_state": self.sampler.rng_state.copy(), "n_rays_per_batch": self.sampler.n_rays_per_batch}}
-        if self.cfg.ckpt_format == "jittor":     # the reference's container: the six keys of runner.py:124-131 as numpy arrays (jt.load reads it); our "extra" entry has no counterpart there
-            from .utils import jittor_pickle
+        if self.cfg.ckpt_format == "jittor":     # the reference's container: EXACTLY the six keys of runner.py:124-131 as numpy arrays (jt.load reads it); our "extra" entry (generator
+            from .utils import jittor_pickle       # state, adaptive ray count) has no counterpart there - a run resumed from this container restarts those two like the reference does
             ck.pop("extra")
             jittor_pickle.dump(ck, path)
         else:
@@ -365,7 +369,9 @@ class Runner:
         from .utils import jittor_pickle
         with open(path, "rb") as f:
             head = f.read()
-        if head.endswith(jittor_pickle.MAGIC) or self.cfg.ckpt_format == "jittor":
+        # the container is chosen by what the file IS, not by the config: jt.save's trailer | a zip (torch.save) | with `ckpt_format = 'jittor'` a bare pickle of numpy arrays
+        is_zip = head[:4] == b"PK\x03\x04"
+        if head.endswith(jittor_pickle.MAGIC) or (self.cfg.ckpt_format == "jittor" and not is_zip):
             # the reference's own container (jt.save: a pickle of numpy arrays + sha1 + magic, utils/jittor_pickle.py) - read without Jittor
             ckpt = jittor_pickle.to_torch(jittor_pickle.loads(head, path))
         else:
@@ -378,8 +384,11 @@ class Runner:
             raise RuntimeError(f"{path}: unexpected checkpoint layout (keys {list(ckpt)[:8] if isinstance(ckpt, dict) else type(ckpt)}); expected the keys of runner/runner.py:123-135")
         self.start = ckpt["global_step"]
         ref_file = "extra" not in ckpt          # written by the reference's Runner: its module tree may hold buffers ours does not register (and vice versa)
-        self.model.load_state_dict(ckpt["model"], strict=not ref_file)
-        self.sampler.load_state_dict(ckpt["sampler"], strict=not ref_file)
+        for name, mod in (("model", self.model), ("sampler", self.sampler)):
+            res = mod.load_state_dict(ckpt[name], strict=not ref_file)
+            missing, unexpected = (list(getattr(res, "missing_keys", ())), list(getattr(res, "unexpected_keys", ()))) if res is not None else ([], [])
+            if missing or unexpected:       # only possible with strict=False (a file written by the reference's Runner): said, not swallowed
+                print(f"[jnerf_amd] load_ckpt {name}: keys the file lacks {missing[:8]}{' ...' if len(missing) > 8 else ''}; keys it has that this build does not {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''}")
         self.optimizer.load_state_dict(ckpt["optimizer"])
         self.optimizer._nested_optimizer.load_state_dict(ckpt["nested_optimizer"])
         self.ema_optimizer.load_state_dict(ckpt["ema_optimizer"])

@@ -68,3 +68,56 @@ def test_rank_rng_streams_are_disjoint():
     assert (st == r.st).all()
     pcg32_advance(st, 5 << 40); r.advance(5 << 40)
     assert (st == r.st).all()
+
+
+class _FakeLib:
+    """stand-in for libngp_hip.so's communicator entry points: what fails is chosen per rank"""
+    def __init__(self, rank, fail_id_on_rank0, fail_init_on):
+        self.rank, self.fail_id, self.fail_init = rank, fail_id_on_rank0, fail_init_on
+        self.inits = 0
+
+    def ngp_comm_unique_id(self, uid):
+        if self.fail_id:
+            return -1
+        uid.raw = bytes(range(128))[:len(uid.raw)]
+        return 0
+
+    def ngp_comm_init(self, handle_ref, rank, world, idbuf):
+        self.inits += 1
+        return -1 if self.rank in self.fail_init else 0
+
+    def ngp_last_error(self):
+        return b"stand-in failure"
+
+
+def _comm_worker(rank, world, port, out_dir, case):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jnerf_amd import dp
+    fail_id, fail_init = {"id": (True, ()), "init1": (False, (1,)), "ok": (False, ())}[case]
+    lib = _FakeLib(rank, fail_id, fail_init)
+    handle, err = dp._create_comm(rank, world, lib=lib, device="cpu")
+    # the agreement that follows in library_comm_or_fallback: every rank reaches it whatever failed where
+    ok = torch.tensor([0 if handle is None else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    np.save(os.path.join(out_dir, f"c{rank}.npy"), np.array([0 if handle is None else 1, int(ok.item()), lib.inits]))
+    dist.destroy_process_group()
+
+
+def test_communicator_agreement_is_symmetric_whatever_fails(tmp_path):
+    """(r4) rank 0 failing to draw the RCCL unique id used to skip the broadcast its peers were waiting in.  Now rank 0 always broadcasts (the id or None) and every
+    rank walks through the same collectives: with rank 0's id failing, with rank 1's init failing, and with nothing failing, both ranks finish and agree."""
+    for case, want in (("id", [(0, 0, 0), (0, 0, 0)]), ("init1", [(1, 0, 1), (0, 0, 1)]), ("ok", [(1, 1, 1), (1, 1, 1)])):
+        port = _free_port()
+        d = tmp_path / case
+        d.mkdir()
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, str(d), case)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0, (case, p.exitcode)          # (a deadlock shows up as a timeout here)
+        got = [tuple(int(v) for v in np.load(d / f"c{r}.npy")) for r in range(2)]
+        assert got == want, (case, got)
+

@@ -309,3 +309,53 @@ def test_jittor_pickle_container_round_trip(tmp_path):
     evil = pickle.dumps(_os.getcwd)                                    # a pickle that imports something other than numpy must be refused
     with pytest.raises(pickle.UnpicklingError):
         JP.loads(evil)
+
+
+def test_fixed_point_conversion_equals_round_half_even():
+    """(r4) `fixed_rn` (csrc/hash_encode.hip): contribution * 2^k -> nearest 64-bit integer, ties to even, in seven instructions instead of __float2ll_rn's generic expansion.
+    The accumulate kernel's exactness rests on it; the same function compiled for the host is held to Python's exact arithmetic here (c * 2^k is exact in a double)."""
+    import ctypes as C
+    from jnerf_amd import _lib
+    f = _lib.lib().ngp_x_fixed_rn
+    f.restype, f.argtypes = C.c_longlong, [C.c_float, C.c_float]
+    rng = np.random.default_rng(0)
+    for k in (0, 1, 20, 31, 32, 33, 38, 45, 60):
+        s = float(2.0 ** k)
+        c = np.concatenate([rng.standard_normal(4000).astype(np.float32) * np.float32(10.0 ** rng.integers(-12, 2)),
+                            (rng.integers(-2 ** 22, 2 ** 22, 2000).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -k),     # exact ties
+                            np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -40, -(2.0 ** -40)], np.float32)])
+        for v in c:
+            t = float(v) * s
+            if abs(t) >= 2.0 ** 62:
+                continue
+            assert f(float(v), s) == round(t), (float(v), k, f(float(v), s), round(t))
+
+
+@pytest.mark.parametrize("aabb_scale", [1, 2, 4])
+def test_edge_records_x_neighbours_share_a_4096_entry_bin(aabb_scale):
+    """(r4) the invariant the edge records rest on: index = (x ^ y*P1 ^ z*P2) & (2^19 - 1) and x + 1 <= res <= 2048 touches bits 0..11 only, so both x-neighbours of any
+    cell edge of such a level fall into the same 4096-entry slice - for every level the kernel routes that way (res <= 2048), every x, random y / z"""
+    from jnerf_amd import ops
+    t, _, _ = ops.level_table(aabb_scale)
+    rng = np.random.default_rng(1)
+    for size, res in ((int(r[1]), int(r[2])) for r in t):
+        if size != 1 << 19 or res > 2048:
+            continue
+        x = np.arange(0, res, dtype=np.uint32)                     # cell corner 0 .. res - 1, neighbour x + 1 <= res
+        for _ in range(8):
+            y, z = rng.integers(0, res + 1, 2, dtype=np.uint32)
+            h = np.uint32((int(y) * 19349663) & 0xffffffff) ^ np.uint32((int(z) * 83492791) & 0xffffffff)
+            i0, i1 = (x ^ h) & np.uint32(size - 1), ((x + np.uint32(1)) ^ h) & np.uint32(size - 1)
+            assert np.array_equal(i0 >> 12, i1 >> 12), (res, int(y), int(z))
+    fine = [int(r[2]) for r in t if int(r[1]) == 1 << 19 and int(r[2]) > 2048]
+    assert (len(fine) > 0) == (aabb_scale > 1)                     # aabb_scale 1 (ngp_base.py): every hashed level pairs; beyond: the finest levels emit single records
+
+
+def test_hash_backward_workspace_size_is_monotonic_and_bounded():
+    """ngp_hash_bwd_workspace_bytes: what the caller allocates once for the whole run: grows with n, both level tables, stays far below the 288 GB of the device"""
+    from jnerf_amd import ops
+    for aabb_scale in (1, 4):
+        t, _, _ = ops.level_table(aabb_scale)
+        sizes = [ops.hash_bwd_workspace_bytes(t, n) for n in (1024, 1 << 14, 1 << 18, 1 << 20)]
+        assert all(a < b for a, b in zip(sizes, sizes[1:])), sizes
+        assert sizes[2] < 3 * 2 ** 30 and sizes[3] < 12 * 2 ** 30, sizes
