@@ -13,10 +13,12 @@
 //  * no extract_position / transpose kernels: positions are read strided from the caller's buffer and features are written
 //    either as the [n,32] rows HashEncoder returns or as a level-major [16][n] stream of pairs that the fused MLP consumes with
 //    fully coalesced 256-B wave accesses (no 4-byte-per-64-byte-line partial writes from sixteen different XCDs).
-//  * backward: three implementations, chosen by what the caller hands over (hash_bwd_impl).  With a workspace (the training path): a binned scatter without any float
-//    atomic - every contribution computed once, written as a record into the list of the bin its entry lives in, summed per bin in 64-bit integer LDS accumulators,
-//    coarse levels with per-thread run combining; bit-reproducible.  Without one: an owner-computes scan (a workgroup owns a slice of a level in LDS and filters the
-//    sample stream).  NGP_HASH_BWD_ATOMICS=1 or a non-power-of-two hashed table: the reference's scheme, one global float atomic per corner.
+//  * backward: chosen by what the caller hands over (hash_bwd_impl).  With a workspace (the training path): a binned scatter without any float atomic - every
+//    contribution computed once, written as a record for the bin its entry lives in, summed per bin in 64-bit integer LDS accumulators, coarse levels with per-thread run
+//    combining; bit-reproducible.  fp32 dL/dy (ngp_base.py), round 4: record REGIONS - no global atomic of any kind, one 16-byte record per cell edge on the fine levels, one
+//    accumulate kernel for all levels (k_bin_runs2 / k_bin_pairs / k_bin_accumulate2).  fp16 dL/dy (ngp_fox.py): round 2/3's per-corner record lists with cursor
+//    reservations (k_bin_records_runs / k_bin_records / k_bin_accumulate).  Without a workspace: an owner-computes scan (a workgroup owns a slice of a level in LDS and
+//    filters the sample stream).  NGP_HASH_BWD_ATOMICS=1 or a non-power-of-two hashed table: the reference's scheme, one global float atomic per corner.
 #include "ngp_common.h"
 #include <stdlib.h>
 #include <string.h>
