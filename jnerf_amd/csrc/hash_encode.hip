@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 //   * The hash is x ^ y*P1 ^ z*P2 masked to 19 bits and x + 1 <= res <= 2048 touches bits 0..11 only: the two x-neighbours of a cell edge ALWAYS fall into the same
 //     4096-entry slice of the level.  Bins are 4096 entries (128 per level) and ONE record carries the edge: {a = g.x*(wy*wz), b = g.y*(wy*wz), fx, slot0 | slot1 << 12},
 //     16 bytes for two contributions (a*(1-fx), b*(1-fx) -> slot0; a*fx, b*fx -> slot1; the accumulate kernel multiplies: three roundings per contribution like the
-//     reference's ((wx*wy)*wz)*g, in another order - within 2 ulp of it per contribution, far inside what the reference's float atomics scatter around the exact sum;
+//     reference's ((wx*wy)*wz)*g, in another order - each within 3 * 2^-24 of the exact product, up to 4 ulp apart (tests/test_host_cpu.py), far inside what the reference's float atomics scatter around the exact sum;
 //     the accumulation itself stays exact, 64-bit integers).
 //   * Every record workgroup owns a REGION of the record area (4 x its samples records): it sorts its edge records by bin in LDS (histogram, prefix, staging - as before)
 //     and writes the staged block out as it is - one contiguous, fully coalesced 64 KiB store stream - plus the 129 bin offsets inside its region (u16).  Nothing is
