@@ -3,7 +3,7 @@
 set -u
 R=$PWD
 mkdir -p gpurun_out
-WHAT=${1:-all}
+WHAT=${1:-all}     # all | tests | bench | profiles | parts | curve | counters (the last one never as part of `all`)
 if [ $WHAT = all ] || [ $WHAT = tests ]; then
 bash tools/gpu.sh tests > /dev/null 2>&1; tail -6 gpurun_out/tests_gpu.log; cp gpurun_out/tests_gpu.log gpurun_out/r04_tests_gpu.log
 fi
@@ -13,7 +13,12 @@ bash tools/gpu.sh bench r04_bench_fox --config fox --no-fox --no-neus
 bash tools/gpu.sh bench r04_bench_driver_style --gpus 1 --steps 20 --warmup 5
 fi
 if [ $WHAT = all ] || [ $WHAT = profiles ]; then
-bash tools/collect_profiles_r04.sh all > gpurun_out/r04_collect.log 2>&1; tail -25 gpurun_out/r04_collect.log
+bash tools/collect_profiles_r04.sh trace > gpurun_out/r04_collect.log 2>&1; tail -12 gpurun_out/r04_collect.log
+fi
+# counter passes ONLY on request and in a call of their own: ~7 minutes EACH on this stack (every dispatch is serialised under --pmc); `all` does not include them
+if [ $WHAT = counters ]; then
+bash tools/collect_profiles_r04.sh pmc > gpurun_out/r04_collect_pmc.log 2>&1; tail -12 gpurun_out/r04_collect_pmc.log
+bash tools/collect_profiles_r04.sh mfma > gpurun_out/r04_collect_mfma.log 2>&1; tail -12 gpurun_out/r04_collect_mfma.log
 fi
 if [ $WHAT = all ] || [ $WHAT = parts ]; then
 cd /tmp && export TMPDIR=/tmp
