@@ -1370,9 +1370,9 @@ struct RunRec { float x, y; uint32_t loc; };
 #define RUN2_OFFS (PAIR_BINS + 2u)
 __host__ __device__ static inline uint32_t run2_region_records() { return RUN_WG * RUN_K * 8u + 4u; }
 static uint32_t run2_stage_bytes(uint32_t stage) { return stage * 12u + (3u * PAIR_BINS + 4u) * 4u; }
-__device__ __forceinline__ uint32_t bin2_of(uint32_t e, bool il) { return il ? (e >> 3) & (PAIR_BINS - 1u) : e >> PAIR_BIN_BITS; }
-__device__ __forceinline__ uint32_t local2_of(uint32_t e, bool il) { return il ? ((e >> 10) << 3) | (e & 7u) : e & (PAIR_BIN_ENTRIES - 1u); }
-__device__ __forceinline__ uint32_t entry2_of(uint32_t bin, uint32_t local, bool il) { return il ? ((local >> 3) << 10) | (bin << 3) | (local & 7u) : (bin << PAIR_BIN_BITS) | local; }
+__host__ __device__ __forceinline__ uint32_t bin2_of(uint32_t e, bool il) { return il ? (e >> 3) & (PAIR_BINS - 1u) : e >> PAIR_BIN_BITS; }
+__host__ __device__ __forceinline__ uint32_t local2_of(uint32_t e, bool il) { return il ? ((e >> 10) << 3) | (e & 7u) : e & (PAIR_BIN_ENTRIES - 1u); }
+__host__ __device__ __forceinline__ uint32_t entry2_of(uint32_t bin, uint32_t local, bool il) { return il ? ((local >> 3) << 10) | (bin << 3) | (local & 7u) : (bin << PAIR_BIN_BITS) | local; }
 
 template <typename T, int LAYOUT, int OCC>
 __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
@@ -1499,6 +1499,14 @@ __host__ __device__ __forceinline__ long long fixed_rn(float c, float s) {
 	return r < 0.f ? -v : v;
 }
 static_assert(ACC2_RB == ACC2_WG, "gather_flat builds one segment-table row per thread");
+// test hook (tests/test_host_cpu.py): entry of a level with `size` entries -> (bin, slot inside the bin, entry rebuilt from them, slots the bin's accumulate workgroup owns) as the region
+// kernels and k_bin_accumulate2 compute them
+NGP_API void ngp_x_bin2_map(uint32_t size, uint32_t e, uint32_t *out4_host) {
+	const bool il = size < BIN_LEVEL_MAX;
+	const uint32_t bin = bin2_of(e, il), local = local2_of(e, il), groups_all = (size + 7u) >> 3;
+	out4_host[0] = bin; out4_host[1] = local; out4_host[2] = entry2_of(bin, local, il);
+	out4_host[3] = il ? (groups_all > bin ? ((groups_all - bin + PAIR_BINS - 1u) / PAIR_BINS) << 3 : 0u) : PAIR_BIN_ENTRIES;
+}
 // test hook (tests/test_host_cpu.py): the same function on the host, against round-half-even of the exact product
 NGP_API long long ngp_x_fixed_rn(float c, float s) { return fixed_rn(c, s); }
 // The records of one (level, bin) lie in n_regions segments (one per record workgroup).  Per block of ACC2_RB regions: segment table (start, length) -> exclusive prefix P in LDS ->

@@ -383,3 +383,25 @@ def test_edge_record_multiplication_order_carries_the_references_error_bound():
                 assert (np.abs(ours[m] - exact[m]) <= bound * np.abs(exact[m]) * (1 + 1e-9)).all() and (np.abs(ref[m] - exact[m]) <= bound * np.abs(exact[m]) * (1 + 1e-9)).all()
                 ulp = np.spacing(np.abs(ref[m])).astype(np.float64)
                 assert (np.abs(ours[m].astype(np.float64) - ref[m].astype(np.float64)) <= 4.0 * ulp).all()
+
+
+@pytest.mark.parametrize("aabb_scale", [1, 4])
+def test_region_path_bin_mapping_is_a_bijection_on_every_level(aabb_scale):
+    """(r4) entry -> (bin, slot) -> entry of the region kernels / k_bin_accumulate2 (csrc/hash_encode.hip: bin2_of, local2_of, entry2_of), compiled for the host: every entry of every
+    level maps to a slot inside the range its bin's accumulate workgroup zeroes and writes out, no two entries share a slot, and the way back is exact - small (dense) levels are dealt to
+    the 128 bins in interleaved groups of eight, full 2^19-entry levels in 4096-entry slices"""
+    import ctypes as C
+    from jnerf_amd import _lib, ops
+    f = _lib.lib().ngp_x_bin2_map
+    f.restype, f.argtypes = None, [C.c_uint32, C.c_uint32, C.c_void_p]
+    out = (C.c_uint32 * 4)()
+    t, _, _ = ops.level_table(aabb_scale)
+    for size in sorted({int(r[1]) for r in t}):
+        step = 1 if size <= 80000 else 37                          # the two largest dense levels and the hashed ones: a stride of entries (plus both ends)
+        seen = set()
+        for e in list(range(0, size, step)) + [size - 1]:
+            f(size, e, out)
+            b, l, back, n_local = int(out[0]), int(out[1]), int(out[2]), int(out[3])
+            assert back == e and b < 128 and l < n_local <= 4096, (size, e, b, l, back, n_local)
+            assert (b, l) not in seen or e == size - 1
+            seen.add((b, l))
