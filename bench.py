@@ -234,6 +234,59 @@ HASH_BWD_STAGE = ("k_level_absmax", "k_bin_records_runs", "k_bin_records", "k_bi
 HASH_BWD_ACC = ("k_bin_accumulate", "k_bin_accumulate2")
 
 
+
+PMC_ROUND = "r05"          # the round whose counter passes describe THIS tree's kernels (profiles/<round>_pmc.json)
+
+
+def pmc_lookup(config, scene):
+    """per-kernel counter entries of this round's committed --pmc passes for (config, scene), and where they came from; ({}, None) if there is no such pass"""
+    path = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc.json")
+    try:
+        pm = json.load(open(path))
+    except Exception:
+        return {}, None
+    if pm.get("_scenes", {}).get(config) != scene or not pm.get(config):
+        return {}, None
+    return pm[config], f"profiles/{PMC_ROUND}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{pm.get('_commands', {}).get(config, '?')}`: this tree, this scene; not measured in this run)"
+
+
+def mfma_roofline(k, alg_flops, n, ms, fp16, counters=None):
+    """The MFMA-side roofline of a fused field kernel, against the pipe its instructions ISSUE on.
+    fp16 configuration / exact-product fp32 kernels: algorithmic FLOPs over the dense peak of their own MFMA (2.5 PFLOP/s fp16 16x16x32 | 157.3 TFLOP/s fp32 16x16x4).
+    Split-operand kernels (fp32-accurate products from three v_mfma_f32_16x16x32_f16 each, csrc/field_split.hip): they run on the fp16 pipe, so `frac` is what they
+    issue there - 3 x the fp32-equivalent products incl. the backward's forward recompute - over 2.5 PFLOP/s (the fp32-MFMA peak is not a ceiling for
+    them - the forward would print 1.06 of it).  The fp32-equivalent rate and its ratio to the fp32 MFMA peak stay as the secondary `fp32_equivalent`."""
+    counters = counters or {}
+    sec = ms * 1e-3
+    split = k in SPLIT_FP16_KERNELS
+    tf_alg = alg_flops / sec / 1e12
+    exec_fps = EXECUTED_FLOPS_PER_SAMPLE[k]                     # FLOP per sample the kernel issues on its pipe (split: 3 fp16 products per fp32-accurate product)
+    tf_issued = exec_fps * n / sec / 1e12
+    if split:
+        r = {"bound": "mfma", "achieved": round(tf_issued, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf_issued / 2500.0, 4),
+             "pipe": "fp16 MFMA (v_mfma_f32_16x16x32_f16), split operands: `achieved` = FLOPs ISSUED on that pipe (3 products per fp32-accurate product, incl. the backward's forward recompute)",
+             "alg_frac_of_pipe": round(tf_alg / 2500.0, 4),         # SURVEY.md 8(d)'s fp32 FLOPs over the pipe the kernel occupies
+             "frac_of_split_ceiling": round(tf_alg / (2500.0 / 3.0), 4),   # the technique's own ceiling: a third of the fp16 pipe in fp32-equivalent products
+             "fp32_equivalent": {"achieved": round(tf_alg, 1), "peak": 157.3, "unit": "TFLOP/s", "ratio": round(tf_alg / 157.3, 4),
+                                 "note": "fp32-accurate algorithmic FLOPs (SURVEY.md 8d) vs the fp32 MFMA peak the configuration would otherwise be limited by - a comparison, NOT a ceiling of this kernel (it can exceed 1)"}}
+    else:
+        peak = 2500.0 if fp16 else 157.3
+        r = {"bound": "mfma", "achieved": round(tf_alg, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf_alg / peak, 4),
+             "executed_frac": round(tf_issued / peak, 4)}         # counts the in-kernel forward recompute of the backward as work
+    r.update({"alg_flop_per_sample": alg_flops / n, "issued_flop_per_sample": exec_fps,
+              "issued_frac_counters": counters.get("mfma_issued_frac"), "pipe_util_counters": counters.get("mfma_pipe_util")})   # this round's MFMA-counter pass, null if absent
+    return r
+
+
+def step_algorithmic_bytes(n, P, fp16):
+    """SURVEY.md 8(d) / DESIGN.md 4: algorithmic bytes of ONE training iteration - every logically required byte once.
+    per sample: hash fwd 12 + 128 T2 + 32 T | field fwd 32 T + 12 + 4 T | compositing fwd 4 T + 28, bwd 8 T + 28 | field bwd 64 T + 12 + 4 T | hash bwd 12 + 32 T + 128 T2
+    | marcher record + compact position 40;   per parameter: 28 (fp32) | 30 (fp16: + the shadow)          (T = 2 | 4 bytes, T2 = one 2-feature entry)"""
+    T = 2 if fp16 else 4
+    per_sample = (12 + 128 * 2 * T + 32 * T) + (36 * T + 12) + (4 * T + 28) + (8 * T + 28) + (68 * T + 12) + (12 + 32 * T + 128 * 2 * T) + 40
+    return n * per_sample + P * (30 if fp16 else 28), per_sample
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,43 +427,24 @@ def main():
     n_runs = int((runner.model.pos_encoder.level_table.reshape(16, 4)[:, 2] <= 300).sum())
     alg, flops = alg_bytes_table(mean_valid, P, mean_rays, n_refresh, fp16, n_runs)
     roof = None
+    pmc, traffic_source = pmc_lookup(args.config, scene)
     if dom is not None and dom_ms:
         cls = batch_class(dom_ms)
         avg_raw = sum(cls) / len(cls)
         avg_ms = max(avg_raw - ev_overhead, 1e-6)
         nbytes = float(alg.get(dom, 0.0))
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch: rocprofv3 cannot run inside this process, so this is a LOOK-UP in the committed --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-        # command (tools/collect_profiles.sh), newest round first; `traffic_source` says which file (null = no such pass committed)
-        traffic, traffic_source, counters = None, None, {}
-        for tag in ("r04", "r03", "r02"):
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
-                ent = pm.get(args.config, {}).get(dom, {})
-                if ent.get("hbm_bytes_per_launch") is not None:
-                    traffic, traffic_source, counters = ent["hbm_bytes_per_launch"], f"profiles/{tag}_pmc.json (rocprofv3 --pmc passes of this command; not measured in this run)", ent
-                    break
-            except Exception:
-                pass
+        # HBM bytes per launch: rocprofv3 cannot run inside this process, so this is a LOOK-UP in the committed --pmc FETCH_SIZE / WRITE_SIZE passes of this round's tree
+        # (tools/collect_profiles.sh -> profiles/r05_pmc.json).  Only a pass of THIS round, THIS configuration and THIS scene counts: anything else is
+        # another kernel generation or another workload, and `traffic` is null.
+        counters = pmc.get(dom, {})
+        traffic = counters.get("hbm_bytes_per_launch")
+        if traffic is None:
+            traffic_source = None if not pmc else traffic_source + " - no entry for this kernel"
         hbm = {"achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4)}
         if dom in flops:    # the fused field kernels are MFMA work (fp16 16x16x32: dense peak 2.5 PFLOP/s; fp32 16x16x4: 157.3 TFLOP/s); their HBM side is reported next to it
-            split = dom in SPLIT_FP16_KERNELS
-            # `peak` is the dense MFMA peak of the ARITHMETIC THE CONFIGURATION ASKS FOR: fp16 products (2.5 PFLOP/s) for ngp_fox.py, fp32 products (157.3 TFLOP/s) for
-            # ngp_base.py - also when the kernel obtains its fp32-accurate products from three fp16 MFMAs each (csrc/field_split.hip); what that kernel does to the pipe it
-            # actually runs on is reported separately in `fp16_pipe`
-            peak = 2500.0 if fp16 else 157.3
-            tf = flops[dom] / (avg_ms * 1e-3) / 1e12
-            exec_fps = EXECUTED_FLOPS_PER_SAMPLE[dom] / (3.0 if split else 1.0)     # fp32-equivalent products the kernel evaluates (incl. its forward recompute)
-            tf_exec = exec_fps * mean_valid / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "hbm": hbm,
-                    "alg_flop_per_sample": flops[dom] / mean_valid, "executed_flop_per_sample": exec_fps,
-                    "executed_frac": round(tf_exec / peak, 4),                      # counts the in-kernel forward recompute of the backward as work
-                    "issued_frac": counters.get("mfma_issued_frac"), "pipe_util": counters.get("mfma_pipe_util")}   # from the committed MFMA-counter pass (same source file as `traffic`), null if absent
-            if split:
-                roof["fp16_pipe"] = {"note": "split operands: every fp32-accurate product is three v_mfma_f32_16x16x32_f16 products; the kernel is LDS- and VALU-bound, not MFMA-bound",
-                                     "issued_TFLOPs": round(3.0 * tf_exec, 1), "peak": 2500.0, "frac": round(3.0 * tf_exec / 2500.0, 4),
-                                     # the ceiling the technique itself allows: a third of the fp16 pipe, in fp32-equivalent products
-                                     "frac_of_split_ceiling": round(tf / (2500.0 / 3.0), 4), "executed_frac_of_split_ceiling": round(tf_exec / (2500.0 / 3.0), 4)}
+            roof = mfma_roofline(dom, flops[dom], mean_valid, avg_ms, fp16, counters)
+            roof["hbm"] = hbm
         else:
             roof = dict(bound="hbm", **hbm)
         # the hash-backward STAGE is four launches under four kernel names (abs-max, two record passes, accumulate): one roofline for the stage, from the probe steps
@@ -419,9 +453,24 @@ def main():
         if any(k in st_kernels for k in HASH_BWD_ACC):
             st_ms = sum(max(sum(batch_class(probe_ms[k])) / len(batch_class(probe_ms[k])) - ev_overhead, 0.0) * (len(probe_ms[k]) / probe if k in HASH_BWD_ACC else 1.0) for k in st_kernels)
             T_ = 2 if fp16 else 4
-            st_bytes = mean_valid * (12 + 32 * T_ + 16 * 8 * 2 * 4)                 # §8(d): pos + dL/dy + 128 scattered fp32 updates per sample
+            st_bytes = mean_valid * (12 + 32 * T_ + 128 * 2 * T_)                  # pos + dL/dy + 128 scattered table-element updates per sample (588 | 1164 B)
+            st_traffic = [pmc.get(k, {}).get("hbm_bytes_per_launch") for k in st_kernels]
+            st_traffic = None if (not st_traffic or any(x is None for x in st_traffic)) else int(sum(st_traffic))
             stage = {"name": "hash_backward", "kernels": st_kernels, "ms": round(st_ms, 4), "alg_bytes": int(st_bytes), "achieved": round(st_bytes / (st_ms * 1e-3) / 1e9, 1),
-                     "peak": 8000.0, "unit": "GB/s", "frac": round(st_bytes / (st_ms * 1e-3) / 8e12, 4)}
+                     "peak": 8000.0, "unit": "GB/s", "frac": round(st_bytes / (st_ms * 1e-3) / 8e12, 4),
+                     # counter bytes of the stage's launches (this round's --pmc passes) over its algorithmic bytes: > 1 = records written and read back, re-reads
+                     "traffic": st_traffic, "traffic_ratio": None if st_traffic is None else round(st_traffic / st_bytes, 3)}
+        # the WHOLE iteration against HBM - the figure SURVEY.md 8(d) asks for: algorithmic bytes of one iteration over the measured step time (timed region, wall clock)
+        step_bytes, per_sample_bytes = step_algorithmic_bytes(mean_valid, P, fp16)
+        step_ms = dt / args.steps * 1e3
+        step_traffic = None
+        if pmc:     # counter bytes of every library launch of one step: per-launch figure x launches per step (probe steps); kernels the pass does not list make it null
+            parts = [(pmc.get(k, {}).get("hbm_bytes_per_launch"), len(v) / probe) for k, v in probe_ms.items() if per_step.get(k, 0.0) > 0.002]
+            step_traffic = None if any(x is None for x, _ in parts) else int(sum(x * c for x, c in parts))
+        roof["step"] = {"alg_bytes": int(step_bytes), "alg_bytes_per_sample": per_sample_bytes, "bytes_per_parameter": 30 if fp16 else 28, "ms": round(step_ms, 4),
+                        "GBps": round(step_bytes / (step_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "frac_hbm": round(step_bytes / (step_ms * 1e-3) / 8e12, 4),
+                        "ceiling_iters_per_s": round(8e12 / step_bytes, 1), "traffic": step_traffic,
+                        "traffic_ratio": None if step_traffic is None else round(step_traffic / step_bytes, 3)}
         roof.update({"kernel": dom, "traffic": traffic, "traffic_source": traffic_source, "stage": stage, "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_raw": round(avg_raw, 4), "event_pair_overhead_ms": round(ev_overhead, 4),
                      "launches_timed": len(cls), "launches_other_size_class": len(dom_ms) - len(cls), "alg_bytes_per_launch": int(nbytes),
                      "share_of_kernel_time": round(per_step[dom] / max(sum(per_step.values()), 1e-9), 4),
@@ -442,9 +491,13 @@ def main():
             row = {"avg_launch_ms": round(ms, 4), "launches_per_step": round(len(v) / probe, 2), "alg_GBps": round(alg.get(k, 0.0) / (ms * 1e-3) / 1e9, 1),
                    "frac_hbm": round(alg.get(k, 0.0) / (ms * 1e-3) / 8e12, 4)}
             if k in flops:
-                row["TFLOPs"] = round(flops[k] / (ms * 1e-3) / 1e12, 1)
+                mr = mfma_roofline(k, flops[k], mean_valid, ms, fp16)
+                row.update({"TFLOPs": mr["achieved"], "mfma_peak": mr["peak"], "frac_mfma": mr["frac"]})
                 if k in SPLIT_FP16_KERNELS:
-                    row["pipe"] = "fp16 MFMA, split operands (3 products per fp32-accurate product); TFLOPs = fp32-equivalent algorithmic rate (fp32 MFMA peak: 157.3)"
+                    row["pipe"] = "fp16 MFMA, split operands: TFLOPs = issued on the fp16 pipe (3 products per fp32-accurate product)"
+                    row["fp32_equivalent_TFLOPs"] = mr["fp32_equivalent"]["achieved"]
+            if pmc.get(k, {}).get("hbm_bytes_per_launch") is not None:
+                row["traffic"] = pmc[k]["hbm_bytes_per_launch"]
             pk[k] = row
         extra["probe_kernels"] = pk
     if not args.no_psnr and rank == 0:

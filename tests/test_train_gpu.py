@@ -307,6 +307,14 @@ def test_bench_contract_small():
     assert rf["ms_per_step_by_kernel"][rf["kernel"]] == max(rf["ms_per_step_by_kernel"].values())
     assert {"k_hash_fwd", "k_adam_ema", "k_composite_fwd", "k_composite_bwd"} <= set(d["extra"]["probe_kernels"])
     assert any(k.startswith("k_march") for k in d["extra"]["probe_kernels"])
+    # (r5) no fraction above 1 is printable: split-operand kernels are scored on the fp16 pipe they issue on; the whole-step HBM fraction is in the line;
+    # `traffic` is null unless this round's counter pass of this scene is committed (this tiny scene has none)
+    assert 0.0 < rf["frac"] <= 1.0 and rf["achieved"] <= rf["peak"]
+    st = rf["step"]
+    assert st["alg_bytes"] > 0 and 0.0 < st["frac_hbm"] <= 1.0 and abs(st["GBps"] - st["alg_bytes"] / (d["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * st["GBps"] + 0.1
+    assert rf["traffic"] is None and rf["traffic_source"] is None
+    for k, row in d["extra"]["probe_kernels"].items():
+        assert row["frac_hbm"] <= 1.0 and row.get("frac_mfma", 0.0) <= 1.0, (k, row)
 
 
 def test_render_survives_sample_capacity_overflow():

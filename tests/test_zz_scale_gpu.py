@@ -1,15 +1,15 @@
 """-m gpu: the hash-grid backward's region path (round 4) at a batch LARGER than anything the training configurations use - more than 512 record regions per level, so the
 accumulate kernel's gather walks its segment table in two blocks (csrc/hash_encode.hip: gather_flat's `w0` loop) and the run kernel fills 293 regions.
 
-WRITTEN AFTER round 4's GPU minutes were spent: the one-block case (n <= 2^19 samples) is what every other test and the bench exercise; this file has not run on an MI355X yet, hence
-xfail(strict=False) - an XPASS in the driver's round-end run is its first hardware evidence, a failure does not stop the suite.  Remove the marker once it has been seen to pass."""
+The one-block case (n <= 2^19 samples) is what every other test and the bench exercise.  First hardware run: the driver's round-4 end-of-round suite (GPUTEST_r04.json: XPASS) - the
+xfail marker it carried until then is gone, a regression now fails the suite."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import oracle as O
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first GPU run happens outside the authoring session (round 4 ended without GPU minutes)")]
+pytestmark = pytest.mark.gpu
 
 
 def test_hash_bwd_region_path_beyond_512_regions():

@@ -3,7 +3,7 @@ by the kernel's base name (what bench.py's `roofline.kernel` names), under the c
 FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: gfx950 tallies 128-B requests at 64 B), WRITE_SIZE taken as reported (KiB); both are the fabric-side
 request counters of the L2, so Infinity-Cache hits are included.  One kernel serves launches of different sizes (k_hash_fwd: the batch and the occupancy
 refresh; k_adam_ema: the table and the weight pack): the class with the most dispatches among the last 64 is reported, like bench.py's batch class.
-usage: rocprof_pmc_json.py fetch.db write.db out.json "<command line profiled>" <config key>"""
+usage: rocprof_pmc_json.py fetch.db write.db out.json "<command line profiled>" <config key> <scene>     (bench.py uses an entry only for the same config AND scene)"""
 import json
 import re
 import sqlite3
@@ -34,7 +34,7 @@ def per_kernel(db, counter):
     return res
 
 
-def main(fetch_db, write_db, out, command, key="lego"):
+def main(fetch_db, write_db, out, command, key="lego", scene="bricks"):
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     try:
         res = json.load(open(out))
@@ -44,7 +44,10 @@ def main(fetch_db, write_db, out, command, key="lego"):
                       "correction": "hbm_bytes_per_launch = 2 * FETCH_SIZE_KiB * 1024 + WRITE_SIZE_KiB * 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads; WRITE_SIZE uncalibrated, as reported). "
                                     "The 256 MiB Infinity Cache sits behind these counters' tap, so re-reads that hit it are still counted."}
     res.setdefault("_commands", {})[key] = command
+    res.setdefault("_scenes", {})[key] = scene
     res[key] = {}
+    if not (set(f) & set(w)):
+        print('NO kernel has both counters - pass incomplete; nothing written for', key); return
     for k in sorted(set(f) & set(w)):
         res[key][k] = {"launches_sampled": f[k]["launches"], "grid": f[k]["grid"], "FETCH_SIZE_KiB": round(f[k]["avg"], 1), "WRITE_SIZE_KiB": round(w[k]["avg"], 1),
                        "hbm_bytes_per_launch": int(2 * f[k]["avg"] * 1024 + w[k]["avg"] * 1024)}
@@ -53,4 +56,4 @@ def main(fetch_db, write_db, out, command, key="lego"):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])
