@@ -299,6 +299,7 @@ def main():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-fox", action="store_true", help="skip the real-fox leg (extra.fox)")
     ap.add_argument("--no-neus", action="store_true", help="skip the NeuS leg (extra.neus: BASELINE configs[4] on the procedural DTU-layout scene)")
+    ap.add_argument("--no-lego-gate", action="store_true", help="skip extra.lego_gate (the 40 000-step NeRF-synthetic lego run + test PSNR; only runs when the data set is mounted)")
     ap.add_argument("--scene", default=None, choices=["bricks", "spheres"], help="procedural scene.  lego config default: bricks = the lego-difficulty stand-in (2.5 %% occupied cells, hard edges, "
                     "thin parts, 35.5 dB after the full schedule; VERDICT r3) - spheres (four soft spheres, > 47 dB: rounds 1-3's headline scene) is reported as extra.spheres; fox config default: spheres")
     ap.add_argument("--no-spheres", action="store_true", help="skip the extra.spheres leg of the lego line")
@@ -411,7 +412,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     last_loss = loss.mean().item() if loss is not None else float("nan")
-    runner.drain()
+    runner.finish()                         # drain + the final (collective, synchronous) poll of the split kernels' range flag
     on_stream.close()
     torch.cuda.synchronize()
     ops.prof_enable("")
@@ -542,6 +543,16 @@ def main():
         extra["fox"] = fox_leg()
     if rank == 0 and not use_dist and not args.no_neus:
         extra["neus"] = neus_leg()
+    if rank == 0 and not use_dist and not args.no_lego_gate:
+        # the headline gate itself (README.md:114-120): runs when NeRF-synthetic lego is mounted ($NGP_LEGO_DIR | data/lego), says "not runnable" otherwise (tools/lego_gate.py)
+        runner = None
+        torch.cuda.empty_cache()
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from lego_gate import lego_gate
+            extra["lego_gate"] = lego_gate()
+        except Exception as e:            # an extra leg must never take the headline line down with it
+            extra["lego_gate"] = {"gate": "failed to run", "error": repr(e)[:300]}
     if rank == 0:
         exact = os.environ.get("NGP_FIELD32_FWD", "split")[:1] in ("m", "0") and os.environ.get("NGP_FIELD32_BWD", "3") != "3"
         field = ("fp32 field network on fp32 MFMAs" if exact else
@@ -635,7 +646,7 @@ def spheres_leg(n_images, res, burn_in=768, timed=200):
     return out
 
 
-def fox_leg(burn_in=1024, timed=200, total=3000):
+def fox_leg(burn_in=1024, timed=200, total=3000, psnr=True, marker=None):
     """BASELINE config [1] on the REAL scene: this repository's projects/ngp/configs/ngp_fox.py - the reference's file restated with `_base_` inheritance, equal key by key
     (tests/test_host_cpu.py) - i.e. fp16 fused MLP, aabb_scale 4, cone stepping, on data/fox
     (50 photographs 1080x1920, copied from the reference checkout by build()): iters/s in steady state and PSNR on the scene's own test split."""
@@ -659,6 +670,8 @@ def fox_leg(burn_in=1024, timed=200, total=3000):
         with r.training_stream():
             for i in range(burn_in):
                 r.train_step(i)
+            if marker is not None:
+                marker()                        # (tools/profile_part.py: the kernel trace is cut here)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for i in range(burn_in, burn_in + timed):
                 r.train_step(i)
@@ -666,15 +679,21 @@ def fox_leg(burn_in=1024, timed=200, total=3000):
             for i in range(burn_in + timed, total):
                 r.train_step(i)
             r.drain()
-        from jnerf_amd.utils.registry import build_from_cfg, DATASETS
-        r.dataset["test"] = build_from_cfg(cfg.dataset.test, DATASETS)
-        ps = []
-        for v in range(r.dataset["test"].n_images):
-            img, _, tar = r.render_img("test", v)
-            ps.append(float(-10 * np.log10(np.mean((img - tar) ** 2))))
         out = {"config": "projects/ngp/configs/ngp_fox.py (the reference's values, restated), data/fox: %d images %dx%d" % (r.dataset["train"].n_images, r.W, r.H), "iters_per_s": round(timed / dt, 1),
-               "ms_per_step": round(dt / timed * 1e3, 4), "steps_timed": timed, "burn_in_steps": burn_in, "psnr_test_split_after_%d_steps" % total: round(float(np.mean(ps)), 2),
+               "ms_per_step": round(dt / timed * 1e3, 4), "steps_timed": timed, "burn_in_steps": burn_in,
                "rays_per_batch": r.sampler.n_rays_per_batch, "load_s": round(t_load, 1), "dtype": "f16"}
+        # whole-step HBM fraction of this leg: algorithmic bytes of one iteration (2^18-sample budget x the fill the sampler reaches; counted at the full
+        # budget here: the leg keeps no device-side sample statistics) over the measured step time
+        sb, _ = step_algorithmic_bytes(float(r.sampler.target_batch_size), r.model.pos_encoder.n_params, True)
+        out["step_roofline"] = {"alg_bytes_at_full_batch": int(sb), "GBps": round(sb / (dt / timed) / 1e9, 1), "frac_hbm": round(sb / (dt / timed) / 8e12, 4)}
+        if psnr:
+            from jnerf_amd.utils.registry import build_from_cfg, DATASETS
+            r.dataset["test"] = build_from_cfg(cfg.dataset.test, DATASETS)
+            ps = []
+            for v in range(r.dataset["test"].n_images):
+                img, _, tar = r.render_img("test", v)
+                ps.append(float(-10 * np.log10(np.mean((img - tar) ** 2))))
+            out["psnr_test_split_after_%d_steps" % total] = round(float(np.mean(ps)), 2)
         del r
         return out
     finally:

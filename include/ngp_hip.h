@@ -232,6 +232,8 @@ int ngp_comm_unique_id(void *id_out_host);
 /* every rank, with its device current: ncclCommInitRank.  *comm_out is an opaque handle for the calls below */
 int ngp_comm_init(void **comm_out, int rank, int world, const void *id_host);
 int ngp_comm_destroy(void *comm);
+/* ncclCommAbort: also terminates the communicator's collectives still in flight on the device (a communicator whose self-test never completed). */
+int ngp_comm_abort(void *comm);
 int ngp_comm_rank_world(void *comm, int *rank_out, int *world_out);
 /* SUM all-reduce, in place, of n_bufs gradient buffers (device pointers in a HOST array; counts in elements; dtypes NGP_F32 | NGP_F16) as one RCCL group on `stream` */
 int ngp_allreduce_grads(void *comm, void *stream, int n_bufs, void *const *bufs_host, const uint64_t *counts_host, const int *dtypes_host);

@@ -114,6 +114,7 @@ SIGNATURES = {
     "ngp_comm_unique_id": (C.c_int, [_vp]),
     "ngp_comm_init": (C.c_int, [C.POINTER(_vp), _i32, _i32, _vp]),
     "ngp_comm_destroy": (C.c_int, [_vp]),
+    "ngp_comm_abort": (C.c_int, [_vp]),
     "ngp_comm_rank_world": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "ngp_allreduce_grads": (C.c_int, [_vp, _vp, _i32, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_i32)]),
     "ngp_dp_plan": (C.c_int, [_vp, _u64, _i32, _i32, _i32, C.POINTER(NgpDpPlan)]),

@@ -24,6 +24,7 @@ struct Rccl {
 	int (*GetUniqueId)(RcclId *) = nullptr;
 	int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
 	int (*CommDestroy)(void *) = nullptr;
+	int (*CommAbort)(void *) = nullptr;
 	int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
 	int (*ReduceScatter)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
 	int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
@@ -42,7 +43,7 @@ void load_rccl() {
 		if (names[i] && names[i][0]) g_rccl.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
 	if (!g_rccl.handle) { snprintf(g_rccl.why, sizeof(g_rccl.why), "cannot load librccl.so.1 (%s); set NGP_RCCL_PATH", dlerror()); return; }
 #define SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(g_rccl.handle, name); if (!g_rccl.field) { snprintf(g_rccl.why, sizeof(g_rccl.why), "librccl: symbol %s missing", name); return; } } while (0)
-	SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(AllReduce, "ncclAllReduce");
+	SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(CommAbort, "ncclCommAbort"); SYM(AllReduce, "ncclAllReduce");
 	SYM(ReduceScatter, "ncclReduceScatter"); SYM(AllGather, "ncclAllGather"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
 	g_rccl.ok = true;
@@ -97,6 +98,18 @@ NGP_API int ngp_comm_destroy(void *comm) {
 	if (c->nccl && g_rccl.ok) rc = g_rccl.CommDestroy(c->nccl);
 	delete c;
 	if (rc) { ngp_set_error("ncclCommDestroy: RCCL error %d", rc); return 1000 + rc; }
+	return 0;
+}
+
+// ncclCommAbort: frees the communicator AND terminates its kernels that are still in flight (a collective whose peers never arrived spins on the device for ever and
+// would block every later device-wide synchronisation of the process - ADVICE r4).  For a communicator that failed its self-test; a healthy one is destroyed.
+NGP_API int ngp_comm_abort(void *comm) {
+	if (!comm) return 0;
+	NgpComm *c = (NgpComm *)comm;
+	int rc = 0;
+	if (c->nccl && g_rccl.ok) rc = g_rccl.CommAbort(c->nccl);
+	delete c;
+	if (rc) { ngp_set_error("ncclCommAbort: RCCL error %d", rc); return 1000 + rc; }
 	return 0;
 }
 

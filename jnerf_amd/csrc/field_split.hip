@@ -439,14 +439,19 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 }
 
 // bit 0: an operand of a split forward came within 4x of fp16's largest finite value since the last reset; bit 1: one left the range (infinities in that launch's
-// results) or a split backward stored a non-finite feature gradient.  Synchronises the device (a 4-byte read-back): call it where the host waits anyway.
+// results) or a split backward stored a non-finite feature gradient.  A 4-byte read-back through the null stream; it does not wait for other streams' kernels - a launch
+// that has not reported yet reports at the next check.  reset clears EXACTLY the bits that were read, atomically on the device (r5, ADVICE r4: a read followed by a
+// plain store of zero could wipe a bit a kernel on another stream raised in between - the one way the "an error, never a silent one" guarantee could be lost).
+__global__ void k_range_flag_clear(uint32_t bits) { atomicAnd(&g_split_range_flag, ~bits); }
 NGP_API int ngp_field32_range_check(int reset) {
 	uint32_t v = 0u;
 	hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_range_flag), sizeof(v), 0, hipMemcpyDeviceToHost);
 	if (e != hipSuccess) { ngp_set_error("ngp_field32_range_check: %s", hipGetErrorString(e)); return NGP_E_ARG; }
-	if (reset && v) { const uint32_t zero = 0u; e = hipMemcpyToSymbol(HIP_SYMBOL(g_split_range_flag), &zero, sizeof(zero), 0, hipMemcpyHostToDevice);
-		if (e != hipSuccess) { ngp_set_error("ngp_field32_range_check: %s", hipGetErrorString(e)); return NGP_E_ARG; } }
-	return (int)v;
+	if (reset && v) {
+		NGP_LAUNCH(k_range_flag_clear, dim3(1), dim3(1), 0, (hipStream_t)0, v);
+		NGP_LAUNCH_CHECK("ngp_field32_range_check");
+	}
+	return (int)(v & 3u);
 }
 
 static uint32_t split_grid(uint32_t n) { uint32_t b = div_up(div_up(n, 16), 4); return b < 1024 ? (b ? b : 1) : 1024; }

@@ -126,7 +126,11 @@ def library_comm_or_fallback():
         if world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
-        if handle is not None and not hung:                             # (a communicator with a collective still in flight is abandoned, not destroyed: destroy would wait for it)
+        if handle is not None and hung:
+            # (r5) a collective of the self-test is still spinning on the device: ncclCommAbort terminates it - abandoning the communicator instead would leave
+            # that kernel in flight for ever and every later device-wide synchronize (bench.py, _sync_params_from_rank0, the range-flag poll) would block on it
+            L.lib().ngp_comm_abort(handle)
+        elif handle is not None:
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             L.lib().ngp_comm_destroy(handle)

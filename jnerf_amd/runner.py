@@ -114,6 +114,11 @@ class Runner:
         if hasattr(self.sampler, "finish_batch_rays_update"):
             self.sampler.finish_batch_rays_update()
 
+    def finish(self):
+        """end of a training run (Runner.train; collective under data parallelism): drain + the FINAL poll of the split kernels' range flag - synchronous, agreed on by all ranks"""
+        self.drain()
+        self._poll_field32_range(final=True)
+
     def __del__(self):
         try:
             self.drain()
@@ -151,7 +156,7 @@ class Runner:
         return {"step": step, "bg": bg, "target": rgb_target, "pos": pos, "dirs": dirs, "state": self.sampler.export_batch_state(),
                 "keep": (img_ids, rays_o, rays_d)}
 
-    def _poll_field32_range(self):
+    def _poll_field32_range(self, final=False, local=False):
         """(r4) The fp32 configuration's default field kernels work on split fp16 operands with fixed prescales (csrc/field_split.hip): features beyond ~255 or
         activations beyond ~4094 do not fit.  The kernels flag operands that come within a factor four of that (ngp_field32_range_check); polled where the host waits
         anyway - every 16th step, after every rendered image.  Near the limit: this process continues on the exact-product fp32-MFMA kernels (nothing has overflowed
@@ -160,7 +165,9 @@ class Runner:
         if not (torch.cuda.is_available() and getattr(m, "fused", False) and getattr(m, "fused_dtype", None) == torch.float32) or getattr(self, "_field32_exact", False):
             return
         from . import ops
-        flag = ops.field32_range_check(reset=True, synchronize=False)
+        flag = ops.field32_range_check(reset=True, synchronize=bool(final))
+        if not local:                       # (after a rendered image: rank 0 may be rendering alone - Runner.test - so that poll acts on this rank's flag only)
+            flag = self._agree_on_range_flag(flag, final)
         if flag & 2:
             raise RuntimeError("fp32 field network: an operand left the range of the split-operand kernels (|feature| > 255 or |activation| > 4094) - the results since the "
                                "last check contain infinities.  Re-run with NGP_FIELD32_FWD=mfma32 NGP_FIELD32_BWD=2 (exact-product kernels, no operand range).")
@@ -168,6 +175,49 @@ class Runner:
             print("[jnerf_amd] fp32 field network: operands within 4x of the split-operand kernels' range; continuing on the exact-product fp32-MFMA kernels", flush=True)
             ops.field32_select(True)
             self._field32_exact = True
+
+    def _agree_on_range_flag(self, flag, final=False):
+        """Data parallel (r5): every rank polls its OWN device's flag, and a rank that raised (or switched kernels) alone would leave its peers blocked in the
+        next collective.  The flags are MAX-all-reduced before anyone acts.  In the loop the reduction is asynchronous - issued at this poll, consumed at the next one, 16
+        steps later (a blocking read-back here would drain the pipeline in every refresh window; bit 0 fires at a quarter of the range, so 16 steps of slack are safe, and an
+        error is still an error 16 steps later) - and the final poll (drain) reduces synchronously, so no flag is ever dropped."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return flag
+        on_gpu = dist.get_backend() == "nccl"
+        carry = getattr(self, "_range_flag_carry", 0) | int(flag)           # bits this rank has seen and not yet acted on
+        pend = getattr(self, "_range_flag_pending", None)
+        agreed = 0
+        if pend is not None:                                                 # the reduction issued at the previous poll
+            work, host, ev = pend
+            if work is not None:
+                work.wait()
+            if ev is not None:
+                ev.synchronize()
+            agreed = int(host.item())
+            self._range_flag_pending = None
+        if final:
+            t = torch.tensor([carry], dtype=torch.int32, device=self.sampler.device if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)                         # (values 0..3: MAX keeps bit 1 whenever any rank holds it - the error wins)
+            self._range_flag_carry = 0
+            return agreed | int(t.item())
+        if on_gpu:
+            # like update_batch_rays (sampler.py): on a stream of its own, result copied to pinned memory, read at the next poll - the training stream is never waited for
+            if getattr(self, "_flag_stream", None) is None:
+                self._flag_stream = torch.cuda.Stream()
+                self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            with torch.cuda.stream(self._flag_stream):
+                t = torch.tensor([carry], dtype=torch.int32, device=self.sampler.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                self._flag_host.copy_(t, non_blocking=True)
+                t.record_stream(self._flag_stream)
+                ev = torch.cuda.Event(); ev.record(self._flag_stream)
+            self._range_flag_pending = (None, self._flag_host, ev)
+        else:
+            t = torch.tensor([carry], dtype=torch.int32)
+            self._range_flag_pending = (dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True), t, None)
+        self._range_flag_carry = 0                                           # handed to the reduction in flight
+        return agreed
 
     def train_step(self, i):
         """Software-pipelined: the ray generation + marching of batches i+1 .. i+depth only read the dataset and the occupancy bitfield, so they are
@@ -283,7 +333,7 @@ class Runner:
                 if i > 0 and i % self.val_freq == 0:
                     psnr = mse2psnr(self.val_img(i))
                     print("STEP={} | LOSS={} | VAL PSNR={}".format(i, loss.mean().item(), psnr))
-            self.drain()
+            self.finish()
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         from .optim import sync_all_sharded
@@ -436,7 +486,7 @@ class Runner:
         if self._native_render_ok():
             self._render_rays_native(rays_o_total, rays_d_total, chunk, imgs, alphas, counts)
             host = counts.tolist()
-            self._poll_field32_range()
+            self._poll_field32_range(local=True)
             self.n_samples_rendered = int(host[0])
             if host[1] and chunk > self.sampler.max_samples // self.sampler.MAX_STEP:
                 return self._render_rays(img_ids, rays_o_total, rays_d_total, self.sampler.max_samples // self.sampler.MAX_STEP)

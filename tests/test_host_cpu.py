@@ -88,7 +88,7 @@ def test_camera_path():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/projects/ngp/configs"), reason="reference checkout not present (GPU box)")
-@pytest.mark.parametrize("name", ["ngp_base.py", "ngp_fox.py"])
+@pytest.mark.parametrize("name", ["ngp_base.py", "ngp_fox.py", "ngp_comp.py"])
 def test_reference_config_files_load_unchanged_and_equal_ours(name):
     """the reference's own config files go through jnerf_amd.utils.config untouched, and projects/ngp/configs/<name> in this repo resolves to the same keys and
     values (ours are written with `_base_` inheritance instead of being copies)"""
@@ -98,9 +98,10 @@ def test_reference_config_files_load_unchanged_and_equal_ours(name):
     for d in (ref, ours):
         for k in ("name", "work_dir", "dataset_dir", "dataset_type"):
             d.pop(k, None)
-    if name == "ngp_fox.py":        # keys our fox config inherits from ngp_base.py that the reference's file simply leaves unset (all read as None / False there)
+    if name in ("ngp_fox.py", "ngp_comp.py"):        # keys our configs inherit from ngp_base.py that the reference's file simply leaves unset (all read as None / False there)
         for k in ("load_ckpt", "ckpt_path", "alpha_image"):
             assert not ours.pop(k, None)
+    if name == "ngp_fox.py":
         ours["dataset"].pop("val", None)
     assert ours == ref, {k: (ours.get(k), ref.get(k)) for k in set(ours) | set(ref) if ours.get(k) != ref.get(k)}
 
@@ -405,3 +406,68 @@ def test_region_path_bin_mapping_is_a_bijection_on_every_level(aabb_scale):
             assert back == e and b < 128 and l < n_local <= 4096, (size, e, b, l, back, n_local)
             assert (b, l) not in seen or e == size - 1
             seen.add((b, l))
+
+
+@pytest.mark.parametrize("scene", ["Scar", "Car", "Scarf"])
+def test_ngp_comp_config_builds_its_datasets(scene, tmp_path):
+    """projects/ngp/configs/ngp_comp.py (the reference's competition config, projects/ngp/configs/ngp_comp.py:41-100 there) goes through init_cfg and the DATASETS
+    registry: per-scene aabb_scale / scale / offset, correct_pose = [-1, -1, 1], a test split WITHOUT images at 800 x 800, white background, fp16"""
+    import json
+    import shutil
+    from PIL import Image
+    from jnerf_amd import dataset as _ds  # noqa: F401  (registers NerfDataset)
+    from jnerf_amd.utils.config import init_cfg
+    from jnerf_amd.utils.registry import DATASETS
+    cdir = tmp_path / "configs"
+    cdir.mkdir()
+    shutil.copy(os.path.join(ROOT, "projects", "ngp", "configs", "ngp_base.py"), cdir / "ngp_base.py")
+    src = open(os.path.join(ROOT, "projects", "ngp", "configs", "ngp_comp.py")).read()
+    data = tmp_path / "data"
+    data.mkdir()
+    src = src.replace('exp_name = "Scar"', f'exp_name = "{scene}"').replace("dataset_dir = 'my/data/' + exp_name", f"dataset_dir = {str(data)!r}")
+    assert f'exp_name = "{scene}"' in src and str(data) in src
+    open(cdir / "ngp_comp.py", "w").write(src)
+    rng = np.random.default_rng(1)
+    W, H = 16, 10
+
+    def frames(prefix, n, with_files=True):
+        out = []
+        for i in range(n):
+            if with_files:
+                Image.fromarray(rng.integers(0, 255, (H, W, 4), dtype=np.uint8)).save(data / f"{prefix}_{i}.png")
+            m = np.eye(4); m[:3, :3] = rng.normal(size=(3, 3)); m[:3, 3] = rng.normal(size=3)
+            out.append({"file_path": f"./{prefix}_{i}", "transform_matrix": m.tolist()})
+        return out
+    tr = frames("train", 3)
+    json.dump({"camera_angle_x": 0.6, "frames": tr}, open(data / "transforms_train.json", "w"))
+    json.dump({"camera_angle_x": 0.6, "frames": frames("val", 11)}, open(data / "transforms_val.json", "w"))
+    te = frames("test", 2, with_files=False)
+    json.dump({"camera_angle_x": 0.6, "frames": te}, open(data / "transforms_test.json", "w"))
+    init_cfg(str(cdir / "ngp_comp.py"))
+    cfg = get_cfg()
+    cfg.device = "cpu"
+    assert cfg.fp16 is True and cfg.const_dt is True and cfg.background_color == [1, 1, 1] and cfg.tot_train_steps == 40000 and cfg.exp_name == scene
+    want_aabb = {"Scar": 5, "Car": 4, "Scarf": 8}[scene]
+    want_scale = 0.05 if scene == "Scarf" else 0.33
+    want_off = np.array([-2.0, -0.5, 0.0] if scene == "Car" else [0.5, 0.5, 0.5], np.float32)
+    train = build_from_cfg(cfg.dataset.train, DATASETS)
+    assert train.n_images == 3 + 11 and train.aabb_scale == want_aabb and train.aabb_range == (0.5 - want_aabb / 2, 0.5 + want_aabb / 2)       # train includes val (dataset.py:77)
+    # dataset.py:255-262 with correct_pose = [-1, -1, 1]: columns 0 and 1 negated, translation * scale + offset, rows cycled [1, 2, 0]
+    by_t = {}
+    for fr in tr:
+        m = np.array(fr["transform_matrix"], np.float32)[:3]
+        m[:, 0] *= -1; m[:, 1] *= -1
+        m[:, 3] = m[:, 3] * np.float32(want_scale) + want_off
+        by_t[tuple(np.round(m[[1, 2, 0]][:, 3], 5))] = m[[1, 2, 0]]
+    ours = train.transforms_gpu.numpy().transpose(0, 2, 1)                  # [n, 3, 4]
+    hits = 0
+    for x in ours:
+        k = tuple(np.round(x[:, 3], 5))
+        if k in by_t:
+            np.testing.assert_allclose(x, by_t[k], atol=1e-6); hits += 1
+    assert hits == 3
+    val = build_from_cfg(cfg.dataset.val, DATASETS)
+    assert val.n_images == 2                                                # every 10th validation frame (dataset.py:93)
+    test = build_from_cfg(cfg.dataset.test, DATASETS)
+    assert test.have_img is False and test.n_images == 2 and test.resolution == [800, 800] and test.image_data.shape == (2, 800 * 800, 4) and float(test.image_data.abs().max()) == 0.0
+    get_cfg().clear()

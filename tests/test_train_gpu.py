@@ -503,3 +503,42 @@ def test_fast_path_equals_module_path(fp16):
     (g0, w0, l0), (g1, w1, l1) = res
     assert torch.allclose(w0, w1, rtol=2e-3, atol=2e-4), (w0 - w1).abs().max()
     assert (g0 - g1).abs().max() < 2e-3 and abs(l0 - l1) < 2e-2 * max(abs(l1), 1e-3)
+
+
+def test_lego_gate_runs_when_the_dataset_is_mounted(tmp_path, monkeypatch):
+    """tools/lego_gate.py (VERDICT r4 'missing' #1): with NeRF-synthetic lego absent it says so; with a data set in lego's LAYOUT at $NGP_LEGO_DIR (here: views of the
+    procedural scene written as PNG + transforms_{train,val,test}.json in the NeRF convention) it runs projects/ngp/configs/ngp_base.py on it and reports it/s, wall
+    seconds and the mean test PSNR - as a plumbing run, labelled as such, when the step count is not the schedule's 40 000."""
+    import json
+    import sys
+    from PIL import Image
+    from jnerf_amd.utils.config import reset_cfg
+    from jnerf_amd.dataset import SyntheticNerfDataset, NERF_SCALE
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import lego_gate as LG
+    monkeypatch.delenv("NGP_LEGO_DIR", raising=False)
+    if LG.find_lego()[0] is None:
+        assert LG.lego_gate()["gate"] == "not runnable: dataset absent"
+    W = H = 64
+    reset_cfg(device="cuda")
+    fov = 40.0
+
+    def split(mode, n, seed):
+        ds = SyntheticNerfDataset(batch_size=64, n_images=n, W=W, H=H, aabb_scale=1, mode=mode, seed=seed, fov_deg=fov)
+        frames = []
+        P = ds.transforms_gpu.transpose(1, 2).cpu().numpy()                     # [n, 3, 4] ngp poses
+        for i in range(n):
+            rgba = (ds.image_data[i].view(H, W, 4).clamp(0, 1) * 255 + 0.5).to(torch.uint8).cpu().numpy()
+            Image.fromarray(rgba, "RGBA").save(tmp_path / f"{mode}_{i}.png")
+            m = P[i][[2, 0, 1]].copy()                                           # undo the row cycle [1, 2, 0] of matrix_nerf2ngp (dataset.py:255-262) ...
+            m[:, 1] *= -1; m[:, 2] *= -1                                         # ... the correct_pose flips [1, -1, -1] ...
+            m[:, 3] = (m[:, 3] - 0.5) / NERF_SCALE                               # ... and translation * 0.33 + 0.5
+            frames.append({"file_path": f"./{mode}_{i}", "transform_matrix": np.vstack([m, [0, 0, 0, 1]]).tolist()})
+        json.dump({"camera_angle_x": float(np.deg2rad(fov)), "frames": frames}, open(tmp_path / f"transforms_{mode}.json", "w"))
+    split("train", 10, 0); split("val", 10, 1); split("test", 2, 2)
+    monkeypatch.setenv("NGP_LEGO_DIR", str(tmp_path))
+    out = LG.lego_gate(steps=400)
+    assert out["gate"].startswith("not the gate: 400 steps") and out["steps"] == 400 and out["dataset"] == str(tmp_path)
+    assert out["train_images"] == 20 and out["resolution"] == [W, H] and out["test_views"] == 2                     # train includes val (dataset.py:77)
+    assert out["iters_per_s"] > 0 and np.isfinite(out["psnr_lego_test"]) and out["psnr_lego_test"] > 18.0, out     # the poses were understood: the scene is being learnt
