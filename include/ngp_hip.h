@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NGP_ABI_VERSION 2
+#define NGP_ABI_VERSION 3
 enum { NGP_F32 = 0, NGP_F16 = 1 };
 enum { NGP_E_ARG = -1, NGP_E_DTYPE = -2, NGP_E_ALIGN = -3, NGP_E_CAPACITY = -4 };
 /* feature-tensor layouts between the encoder and the MLP */
@@ -67,23 +67,22 @@ int ngp_hash_encode_bwd_input_bwd_grid(void *stream, uint32_t n, const float *po
 int ngp_hash_encode_bwd(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, const uint32_t *level_table_host,
                         void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid);
 
-/* Same contract, exclusive table slices accumulated in 32-bit FIXED POINT (one 64-bit LDS integer atomic per corner instead of two LDS float
- * atomics, which gfx950 retires ~12x slower).  level_scratch: device f32[16], receives the per-level L1 norm of dLdy that bounds every entry's
- * sum (=> overflow-free scale); resolution = L1(level) / 2^30, results independent of the order of accumulation. */
-int ngp_hash_encode_bwd_fx(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, const uint32_t *level_table_host,
-                           void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid,
-                           float *level_scratch);
-
-/* Same contract with a caller-provided workspace (>= ngp_hash_bwd_workspace_bytes(level table, n)) — the fastest path:
- *  - hashed levels: corner indices are computed ONCE per sample and binned (64 bins of 8192 entries per level, 8-byte records), then every bin is
- *    accumulated by one workgroup in exact 64-bit integer arithmetic in LDS (contributions rounded to scaled fp16 once; order-independent,
- *    bit-reproducible).  Used when dtype == NGP_F16, grad_dtype == NGP_F32 and level_scratch == NULL (otherwise the owner-computes scan);
- *  - small dense levels: 32 sample chunks per slice, partial slabs in the workspace, reduced by a second kernel (no global atomics, no memset).
- * level_scratch may be NULL or device f32[16] (selects the fixed-point owner-computes scan for the hashed levels instead of binning). */
+/* Same contract with a caller-provided workspace - the training path.  No float atomic anywhere, every level through records that one workgroup per bin of table
+ * entries sums in exact 64-bit integer arithmetic in LDS: order-independent, bit-reproducible, the gradient is OVERWRITTEN entry by entry (no memset).  Routed by the level
+ * table and the dtypes (csrc/hash_encode.hip: hash_bwd_path):
+ *   dtype == grad_dtype == NGP_F32 (ngp_base.py): record REGIONS - run-combined 12-byte records for the levels up to resolution 300, one 16-byte edge record per cell
+ *     edge for the finer ones, one accumulate kernel (r4);
+ *   fp16 dL/dy (ngp_fox.py): per-corner record lists (6-byte fp16 records for the fine levels) with cursor reservations (r2 / r3).
+ * A level table the bins cannot take (a level beyond 2^19 entries, a hashed table that is not a power of two) runs the reference's scheme - one global float atomic per
+ * corner - as ngp_hash_encode_bwd without a workspace does: the ONE fallback of this stage (r5: the owner-computes scan of rounds 1-2 and its fixed-point entry point
+ * ngp_hash_encode_bwd_fx are gone).
+ * workspace: >= ngp_hash_bwd_workspace_bytes_for(level table, n, dtype, grad_dtype) bytes (fp32: ~0.6 GB at n = 2^18, fp16: ~1.7 GB); a smaller one is NGP_E_CAPACITY
+ * (rounds 2-4 silently took a slower path).  ngp_hash_bwd_workspace_bytes(level table, n) = the larger of the two, for a caller that serves both. */
 uint64_t ngp_hash_bwd_workspace_bytes(const uint32_t *level_table_host, uint32_t n);
+uint64_t ngp_hash_bwd_workspace_bytes_for(const uint32_t *level_table_host, uint32_t n, int dtype, int grad_dtype);
 int ngp_hash_encode_bwd_ws(void *stream, uint32_t n, const float *pos, uint32_t pos_stride_floats, const void *dLdy, const uint32_t *level_table_host,
                            void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid,
-                           float *level_scratch, void *workspace, uint64_t workspace_bytes);
+                           void *workspace, uint64_t workspace_bytes);
 
 /* ---- direction encoding: replaces SHEncoder.execute (position_encoders/sh_encoder/sh_encoder.py:29-51, SphericalEncode.h:45-95) */
 int ngp_sh_encode(void *stream, uint32_t n, const float *dir, uint32_t dir_stride_floats, void *out /*[n,16]*/, int dtype);

@@ -65,9 +65,9 @@ SIGNATURES = {
     "ngp_neus_composite_fwd": (C.c_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "ngp_neus_composite_bwd": (C.c_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ngp_hash_encode_bwd": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp]),
-    "ngp_hash_encode_bwd_fx": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ngp_hash_bwd_workspace_bytes": (C.c_uint64, [_vp, _u32]),
-    "ngp_hash_encode_bwd_ws": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _u64]),
+    "ngp_hash_bwd_workspace_bytes_for": (C.c_uint64, [_vp, _u32, _i32, _i32]),
+    "ngp_hash_encode_bwd_ws": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _i32, _i32, _i32, _i32, _vp, _vp, _u64]),
     "ngp_sh_encode": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _i32]),
     "ngp_field_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _u32, _vp, _vp, _vp, _i32, _vp]),
     "ngp_density_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _i32]),
@@ -137,7 +137,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_lib, name)       # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
-        if _lib.ngp_abi_version() != 2:
+        if _lib.ngp_abi_version() != 3:
             raise RuntimeError("libngp_hip.so ABI version mismatch")
     return _lib
 

@@ -178,23 +178,44 @@ __global__ void k_occ_bounds_reset(int32_t *__restrict__ bounds, int cascades) {
 	const int i = threadIdx.x;
 	if (i < cascades * 6) bounds[i] = (i % 6) < 3 ? (int)NGP_GRIDSIZE : -1;
 }
+// (r5) 16 bytes (128 cells) per thread, reduced over the wavefront and then over the workgroup's four wavefronts in LDS: six atomics per WORKGROUP with an occupied cell -
+// 64 workgroups per cascade.  Round 3's version issued them per wavefront (4096 per cascade): ~120 k same-address atomics, which the L2 retires one at a time - 72 us per
+// refresh for ngp_base.py's bitfield, 585 us for ngp_fox.py's (profiles/r05a_realfox_kernel_trace.md: 7 % of that configuration's iteration).  min / max: same result.
 __global__ __launch_bounds__(256) void k_occ_bounds(const uint8_t *__restrict__ bitfield, int32_t *__restrict__ bounds) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;              // byte within the cascade blockIdx.y (G3 / 8 bytes each)
+	__shared__ int red[4][6];
+	const uint32_t q = blockIdx.x * 256u + threadIdx.x;              // 16-byte group within the cascade blockIdx.y (G3 / 8 bytes each)
 	const uint32_t c = blockIdx.y;
 	int lo[3] = {(int)NGP_GRIDSIZE, (int)NGP_GRIDSIZE, (int)NGP_GRIDSIZE}, hi[3] = {-1, -1, -1};
-	if (i < G3 / 8 && bitfield[(size_t)c * (G3 / 8) + i]) {
-		const uint32_t m = i * 8u;
-		const int x = (int)morton3D_invert(m), y = (int)morton3D_invert(m >> 1), z = (int)morton3D_invert(m >> 2);
-		lo[0] = x; lo[1] = y; lo[2] = z; hi[0] = x + 1; hi[1] = y + 1; hi[2] = z + 1;
+	if (q < G3 / 128) {
+		const uint4 v = reinterpret_cast<const uint4 *>(bitfield + (size_t)c * (G3 / 8))[q];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (uint32_t j = 0; j < 16; ++j) {
+			if ((w[j >> 2] >> (8u * (j & 3u))) & 0xffu) {
+				const uint32_t m = (q * 16u + j) * 8u;                   // Morton index of the byte's first cell: the 2 x 2 x 2 block at (x, y, z)
+				const int x = (int)morton3D_invert(m), y = (int)morton3D_invert(m >> 1), z = (int)morton3D_invert(m >> 2);
+				lo[0] = min(lo[0], x); lo[1] = min(lo[1], y); lo[2] = min(lo[2], z);
+				hi[0] = max(hi[0], x + 1); hi[1] = max(hi[1], y + 1); hi[2] = max(hi[2], z + 1);
+			}
+		}
 	}
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1) { lo[k] = min(lo[k], __shfl_xor(lo[k], off)); hi[k] = max(hi[k], __shfl_xor(hi[k], off)); }
 	}
-	if ((threadIdx.x & 63u) == 0 && hi[0] >= 0) {
+	if ((threadIdx.x & 63u) == 0) {
 #pragma unroll
-		for (int k = 0; k < 3; ++k) { atomicMin(&bounds[c * 6 + k], lo[k]); atomicMax(&bounds[c * 6 + 3 + k], hi[k]); }
+		for (int k = 0; k < 3; ++k) { red[threadIdx.x >> 6][k] = lo[k]; red[threadIdx.x >> 6][3 + k] = hi[k]; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 6) {
+		const int k = (int)threadIdx.x;
+		int r = red[0][k];
+#pragma unroll
+		for (int wv = 1; wv < 4; ++wv) r = k < 3 ? min(r, red[wv][k]) : max(r, red[wv][k]);
+		if (k < 3) { if (r < (int)NGP_GRIDSIZE) atomicMin(&bounds[c * 6 + k], r); }
+		else if (r >= 0) atomicMax(&bounds[c * 6 + k], r);
 	}
 }
 // Coarse map of the unit cube (NGP_OCC_COARSE^3 = 32^3 cells of 4^3 fine cells): a coarse cell is marked when any cascade-0 cell inside it, or any cascade-1 cell
@@ -223,10 +244,10 @@ __global__ __launch_bounds__(256) void k_occ_dilate(const uint8_t *__restrict__ 
 }
 NGP_API int ngp_grid_occupied_bounds(void *stream, const uint8_t *bitfield, int cascades, int32_t *bounds) {
 	NGP_REQUIRE(bitfield && bounds && cascades >= 1 && cascades <= 8, NGP_E_ARG, "ngp_grid_occupied_bounds: bad arguments");
-	NGP_REQUIRE(((uintptr_t)bitfield & 7) == 0, NGP_E_ALIGN, "ngp_grid_occupied_bounds: bitfield must be 8-byte aligned");
+	NGP_REQUIRE(((uintptr_t)bitfield & 15) == 0, NGP_E_ALIGN, "ngp_grid_occupied_bounds: bitfield must be 16-byte aligned");
 	hipStream_t s = (hipStream_t)stream;
 	NGP_LAUNCH(k_occ_bounds_reset, dim3(1), dim3(64), 0, s, bounds, cascades);
-	NGP_LAUNCH(k_occ_bounds, dim3(div_up(G3 / 8, 256), cascades), dim3(256), 0, s, bitfield, bounds);
+	NGP_LAUNCH(k_occ_bounds, dim3(div_up(G3 / 128, 256), cascades), dim3(256), 0, s, bitfield, bounds);
 	uint8_t *dil = reinterpret_cast<uint8_t *>(bounds + NGP_OCC_COARSE_OFFSET_INTS), *raw = dil + NGP_OCC_COARSE * NGP_OCC_COARSE * NGP_OCC_COARSE;
 	const uint32_t nc = NGP_OCC_COARSE * NGP_OCC_COARSE * NGP_OCC_COARSE;
 	NGP_LAUNCH(k_occ_coarse, dim3(div_up(nc, 256)), dim3(256), 0, s, bitfield, cascades, raw);

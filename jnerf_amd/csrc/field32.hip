@@ -196,219 +196,10 @@ __global__ __launch_bounds__(256) void k_field32_fwd(uint32_t n, const float *__
 
 // ---------------------------------------------------------------------------------------------------------------- backward
 #define BT32 128               // samples per workgroup trip: 8 waves x 16
-#define RS32 (BT32 + 4)        // LDS row stride in floats (528 B: rows 16-byte aligned; consecutive rows shift by one 16-byte slot => ds_read_b128 of 16 rows is conflict-free up to one pair)
-#define N_ROWS32 128           // largest staging phase
-// weight-gradient staging phases (rows of the [neuron][sample] region); every phase: all waves write their 16 sample columns, barrier, every wave accumulates
-// its tiles over the 128 samples (32 MFMAs per 16x16 tile), barrier:
-//   A : dG1 0..63 | G0 64..127     -> V1  (16 tiles: wave w -> (to = w>>1, ti = 2(w&1), 2(w&1)+1))
-//   B1: dH  0..63 | F  64..95      -> W0  ( 8 tiles: wave w -> (to = w>>1, tj = w&1))
-//   B2: dG0 0..63 | IN2 64..95     -> V0  ( 8 tiles: same map)
-//   C1: dD  0..15 | H  16..79      -> W1  ( 4 tiles: wave w -> tile w&3 over samples 64(w>>2) .. +63)
-//   C2: dO  0..15 | G1 16..79      -> V2  ( 4 tiles: same map)
-
-__device__ __forceinline__ void st_tiles(float *stage, int row0, int col, int g, const floatx4 *v) {      // four 16-neuron tiles
-#pragma unroll
-	for (int t = 0; t < 4; ++t)
-#pragma unroll
-		for (int r = 0; r < 4; ++r) stage[(row0 + 16 * t + 4 * g + r) * RS32 + col] = v[t][r];
-}
-__device__ __forceinline__ floatx4 ld_rows32(const float *stage, int row, int col) { return *reinterpret_cast<const floatx4 *>(stage + row * RS32 + col); }
-// acc += A-rows x B-rows over samples [c0, c1) of the staged region (16 samples per step: lanes g = 0..3 take samples 4g..4g+3 of the step, MFMA j uses sample 4g+j)
-__device__ __forceinline__ floatx4 wgrad_tile(const float *stage, int row_a, int row_b, int o, int g, int c0, int c1, floatx4 acc) {
-#pragma unroll 4
-	for (int c = c0; c < c1; c += 16) {
-		const floatx4 a = ld_rows32(stage, row_a + o, c + 4 * g), b = ld_rows32(stage, row_b + o, c + 4 * g);
-#pragma unroll
-		for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], b[j], acc);
-	}
-	return acc;
-}
-
-template <int LAYOUT>
-__global__ __launch_bounds__(512, 1) void k_field32_bwd(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
-                                                        const float *__restrict__ packed, const float *__restrict__ dout,
-                                                        float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
-	extern __shared__ __attribute__((aligned(16))) float smem32[];
-	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // running max |dL/dfeature| of levels 8u + 2g + pr over this lane's samples (absmax_epilogue)
-	float *wl = smem32;                                   // 76 fragments
-	float *stage = smem32 + NF32_ALL * 256;               // [N_ROWS32][RS32]
-	stage_weights32(wl, packed, NF32_ALL);
-	const float *wb = wl + NF32_FWD * 256;
-	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
-	const uint32_t n_bt = (lim + BT32 - 1) / BT32;
-	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-	const int to = w >> 1, ti0 = 2 * (w & 1), tj = w & 1, tx = w & 3, half = w >> 2;
-	floatx4 aV1[2] = {z, z}, aW0 = z, aV0 = z, aW1 = z, aV2 = z;
-	__syncthreads();
-	struct Inputs { float f[8]; float d3[3]; float go[4]; };
-	auto fetch = [&](uint32_t bt, Inputs &in) {
-		const uint32_t i = bt * BT32 + 16u * w + s;
-		const bool valid = i < lim;
-		const uint32_t ic = valid ? i : lim - 1;
-		load_feat32<LAYOUT>(feat, n, ic, g, in.f);
-		in.d3[0] = dir[(size_t)ic * dir_stride]; in.d3[1] = dir[(size_t)ic * dir_stride + 1]; in.d3[2] = dir[(size_t)ic * dir_stride + 2];
-		in.go[0] = in.go[1] = in.go[2] = in.go[3] = 0.f;
-		if (valid) { const float4 v = *reinterpret_cast<const float4 *>(dout + (size_t)i * 4); in.go[0] = v.x; in.go[1] = v.y; in.go[2] = v.z; in.go[3] = v.w; }
-	};
-	Inputs cur, nxt;
-	if (blockIdx.x < n_bt) fetch(blockIdx.x, cur);
-	for (uint32_t bt = blockIdx.x; bt < n_bt; bt += gridDim.x) {
-		const uint32_t i = bt * BT32 + 16u * w + s;
-		const bool valid = i < lim;
-		const bool more = bt + gridDim.x < n_bt;
-		if (more) fetch(bt + gridDim.x, nxt);
-		float sh[4]; sh4_32(cur.d3, g, sh);
-		Fwd32 st;
-		forward32<false>(wl, lane, cur.f, sh, st);
-		// ---- dgrad chain (register resident, transposed weight fragments)
-		floatx4 dO = z;                                          // register j <-> gradient of output neuron 4g+j; only neurons 0..2 (g == 0) are non-zero
-		if (g == 0) { dO[0] = cur.go[0]; dO[1] = cur.go[1]; dO[2] = cur.go[2]; }
-		floatx4 dG1[4], dG0[4], dH[4], dF[2];
-		{
-			floatx4 a[4];
-#pragma unroll
-			for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, u, lane); dG1[u] = z; }
-#pragma unroll
-			for (int j = 0; j < 3; ++j)                           // k-step 3 would contract output neurons 3, 7, 11, 15: all zero-gradient padding rows
-#pragma unroll
-				for (int u = 0; u < 4; ++u) dG1[u] = MFMA32(a[u][j], dO[j], dG1[u]);
-#pragma unroll
-			for (int u = 0; u < 4; ++u) dG1[u] = mask4(dG1[u], st.g1[u]);
-		}
-#pragma unroll
-		for (int u = 0; u < 4; ++u) dG0[u] = z;
-#pragma unroll
-		for (int t = 0; t < 4; ++t) {
-			floatx4 a[4];
-#pragma unroll
-			for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wb, 4 + 4 * u + t, lane);
-#pragma unroll
-			for (int j = 0; j < 4; ++j)
-#pragma unroll
-				for (int u = 0; u < 4; ++u) dG0[u] = MFMA32(a[u][j], dG1[t][j], dG0[u]);
-		}
-#pragma unroll
-		for (int u = 0; u < 4; ++u) dG0[u] = mask4(dG0[u], st.g0[u]);
-		floatx4 dD;
-		{
-			floatx4 d0 = z, d1 = z;
-#pragma unroll
-			for (int t = 0; t < 4; ++t) {
-				const floatx4 a = ld_frag32(wb, 20 + t, lane);
-				d0 = MFMA32(a[0], dG0[t][0], d0); d1 = MFMA32(a[1], dG0[t][1], d1);
-				d0 = MFMA32(a[2], dG0[t][2], d0); d1 = MFMA32(a[3], dG0[t][3], d1);
-			}
-			dD = d0 + d1;
-			if (g == 0) dD[0] += cur.go[3];                       // out[:,3] = den[:,0]  (ngp_network.py:83)
-		}
-		{
-			floatx4 a[4];
-#pragma unroll
-			for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, 24 + u, lane); dH[u] = z; }
-#pragma unroll
-			for (int j = 0; j < 4; ++j)
-#pragma unroll
-				for (int u = 0; u < 4; ++u) dH[u] = MFMA32(a[u][j], dD[j], dH[u]);
-#pragma unroll
-			for (int u = 0; u < 4; ++u) dH[u] = mask4(dH[u], st.h[u]);
-		}
-		dF[0] = z; dF[1] = z;
-#pragma unroll
-		for (int t = 0; t < 4; ++t) {
-			const floatx4 a0 = ld_frag32(wb, 28 + t, lane), a1 = ld_frag32(wb, 32 + t, lane);
-#pragma unroll
-			for (int j = 0; j < 4; ++j) { dF[0] = MFMA32(a0[j], dH[t][j], dF[0]); dF[1] = MFMA32(a1[j], dH[t][j], dF[1]); }
-		}
-		if (valid) {                                              // feature 16u+4g+r  ->  level 8u+2g+(r>>1), component r&1
-#pragma unroll
-			for (int u = 0; u < 2; ++u)
-#pragma unroll
-				for (int pr = 0; pr < 2; ++pr) {
-					const float2 v = make_float2(dF[u][2 * pr], dF[u][2 * pr + 1]);
-					const uint32_t level = 8 * u + 2 * g + pr;
-					lmax[u][pr] = fmaxf(lmax[u][pr], fmaxf(fabsf(v.x), fabsf(v.y)));
-					if (LAYOUT == NGP_LAYOUT_SOA) reinterpret_cast<float2 *>(dfeat)[(size_t)level * n + i] = v;
-					else *reinterpret_cast<float2 *>(dfeat + (size_t)i * 32 + 2 * level) = v;
-				}
-		}
-		// ---- weight gradients: dW[o][i] += sum_s dY[s][o] X[s][i]   (A = dY^T rows o, B = X^T rows i, k = sample)
-		const int col = 16 * w + s, o = lane & 15;
-		// phase A: V1
-		st_tiles(stage, 0, col, g, dG1);
-		st_tiles(stage, 64, col, g, st.g0);
-		__syncthreads();
-		aV1[0] = wgrad_tile(stage, 16 * to, 64 + 16 * ti0, o, g, 0, BT32, aV1[0]);
-		aV1[1] = wgrad_tile(stage, 16 * to, 64 + 16 * (ti0 + 1), o, g, 0, BT32, aV1[1]);
-		__syncthreads();
-		// phase B1: W0
-		st_tiles(stage, 0, col, g, dH);
-#pragma unroll
-		for (int q = 0; q < 8; ++q) stage[(64 + 8 * g + q) * RS32 + col] = cur.f[q];
-		__syncthreads();
-		aW0 = wgrad_tile(stage, 16 * to, 64 + 16 * tj, o, g, 0, BT32, aW0);
-		__syncthreads();
-		// phase B2: V0
-		st_tiles(stage, 0, col, g, dG0);
-#pragma unroll
-		for (int r = 0; r < 4; ++r) { stage[(64 + 4 * g + r) * RS32 + col] = st.den[r]; stage[(80 + 4 * g + r) * RS32 + col] = sh[r]; }
-		__syncthreads();
-		aV0 = wgrad_tile(stage, 16 * to, 64 + 16 * tj, o, g, 0, BT32, aV0);
-		__syncthreads();
-		// phase C1: W1 (each tile's samples split between waves w and w+4)
-#pragma unroll
-		for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RS32 + col] = dD[r];
-		st_tiles(stage, 16, col, g, st.h);
-		__syncthreads();
-		aW1 = wgrad_tile(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64, aW1);
-		__syncthreads();
-		// phase C2: V2
-#pragma unroll
-		for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RS32 + col] = dO[r];
-		st_tiles(stage, 16, col, g, st.g1);
-		__syncthreads();
-		aV2 = wgrad_tile(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64, aV2);
-		__syncthreads();
-		if (more) cur = nxt;
-	}
-	// ---- W1 / V2 partial sums of waves 4..7 join those of waves 0..3 through LDS, then one fp32 slab per workgroup, packed like the weights
-	// (wd part 0..3071, wc part 3072..10239); C rows = 4g+r (output neuron within the tile), cols = lane&15 (input neuron within the tile)
-	float *xch = stage;                                       // [4 tiles][2][64 lanes][4]
-	if (half == 1) {
-#pragma unroll
-		for (int r = 0; r < 4; ++r) { xch[((tx * 2 + 0) * 64 + lane) * 4 + r] = aW1[r]; xch[((tx * 2 + 1) * 64 + lane) * 4 + r] = aV2[r]; }
-	}
-	__syncthreads();
-	float *slab = slabs + (size_t)blockIdx.x * 10240;
-	const int ci = lane & 15;
-#pragma unroll
-	for (int r = 0; r < 4; ++r) {
-		const int ro = 4 * g + r;
-#pragma unroll
-		for (int q = 0; q < 2; ++q) slab[3072 + 2048 + (16 * to + ro) * 64 + 16 * (ti0 + q) + ci] = aV1[q][r];
-		slab[(16 * to + ro) * 32 + 16 * tj + ci] = aW0[r];
-		slab[3072 + (16 * to + ro) * 32 + 16 * tj + ci] = aV0[r];
-		if (half == 0) {
-			slab[2048 + ro * 64 + 16 * tx + ci] = aW1[r] + xch[((tx * 2 + 0) * 64 + lane) * 4 + r];
-			slab[3072 + 6144 + ro * 64 + 16 * tx + ci] = aV2[r] + xch[((tx * 2 + 1) * 64 + lane) * 4 + r];
-		}
-	}
-	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, stage, 8); }
-}
-
-// ---------------------------------------------------------------------------------------------------------------- backward, ping-pong variant (r3)
-// k_field32_bwd above ran at 68 % of the MFMA pipe: its eight waves walk through the five staging phases in lock step, so whenever they all write their activations to
-// LDS (240 KB per 128-sample trip at the ~64 B/clk a CU's LDS takes from ds_write_b32: ~3.7 k of the trip's 29 k MFMA cycles) or wait at one of the ten barriers, no
-// wave on the CU has a matrix instruction to issue - one workgroup per CU, nothing else resident.  Here the two halves of the workgroup (waves 0-3 / 4-7: one wave
-// of each half per SIMD) are ROLE-SPECIALISED and half a trip out of phase:
-//   role X  forward recompute + dgrad chain of the half's NEXT 64 samples - 300 MFMAs per wave, registers and read-only weight fragments only;
-//   role Y  weight gradients of the 64 samples the half did in its previous X: five (stage, barrier, 16..64 MFMAs, barrier) phases through ONE 35-KiB region.
-// Every iteration one half is in X and the other in Y, then they swap.  Both code paths execute exactly ten barriers per iteration (X after each of its ten layer
-// blocks), so the workgroup barrier pairs an X block with a Y phase: while the Y waves write LDS or drain at a barrier, the X wave on the same SIMD keeps issuing
-// MFMAs; while they accumulate, both feed the pipe.  The activations a wave needs in Y are still in its registers from X (same wave): nothing is recomputed twice.
+// (r5) The lock-step kernel of round 2 (145 us) and the ping-pong experiment of round 3 (151 us) are gone from the binary: measurements and what they taught are in
+// DESIGN.md 6.  One exact-product backward remains - two free-running groups, below - as the fallback of the split-operand kernels (ngp_field32_select).
 #define HT32 64                 // samples per half trip: 4 waves x 16
 #define RSH32 (HT32 + 4)        // LDS row stride in floats (272 B: 16-byte aligned rows, consecutive rows shift by one 16-byte slot)
-#define PP_BAR() __syncthreads()
 __device__ __forceinline__ void st_tiles_h(float *stage, int row0, int col, int g, const floatx4 *v) {
 #pragma unroll
 	for (int t = 0; t < 4; ++t)
@@ -423,301 +214,6 @@ __device__ __forceinline__ floatx4 wgrad_tile_h(const float *stage, int row_a, i
 		for (int j = 0; j < 4; ++j) acc = MFMA32(a[j], b[j], acc);
 	}
 	return acc;
-}
-
-template <int LAYOUT>
-__global__ __launch_bounds__(512, 2) void k_field32_bwd_pp(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
-                                                           const float *__restrict__ packed, const float *__restrict__ dout,
-                                                           float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
-	extern __shared__ __attribute__((aligned(16))) float smem32[];
-	float *wl = smem32;                                   // 76 fragments
-	float *stage = smem32 + NF32_ALL * 256;               // [128][RSH32]
-	stage_weights32(wl, packed, NF32_ALL);
-	const float *wb = wl + NF32_FWD * 256;
-	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6, half = w >> 2, wq = w & 3;
-	const uint32_t n_ht = (lim + HT32 - 1) / HT32;
-	const uint32_t K = blockIdx.x < n_ht ? (n_ht - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;      // half trips of this workgroup: blockIdx.x, + gridDim.x, ...
-	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-	floatx4 aV1[4] = {z, z, z, z}, aW0[2] = {z, z}, aV0[2] = {z, z}, aW1 = z, aV2 = z;            // this wave's ten weight-gradient tiles (summed over its half's samples)
-	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-	__syncthreads();
-	struct Inputs { float f[8]; float d3[3]; float go[4]; };
-	auto fetch = [&](uint32_t k, Inputs &in) {
-		const uint32_t i = (blockIdx.x + k * gridDim.x) * HT32 + 16u * wq + s;
-		const bool valid = i < lim;
-		const uint32_t ic = valid ? i : lim - 1;
-		load_feat32<LAYOUT>(feat, n, ic, g, in.f);
-		in.d3[0] = dir[(size_t)ic * dir_stride]; in.d3[1] = dir[(size_t)ic * dir_stride + 1]; in.d3[2] = dir[(size_t)ic * dir_stride + 2];
-		in.go[0] = in.go[1] = in.go[2] = in.go[3] = 0.f;
-		if (valid) { const float4 v = *reinterpret_cast<const float4 *>(dout + (size_t)i * 4); in.go[0] = v.x; in.go[1] = v.y; in.go[2] = v.z; in.go[3] = v.w; }
-	};
-	// what role X leaves in registers for role Y
-	Inputs cur;
-	float sh[4] = {0.f, 0.f, 0.f, 0.f};
-	Fwd32 st;
-	floatx4 dO = z, dG1[4], dG0[4], dH[4], dD = z;
-#pragma unroll
-	for (int u = 0; u < 4; ++u) { st.h[u] = z; st.g0[u] = z; st.g1[u] = z; dG1[u] = z; dG0[u] = z; dH[u] = z; }
-	st.den = z; st.rgb = z;
-#pragma unroll
-	for (int q = 0; q < 8; ++q) cur.f[q] = 0.f;
-	if ((uint32_t)half < K) fetch((uint32_t)half, cur);           // half h does X on k = h, h + 2, ...
-	const int o = lane & 15, col = 16 * wq + s;
-	for (uint32_t it = 0; it <= K; ++it) {
-		const bool role_x = (int)(it & 1u) == half;
-		if (role_x) {
-			// ------------------------------------------------------------ role X: forward recompute + dgrad of half trip `it` (ten blocks, a barrier after each)
-			const bool work = it < K;
-			const uint32_t i = (blockIdx.x + it * gridDim.x) * HT32 + 16u * wq + s;
-			const bool valid = work && i < lim;
-			floatx4 acc[4] = {z, z, z, z};
-			if (work) {
-				sh4_32(cur.d3, g, sh);
-#pragma unroll
-				for (int kq = 0; kq < 2; ++kq) {                       // L0: 32 -> 64
-					floatx4 a[4];
-#pragma unroll
-					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 2 * u + kq, lane);
-#pragma unroll
-					for (int j = 0; j < 4; ++j)
-#pragma unroll
-						for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], cur.f[4 * kq + j], acc[u]);
-				}
-#pragma unroll
-				for (int u = 0; u < 4; ++u) st.h[u] = relu4(acc[u]);
-			}
-			PP_BAR();                                                  // 1
-			if (work) {
-				floatx4 d0 = z, d1 = z;                                // L1: 64 -> 16
-#pragma unroll
-				for (int kq = 0; kq < 4; ++kq) {
-					const floatx4 a = ld_frag32(wl, 8 + kq, lane);
-					d0 = MFMA32(a[0], st.h[kq][0], d0); d1 = MFMA32(a[1], st.h[kq][1], d1);
-					d0 = MFMA32(a[2], st.h[kq][2], d0); d1 = MFMA32(a[3], st.h[kq][3], d1);
-				}
-				st.den = d0 + d1;
-			}
-			PP_BAR();                                                  // 2
-			if (work) {
-#pragma unroll
-				for (int u = 0; u < 4; ++u) acc[u] = z;
-#pragma unroll
-				for (int kq = 0; kq < 2; ++kq) {                       // L2: [density(16) | SH(16)] -> 64
-					floatx4 a[4];
-#pragma unroll
-					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 12 + 2 * u + kq, lane);
-#pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						const float b = kq == 0 ? st.den[j] : sh[j];
-#pragma unroll
-						for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], b, acc[u]);
-					}
-				}
-#pragma unroll
-				for (int u = 0; u < 4; ++u) st.g0[u] = relu4(acc[u]);
-			}
-			PP_BAR();                                                  // 3
-			if (work) {
-#pragma unroll
-				for (int u = 0; u < 4; ++u) acc[u] = z;
-#pragma unroll
-				for (int kq = 0; kq < 4; ++kq) {                       // L3: 64 -> 64
-					floatx4 a[4];
-#pragma unroll
-					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wl, 20 + 4 * u + kq, lane);
-#pragma unroll
-					for (int j = 0; j < 4; ++j)
-#pragma unroll
-						for (int u = 0; u < 4; ++u) acc[u] = MFMA32(a[u][j], st.g0[kq][j], acc[u]);
-				}
-#pragma unroll
-				for (int u = 0; u < 4; ++u) st.g1[u] = relu4(acc[u]);
-			}
-			PP_BAR();                                                  // 4
-			// (L4, the rgb output, is not needed by the backward pass: dL/d(rgb logits) comes in from the compositor)
-			if (work) {
-				dO = z;                                                // register j <-> gradient of output neuron 4g+j; only neurons 0..2 (g == 0) are non-zero
-				if (g == 0) { dO[0] = cur.go[0]; dO[1] = cur.go[1]; dO[2] = cur.go[2]; }
-				floatx4 a[4];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, u, lane); dG1[u] = z; }
-#pragma unroll
-				for (int j = 0; j < 3; ++j)
-#pragma unroll
-					for (int u = 0; u < 4; ++u) dG1[u] = MFMA32(a[u][j], dO[j], dG1[u]);
-#pragma unroll
-				for (int u = 0; u < 4; ++u) dG1[u] = mask4(dG1[u], st.g1[u]);
-			}
-			PP_BAR();                                                  // 5
-			if (work) {
-#pragma unroll
-				for (int u = 0; u < 4; ++u) dG0[u] = z;
-#pragma unroll
-				for (int t = 0; t < 2; ++t) {
-					floatx4 a[4];
-#pragma unroll
-					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wb, 4 + 4 * u + t, lane);
-#pragma unroll
-					for (int j = 0; j < 4; ++j)
-#pragma unroll
-						for (int u = 0; u < 4; ++u) dG0[u] = MFMA32(a[u][j], dG1[t][j], dG0[u]);
-				}
-			}
-			PP_BAR();                                                  // 6
-			if (work) {
-#pragma unroll
-				for (int t = 2; t < 4; ++t) {
-					floatx4 a[4];
-#pragma unroll
-					for (int u = 0; u < 4; ++u) a[u] = ld_frag32(wb, 4 + 4 * u + t, lane);
-#pragma unroll
-					for (int j = 0; j < 4; ++j)
-#pragma unroll
-						for (int u = 0; u < 4; ++u) dG0[u] = MFMA32(a[u][j], dG1[t][j], dG0[u]);
-				}
-#pragma unroll
-				for (int u = 0; u < 4; ++u) dG0[u] = mask4(dG0[u], st.g0[u]);
-			}
-			PP_BAR();                                                  // 7
-			if (work) {
-				floatx4 d0 = z, d1 = z;
-#pragma unroll
-				for (int t = 0; t < 4; ++t) {
-					const floatx4 a = ld_frag32(wb, 20 + t, lane);
-					d0 = MFMA32(a[0], dG0[t][0], d0); d1 = MFMA32(a[1], dG0[t][1], d1);
-					d0 = MFMA32(a[2], dG0[t][2], d0); d1 = MFMA32(a[3], dG0[t][3], d1);
-				}
-				dD = d0 + d1;
-				if (g == 0) dD[0] += cur.go[3];                       // out[:,3] = den[:,0]  (ngp_network.py:83)
-				floatx4 a[4];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) { a[u] = ld_frag32(wb, 24 + u, lane); dH[u] = z; }
-#pragma unroll
-				for (int j = 0; j < 4; ++j)
-#pragma unroll
-					for (int u = 0; u < 4; ++u) dH[u] = MFMA32(a[u][j], dD[j], dH[u]);
-#pragma unroll
-				for (int u = 0; u < 4; ++u) dH[u] = mask4(dH[u], st.h[u]);
-			}
-			PP_BAR();                                                  // 8
-			floatx4 dF[2] = {z, z};
-			if (work) {
-#pragma unroll
-				for (int t = 0; t < 2; ++t) {
-					const floatx4 a0 = ld_frag32(wb, 28 + t, lane), a1 = ld_frag32(wb, 32 + t, lane);
-#pragma unroll
-					for (int j = 0; j < 4; ++j) { dF[0] = MFMA32(a0[j], dH[t][j], dF[0]); dF[1] = MFMA32(a1[j], dH[t][j], dF[1]); }
-				}
-			}
-			PP_BAR();                                                  // 9
-			if (work) {
-#pragma unroll
-				for (int t = 2; t < 4; ++t) {
-					const floatx4 a0 = ld_frag32(wb, 28 + t, lane), a1 = ld_frag32(wb, 32 + t, lane);
-#pragma unroll
-					for (int j = 0; j < 4; ++j) { dF[0] = MFMA32(a0[j], dH[t][j], dF[0]); dF[1] = MFMA32(a1[j], dH[t][j], dF[1]); }
-				}
-				if (valid) {                                          // feature 16u+4g+r  ->  level 8u+2g+(r>>1), component r&1
-#pragma unroll
-					for (int u = 0; u < 2; ++u)
-#pragma unroll
-						for (int pr = 0; pr < 2; ++pr) {
-							const float2 v = make_float2(dF[u][2 * pr], dF[u][2 * pr + 1]);
-							const uint32_t level = 8 * u + 2 * g + pr;
-							lmax[u][pr] = fmaxf(lmax[u][pr], fmaxf(fabsf(v.x), fabsf(v.y)));
-							if (LAYOUT == NGP_LAYOUT_SOA) reinterpret_cast<float2 *>(dfeat)[(size_t)level * n + i] = v;
-							else *reinterpret_cast<float2 *>(dfeat + (size_t)i * 32 + 2 * level) = v;
-						}
-				}
-			}
-			PP_BAR();                                                  // 10
-		} else {
-			// ------------------------------------------------------------ role Y: weight gradients of half trip `it - 1` (whose activations this wave holds), five phases
-			const bool work = it >= 1;
-			// phase A: dG1 rows 0..63 | G0 rows 64..127 -> V1: wave wq owns output tile `wq` against the four input tiles
-			if (work) { st_tiles_h(stage, 0, col, g, dG1); st_tiles_h(stage, 64, col, g, st.g0); }
-			PP_BAR();                                                  // 1
-			if (work) {
-#pragma unroll
-				for (int ti = 0; ti < 4; ++ti) aV1[ti] = wgrad_tile_h(stage, 16 * wq, 64 + 16 * ti, o, g, aV1[ti]);
-			}
-			PP_BAR();                                                  // 2
-			// phase B1: dH 0..63 | F 64..95 -> W0
-			if (work) {
-				st_tiles_h(stage, 0, col, g, dH);
-#pragma unroll
-				for (int q = 0; q < 8; ++q) stage[(64 + 8 * g + q) * RSH32 + col] = cur.f[q];
-			}
-			PP_BAR();                                                  // 3
-			if (work) {
-				aW0[0] = wgrad_tile_h(stage, 16 * wq, 64, o, g, aW0[0]);
-				aW0[1] = wgrad_tile_h(stage, 16 * wq, 80, o, g, aW0[1]);
-			}
-			PP_BAR();                                                  // 4
-			// phase B2: dG0 0..63 | IN2 = [density(16) | SH(16)] 64..95 -> V0
-			if (work) {
-				st_tiles_h(stage, 0, col, g, dG0);
-#pragma unroll
-				for (int r = 0; r < 4; ++r) { stage[(64 + 4 * g + r) * RSH32 + col] = st.den[r]; stage[(80 + 4 * g + r) * RSH32 + col] = sh[r]; }
-			}
-			PP_BAR();                                                  // 5
-			if (work) {
-				aV0[0] = wgrad_tile_h(stage, 16 * wq, 64, o, g, aV0[0]);
-				aV0[1] = wgrad_tile_h(stage, 16 * wq, 80, o, g, aV0[1]);
-			}
-			PP_BAR();                                                  // 6
-			// phase C1: dD 0..15 | H 16..79 -> W1: input tile wq
-			if (work) {
-#pragma unroll
-				for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RSH32 + col] = dD[r];
-				st_tiles_h(stage, 16, col, g, st.h);
-			}
-			PP_BAR();                                                  // 7
-			if (work) aW1 = wgrad_tile_h(stage, 0, 16 + 16 * wq, o, g, aW1);
-			PP_BAR();                                                  // 8
-			// phase C2: dO 0..15 | G1 16..79 -> V2
-			if (work) {
-#pragma unroll
-				for (int r = 0; r < 4; ++r) stage[(4 * g + r) * RSH32 + col] = dO[r];
-				st_tiles_h(stage, 16, col, g, st.g1);
-			}
-			PP_BAR();                                                  // 9
-			if (work) aV2 = wgrad_tile_h(stage, 0, 16 + 16 * wq, o, g, aV2);
-			if (it + 1 < K) fetch(it + 1, cur);                       // inputs of this half's next X (half trip it + 1): in flight across the last barrier
-			PP_BAR();                                                  // 10
-		}
-	}
-	// ---- the two halves hold partial sums of the same ten tiles per wave index: half 1 hands its sums over through LDS (the fragment region is free now), half 0
-	// adds and writes the workgroup's slab, packed like the weights (wd part 0..3071, wc part 3072..10239); C rows = 4g+r, cols = lane&15
-	float *xch = wl + (size_t)wq * 10 * 256;                    // [wave][10 tiles][64 lanes][4]
-	auto put = [&](int tile, const floatx4 &v) { *reinterpret_cast<floatx4 *>(xch + tile * 256 + lane * 4) = v; };
-	auto get = [&](int tile) { return *reinterpret_cast<const floatx4 *>(xch + tile * 256 + lane * 4); };
-	__syncthreads();
-	if (half == 1) {
-#pragma unroll
-		for (int t = 0; t < 4; ++t) put(t, aV1[t]);
-		put(4, aW0[0]); put(5, aW0[1]); put(6, aV0[0]); put(7, aV0[1]); put(8, aW1); put(9, aV2);
-	}
-	__syncthreads();
-	if (half == 0) {
-#pragma unroll
-		for (int t = 0; t < 4; ++t) aV1[t] += get(t);
-		aW0[0] += get(4); aW0[1] += get(5); aV0[0] += get(6); aV0[1] += get(7); aW1 += get(8); aV2 += get(9);
-		float *slab = slabs + (size_t)blockIdx.x * 10240;
-		const int ci = lane & 15;
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			const int ro = 4 * g + r;
-#pragma unroll
-			for (int ti = 0; ti < 4; ++ti) slab[3072 + 2048 + (16 * wq + ro) * 64 + 16 * ti + ci] = aV1[ti][r];
-#pragma unroll
-			for (int tj = 0; tj < 2; ++tj) { slab[(16 * wq + ro) * 32 + 16 * tj + ci] = aW0[tj][r]; slab[3072 + (16 * wq + ro) * 32 + 16 * tj + ci] = aV0[tj][r]; }
-			slab[2048 + ro * 64 + 16 * wq + ci] = aW1[r];
-			slab[3072 + 6144 + ro * 64 + 16 * wq + ci] = aV2[r];
-		}
-	}
-	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, stage, 8); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- backward, two free-running groups (r3)
@@ -1089,7 +585,11 @@ static int bwd_variant() {
 // range), exact = 0 -> the split-operand kernels (default).  Both fragment sets are always present in a packed weight buffer.  Returns the previous setting.
 NGP_API int ngp_field32_select(int exact) {
 	const int was = (fwd_split() ? 0 : 1);
-	g_fwd_split = exact ? 0 : 1; g_bwd_variant = exact ? 2 : 3;
+	// the choice the environment made (NGP_FIELD32_FWD / NGP_FIELD32_BWD, else the split default), remembered at the first call: select(0) goes back to THAT, not to a
+	// hard-coded pair (a process started on the exact-product kernels was silently moved to the split ones by a select(1) ... select(0) round trip)
+	static const int env_fwd = fwd_split() ? 1 : 0, env_bwd = bwd_variant();
+	if (exact) { g_fwd_split = 0; g_bwd_variant = 2; }
+	else { g_fwd_split = env_fwd; g_bwd_variant = env_bwd; }
 	return was;
 }
 // n_frags fp32 fragments (n_frags < 0: the first -n_frags split fp16 fragments of the forward instead) of raw weight packs in a per-(device, stream) scratch, or the caller's packed buffer
@@ -1161,46 +661,21 @@ int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, 
 	NGP_REQUIRE(dir && dLdout && dLdfeat && wgrad_slabs && dir_stride >= 3, NGP_E_ARG, "ngp_field32_bwd: null pointer");
 	NGP_REQUIRE((int)n_slabs == ngp_field32_bwd_slabs(n), NGP_E_ARG, "ngp_field32_bwd: n_slabs %u != ngp_field32_bwd_slabs(%u)", n_slabs, n);
 	if (n == 0) return 0;
-	const size_t shmem = ((size_t)NF32_ALL * 256 + (size_t)N_ROWS32 * RS32) * sizeof(float);
 	const dim3 grid(n_slabs), block(512);
 	hipStream_t s = (hipStream_t)stream;
-	// 3 = split fp16 operands on the fp16 matrix cores (field_split.hip, r3), 2 = two free-running groups on fp32 MFMAs, 0 / 1: see below
+	// 3 = split fp16 operands on the fp16 matrix cores (field_split.hip, r3: the default)
 	const int variant = bwd_variant();
 	const float *packed = pack_weights32("ngp_field32_bwd", s, wd, wc, variant == 3 ? -NSPLIT_FRAGS : NF32_ALL, layout_flags); if (!packed) return NGP_E_ARG;
 	if (variant == 3) return ngp_field32_bwd_split(stream, n, feat, layout, dir, dir_stride, packed + NF32_ALL * 256, dLdout, dLdfeat, wgrad_slabs, n_slabs, n_valid, am_in);
-	// 2 = two free-running groups (r3, default: 138 us, +1 % it/s), 0 = lock-step phases (r2: 145 us), 1 = ping-pong roles sharing barriers (r3 experiment: 151 us - ten
-	// barrier-separated blocks per role expose the fragment-load latency ten times); same results up to the order the two groups' partial weight-gradient sums are added in
-	if (variant == 2) {
-		const size_t shmem_2g = ((size_t)NF32_ALL * 256 + (size_t)2 * 128 * RSH32) * sizeof(float);
+	// anything else = the exact-product kernel: two free-running groups on v_mfma_f32_16x16x4_f32 (r3: 138 us; the fallback ngp_field32_select(1) switches to)
+	const size_t shmem_2g = ((size_t)NF32_ALL * 256 + (size_t)2 * 128 * RSH32) * sizeof(float);
 #define GO2G(L) do { \
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_2g<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_2g); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
 	NGP_LAUNCH((k_field32_bwd_2g<L>), grid, block, shmem_2g, s, n, feat, dir, dir_stride, packed, dLdout, dLdfeat, wgrad_slabs, n_valid, am); } while (0)
-		if (layout == NGP_LAYOUT_SOA) GO2G(NGP_LAYOUT_SOA); else GO2G(NGP_LAYOUT_AOS);
+	if (layout == NGP_LAYOUT_SOA) GO2G(NGP_LAYOUT_SOA); else GO2G(NGP_LAYOUT_AOS);
 #undef GO2G
-		NGP_LAUNCH_CHECK("ngp_field32_bwd");
-		return 0;
-	}
-	if (variant == 1) {
-		const size_t shmem_pp = ((size_t)NF32_ALL * 256 + (size_t)128 * RSH32) * sizeof(float);
-#define GOPP(L) do { \
-	static bool attr_set = false; \
-	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_pp<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_pp); \
-		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	NGP_LAUNCH((k_field32_bwd_pp<L>), grid, block, shmem_pp, s, n, feat, dir, dir_stride, packed, dLdout, dLdfeat, wgrad_slabs, n_valid, am); } while (0)
-		if (layout == NGP_LAYOUT_SOA) GOPP(NGP_LAYOUT_SOA); else GOPP(NGP_LAYOUT_AOS);
-#undef GOPP
-		NGP_LAUNCH_CHECK("ngp_field32_bwd");
-		return 0;
-	}
-#define GO(L) do { \
-	static bool attr_set = false; \
-	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	NGP_LAUNCH((k_field32_bwd<L>), grid, block, shmem, s, n, feat, dir, dir_stride, packed, dLdout, dLdfeat, wgrad_slabs, n_valid, am); } while (0)
-	if (layout == NGP_LAYOUT_SOA) GO(NGP_LAYOUT_SOA); else GO(NGP_LAYOUT_AOS);
-#undef GO
 	NGP_LAUNCH_CHECK("ngp_field32_bwd");
 	return 0;
 }

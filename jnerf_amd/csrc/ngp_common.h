@@ -24,17 +24,6 @@ struct NgpProfScope { int id; hipStream_t s; hipEvent_t a, b; NgpProfScope(int i
 	NgpProfScope ngp_ps_(ngp_kid_, (hipStream_t)(stream)); \
 	hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
 
-// The same, for a kernel that does not depend on the kernel launched before it on the stream: with NGP_ANYORDER=1 it is launched through hipExtLaunchKernelGGL with
-// hipExtAnyOrderLaunch (no barrier bit: it may run beside its predecessor).  Probe hook - hip_ext.h says the flag is not honoured on every gfx9 board.
-#include <hip/hip_ext.h>
-#include <stdlib.h>
-static inline unsigned ngp_anyorder_flag() { static const unsigned f = [] { const char *e = getenv("NGP_ANYORDER"); return (e && e[0] == '1') ? (unsigned)hipExtAnyOrderLaunch : 0u; }(); return f; }
-#define NGP_LAUNCH_INDEPENDENT(kernel, grid, block, shmem, stream, ...) do { \
-	static const int ngp_kid_ = ngp_prof_register(#kernel); \
-	NgpProfScope ngp_ps_(ngp_kid_, (hipStream_t)(stream)); \
-	if (ngp_anyorder_flag()) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, nullptr, ngp_anyorder_flag(), __VA_ARGS__); \
-	else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
-
 // internal cross-file entry points (not exported)
 int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host, void *grad, uint64_t n_params, int dtype,
                                   int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse, int absmax_done);
@@ -45,7 +34,7 @@ int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, ui
 #define NGP_ABSMAX_PARTS 256u
 struct AbsmaxOut { uint32_t *parts; uint32_t *cursors; uint32_t n_cursors; uint32_t *spill_count; };
 // where the abs-max partials / cursors of a hash-backward workspace live, or parts == nullptr when that call would not take the binned path
-AbsmaxOut ngp_hash_bwd_absmax_slots(const uint32_t *level_table_host, uint32_t n, int dtype, int grad_dtype, void *workspace, uint64_t workspace_bytes);
+AbsmaxOut ngp_hash_bwd_absmax_slots(const uint32_t *level_table_host, uint32_t n, int dtype, int grad_dtype, void *workspace, uint64_t workspace_bytes, const void *grad);
 int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const float *wd, const float *wc,
                        const float *dLdout, float *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am);
 int ngp_field_bwd_am(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,

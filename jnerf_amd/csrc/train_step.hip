@@ -141,7 +141,7 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	if (getenv("NGP_NO_FUSED_MLP_TAIL")) t_pack = -1;           // probe hook
 	if (do_bwd) {
 	// largest |dL/dfeature| per level: written by the field backward kernel's epilogue when the scatter takes the binned path (one pass and one launch less)
-	AbsmaxOut am = ngp_hash_bwd_absmax_slots(a->level_table_host, a->n, T, NGP_F32, a->hash_workspace, a->hash_workspace_bytes);
+	AbsmaxOut am = ngp_hash_bwd_absmax_slots(a->level_table_host, a->n, T, NGP_F32, a->hash_workspace, a->hash_workspace_bytes, a->table_grad);
 	if (T == NGP_F16) {
 		STAGE(NGP_STAGE_PACK, ngp_field_pack_weights(stream, a->wd, a->wc, a->packed_weights));
 		STAGE(NGP_STAGE_HASH_FWD, ngp_hash_encode_fwd(stream, a->n, a->pos, 3, a->table, a->level_table_host, a->feat, NGP_F16, NGP_LAYOUT_SOA, a->n_valid));

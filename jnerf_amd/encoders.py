@@ -94,10 +94,6 @@ class HashEncoder(nn.Module):
         self.m_grid = nn.Parameter(torch.empty(self.n_params, dtype=torch.float32, device=dev).uniform_(-1e-4, 1e-4))   # hash_encoder.py:22-23
         self.register_buffer("m_grid_half", self.m_grid.detach().half() if self.using_fp16 else None, persistent=False)
         self.shadow_dirty = False
-        # `hash_grad_fixed_point = True` in the config selects the order-independent fixed-point accumulation (bit-reproducible table gradient,
-        # measured ~20 % slower than the float path: the kernel is VALU-bound, not LDS-atomic-bound — profiles/r01_microbench_scatter.md)
-        self.fixed_point_grad = self.cfg.hash_grad_fixed_point is True
-        self._fx_scratch = None
         self._bwd_ws = None
         self._input_grad_only = False
         self.out_dim = 32
@@ -120,16 +116,10 @@ class HashEncoder(nn.Module):
 
     def accumulate_grad(self, x, dy, layout, n_valid=None):
         """scatter-add dL/dy into m_grid.grad (fp32 accumulation; the buffer is zeroed by the optimiser sweep, not per call)"""
-        fx = None
-        if self.using_fp16 and self.fixed_point_grad:
-            if self._fx_scratch is None:
-                self._fx_scratch = torch.zeros(16, dtype=torch.float32, device=self.m_grid.device)
-            fx = self._fx_scratch
-        need = ops.hash_bwd_workspace_bytes(self.level_table, x.shape[0])
+        need = ops.hash_bwd_workspace_bytes(self.level_table, x.shape[0], dy.dtype)
         if self._bwd_ws is None or self._bwd_ws.numel() < need:
             self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=self.m_grid.device)
-        ops.hash_encode_bwd(x, dy, self.level_table, self.n_params, grad=self.grad_buffer(), layout=layout, zero_first=False, n_valid=n_valid, fixed_point_scratch=fx,
-                            workspace=self._bwd_ws)
+        ops.hash_encode_bwd(x, dy, self.level_table, self.n_params, grad=self.grad_buffer(), layout=layout, zero_first=False, n_valid=n_valid, workspace=self._bwd_ws)
 
     def forward(self, x):
         return _HashEncode.apply(x, self.m_grid, self)

@@ -63,7 +63,7 @@ class FusedTrainStep:
         self._level_table = ops._tbl(enc.level_table)                  # keeps the host array alive
         a.level_table_host = self._level_table
         a.table_grad, a.n_params = P(enc.grad_buffer()), enc.n_params
-        need = ops.hash_bwd_workspace_bytes(enc.level_table, n)
+        need = ops.hash_bwd_workspace_bytes(enc.level_table, n, m.fused_dtype)           # sized for the path this precision takes (fp32: ~0.6 GB, fp16: ~1.7 GB)
         if enc._bwd_ws is None or enc._bwd_ws.numel() < need:
             enc._bwd_ws = torch.empty(need, dtype=torch.uint8, device=dev)
         a.hash_workspace, a.hash_workspace_bytes = P(enc._bwd_ws), enc._bwd_ws.numel()

@@ -144,9 +144,9 @@ def hash_encode_bwd_input_bwd_grid(pos, dLdy, u, level_tbl, grad):
     return grad
 
 
-def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, layout=LAYOUT_AOS, zero_first=True, n_valid=None, fixed_point_scratch=None, workspace=None):
-    """fixed_point_scratch: device f32[16] -> fixed-point LDS accumulation; workspace: uint8 tensor of >= hash_bwd_workspace_bytes(level_tbl) ->
-    atomic-free dense levels (ngp_hash_encode_bwd_ws)"""
+def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, layout=LAYOUT_AOS, zero_first=True, n_valid=None, workspace=None):
+    """workspace: uint8 tensor of >= hash_bwd_workspace_bytes(level_tbl, n, dLdy.dtype) -> the binned scatter, no float atomics, bit-reproducible (ngp_hash_encode_bwd_ws);
+    without one: the reference's scheme, one global float atomic per corner (ngp_hash_encode_bwd)"""
     pos, stride = _rows(pos, 3)
     n = pos.shape[0]
     assert dLdy.is_contiguous()
@@ -154,18 +154,20 @@ def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, 
         grad = torch.empty(n_params, dtype=grad_dtype or dLdy.dtype, device=pos.device)
     if workspace is not None:
         check(L.lib().ngp_hash_encode_bwd_ws(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
-                                             int(zero_first), _p(n_valid), _p(fixed_point_scratch), _p(workspace), workspace.numel() * workspace.element_size()), "ngp_hash_encode_bwd_ws")
-    elif fixed_point_scratch is not None:
-        check(L.lib().ngp_hash_encode_bwd_fx(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
-                                             int(zero_first), _p(n_valid), _p(fixed_point_scratch)), "ngp_hash_encode_bwd_fx")
+                                             int(zero_first), _p(n_valid), _p(workspace), workspace.numel() * workspace.element_size()), "ngp_hash_encode_bwd_ws")
     else:
         check(L.lib().ngp_hash_encode_bwd(_stream(), n, _p(pos), stride, _p(dLdy), _tbl(level_tbl), _p(grad), n_params, _dt(dLdy), _dt(grad), layout,
                                           int(zero_first), _p(n_valid)), "ngp_hash_encode_bwd")
     return grad
 
 
-def hash_bwd_workspace_bytes(level_tbl, n):
-    return int(L.lib().ngp_hash_bwd_workspace_bytes(_tbl(level_tbl), n))
+def hash_bwd_workspace_bytes(level_tbl, n, dtype=None, grad_dtype=torch.float32):
+    """bytes of workspace the binned scatter needs for n samples: for the path dL/dy of `dtype` takes (fp32: record regions, fp16: per-corner lists), or - dtype None -
+    enough for either"""
+    if dtype is None:
+        return int(L.lib().ngp_hash_bwd_workspace_bytes(_tbl(level_tbl), n))
+    code = lambda t: L.F16 if t == torch.float16 else L.F32
+    return int(L.lib().ngp_hash_bwd_workspace_bytes_for(_tbl(level_tbl), n, code(dtype), code(grad_dtype)))
 
 
 def sh_encode(d, dtype=torch.float32):

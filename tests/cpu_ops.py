@@ -70,8 +70,8 @@ def oracle_backed_ops():
         assert out is None and layout == ops.LAYOUT_AOS and n_valid is None
         return torch.from_numpy(O.hash_encode_fwd(_np(pos), _np(table), level_tbl))
 
-    def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, layout=ops.LAYOUT_AOS, zero_first=True, n_valid=None, fixed_point_scratch=None, workspace=None):
-        assert layout == ops.LAYOUT_AOS and n_valid is None and fixed_point_scratch is None
+    def hash_encode_bwd(pos, dLdy, level_tbl, n_params, grad=None, grad_dtype=None, layout=ops.LAYOUT_AOS, zero_first=True, n_valid=None, workspace=None):
+        assert layout == ops.LAYOUT_AOS and n_valid is None
         g = torch.from_numpy(O.hash_encode_bwd(_np(pos), _np(dLdy), level_tbl, n_params))
         if grad is None:
             return g
@@ -127,7 +127,7 @@ def oracle_backed_ops():
         return bitfield, mean
 
     for name, fn in dict(generate_rays=generate_rays, march_rays_compacted=march_rays_compacted, march_rays=march_rays, march_scratch_elems=lambda n: n + 1024,
-                         hash_encode_fwd=hash_encode_fwd, hash_encode_bwd=hash_encode_bwd, hash_bwd_workspace_bytes=lambda tbl, n: 16, sh_encode=sh_encode,
+                         hash_encode_fwd=hash_encode_fwd, hash_encode_bwd=hash_encode_bwd, hash_bwd_workspace_bytes=lambda tbl, n, dtype=None, grad_dtype=None: 16, sh_encode=sh_encode,
                          composite_fwd=composite_fwd, composite_bwd=composite_bwd, composite_inference=composite_inference, grid_mark_untrained=grid_mark_untrained,
                          grid_generate_samples=grid_generate_samples, grid_splat_max=grid_splat_max, grid_ema=grid_ema, grid_update_bitfield=grid_update_bitfield).items():
         bind(name, fn)

@@ -19,7 +19,7 @@ def H():
 
 def test_extension_loaded_and_mfma_layout(H):
     from jnerf_amd import ops, _lib
-    assert _lib.lib().ngp_abi_version() == 2
+    assert _lib.lib().ngp_abi_version() == 3
     bad, magic = ops.selftest_mfma()
     assert magic == 0xC0FFEE, "self-test kernel did not run"
     assert bad == 0, f"MFMA fragment layout assumption violated for {bad} elements"
@@ -158,37 +158,6 @@ def test_hash_bwd_workspace_other_level_tables(H, aabb_scale):
             GC.close(out[lo:hi], ref[lo:hi], what=f"aabb {aabb_scale} level {l} (res {int(table[l, 2])}, size {int(table[l, 1])}) grad {gdt}", **tol)
     x32 = H.hash_encode_bwd(x, dy.astype(np.float32), table, n_params)             # fp32 table / fp32 gradient
     GC.close(x32, ref, atol=1e-7, rtol=1e-5, what=f"aabb {aabb_scale} fp32")
-
-
-def test_hash_bwd_fixed_point_vs_oracle_and_deterministic(H):
-    """ngp_hash_encode_bwd_fx: 32-bit fixed-point LDS accumulation with the provable scale 2^30 / L1(level)"""
-    from jnerf_amd import ops
-    table, offsets, n_params = O.level_table(4)
-    rng = np.random.default_rng(4)
-    n = 5003
-    x = synth.uniform_positions(n, seed=8)
-    x[:2000] = 0.5 + (x[:2000] - 0.5) * 0.02                 # a dense cluster: many hits per entry on the coarse levels
-    dy = (rng.normal(size=(n, 32)) * 1e-3 * np.exp(rng.normal(size=(n, 1)) * 2)).astype(np.float16)     # gradients spanning ~3 decades
-    ref = O.hash_encode_bwd(x, dy.astype(np.float32), table, n_params)
-    T = H.T
-    scratch = torch.zeros(16, device="cuda")
-    dys = np.ascontiguousarray(dy.reshape(-1, 16, 2).transpose(1, 0, 2))
-    outs = []
-    for _ in range(2):
-        g = ops.hash_encode_bwd(T(x), T(dys), table, n_params, grad_dtype=torch.float32, layout=ops.LAYOUT_SOA, fixed_point_scratch=scratch)
-        outs.append(H.N(g))
-    l1 = H.N(scratch)
-    exact_l1 = np.abs(dy.astype(np.float64)).reshape(n, 16, 2).sum((0, 2))
-    assert np.allclose(l1, exact_l1, rtol=1e-3) and (l1 >= exact_l1).all()          # the bound really bounds
-    for l in range(16):
-        lo, hi = int(offsets[l]) * 2, int(offsets[l + 1]) * 2
-        res = 2.0 ** (np.ceil(np.log2(l1[l])) - 30 + 1)                               # one fixed-point ulp (scale is a power of two <= 2^30/L1)
-        hits = 8 * n                                                                  # worst case: every contribution rounded separately into one entry
-        err = np.abs(outs[0][lo:hi].astype(np.float64) - ref[lo:hi]).max()
-        assert err <= 0.5 * res * 64 + 1e-6 * np.abs(ref[lo:hi]).max(), (l, err, res)
-        if table[l, 1] == 1 << 19:      # exclusive (hashed) slices: integer accumulation => bit-reproducible
-            assert np.array_equal(outs[0][lo:hi], outs[1][lo:hi])
-    GC.close(outs[0], ref, atol=4e-9 * float(l1.max()) * 64, rtol=1e-4, what="fx scatter")
 
 
 def _field_inputs(n, seed=0):
@@ -472,6 +441,17 @@ def test_occupied_bounds_culling_changes_nothing(H, const_dt, aabb, border, coun
         bounds = ops.grid_occupied_bounds(tb, 5)
         b = bounds.cpu().numpy()[:30].reshape(5, 6)
         assert (b[:, 3] >= b[:, 0]).all() and (b[0, 3:] - b[0, :3] < 60).all()         # cascade 0: a small box
+        # (r5: the kernel reduces per workgroup now) the boxes themselves, exactly: per cascade the min / max coordinates of the 2 x 2 x 2 blocks (one bitfield byte each)
+        # that hold an occupied cell - block (x, y, z) spans cells x .. x + 1
+        g = 128
+        ii = np.arange(0, g, 2)
+        X, Y, Z = np.meshgrid(ii, ii, ii, indexing="ij")
+        mb = (synth.morton3D(X.ravel(), Y.ravel(), Z.ravel()) // 8).astype(np.int64)       # byte index of the block inside a cascade
+        for c in range(5):
+            byte = bits[c * g ** 3 // 8:(c + 1) * g ** 3 // 8][mb] != 0
+            want = [g, g, g, -1, -1, -1] if not byte.any() else [int(X.ravel()[byte].min()), int(Y.ravel()[byte].min()), int(Z.ravel()[byte].min()),
+                                                               int(X.ravel()[byte].max()) + 1, int(Y.ravel()[byte].max()) + 1, int(Z.ravel()[byte].max()) + 1]
+            assert b[c].tolist() == want, (c, b[c].tolist(), want)
         dil = bounds.cpu().numpy()[64:64 + 32 ** 3 // 4].view(np.uint8).reshape(32, 32, 32)      # [z][y][x]: the dilated coarse map of the unit cube
         assert 0 < dil.mean() < 0.5 and dil[int(0.55 * 32), int(0.41 * 32), int(0.62 * 32)] == 1
         cap = 1 << 18

@@ -254,36 +254,6 @@ def test_parallel_walk_guess_is_accepted_only_when_it_is_the_orbit():
     assert all(pm[c - 1] == c for c in range(1, NC))
 
 
-def test_balanced_forward_map_covers_every_chunk_once():
-    """csrc/hash_encode.hip: the XCD-balanced blockIdx -> (level, chunk range) map of the forward gather (r3) is a partition of all (level, chunk) pairs for every
-    table / launch size, and its eight cost shares are equal to within one chunk (host arithmetic, probed through ngp_x_fwd_map)"""
-    import ctypes as C
-    from jnerf_amd import _lib, ops
-    lib = _lib.lib()
-    lib.ngp_x_fwd_map.restype = C.c_uint32
-    S = 17
-    for aabb in (1, 2, 4, 16):
-        t, _, _ = ops.level_table(aabb)
-        for light in (0.12, 0.5, 1.0):
-            for nblk in (1, 3, 64, 1016, 2048):
-                out = np.zeros((8, S, 3), np.uint32)
-                slots = lib.ngp_x_fwd_map(np.ascontiguousarray(t).ctypes.data_as(C.c_void_p), nblk, C.c_float(light), out.ctypes.data_as(C.c_void_p))
-                cov = np.zeros((16, nblk), int)
-                cost = np.zeros(8)
-                for x in range(8):
-                    blocks = 0
-                    for g in range(S):
-                        l, b, n = (int(v) for v in out[x, g])
-                        cov[l, b:b + n] += 1
-                        heavy = t[l, 2] > 300
-                        cost[x] += n * (1.0 if heavy else light)
-                        blocks += n if heavy else -(-n // 8)
-                    assert blocks <= slots
-                assert (cov == 1).all(), (aabb, light, nblk)
-                if nblk >= 64:
-                    assert cost.max() - cost.min() <= 0.05 * cost.mean() + 2.0, (aabb, light, nblk, cost)
-
-
 def test_jittor_pickle_container_round_trip(tmp_path):
     """the container jt.save / jt.load use for .pkl files (pickle protocol 4 of numpy arrays + sha1 + b'HCAJSLHD'), restated from Jittor's published
     source and read / written WITHOUT Jittor: round trip, trailer, corruption detection, a bare pickle without trailer, and refusal to import code."""
@@ -360,6 +330,11 @@ def test_hash_backward_workspace_size_is_monotonic_and_bounded():
         sizes = [ops.hash_bwd_workspace_bytes(t, n) for n in (1024, 1 << 14, 1 << 18, 1 << 20)]
         assert all(a < b for a, b in zip(sizes, sizes[1:])), sizes
         assert sizes[2] < 3 * 2 ** 30 and sizes[3] < 12 * 2 ** 30, sizes
+        # (r5, VERDICT r4 #12 / ADVICE r4) sized for the path the dtypes take, not for the sum of both designs: the fp32 configuration's record regions need well under
+        # a gigabyte at the training batch (was ~2.3 GB), and the dtype-agnostic figure is the larger of the two
+        import torch
+        f32, f16 = ops.hash_bwd_workspace_bytes(t, 1 << 18, torch.float32), ops.hash_bwd_workspace_bytes(t, 1 << 18, torch.float16)
+        assert f32 < (0.65 if aabb_scale == 1 else 0.85) * 2 ** 30 and f16 < 1.9 * 2 ** 30 and sizes[2] == max(f32, f16), (f32, f16, sizes[2])
 
 
 def test_edge_record_multiplication_order_carries_the_references_error_bound():

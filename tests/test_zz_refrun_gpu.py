@@ -113,7 +113,7 @@ def test_hip_path_replays_the_references_training_run(tmp_path):
     # same samples, same pixels, same backgrounds: what is left is fp32 rounding of two implementations of the network / scatter / Adam over 18 iterations
     # (iterations 0-15 share the untrained network's occupancy: pure rounding, 1e-5 or better; after the 16 eps = 1e-15 Adam steps the parameters of rarely hit entries
     # have drifted apart - the same drift tests/test_trajectory_gpu.py documents against the oracle - and the last two iterations agree to 1e-3)
-    import json, os
+    import json
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):          # the MEASURED values next to the bounds: kept with the run's artefacts, quoted in DESIGN.md 7
         json.dump({"max_rel_loss_diff_iterations_0_15": float(rel[:16].max()), "bound_0_15": 1e-4, "max_rel_loss_diff_all_18": float(rel.max()), "bound_all": 1e-3,

@@ -78,22 +78,17 @@ def per_level():
     uni = torch.rand((n, 3), device="cuda")
     dy = (torch.randn((16, n, 2), device="cuda") * 1e-3).half()
     gb = torch.zeros(n_params, device="cuda")
-    fxs = torch.zeros(16, device="cuda")
-    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n), dtype=torch.uint8, device="cuda")
-    for name, pos, fx, w in (("uniform", uni, None, None), ("concentrated", conc, None, None), ("uniform, workspace", uni, None, ws), ("concentrated, workspace", conc, None, ws)):
-        row = []
-        for l in list(range(16)) + [None]:
-            os.environ["NGP_PROBE_LEVEL_MASK"] = hex(1 << l) if l is not None else "0xffff"
-            fn = lambda: ops.hash_encode_bwd(pos, dy, table, n_params, grad=gb, layout=ops.LAYOUT_SOA, zero_first=False, fixed_point_scratch=fx, workspace=w)
-            fn(); torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(5):
-                fn()
-            b.record(); torch.cuda.synchronize()
-            row.append(a.elapsed_time(b) / 5 * 1e3)
-        print(f"owner scatter per level [{name}] us: " + " ".join(f"{v:.0f}" for v in row[:-1]) + f" | all levels {row[-1]:.0f}")
-    os.environ.pop("NGP_PROBE_LEVEL_MASK", None)
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n, dy.dtype), dtype=torch.uint8, device="cuda")
+    # (r5) the owner-computes scan these rows used to time level by level is gone: without a workspace the call takes the reference's scheme (global float atomics)
+    for name, pos, w in (("uniform, atomics", uni, None), ("concentrated, atomics", conc, None), ("uniform, workspace", uni, ws), ("concentrated, workspace", conc, ws)):
+        fn = lambda: ops.hash_encode_bwd(pos, dy, table, n_params, grad=gb, layout=ops.LAYOUT_SOA, zero_first=False, workspace=w)
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        print(f"hash backward [{name}]: {a.elapsed_time(b) / 5 * 1e3:.0f} us")
 
 
 if __name__ == "__main__":
