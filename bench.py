@@ -221,14 +221,14 @@ def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
 
 
 # kernel variants: same algorithmic bytes / flops as the kernel they replace
-KERNEL_VARIANTS = {"k_field32_bwd_2g": "k_field32_bwd", "k_field32_bwd_pp": "k_field32_bwd", "k_field_bwd_g": "k_field_bwd", "k_hash_fwd_bal": "k_hash_fwd", "k_hash_fwd_dydx": "k_hash_fwd",
+KERNEL_VARIANTS = {"k_field32_bwd_2g": "k_field32_bwd", "k_hash_fwd_dydx": "k_hash_fwd",
                    "k_field32_fwd_split": "k_field32_fwd", "k_field32_bwd_split": "k_field32_bwd"}
 # kernels that do fp32-accurate work on the fp16 matrix cores (split operands, three v_mfma_f32_16x16x32_f16 per product sum, csrc/field_split.hip): the algorithmic
 # FLOPs are SURVEY.md §8(d)'s, the pipe they run on peaks at 2.5 PFLOP/s dense, and they execute 3x the products
 SPLIT_FP16_KERNELS = ("k_field32_fwd_split", "k_field32_bwd_split")
 # FLOP per sample the kernels EXECUTE: the backward kernels recompute the forward (their choice, not algorithmic work); the r3 fp32 variants skip the rgb layer the backward never reads
-EXECUTED_FLOPS_PER_SAMPLE = {"k_field_fwd": 20480.0, "k_field_bwd": 61440.0, "k_field32_fwd": 20480.0, "k_field32_bwd": 61440.0, "k_field32_bwd_2g": 59392.0, "k_field32_bwd_pp": 59392.0,
-                             "k_field_bwd_g": 61440.0, "k_field32_fwd_split": 3 * 20480.0, "k_field32_bwd_split": 3 * 59392.0}
+EXECUTED_FLOPS_PER_SAMPLE = {"k_field_fwd": 20480.0, "k_field_bwd": 61440.0, "k_field32_fwd": 20480.0, "k_field32_bwd": 61440.0, "k_field32_bwd_2g": 59392.0,
+                             "k_field32_fwd_split": 3 * 20480.0, "k_field32_bwd_split": 3 * 59392.0}
 # the hash-backward stage's kernels: round 3's per-corner records (the fp16 configuration still) | round 4's region records of the fp32 configuration
 HASH_BWD_STAGE = ("k_level_absmax", "k_bin_records_runs", "k_bin_records", "k_bin_accumulate", "k_bin_runs2", "k_bin_pairs", "k_bin_accumulate2")
 HASH_BWD_ACC = ("k_bin_accumulate", "k_bin_accumulate2")

@@ -92,6 +92,7 @@ SIGNATURES = {
     "ngp_composite_fwd": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ngp_composite_fwd_huber": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp]),
     "ngp_composite_bwd": (C.c_int, [_vp, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32]),
+    "ngp_composite_train": (C.c_int, [_vp, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
     "ngp_composite_inference": (C.c_int, [_vp, _u32, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ngp_huber": (C.c_int, [_vp, _u32, _vp, _vp, _f32, _vp, _vp]),
     "ngp_grid_mark_untrained": (C.c_int, [_vp, _u32, _vp, _u32, _vp, _vp, _i32, _i32]),

@@ -349,183 +349,8 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 	if (am.parts) absmax_epilogue(am, lmax, reinterpret_cast<float *>(stage), 8);      // (the trip loop ends with a barrier: the staging region is free)
 }
 
-// ---------------------------------------------------------------------------------------------------------------- backward, free-running groups (r3)
-// k_field_bwd above is latency-bound, not MFMA-bound (14 % of the fp16 pipe): 42 dependent MFMA steps per tile, three staging phases and six workgroup barriers per
-// trip, and only two waves per SIMD to hide them behind - the 95 KB of LDS (43 KB of weight fragments + a 52 KB staging region) admit one workgroup per CU.  Here ONE
-// workgroup holds NG independent groups of four waves that share nothing but the read-only fragments: every group has its own 27 KB staging region (64 samples per
-// half trip), its own barrier (an LDS arrival counter polled by the group's four waves - s_barrier would stop the other groups too) and its own half trips, and the
-// groups start staggered.  NG = 4: sixteen waves per CU = four per SIMD, twice the latency cover, 154 KB of LDS.  Ten weight-gradient tiles per wave (V1: output tile
-// wq x 4 input tiles, W0 / V0: wq x 2, W1 / V2: tile wq); the groups' partial sums meet through LDS at the end - still one slab per workgroup.
-#define HBT 64
-#define HRS (HBT + 8)
-__device__ __forceinline__ void st_rows64h(_Float16 *stage, int row0, int col, int g, half8 lo, half8 hi) {
-#pragma unroll
-	for (int j = 0; j < 8; ++j) { stage[(row0 + k64(0, g, j)) * HRS + col] = lo[j]; stage[(row0 + k64(1, g, j)) * HRS + col] = hi[j]; }
-}
-__device__ __forceinline__ half8 ld_rowsh(const _Float16 *stage, int row, int col) { return *reinterpret_cast<const half8 *>(stage + row * HRS + col); }
-
-template <typename T, int LAYOUT, int NG>
-__global__ __launch_bounds__(NG * 256) void k_field_bwd_g(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
-                                                          const _Float16 *__restrict__ packed, const T *__restrict__ dout,
-                                                          _Float16 *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
-	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-	extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
-	const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4, w = threadIdx.x >> 6, grp = w >> 2, wq = w & 3;
-	_Float16 *wl = smem;                                                          // 42 fragments, shared by all groups
-	_Float16 *stage = smem + (N_FWD_FRAGS + N_BWD_FRAGS) * 512 + (size_t)grp * N_ROWS * HRS;   // this group's [N_ROWS][HRS]
-	__shared__ uint32_t gctr[NG];                                                 // arrival counters of the groups' barriers (monotonic)
-	__shared__ uint32_t gstart[NG];                                               // group k -> group k + 1: "my first tile's chain is done" (staggered start)
-	if (threadIdx.x < NG) { gctr[threadIdx.x] = 0u; gstart[threadIdx.x] = 0u; }
-	stage_weights(wl, packed, N_FWD_FRAGS + N_BWD_FRAGS);
-	const _Float16 *wb = wl + N_FWD_FRAGS * 512;
-	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
-	const uint32_t n_ht = (lim + HBT - 1) / HBT;
-	const uint32_t K = blockIdx.x < n_ht ? (n_ht - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;      // half trips of this workgroup: blockIdx.x, + gridDim.x, ...; group k takes k, k + NG, ...
-	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-	floatx4 aV1[4] = {z, z, z, z}, aW0[2] = {z, z}, aV0[2] = {z, z}, aW1 = z, aV2 = z;
-	__syncthreads();
-	struct Inputs { half8 f; float d3[3]; float go[4]; };
-	auto fetch = [&](uint32_t k, Inputs &in) {
-		const uint32_t i = (blockIdx.x + k * gridDim.x) * HBT + 16u * wq + s;
-		const bool valid = i < lim;
-		const uint32_t ic = valid ? i : lim - 1;
-		in.f = load_feat<LAYOUT>(feat, n, ic, g);
-		in.d3[0] = dir[(size_t)ic * dir_stride]; in.d3[1] = dir[(size_t)ic * dir_stride + 1]; in.d3[2] = dir[(size_t)ic * dir_stride + 2];
-		in.go[0] = in.go[1] = in.go[2] = in.go[3] = 0.f;
-		if (valid) load_dout<T>(dout + (size_t)i * 4, in.go);
-	};
-	uint32_t gepoch = 0;
-#define GROUP_BAR() do { gepoch += 4u; if (lane == 0) __hip_atomic_fetch_add(&gctr[grp], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
-	for (uint32_t spin_ = 0; __hip_atomic_load(&gctr[grp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < gepoch && spin_ < (1u << 24); ++spin_) __builtin_amdgcn_s_sleep(1); } while (0)   /* (bounded: a bug must not hang the GPU) */
-	Inputs cur, nxt;
-	if ((uint32_t)grp < K) fetch((uint32_t)grp, cur);
-	if (grp > 0 && (uint32_t)grp <= K) for (uint32_t spin_ = 0; __hip_atomic_load(&gstart[grp - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u && spin_ < (1u << 22); ++spin_) __builtin_amdgcn_s_sleep(4);
-	const int col = 16 * wq + s, o = lane & 15;
-	for (uint32_t it = (uint32_t)grp; it < K; it += (uint32_t)NG) {
-		const uint32_t i = (blockIdx.x + it * gridDim.x) * HBT + 16u * wq + s;
-		const bool valid = i < lim;
-		const bool more = it + NG < K;
-		if (more) fetch(it + NG, nxt);
-		const half8 f = cur.f;
-		float sh[4]; sh4(cur.d3, g, sh);
-		float go[4] = {cur.go[0], cur.go[1], cur.go[2], cur.go[3]};
-		FwdState st;
-		forward_tile<false>(wl, lane, f, sh, st);
-		// ---- dgrad chain (register resident, transposed weights)
-		half8 dO;
-#pragma unroll
-		for (int j = 0; j < 8; ++j) dO[j] = (_Float16)0;
-		if (g == 0) { dO[0] = (_Float16)go[0]; dO[1] = (_Float16)go[1]; dO[2] = (_Float16)go[2]; }
-		floatx4 c[4];
-#pragma unroll
-		for (int t = 0; t < 4; ++t) c[t] = MFMA(ld_frag(wb, t, lane), dO, z);
-		const half8 dG1lo = pack_masked(c[0], c[1], st.mg1[0]), dG1hi = pack_masked(c[2], c[3], st.mg1[1]);
-#pragma unroll
-		for (int t = 0; t < 4; ++t) { c[t] = MFMA(ld_frag(wb, 4 + 2 * t, lane), dG1lo, z); c[t] = MFMA(ld_frag(wb, 5 + 2 * t, lane), dG1hi, c[t]); }
-		const half8 dG0lo = pack_masked(c[0], c[1], st.mg0[0]), dG0hi = pack_masked(c[2], c[3], st.mg0[1]);
-		floatx4 dD = MFMA(ld_frag(wb, 12, lane), dG0lo, z);
-		dD = MFMA(ld_frag(wb, 13, lane), dG0hi, dD);
-		if (g == 0) dD[0] += go[3];                               // out[:,3] = den[:,0]  (ngp_network.py:83)
-		half8 dDf;
-#pragma unroll
-		for (int j = 0; j < 4; ++j) { dDf[j] = (_Float16)dD[j]; dDf[4 + j] = (_Float16)0; }
-#pragma unroll
-		for (int t = 0; t < 4; ++t) c[t] = MFMA(ld_frag(wb, 14 + t, lane), dDf, z);
-		const half8 dHlo = pack_masked(c[0], c[1], st.mh[0]), dHhi = pack_masked(c[2], c[3], st.mh[1]);
-		floatx4 dF[2];
-#pragma unroll
-		for (int t = 0; t < 2; ++t) { dF[t] = MFMA(ld_frag(wb, 18 + 2 * t, lane), dHlo, z); dF[t] = MFMA(ld_frag(wb, 19 + 2 * t, lane), dHhi, dF[t]); }
-		if (valid) {                                              // feature 16t+4g+r  ->  level 8t+2g+(r>>1), component r&1
-#pragma unroll
-			for (int t = 0; t < 2; ++t)
-#pragma unroll
-				for (int pr = 0; pr < 2; ++pr) {
-					half2v v = {(_Float16)dF[t][2 * pr], (_Float16)dF[t][2 * pr + 1]};
-					const uint32_t level = 8 * t + 2 * g + pr;
-					lmax[t][pr] = fmaxf(lmax[t][pr], fmaxf(fabsf((float)v[0]), fabsf((float)v[1])));
-					if (LAYOUT == NGP_LAYOUT_SOA) *reinterpret_cast<half2v *>(dfeat + ((size_t)level * n + i) * 2) = v;
-					else *reinterpret_cast<half2v *>(dfeat + (size_t)i * 32 + 2 * level) = v;
-				}
-		}
-		if (it == (uint32_t)grp && lane == 0 && wq == 0) __hip_atomic_store(&gstart[grp], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     // lets the next group start
-		// ---- weight gradients of these 64 samples: three staging phases through the GROUP's region, barriers among the group's four waves only
-		// phase A: dG1 0..63 | G0 64..127 -> V1 (output tile wq x four input tiles)
-		st_rows64h(stage, 0, col, g, dG1lo, dG1hi);
-		st_rows64h(stage, 64, col, g, st.g0[0], st.g0[1]);
-		GROUP_BAR();
-#pragma unroll
-		for (int kb = 0; kb < HBT / 32; ++kb) {
-			const int cs = 32 * kb + 8 * g;
-			const half8 a_dg1 = ld_rowsh(stage, 16 * wq + o, cs);
-#pragma unroll
-			for (int ti = 0; ti < 4; ++ti) aV1[ti] = MFMA(a_dg1, ld_rowsh(stage, 64 + 16 * ti + o, cs), aV1[ti]);
-		}
-		GROUP_BAR();
-		// phase B: dH 0..63 | F 64..95 | dG0 96..159 | IN2 160..191 -> W0, V0 (output tile wq x two input tiles each)
-		st_rows64h(stage, 0, col, g, dHlo, dHhi);
-		st_rows64h(stage, 96, col, g, dG0lo, dG0hi);
-#pragma unroll
-		for (int j = 0; j < 8; ++j) { stage[(64 + k32(g, j)) * HRS + col] = st.feat[j]; stage[(160 + k64(0, g, j)) * HRS + col] = st.in2[j]; }
-		GROUP_BAR();
-#pragma unroll
-		for (int kb = 0; kb < HBT / 32; ++kb) {
-			const int cs = 32 * kb + 8 * g;
-			const half8 a_dh = ld_rowsh(stage, 16 * wq + o, cs), a_dg0 = ld_rowsh(stage, 96 + 16 * wq + o, cs);
-#pragma unroll
-			for (int tj = 0; tj < 2; ++tj) { aW0[tj] = MFMA(a_dh, ld_rowsh(stage, 64 + 16 * tj + o, cs), aW0[tj]); aV0[tj] = MFMA(a_dg0, ld_rowsh(stage, 160 + 16 * tj + o, cs), aV0[tj]); }
-		}
-		GROUP_BAR();
-		// phase C: dD 0..15 | H 16..79 | dO 80..95 | G1 96..159 -> W1, V2 (input tile wq each)
-#pragma unroll
-		for (int j = 0; j < 4; ++j) { stage[(4 * g + j) * HRS + col] = dDf[j]; stage[(80 + 4 * g + j) * HRS + col] = dO[j]; }
-		st_rows64h(stage, 16, col, g, st.hfrag[0], st.hfrag[1]);
-		st_rows64h(stage, 96, col, g, st.g1[0], st.g1[1]);
-		GROUP_BAR();
-#pragma unroll
-		for (int kb = 0; kb < HBT / 32; ++kb) {
-			const int cs = 32 * kb + 8 * g;
-			aW1 = MFMA(ld_rowsh(stage, o, cs), ld_rowsh(stage, 16 + 16 * wq + o, cs), aW1);
-			aV2 = MFMA(ld_rowsh(stage, 80 + o, cs), ld_rowsh(stage, 96 + 16 * wq + o, cs), aV2);
-		}
-		GROUP_BAR();
-		if (more) cur = nxt;
-	}
-#undef GROUP_BAR
-	// ---- the groups' partial sums of the same ten tiles per wave index meet through LDS (the fragment region is free now): groups 1 .. NG-1 in turn, group 0 adds and
-	// writes the workgroup's slab, packed like the weights (wd part 0..3071, wc part 3072..10239); C rows = 4g+r, cols = lane&15
-	float *xch = reinterpret_cast<float *>(wl) + (size_t)wq * 10 * 256;             // [wave][10 tiles][64 lanes][4] = 40 KiB
-	auto put = [&](int tile, const floatx4 &v) { *reinterpret_cast<floatx4 *>(xch + tile * 256 + lane * 4) = v; };
-	auto get = [&](int tile) { return *reinterpret_cast<const floatx4 *>(xch + tile * 256 + lane * 4); };
-	for (int src = 1; src < NG; ++src) {
-		__syncthreads();
-		if (grp == src) {
-#pragma unroll
-			for (int t = 0; t < 4; ++t) put(t, aV1[t]);
-			put(4, aW0[0]); put(5, aW0[1]); put(6, aV0[0]); put(7, aV0[1]); put(8, aW1); put(9, aV2);
-		}
-		__syncthreads();
-		if (grp == 0) {
-#pragma unroll
-			for (int t = 0; t < 4; ++t) aV1[t] += get(t);
-			aW0[0] += get(4); aW0[1] += get(5); aV0[0] += get(6); aV0[1] += get(7); aW1 += get(8); aV2 += get(9);
-		}
-	}
-	if (grp == 0) {
-		float *slab = slabs + (size_t)blockIdx.x * 10240;
-		const int ci = lane & 15;
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			const int ro = 4 * g + r;
-#pragma unroll
-			for (int ti = 0; ti < 4; ++ti) slab[3072 + 2048 + (16 * wq + ro) * 64 + 16 * ti + ci] = aV1[ti][r];
-#pragma unroll
-			for (int tj = 0; tj < 2; ++tj) { slab[(16 * wq + ro) * 32 + 16 * tj + ci] = aW0[tj][r]; slab[3072 + (16 * wq + ro) * 32 + 16 * tj + ci] = aV0[tj][r]; }
-			slab[2048 + ro * 64 + 16 * wq + ci] = aW1[r];
-			slab[3072 + 6144 + ro * 64 + 16 * wq + ci] = aV2[r];
-		}
-	}
-	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, reinterpret_cast<float *>(smem + (N_FWD_FRAGS + N_BWD_FRAGS) * 512), NG * 4); }
-}
+// (r5) The free-running-groups variant of this kernel (k_field_bwd_g, NGP_FIELD_BWD_GROUPS = 2 | 3 | 4: round 3) is gone: alone it ran 61 -> 50 us, in the training step it
+// never gained - re-measured in round 5 on the real fox scene, in one call: 1924 vs 1936 it/s (profiles/r05a_fox_ab.txt).  The chain needs ~220 VGPRs, so more than two groups spill.
 
 __global__ __launch_bounds__(1024) void k_reduce_slabs(const float *__restrict__ slabs, uint32_t n_slabs, uint32_t width, float *__restrict__ out, int accumulate) {
 	// 64 columns x 16 slab groups per workgroup; LDS tree over the groups
@@ -540,6 +365,37 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs(const float *__restrict__
 #pragma unroll
 		for (int g = 0; g < 16; ++g) t += part[g][threadIdx.x];
 		out[col] = accumulate ? out[col] + t : t;
+	}
+}
+
+// (r5) The tail of the fp16 configuration's iteration in ONE launch: k_reduce_slabs' column sums, and - in the thread that holds a column's total - the Adam + EMA
+// update of the parameter that column is the gradient of (optim.hip: adam_ema_update, the same function on the same values: the gradient a separate sweep would load
+// back is the sum this thread just stored).  The weight gradients tile one flat buffer (3072 of the density MLP's pack, then 7168 of the colour MLP's), each pack with its
+// own fp32 master, moments, EMA state and fp16 shadow.  Replaces three launches (k_reduce_slabs + two 3 k / 7 k-element k_adam_ema: 8 + 5 + 5 us of an iteration).
+struct PackSweep { float *p, *m, *v, *ema; __half *p_half; uint32_t begin, count; };     // columns [begin, begin + count) of the flat gradient
+__global__ __launch_bounds__(1024) void k_reduce_slabs_sweep(const float *__restrict__ slabs, uint32_t n_slabs, uint32_t width, float *__restrict__ out, PackSweep a, PackSweep b, AdamConsts c) {
+	__shared__ float part[16][65];
+	const uint32_t col = blockIdx.x * 64u + (threadIdx.x & 63u), grp = threadIdx.x >> 6;
+	float s = 0.f;
+	if (col < width) for (uint32_t k = grp; k < n_slabs; k += 16) s += slabs[(size_t)k * width + col];
+	part[grp][threadIdx.x & 63u] = s;
+	__syncthreads();
+	if (grp == 0 && col < width) {
+		float t = 0.f;
+#pragma unroll
+		for (int g = 0; g < 16; ++g) t += part[g][threadIdx.x];
+		out[col] = t;                                                      // (overwrite: the fused tail only runs with grad_overwrite)
+		const PackSweep &w = col >= b.begin ? b : a;
+		if (col >= w.begin && col - w.begin < w.count) {
+			const uint32_t e = col - w.begin;
+			float P = w.p[e], M = w.m[e], V = w.v[e], E = 0.f;
+			const bool has_ema = w.ema != nullptr, alias = w.ema == w.p;
+			if (has_ema) E = alias ? P : w.ema[e];
+			if (has_ema) adam_ema_update<true>(P, M, V, E, t, c); else adam_ema_update<false>(P, M, V, E, t, c);
+			w.p[e] = P; w.m[e] = M; w.v[e] = V;
+			if (has_ema && !alias) w.ema[e] = E;
+			if (w.p_half) w.p_half[e] = __float2half_rn(P);
+		}
 	}
 }
 
@@ -662,24 +518,6 @@ int ngp_field_bwd_am(void *stream, uint32_t n, const void *feat, int layout, con
 	const dim3 grid(n_slabs), block(512);
 	hipStream_t s = (hipStream_t)stream;
 	const _Float16 *packed = pack_weights("ngp_field_bwd", s, wd, wc, N_FWD_FRAGS + N_BWD_FRAGS, layout_flags); if (!packed) return NGP_E_ARG;
-	// NGP_FIELD_BWD_GROUPS: 0 = the lock-step kernel (rounds 1-2, default), 2 | 3 | 4 = that many free-running four-wave groups per workgroup (r3 experiment)
-	// (the chain needs ~220 VGPRs: at NG = 3 / 4 the compiler spills 112 / 157 registers, so only NG = 2 - the occupancy of the lock-step kernel, desynchronised - is usable)
-	static const int groups = [] { const char *e = getenv("NGP_FIELD_BWD_GROUPS"); const int v = e ? atoi(e) : 0; return (v >= 2 && v <= 4) ? v : 0; }();
-	if (groups) {
-#define GOG(T, L, NGR) do { \
-	const size_t shmem_g = ((size_t)(N_FWD_FRAGS + N_BWD_FRAGS) * 512 + (size_t)NGR * N_ROWS * HRS) * sizeof(_Float16); \
-	static bool attr_set = false; \
-	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field_bwd_g<T, L, NGR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_g); \
-		if (e != hipSuccess) { ngp_set_error("ngp_field_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	NGP_LAUNCH((k_field_bwd_g<T, L, NGR>), grid, dim3(NGR * 256), shmem_g, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid, am); } while (0)
-#define GOG2(T, L) do { if (groups == 4) GOG(T, L, 4); else if (groups == 3) GOG(T, L, 3); else GOG(T, L, 2); } while (0)
-		if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GOG2(float, NGP_LAYOUT_SOA); else GOG2(float, NGP_LAYOUT_AOS); }
-		else { if (layout == NGP_LAYOUT_SOA) GOG2(__half, NGP_LAYOUT_SOA); else GOG2(__half, NGP_LAYOUT_AOS); }
-#undef GOG2
-#undef GOG
-		NGP_LAUNCH_CHECK("ngp_field_bwd");
-		return 0;
-	}
 #define GO(T, L) do { \
 	static bool attr_set = false; \
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field_bwd<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
@@ -695,6 +533,21 @@ NGP_API int ngp_reduce_slabs(void *stream, const float *slabs, uint32_t n_slabs,
 	NGP_REQUIRE(slabs && out, NGP_E_ARG, "ngp_reduce_slabs: null pointer");
 	NGP_LAUNCH(k_reduce_slabs, dim3(div_up(width, 64)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, width, out, accumulate);
 	NGP_LAUNCH_CHECK("ngp_reduce_slabs");
+	return 0;
+}
+// internal (csrc/train_step.hip): ngp_reduce_slabs (overwrite) + ngp_adam_ema_step of the two weight packs whose gradients tile `out`, one launch
+int ngp_reduce_slabs_sweep(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out, const float *const pk[2][5] /* p, m, v, ema, p_half */, const uint32_t begin[2],
+                           const uint32_t count[2], float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay) {
+	NGP_REQUIRE(slabs && out && pk && step >= 1, NGP_E_ARG, "ngp_reduce_slabs_sweep: bad arguments");
+	PackSweep w[2];
+	for (int k = 0; k < 2; ++k) {
+		NGP_REQUIRE(pk[k][0] && pk[k][1] && pk[k][2] && begin[k] + count[k] <= width, NGP_E_ARG, "ngp_reduce_slabs_sweep: bad pack %d", k);
+		w[k] = PackSweep{(float *)pk[k][0], (float *)pk[k][1], (float *)pk[k][2], (float *)pk[k][3], (__half *)pk[k][4], begin[k], count[k]};
+	}
+	NGP_REQUIRE(w[0].begin + w[0].count <= w[1].begin, NGP_E_ARG, "ngp_reduce_slabs_sweep: packs must be ordered and disjoint");
+	const AdamConsts c = adam_consts(lr, beta0, beta1, eps, step, ema_decay, 1.0f);
+	NGP_LAUNCH(k_reduce_slabs_sweep, dim3(div_up(width, 64)), dim3(1024), 0, (hipStream_t)stream, slabs, n_slabs, width, out, w[0], w[1], c);
+	NGP_LAUNCH_CHECK("ngp_reduce_slabs_sweep");
 	return 0;
 }
 NGP_API int ngp_sh_encode(void *stream, uint32_t n, const float *dir, uint32_t stride, void *out, int dtype) {

@@ -35,6 +35,8 @@ int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, ui
 struct AbsmaxOut { uint32_t *parts; uint32_t *cursors; uint32_t n_cursors; uint32_t *spill_count; };
 // where the abs-max partials / cursors of a hash-backward workspace live, or parts == nullptr when that call would not take the binned path
 AbsmaxOut ngp_hash_bwd_absmax_slots(const uint32_t *level_table_host, uint32_t n, int dtype, int grad_dtype, void *workspace, uint64_t workspace_bytes, const void *grad);
+int ngp_reduce_slabs_sweep(void *stream, const float *slabs, uint32_t n_slabs, uint32_t width, float *out, const float *const pk[2][5], const uint32_t begin[2], const uint32_t count[2],
+                           float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay);
 int ngp_field32_bwd_am(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const float *wd, const float *wc,
                        const float *dLdout, float *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am);
 int ngp_field_bwd_am(void *stream, uint32_t n, const void *feat, int layout, const float *dir, uint32_t dir_stride, const void *wd, const void *wc,

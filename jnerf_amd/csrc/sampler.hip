@@ -910,6 +910,104 @@ __global__ __launch_bounds__(256) void k_composite_bwd(uint32_t n_rays, const T 
 	}
 }
 
+// (r5) The training path's compositing in ONE launch: forward (k_composite_fwd's loop), Huber on the ray's colour, backward (k_composite_bwd's loop) - what
+// ngp_composite_fwd_huber followed by ngp_composite_bwd compute, expression for expression: the forward leaves a ray's colour and loss gradient in EVERY lane of its group
+// (the butterfly sum adds the same pairs in every lane), so the backward reads from registers what the two-launch sequence stores and reloads as the same fp32 values.
+// rgb / loss / loss_grad are still written (the step returns the loss; the tests read all three).  Bit-identical to the two launches (tests/test_hip_parity.py).
+template <typename T, uint32_t CG /*lanes per ray*/>
+__global__ __launch_bounds__(256) void k_composite_train(uint32_t n_rays, const T *__restrict__ net, const float *__restrict__ coords, const uint32_t *__restrict__ numsteps,
+                                                         const uint32_t *__restrict__ numsteps_c, const float *__restrict__ bg, int cascades, float *__restrict__ rgb_out,
+                                                         HuberArgs hub, const float *__restrict__ density_grid_mean, T *__restrict__ dout) {
+	const uint32_t lane = threadIdx.x & (CG - 1u), i = blockIdx.x * (256u / CG) + threadIdx.x / CG;
+	if (i >= n_rays) return;
+	const uint32_t ns = numsteps_c[2 * i], base = numsteps_c[2 * i + 1];
+	if (ns == 0) {
+		if (lane < 3) {
+			const float v = bg[3 * i + lane];
+			rgb_out[3 * i + lane] = v;
+			huber3(hub.target, hub.delta, hub.loss, hub.grad, i, lane, v);
+		}
+		return;
+	}
+	// ---- forward: k_composite_fwd<T, false, CG>
+	float T_ = 1.f, ray[3] = {0.f, 0.f, 0.f};
+	for (uint32_t c0 = 0; c0 < ns; c0 += CG) {
+		const uint32_t m = min(CG, ns - c0);
+		float rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f;
+		if (lane < m) {
+			const size_t s = (size_t)base + c0 + lane;
+			float o[4]; load4<T>(net + s * 4, o);
+			const float dt = unwarp_dt(coords[s * 7 + 3], cascades);
+			const float density = __expf(o[3]);
+			alpha = 1.f - __expf(-density * dt);
+#pragma unroll
+			for (int c = 0; c < 3; ++c) rgb[c] = logistic(o[c]);
+		}
+		const float P = group_scan_mul<CG>(1.f - alpha, lane);
+		float Pex = __shfl_up(P, 1, (int)CG); if (lane == 0) Pex = 1.f;
+		const float weight = alpha * (T_ * Pex);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) ray[c] += weight * rgb[c];
+		T_ *= bcast<CG>(P, CG - 1u);
+	}
+#pragma unroll
+	for (int c = 0; c < 3; ++c) ray[c] = group_sum<CG>(ray[c]);
+	if (ns == numsteps[2 * i]) {
+#pragma unroll
+		for (int c = 0; c < 3; ++c) ray[c] += T_ * bg[3 * i + c];
+	}
+	// ---- Huber (huber3's expressions), in every lane; lane 0 stores
+	float G[3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const float d = ray[c] - hub.target[3 * i + c], rel = fabsf(d);
+		G[c] = rel > hub.delta ? (d > 0 ? 1.0f : -1.0f) : d / hub.delta;
+		if (lane == 0) {
+			rgb_out[3 * i + c] = ray[c];
+			if (hub.loss) hub.loss[3 * i + c] = rel > hub.delta ? rel - 0.5f * hub.delta : 0.5f / hub.delta * rel * rel;
+			hub.grad[3 * i + c] = G[c];
+		}
+	}
+	// ---- backward: k_composite_bwd<T, CG> with R = ray, G from above
+	float loss_scale = 128; loss_scale /= n_rays;
+	const float l1 = *density_grid_mean < 0.01f ? 1e-4f : 0.0f;
+	T_ = 1.f;
+	float ray2[3] = {0.f, 0.f, 0.f};
+	for (uint32_t c0 = 0; c0 < ns; c0 += CG) {
+		const uint32_t m = min(CG, ns - c0);
+		const size_t s = (size_t)base + c0 + lane;
+		float o[4] = {0.f, 0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f, dt = 0.f;
+		if (lane < m) {
+			load4<T>(net + s * 4, o);
+#pragma unroll
+			for (int c = 0; c < 3; ++c) rgb[c] = logistic(o[c]);
+			dt = unwarp_dt(coords[s * 7 + 3], cascades);
+			const float density = __expf(o[3]);
+			alpha = 1.f - __expf(-density * dt);
+		}
+		const float P = group_scan_mul<CG>(1.f - alpha, lane);
+		float Pex = __shfl_up(P, 1, (int)CG); if (lane == 0) Pex = 1.f;
+		const float my_w = alpha * (T_ * Pex), my_T = T_ * P;
+		float my_r2[3];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) { const float S = group_scan_add<CG>(my_w * rgb[c], lane); my_r2[c] = ray2[c] + S; ray2[c] += bcast<CG>(S, CG - 1u); }
+		T_ *= bcast<CG>(P, CG - 1u);
+		if (lane < m) {
+			float dl[4], dv[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const float suffix = ray[c] - my_r2[c];
+				dl[c] = loss_scale * ((my_w * G[c]) * (rgb[c] * (1 - rgb[c])) + fmaxf(0.0f, 0.0f * o[c]));
+				dv[c] = G[c] * (my_T * rgb[c] - suffix);
+			}
+			const float dotv = dv[0] + (dv[1] + dv[2]);
+			const float dd = __expf(clampf(o[3], -15.0f, 15.0f));
+			dl[3] = loss_scale * (dd * (dt * dotv)) + (o[3] < 0 ? -l1 : 0.0f);
+			store4<T>(dout + s * 4, dl);
+		}
+	}
+}
+
 static int composite_fwd_impl(void *stream, uint32_t n_rays, const void *net, int dtype, const float *coords, const uint32_t *numsteps,
                               const uint32_t *numsteps_c, const float *bg, int cascades, float *rgb_out, HuberArgs hub);
 NGP_API int ngp_composite_fwd(void *stream, uint32_t n_rays, const void *net, int dtype, const float *coords, const uint32_t *numsteps,
@@ -967,6 +1065,25 @@ NGP_API int ngp_composite_bwd(void *stream, uint32_t n_rays, uint32_t n_elems, c
 	else { if (wide) CB_GO(__half, CG_INFER); else CB_GO(__half, CG_TRAIN); }
 #undef CB_GO
 	NGP_LAUNCH_CHECK("ngp_composite_bwd");
+	return 0;
+}
+
+// ngp_composite_fwd_huber + ngp_composite_bwd (without zero_first) as one launch - the training step's form (csrc/train_step.hip); same arguments, same results bit for bit
+NGP_API int ngp_composite_train(void *stream, uint32_t n_rays, uint32_t n_elems, const void *net, int dtype, const float *coords, const uint32_t *numsteps, const uint32_t *numsteps_c,
+                                const float *bg, int cascades, float *rgb_out, const float *target, float delta, float *loss, float *loss_grad, const float *density_grid_mean, void *dout) {
+	NGP_REQUIRE(net && coords && numsteps && numsteps_c && bg && rgb_out && target && loss_grad && density_grid_mean && dout, NGP_E_ARG, "ngp_composite_train: null pointer");
+	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_composite_train: bad dtype %d", dtype);
+	if (n_rays == 0) return 0;
+	hipStream_t s = (hipStream_t)stream;
+	const bool wide = (uint64_t)n_rays * 24u <= (uint64_t)n_elems;          // >= 24 samples per ray on average: a wavefront per ray (see composite_fwd_impl)
+	const uint32_t cg = wide ? CG_INFER : CG_TRAIN;
+	const dim3 grid(div_up(n_rays, 256u / cg)), block(256);
+	const HuberArgs hub{target, delta, loss, loss_grad};
+#define CT_GO(T, W) NGP_LAUNCH((k_composite_train<T, W>), grid, block, 0, s, n_rays, (const T *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, hub, density_grid_mean, (T *)dout)
+	if (dtype == NGP_F32) { if (wide) CT_GO(float, CG_INFER); else CT_GO(float, CG_TRAIN); }
+	else { if (wide) CT_GO(__half, CG_INFER); else CT_GO(__half, CG_TRAIN); }
+#undef CT_GO
+	NGP_LAUNCH_CHECK("ngp_composite_train");
 	return 0;
 }
 

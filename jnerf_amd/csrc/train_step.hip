@@ -138,7 +138,17 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	int t_pack = -1;
 	if (T == NGP_F32) for (int t = 0; t < a->n_opt; ++t)
 		if (a->p[t] == (float *)a->wd && a->numel[t] == 10240 && (const float *)a->wc == (const float *)a->wd + 3072 && a->ema[t] == a->p[t] && !a->p_half[t] && a->g[t] == a->wgrad_flat && ow) t_pack = t;
-	if (getenv("NGP_NO_FUSED_MLP_TAIL")) t_pack = -1;           // probe hook
+	// fp16 network: the two weight packs (density MLP 3072, colour MLP 7168 elements) whose gradients tile the flat weight-gradient buffer - swept by the slab reduction
+	// itself (ngp_reduce_slabs_sweep) when backward and sweep are one call on one GPU (no exchange step between them)
+	int t_mlp16[2] = {-1, -1};
+	if (T == NGP_F16 && do_bwd && do_sweep && !dp && !host_sharded && ow && a->wgrad_flat) {
+		for (int t = 0; t < a->n_opt; ++t) {
+			if (a->g[t] == a->wgrad_flat && a->numel[t] == 3072) t_mlp16[0] = t;
+			if (a->g[t] == a->wgrad_flat + 3072 && a->numel[t] == 7168) t_mlp16[1] = t;
+		}
+		if (t_mlp16[0] < 0 || t_mlp16[1] < 0) t_mlp16[0] = t_mlp16[1] = -1;
+	}
+	if (getenv("NGP_NO_FUSED_MLP_TAIL")) { t_pack = -1; t_mlp16[0] = t_mlp16[1] = -1; }           // A/B hook
 	if (do_bwd) {
 	// largest |dL/dfeature| per level: written by the field backward kernel's epilogue when the scatter takes the binned path (one pass and one launch less)
 	AbsmaxOut am = ngp_hash_bwd_absmax_slots(a->level_table_host, a->n, T, NGP_F32, a->hash_workspace, a->hash_workspace_bytes, a->table_grad);
@@ -153,16 +163,33 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		STAGE(NGP_STAGE_HASH_FWD, ngp_hash_encode_fwd(stream, a->n, a->pos, 3, a->table, a->level_table_host, a->feat, NGP_F32, NGP_LAYOUT_SOA, a->n_valid));
 		STAGE(NGP_STAGE_FIELD_FWD, ngp_field32_fwd(stream, a->n, (const float *)a->feat, lay, dirs, 7, (const float *)a->packed_weights, nullptr, (float *)a->out, a->n_valid));
 	}
-	STAGE(NGP_STAGE_COMPOSITE_FWD, ngp_composite_fwd_huber(stream, a->n_rays, a->out, T, a->coords, a->numsteps, a->numsteps_compacted, a->bg, a->cascades, a->rgb,
-	                                                       a->target, a->huber_delta, a->loss, a->loss_grad));
-	STAGE(NGP_STAGE_COMPOSITE_BWD, ngp_composite_bwd(stream, a->n_rays, a->n, a->out, T, a->coords, a->numsteps_compacted, a->loss_grad, a->rgb, a->density_grid_mean, a->cascades, a->dout, 0));
+	// compositing forward + Huber + compositing backward: one launch (r5; bit-identical to the two launches it replaces, which remain the module path's)
+	const bool split_composite = getenv("NGP_SPLIT_COMPOSITE") != nullptr;            // A/B hook (read per call: the tests toggle it)
+	if (!split_composite) {
+		STAGE(NGP_STAGE_COMPOSITE_FWD, ngp_composite_train(stream, a->n_rays, a->n, a->out, T, a->coords, a->numsteps, a->numsteps_compacted, a->bg, a->cascades, a->rgb,
+		                                                   a->target, a->huber_delta, a->loss, a->loss_grad, a->density_grid_mean, a->dout));
+	} else {
+		STAGE(NGP_STAGE_COMPOSITE_FWD, ngp_composite_fwd_huber(stream, a->n_rays, a->out, T, a->coords, a->numsteps, a->numsteps_compacted, a->bg, a->cascades, a->rgb,
+		                                                       a->target, a->huber_delta, a->loss, a->loss_grad));
+		STAGE(NGP_STAGE_COMPOSITE_BWD, ngp_composite_bwd(stream, a->n_rays, a->n, a->out, T, a->coords, a->numsteps_compacted, a->loss_grad, a->rgb, a->density_grid_mean, a->cascades, a->dout, 0));
+	}
 	if (T == NGP_F16) {
 		STAGE(NGP_STAGE_FIELD_BWD, ngp_field_bwd_am(stream, a->n, a->feat, lay, dirs, 7, a->packed_weights, nullptr, a->dout, NGP_F16, a->dfeat, a->wgrad_slabs, a->n_slabs, a->n_valid, &am));
 	} else {
 		STAGE(NGP_STAGE_FIELD_BWD, ngp_field32_bwd_am(stream, a->n, (const float *)a->feat, lay, dirs, 7, (const float *)a->packed_weights, nullptr, (const float *)a->dout, (float *)a->dfeat,
 		                                               a->wgrad_slabs, a->n_slabs, a->n_valid, &am));
 	}
-	STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, ow ? 0 : 1));
+	if (t_mlp16[0] >= 0) {      // fp16 configuration, single GPU: the slab reduction also sweeps the two weight packs (their gradient is the sum it has just formed)
+		const float *pk[2][5]; uint32_t begin[2], count[2];
+		for (int k = 0; k < 2; ++k) {
+			const int t = t_mlp16[k];
+			pk[k][0] = a->p[t]; pk[k][1] = a->m[t]; pk[k][2] = a->v[t]; pk[k][3] = a->ema[t]; pk[k][4] = (const float *)a->p_half[t];
+			begin[k] = (uint32_t)(a->g[t] - a->wgrad_flat); count[k] = (uint32_t)a->numel[t];
+		}
+		STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs_sweep(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, pk, begin, count, a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay));
+	} else {
+		STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, ow ? 0 : 1));
+	}
 	STAGE(NGP_STAGE_HASH_BWD, ngp_hash_encode_bwd_ws_marked(stream, a->n, a->pos, 3, a->dfeat, a->level_table_host, a->table_grad, a->n_params, T, NGP_F32, NGP_LAYOUT_SOA, ow ? 1 : 0, a->n_valid,
 	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr, am.parts != nullptr));
 	}
@@ -199,6 +226,8 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 				const NgpDpPlan *pl = a->dp;
 				for (uint32_t b = 0; b < pl->n_buckets; ++b) if ((rc = sweep_range(stream, a, t, pl->shard_begin[b], pl->shard_count[b], wire, 0))) return rc;
 				if ((rc = sweep_range(stream, a, t, pl->tail_begin, pl->tail_count, false, 0))) return rc;
+			} else if (t == t_mlp16[0] || t == t_mlp16[1]) {
+				continue;                                        // already swept by ngp_reduce_slabs_sweep
 			} else if (t == t_pack) {
 				if ((rc = ngp_mlp32_sweep_pack(stream, a->p[t], a->g[t], a->m[t], a->v[t], a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, (float *)a->packed_weights))) return rc;
 			} else if ((rc = ngp_adam_ema_step(stream, a->numel[t], a->p[t], a->g[t], NGP_F32, a->m[t], a->v[t], a->ema[t], a->p_half[t], a->lr, a->beta0, a->beta1, a->eps,

@@ -391,6 +391,18 @@ def composite_fwd_huber(net, coords, numsteps, numsteps_c, bg, target, delta, ca
     return out, loss, grad
 
 
+def composite_train(net, coords, numsteps, numsteps_c, bg, target, delta, density_grid_mean, cascades=5, out=None, loss=None, grad=None, dout=None, n_elems=None):
+    """composite_fwd_huber + composite_bwd in one launch (ngp_composite_train: the native training step's form) -> (rgb, loss, loss_grad, dLdout)"""
+    n = numsteps.shape[0]
+    out = out if out is not None else torch.empty((n, 3), dtype=torch.float32, device=net.device)
+    loss = loss if loss is not None else torch.empty((n, 3), dtype=torch.float32, device=net.device)
+    grad = grad if grad is not None else torch.empty((n, 3), dtype=torch.float32, device=net.device)
+    dout = dout if dout is not None else torch.zeros_like(net)
+    check(L.lib().ngp_composite_train(_stream(), n, int(n_elems or net.shape[0]), _p(net), _dt(net), _p(coords), _p(numsteps), _p(numsteps_c), _p(bg), cascades, _p(out), _p(target), delta,
+                                      _p(loss), _p(grad), _p(density_grid_mean), _p(dout)), "ngp_composite_train")
+    return out, loss, grad, dout
+
+
 def composite_bwd(net, coords, numsteps_c, loss_grad, rgb_ray, density_grid_mean, cascades=5, dout=None, zero_first=True):
     n = numsteps_c.shape[0]
     assert net.is_contiguous() and loss_grad.is_contiguous() and rgb_ray.is_contiguous()

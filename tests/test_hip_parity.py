@@ -519,6 +519,37 @@ def test_composite_fwd_huber_equals_the_two_calls(H, dtype):
     assert (ns[:, 0] == 0).any()            # rays without samples take the background branch
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("n_rays,cap", [(12000, 1 << 16), (600, 1 << 16)])       # 16 lanes per ray (many short rays) | a wavefront per ray (few long ones): both variants
+def test_composite_train_equals_the_two_launches(H, dtype, n_rays, cap):
+    """(r5) ngp_composite_train - forward + Huber + backward of the compositing in ONE launch, what the native training step issues - against ngp_composite_fwd_huber followed
+    by ngp_composite_bwd: rgb, loss, loss gradient and dL/dout are the same BITS (the fused kernel evaluates the same expressions; a ray's colour and loss gradient stay in
+    registers instead of going through memory).  Rays without samples and a density-grid mean on both sides of the 0.01 switch of the L1 term included."""
+    import torch
+    from jnerf_amd import ops
+    xf, focal, meta = synth.camera_ring(8, radius=1.3)
+    _, o, d, _ = synth.rays_from_cameras(xf, focal, meta, 64, 48, n_rays, seed=3)
+    coords, ns, nsc, cnt = H.march_rays_compacted(o, d, synth.shell_bitfield(), (0.0, 1.0), O.PCG32(1337), 4096 * 1024, cap, const_dt=True)
+    rng = np.random.default_rng(5)
+    net = rng.standard_normal((coords.shape[0], 4)).astype(dtype)
+    bg, target = rng.random((n_rays, 3), dtype=np.float32), rng.random((n_rays, 3), dtype=np.float32)
+    T = H.T
+    tnet, tc, tns, tnsc, tbg, ttar = T(net), T(coords), T(ns.view(np.int32)), T(nsc.view(np.int32)), T(bg), T(target)
+    n_elems = coords.shape[0]
+    assert (n_rays * 24 <= n_elems) == (n_rays == 600) and (n_rays * 24 <= (1 << 18)) == (n_rays == 600)     # all three launches pick the same lanes-per-ray variant, and the two shapes are the two variants
+    for mean in (0.5, 0.001):
+        gm = torch.full((1,), mean, device="cuda")
+        rgb = torch.empty((n_rays, 3), device="cuda"); loss = torch.empty_like(rgb); lg = torch.empty_like(rgb)
+        ops.composite_fwd_huber(tnet, tc, tns, tnsc, tbg, ttar, 0.1, out=rgb, loss=loss, grad=lg)
+        dout = torch.full_like(tnet, 7.0)
+        ops.composite_bwd(tnet, tc, tnsc, lg, rgb, gm, dout=dout, zero_first=False)
+        dout2 = torch.full_like(tnet, 7.0)
+        rgb2, loss2, lg2, _ = ops.composite_train(tnet, tc, tns, tnsc, tbg, ttar, 0.1, gm, dout=dout2)
+        assert torch.equal(rgb, rgb2) and torch.equal(loss, loss2) and torch.equal(lg, lg2)
+        assert torch.equal(dout.view(torch.int32 if dtype == np.float32 else torch.int16), dout2.view(torch.int32 if dtype == np.float32 else torch.int16))     # bit patterns (rows beyond the valid samples keep the fill value in both)
+    assert (ns[:, 0] == 0).any() and int(cnt[3]) > 0
+
+
 def test_grad_to_half(H):
     import torch
     from jnerf_amd import ops

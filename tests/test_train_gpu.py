@@ -542,3 +542,27 @@ def test_lego_gate_runs_when_the_dataset_is_mounted(tmp_path, monkeypatch):
     assert out["gate"].startswith("not the gate: 400 steps") and out["steps"] == 400 and out["dataset"] == str(tmp_path)
     assert out["train_images"] == 20 and out["resolution"] == [W, H] and out["test_views"] == 2                     # train includes val (dataset.py:77)
     assert out["iters_per_s"] > 0 and np.isfinite(out["psnr_lego_test"]) and out["psnr_lego_test"] > 18.0, out     # the poses were understood: the scene is being learnt
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+def test_fused_launches_of_the_native_step_change_no_bit(fp16, monkeypatch):
+    """(r5) Two fusions inside ngp_train_step - compositing forward + Huber + backward as one launch (ngp_composite_train), and, fp16 configuration, the slab reduction that also
+    sweeps the two MLP weight packs (ngp_reduce_slabs_sweep) - against the launches they replace (NGP_SPLIT_COMPOSITE / NGP_NO_FUSED_MLP_TAIL select those): 24 iterations
+    from the same seed, refresh included, must leave the SAME BITS in every parameter, every Adam moment of the MLP packs and the last loss."""
+    def run():
+        r = _runner(fp16=fp16, aabb_scale=1, const_dt=True, pipeline_sampling=False)
+        for i in range(24):
+            loss = r.train_step(i)
+        r.drain()
+        assert r._fast and r._fast.native
+        adam = r.optimizer._nested_optimizer
+        state = [p.detach().clone() for p in r.model.parameters()] + [t.detach().clone() for t in adam.param_groups[0]["m"]] + [t.detach().clone() for t in adam.param_groups[0]["values"]]
+        return state, loss.detach().clone()
+    monkeypatch.delenv("NGP_SPLIT_COMPOSITE", raising=False); monkeypatch.delenv("NGP_NO_FUSED_MLP_TAIL", raising=False)
+    fused, l_fused = run()
+    monkeypatch.setenv("NGP_SPLIT_COMPOSITE", "1"); monkeypatch.setenv("NGP_NO_FUSED_MLP_TAIL", "1")
+    split, l_split = run()
+    assert torch.equal(l_fused, l_split)
+    for a, b in zip(fused, split):
+        assert torch.equal(a, b)
+    assert any(float(t.abs().max()) > 0 for t in fused)
