@@ -196,12 +196,12 @@ def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
     d = {
         "k_hash_fwd": n * hf, "k_field_fwd": n * fio, "k_field_bwd": n * (fio + 32 * T),
         "k_field32_fwd": n * fio, "k_field32_bwd": n * (fio + 32 * T),
-        "k_composite_fwd": n * (4 * T + 28), "k_composite_bwd": n * (4 * T + 28 + 4 * T),
+        "k_composite_fwd": n * (4 * T + 28), "k_composite_bwd": n * (4 * T + 28 + 4 * T), "k_composite_train": n * (4 * T + 28) + n * (4 * T + 28 + 4 * T),       # (the fused launch does both passes' algorithmic work)
         "k_adam_ema": P * (30 if fp16 else 28),                # read p, g, m, v; write p, m, v (+ the fp16 shadow); the gradient is overwritten by the next backward, not zeroed here
         # hash backward: the stage's necessary traffic is pos 12 + dL/dy 32*T + 128 scattered fp32 updates (4 B each as one write); attributed to the kernels that do each part
         "k_level_absmax": n * 32 * T, "k_bin_records": n * (12 + 32 * T) * (16 - n_runs) / 16, "k_bin_records_runs": n * (12 + 32 * T) * n_runs / 16, "k_bin_accumulate": n * 16 * 8 * 2 * 4,
         "k_bin_pairs": n * (12 + 32 * T) * (16 - n_runs) / 16, "k_bin_runs2": n * (12 + 32 * T) * n_runs / 16, "k_bin_accumulate2": n * 16 * 8 * 2 * 4,
-        "k_reduce_slabs": 10240 * 4, "k_pack_frags": 21504 * 2 * 2,
+        "k_reduce_slabs": 10240 * 4, "k_reduce_slabs_sweep": 10240 * (4 + 30), "k_pack_frags": 21504 * 2 * 2,
         # sampling: ray in (24 B) + one 28-byte record and one 12-byte position out per sample
         "k_march_count": R * 24 + n * 4, "k_march_wave": R * 24 + n * 4, "k_mscan_totals": R * 4, "k_mscan_ok": R * 4, "k_mscan_final": R * 20, "k_march_write_cached": n * (4 + 40),
         "k_generate_rays": R * (8 + 16 + 12 + 40),
