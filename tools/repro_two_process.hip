@@ -5,6 +5,9 @@
 //                                                      1 = hipDeviceSynchronize before every launch
 //                                                      2 = every launch reads PRIVATE copies of positions and table (copied right before it, same stream)
 //                                                      3 = a second stream runs an unrelated streaming kernel all the time (the marcher's role in training)
+//                                                      4 = (r5) NOT this library at all: a five-line random gather out[i] = table[hash(i) % m] over the same 48 MB table - if even
+//                                                          that differs between identical launches beside another process, the effect is the platform's
+//                                                      5 = control for 4: a coalesced streaming read of the same table (out[i] = 2 table[i % m])
 // Every repetition writes the 16 x n x 2 fp32 features into the same output buffer and a device-side comparison counts the values that differ from the first
 // repetition's.  Run one copy alone and two copies concurrently; a non-zero count in either says the kernel (or the platform under it) is not a function of its inputs.
 #include <hip/hip_runtime.h>
@@ -27,6 +30,15 @@ __global__ void k_diff(const uint32_t *a, const uint32_t *b, size_t n, unsigned 
 	unsigned long long c = 0;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
 	if (c) atomicAdd(count, c);
+}
+__global__ void k_plain_gather(const float *__restrict__ tab, uint32_t m, float *__restrict__ out, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		uint32_t x = (uint32_t)i * 2654435761u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+		out[i] = tab[x % m] + tab[(x ^ 0x9e3779b9u) % m];
+	}
+}
+__global__ void k_plain_stream(const float *__restrict__ tab, uint32_t m, float *__restrict__ out, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = 2.0f * tab[i % m];
 }
 __global__ void k_noise(float *p, size_t n) {
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = p[i] * 1.0001f + 1.0f;
@@ -55,6 +67,8 @@ int main(int argc, char **argv) {
 		const float *p = pos, *t = table;
 		if (mode == 2) { if (hipMemcpyAsync(pos2, pos, (size_t)n * 3 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess || hipMemcpyAsync(table2, table, (size_t)n_params * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1; p = pos2; t = table2; }
 		if (mode == 1 && hipDeviceSynchronize() != hipSuccess) return 1;
+		if (mode == 5) { hipLaunchKernelGGL(k_plain_stream, dim3(8192), dim3(256), 0, s, t, n_params, dst, (size_t)n * 32); return hipGetLastError() == hipSuccess ? 0 : 1; }
+		if (mode == 4) { hipLaunchKernelGGL(k_plain_gather, dim3(8192), dim3(256), 0, s, t, n_params, dst, (size_t)n * 32); return hipGetLastError() == hipSuccess ? 0 : 1; }
 		return ngp_hash_encode_fwd(s, n, p, 3, t, table_host, dst, NGP_F32, NGP_LAYOUT_SOA, nullptr);
 	};
 	if (run(ref)) { fprintf(stderr, "hash fwd: %s\n", ngp_last_error()); return 2; }
