@@ -428,7 +428,8 @@ def main():
     n_runs = int((runner.model.pos_encoder.level_table.reshape(16, 4)[:, 2] <= 300).sum())
     alg, flops = alg_bytes_table(mean_valid, P, mean_rays, n_refresh, fp16, n_runs)
     roof = None
-    pmc, traffic_source = pmc_lookup(args.config, scene)
+    # (the committed counter passes describe the BENCH workload: default image count and resolution - a run with --images / --res is another workload and gets no traffic figure)
+    pmc, traffic_source = pmc_lookup(args.config, scene) if not (args.images or args.res) else ({}, None)
     if dom is not None and dom_ms:
         cls = batch_class(dom_ms)
         avg_raw = sum(cls) / len(cls)

@@ -28,10 +28,14 @@ __device__ __forceinline__ bool level_is_dense(uint32_t size, uint32_t res) {
 }
 
 __device__ __forceinline__ void block_to_level_chunk(uint32_t nblk, uint32_t &level, uint32_t &chunk) {
+#ifdef NGP_PROBE_LINEAR_MAP      // (diagnosis build only, tools/probe_shared_gpu.sh: levels laid end to end, no XCD-aware placement)
+	level = blockIdx.x / nblk; chunk = blockIdx.x - level * nblk;
+#else
 	const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
 	const uint32_t phase = slot / nblk;
 	chunk = slot - phase * nblk;
 	level = phase == 0 ? 15u - xcd : xcd;
+#endif
 }
 
 static LevelTable load_table(const uint32_t *host) { LevelTable lt; for (int i = 0; i < 64; ++i) lt.v[i] = host[i]; return lt; }

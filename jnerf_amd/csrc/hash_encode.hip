@@ -68,7 +68,11 @@ __device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restric
 		const float wy = (j & 1u) ? c.w[1] : 1 - c.w[1], wz = (j >> 1) ? c.w[2] : 1 - c.w[2];
 		w[2 * j] = ((1 - c.w[0]) * wy) * wz; w[2 * j + 1] = (c.w[0] * wy) * wz;          // the reference's x, y, z multiplication order
 		const uint32_t i0 = grid_index(size, res, dense, c.g[0], gy, gz), i1 = grid_index(size, res, dense, c.g[0] + 1, gy, gz);
+#ifdef NGP_PROBE_NO_WIDE_LOADS   // (diagnosis build only, tools/probe_shared_gpu.sh: every corner a load of its own)
+		const bool adjacent_up = false, adjacent_dn = false;
+#else
 		const bool adjacent_up = i1 == i0 + 1u && (dense || pow2), adjacent_dn = i0 == i1 + 1u && !dense && pow2;     // (x^h)^1 is either one above or one below
+#endif
 		if (adjacent_up) { const PP t = *reinterpret_cast<const PP *>(tab + i0); v[2 * j] = t.a; v[2 * j + 1] = t.b; }
 		else if (adjacent_dn) { const PP t = *reinterpret_cast<const PP *>(tab + i1); v[2 * j] = t.b; v[2 * j + 1] = t.a; }
 		else { v[2 * j] = tab[i0]; v[2 * j + 1] = tab[i1]; }

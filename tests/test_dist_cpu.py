@@ -121,3 +121,31 @@ def test_communicator_agreement_is_symmetric_whatever_fails(tmp_path):
         got = [tuple(int(v) for v in np.load(d / f"c{r}.npy")) for r in range(2)]
         assert got == want, (case, got)
 
+
+
+def _flag_worker(rank, world, port, out_dir):
+    """Runner._agree_on_range_flag on two ranks over gloo: rank 1 sees bit 0 at the second poll and bit 1 (the error) at the fourth; rank 0 never sees anything itself."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jnerf_amd.runner import Runner
+
+    class _S:
+        device = torch.device("cpu")
+    r = Runner.__new__(Runner)                      # only the agreement logic: no model, no data set
+    r.sampler = _S()
+    local = {1: [0, 1, 0, 2, 0], 0: [0, 0, 0, 0, 0]}[rank]
+    seen = [Runner._agree_on_range_flag(r, f, final=False) for f in local]
+    seen.append(Runner._agree_on_range_flag(r, 0, final=True))
+    np.save(os.path.join(out_dir, f"f{rank}.npy"), np.asarray(seen))
+    dist.destroy_process_group()
+
+
+def test_range_flag_is_agreed_on_by_all_ranks(tmp_path):
+    """(r5) a rank that acted on its own device's range flag - raised, or switched kernels - would leave its peers blocked in the next collective.  Every poll
+    MAX-reduces the flags; in the loop the reduction issued at poll k is consumed at poll k + 1 (no host wait inside the pipeline), the final poll reduces synchronously.
+    Both ranks must see the SAME sequence, every raised bit must arrive, one poll late at most."""
+    port = _free_port()
+    mp.spawn(_flag_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "f0.npy"), np.load(tmp_path / "f1.npy")
+    assert np.array_equal(a, b), (a, b)
+    assert a.tolist() == [0, 0, 1, 0, 2, 0], a      # raised at polls 1 and 3 on rank 1 -> agreed on at polls 2 and 4; nothing is pending at the final poll

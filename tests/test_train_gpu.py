@@ -510,6 +510,7 @@ def test_lego_gate_runs_when_the_dataset_is_mounted(tmp_path, monkeypatch):
     procedural scene written as PNG + transforms_{train,val,test}.json in the NeRF convention) it runs projects/ngp/configs/ngp_base.py on it and reports it/s, wall
     seconds and the mean test PSNR - as a plumbing run, labelled as such, when the step count is not the schedule's 40 000."""
     import json
+    import os
     import sys
     from PIL import Image
     from jnerf_amd.utils.config import reset_cfg

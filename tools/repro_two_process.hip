@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <time.h>
 #include "ngp_hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
@@ -71,8 +72,24 @@ int main(int argc, char **argv) {
 		if (mode == 4) { hipLaunchKernelGGL(k_plain_gather, dim3(8192), dim3(256), 0, s, t, n_params, dst, (size_t)n * 32); return hipGetLastError() == hipSuccess ? 0 : 1; }
 		return ngp_hash_encode_fwd(s, n, p, 3, t, table_host, dst, NGP_F32, NGP_LAYOUT_SOA, nullptr);
 	};
-	if (run(ref)) { fprintf(stderr, "hash fwd: %s\n", ngp_last_error()); return 2; }
-	CK(hipStreamSynchronize(s));
+	// (r5) REPRO_REF=<file>: the reference result is computed by a run that had the GPU to itself and stored; later runs beside another process compare with THAT
+	const char *ref_file = getenv("REPRO_REF");
+	FILE *rf = ref_file ? fopen(ref_file, "rb") : nullptr;
+	if (rf) {
+		float *h = (float *)malloc((size_t)n * 32 * 4);
+		if (fread(h, 4, (size_t)n * 32, rf) != (size_t)n * 32) { fprintf(stderr, "short reference file\n"); return 2; }
+		fclose(rf);
+		CK(hipMemcpy(ref, h, (size_t)n * 32 * 4, hipMemcpyHostToDevice)); free(h);
+	} else {
+		if (run(ref)) { fprintf(stderr, "hash fwd: %s\n", ngp_last_error()); return 2; }
+		CK(hipStreamSynchronize(s));
+		if (ref_file) {
+			float *h = (float *)malloc((size_t)n * 32 * 4);
+			CK(hipMemcpy(h, ref, (size_t)n * 32 * 4, hipMemcpyDeviceToHost));
+			FILE *wf = fopen(ref_file, "wb"); if (wf) { fwrite(h, 4, (size_t)n * 32, wf); fclose(wf); } free(h);
+		}
+	}
+	float *bad_host = nullptr, *ref_host = nullptr;
 	unsigned long long bad_reps = 0, worst = 0, reps = 0;
 	const auto t0 = std::chrono::steady_clock::now();
 	while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
@@ -84,9 +101,23 @@ int main(int argc, char **argv) {
 		CK(hipMemcpyAsync(&c, count, 8, hipMemcpyDeviceToHost, s));
 		CK(hipStreamSynchronize(s));
 		++reps;
-		if (c) { ++bad_reps; if (c > worst) worst = c; }
+		if (c) {
+			++bad_reps; if (c > worst) worst = c;
+			if (!bad_host) {          // keep the first differing result for the report below
+				bad_host = (float *)malloc((size_t)n * 32 * 4); ref_host = (float *)malloc((size_t)n * 32 * 4);
+				CK(hipMemcpy(bad_host, out, (size_t)n * 32 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ref_host, ref, (size_t)n * 32 * 4, hipMemcpyDeviceToHost));
+			}
+		}
 	}
 	CK(hipDeviceSynchronize());
+	if (bad_host) {                // where the first differing repetition differs: flat index = level * 2 n + 2 sample + component (level-major pairs)
+		int shown = 0; unsigned long long per_level[16] = {0};
+		for (size_t i = 0; i < (size_t)n * 32; ++i) if (memcmp(&bad_host[i], &ref_host[i], 4)) {
+			const unsigned level = (unsigned)(i / ((size_t)n * 2)); ++per_level[level & 15u];
+			if (shown < 12) { const size_t r = i % ((size_t)n * 2); printf("    [%s] level %u sample %zu (block %zu, thread %zu) comp %zu: %.9g  vs reference %.9g\n", tag, level, r / 2, r / 2 / 256, (r / 2) % 256, r % 2, bad_host[i], ref_host[i]); ++shown; }
+		}
+		printf("    [%s] differing values per level:", tag); for (int l = 0; l < 16; ++l) printf(" %llu", per_level[l]); printf("\n");
+	}
 	printf("[%s] mode %d: %llu of %llu repetitions differ from the first result (worst: %llu of %llu values)\n", tag, mode, bad_reps, reps, worst, (unsigned long long)n * 32ull);
 	return 0;
 }
