@@ -7,6 +7,8 @@
 //                                                      3 = a second stream runs an unrelated streaming kernel all the time (the marcher's role in training)
 //                                                      4 = (r5) NOT this library at all: a five-line random gather out[i] = table[hash(i) % m] over the same 48 MB table - if even
 //                                                          that differs between identical launches beside another process, the effect is the platform's
+//                                                      6 = (r5) ONE process, two streams: a second stream runs ngp_hash_encode_fwd on OTHER positions all the time (what the three
+//                                                          chunk streams of Runner.render_img do) - is concurrency inside one process enough?
 //                                                      5 = control for 4: a coalesced streaming read of the same table (out[i] = 2 table[i % m])
 // Every repetition writes the 16 x n x 2 fp32 features into the same output buffer and a device-side comparison counts the values that differ from the first
 // repetition's.  Run one copy alone and two copies concurrently; a non-zero count in either says the kernel (or the platform under it) is not a function of its inputs.
@@ -58,11 +60,14 @@ int main(int argc, char **argv) {
 	CK(hipMalloc(&table, (size_t)n_params * 4)); CK(hipMalloc(&table2, (size_t)n_params * 4));
 	CK(hipMalloc(&out, (size_t)n * 32 * 4)); CK(hipMalloc(&ref, (size_t)n * 32 * 4));
 	CK(hipMalloc(&noise, (size_t)64 << 20)); CK(hipMalloc(&count, 8));
+	float *out2 = nullptr;
+	if (mode == 6) CK(hipMalloc(&out2, (size_t)n * 32 * 4));
 	hipStream_t s, s2;
 	CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
 	hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, pos, (size_t)n * 3, 1u, 0.0f, 1.0f);
 	hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, table, (size_t)n_params, 2u, -1e-4f, 1e-4f);
 	CK(hipMemsetAsync(noise, 0, (size_t)64 << 20, s));
+	if (mode == 6) hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, pos2, (size_t)n * 3, 77u, 0.0f, 1.0f);
 	CK(hipStreamSynchronize(s));
 	auto run = [&](float *dst) -> int {
 		const float *p = pos, *t = table;
@@ -94,6 +99,7 @@ int main(int argc, char **argv) {
 	const auto t0 = std::chrono::steady_clock::now();
 	while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
 		if (mode == 3) for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_noise, dim3(512), dim3(256), 0, s2, noise, (size_t)16 << 20);
+		if (mode == 6) for (int k = 0; k < 2; ++k) if (ngp_hash_encode_fwd(s2, n, pos2, 3, table, table_host, out2, NGP_F32, NGP_LAYOUT_SOA, nullptr)) return 2;
 		CK(hipMemsetAsync(count, 0, 8, s));
 		if (run(out)) { fprintf(stderr, "hash fwd: %s\n", ngp_last_error()); return 2; }
 		hipLaunchKernelGGL(k_diff, dim3(2048), dim3(256), 0, s, (const uint32_t *)out, (const uint32_t *)ref, (size_t)n * 32, count);
