@@ -57,10 +57,19 @@ __device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restric
 	for (uint32_t i = chunk * 256u + threadIdx.x; i < lim; i += nblk * 256u) {
 	const Corner c = locate(pos, stride, i, scale);
 	P v[8]; float w[8];
-	// The kernel is bound by the L2 request rate (one gather = one request), so the two x-neighbours of a cell edge are fetched with ONE double-width load
-	// whenever they are adjacent in memory: always on dense levels (index x + ...; not across the wrap), and on hashed levels when x is even
-	// ((x+1) ^ h == (x ^ h) ^ 1 then) - 6 requests per (sample, level) on average instead of 8.  The second single load is issued only by the other lanes.
+	// The two x-neighbours of a cell edge are adjacent in memory on dense levels (index x + ...; not across the wrap) and on hashed levels when x is even
+	// ((x+1) ^ h == (x ^ h) ^ 1 then).  fp16 table: they are fetched with ONE 8-byte load then - 6 requests per (sample, level) on average instead of 8; the second single load
+	// is issued only by the other lanes.  fp32 table (r5): NOT - rounds 1-4 used 16-byte loads there and measured them against nothing; an A/B in one call
+	// (profiles/r05e_wide_loads_ab.txt) has the plain eight 8-byte loads FASTER (k_hash_fwd 101 -> 86 us per iteration incl. the refresh share, +2.4 % it/s: the three-way
+	// branch serialises a wavefront's loads), and the 16-byte gathers were the one thing that made this kernel return wrong values for a quarter wavefront while ANOTHER PROCESS
+	// trained with this package on the same GPU (profiles/r05d_shared_gpu.txt, DESIGN.md 6: 506 of 2909 launches with them, 0 of 3369 without; alone, or with two streams in one
+	// process, never).  -DNGP_PROBE_WIDE_LOADS_F32 rebuilds the old kernel for that diagnosis (tools/probe_shared_gpu.sh).
 	struct alignas(sizeof(P)) PP { P a, b; };
+#ifdef NGP_PROBE_WIDE_LOADS_F32
+	constexpr bool WIDE = true;
+#else
+	constexpr bool WIDE = sizeof(P) == 4;
+#endif
 	const bool pow2 = (size & (size - 1)) == 0;
 #pragma unroll
 	for (uint32_t j = 0; j < 4; ++j) {        // j = (y corner, z corner); all gathers are issued before the first use
@@ -68,11 +77,7 @@ __device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restric
 		const float wy = (j & 1u) ? c.w[1] : 1 - c.w[1], wz = (j >> 1) ? c.w[2] : 1 - c.w[2];
 		w[2 * j] = ((1 - c.w[0]) * wy) * wz; w[2 * j + 1] = (c.w[0] * wy) * wz;          // the reference's x, y, z multiplication order
 		const uint32_t i0 = grid_index(size, res, dense, c.g[0], gy, gz), i1 = grid_index(size, res, dense, c.g[0] + 1, gy, gz);
-#ifdef NGP_PROBE_NO_WIDE_LOADS   // (diagnosis build only, tools/probe_shared_gpu.sh: every corner a load of its own)
-		const bool adjacent_up = false, adjacent_dn = false;
-#else
-		const bool adjacent_up = i1 == i0 + 1u && (dense || pow2), adjacent_dn = i0 == i1 + 1u && !dense && pow2;     // (x^h)^1 is either one above or one below
-#endif
+		const bool adjacent_up = WIDE && i1 == i0 + 1u && (dense || pow2), adjacent_dn = WIDE && i0 == i1 + 1u && !dense && pow2;     // (x^h)^1 is either one above or one below
 		if (adjacent_up) { const PP t = *reinterpret_cast<const PP *>(tab + i0); v[2 * j] = t.a; v[2 * j + 1] = t.b; }
 		else if (adjacent_dn) { const PP t = *reinterpret_cast<const PP *>(tab + i1); v[2 * j] = t.b; v[2 * j + 1] = t.a; }
 		else { v[2 * j] = tab[i0]; v[2 * j + 1] = tab[i1]; }
