@@ -1,5 +1,5 @@
-"""Hash-grid backward of the ngp_base.py (lego, fp32) configuration on a REAL training batch, under the probe switches of csrc/hash_encode.hip: per-kernel
-HIP-event times (csrc/prof.hip) and the gradient of every variant against round 3's per-corner records (NGP_HASH_BWD_PAIRS=0).  Run through gpurun.
+"""Hash-grid backward of the ngp_base.py (lego, fp32) configuration on a REAL training batch, under the timing probes of csrc/hash_encode.hip: per-kernel
+HIP-event times (csrc/prof.hip); the product path twice (bit-reproducibility).  Run through gpurun.
 usage: python tools/probe_scatter.py [steps] [scene] [lego|fox]      (fox: the fp16 / aabb_scale 4 / cone-stepping configuration)"""
 import os
 import sys
@@ -34,7 +34,7 @@ def main():
     print("config", "fox" if fox else "lego", "scene", scene, "n", n, "n_valid", nv, flush=True)
     pos = f.s._pos_train
     table = enc.level_table
-    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(ops.hash_bwd_workspace_bytes(table, n, dfeat.dtype), dtype=torch.uint8, device="cuda")
     print("workspace MB", ws.numel() / 2 ** 20)
 
     def run_once(g):
@@ -70,13 +70,14 @@ def main():
         print(f"{name:58s} {total:7.1f} us  repro={repro} " + " ".join(f"{k}={v:.1f}" for k, v in sorted(pk.items())) + diff, flush=True)
         return g
 
-    ref = variant("round-3 path: per-corner records, cursor atomics (PAIRS=0)", {"NGP_HASH_BWD_PAIRS": "0"})
-    variant("r4 path: record regions, no global atomics, one accumulate kernel", {}, ref)
+    ref = variant("product path (fp32: record regions | fp16: per-corner lists)", {})
+    # timing probes (results wrong by design): where the stage's time goes
+    variant("accumulate: records loaded, not processed (NGP_ACC_PROBE=1)", {"NGP_ACC_PROBE": "1"})
+    variant("accumulate: records not loaded (NGP_ACC_PROBE=2)", {"NGP_ACC_PROBE": "2"})
     if not fox:
-        variant("r4 path, edge WG=512", {"NGP_HASH_BWD_PAIR_WG": "512"}, ref)
-    variant("r4 path, run combining up to res 600", {"NGP_HASH_BWD_RUN_RES": "600"}, ref)
-    variant("r4 path, run combining up to res 200", {"NGP_HASH_BWD_RUN_RES": "200"}, ref)
-
+        variant("run kernel: probe 2 (NGP_RUN_PROBE=2)", {"NGP_RUN_PROBE": "2"})
+        variant("edge kernel: probe 2 (NGP_PAIR_PROBE=2)", {"NGP_PAIR_PROBE": "2"})
+    variant("product path again", {}, ref)
 
 if __name__ == "__main__":
     main()
