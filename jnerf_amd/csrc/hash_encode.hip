@@ -280,27 +280,10 @@ __device__ __forceinline__ uint32_t sub_tail(const SubLists &m, uint32_t t, uint
 // partial slots per level - no atomics (same-address global atomics retire one at a time at the L2: 8192 of them on 16 addresses took ~90 us), nothing to zero
 // beforehand; the consumers take the maximum of a level's partials with scalar loads (level_absmax).  The pass also zeroes the record cursors and the spill
 // count for the kernels behind it in the stream (that was a separate 5 us memset launch).
-// (diagnosis build -DNGP_PROBE_BWD_NARROW, tools/probe_shared_gpu.sh: the backward's 16- / 12-byte loads as 8- and 4-byte loads - relaxed atomic loads, which the compiler does not merge)
-__device__ __forceinline__ unsigned long long ld64_narrow(const void *p) { return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-__device__ __forceinline__ uint32_t ld32_narrow(const void *p) { return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-template <typename Rec> __device__ __forceinline__ Rec load_record(const Rec *p) {
-#ifdef NGP_PROBE_BWD_NARROW
-	Rec r;
-	if (sizeof(Rec) == 16) { unsigned long long a = ld64_narrow(p), b = ld64_narrow(reinterpret_cast<const char *>(p) + 8); memcpy(&r, &a, 8); memcpy(reinterpret_cast<char *>(&r) + 8, &b, 8); }
-	else { uint32_t w[3] = {ld32_narrow(p), ld32_narrow(reinterpret_cast<const char *>(p) + 4), ld32_narrow(reinterpret_cast<const char *>(p) + 8)}; memcpy(&r, w, sizeof(Rec) < 12 ? sizeof(Rec) : 12); }
-	return r;
-#else
-	return *p;
-#endif
-}
 #define ABSMAX_PARTS NGP_ABSMAX_PARTS
 #define ABSMAX_OWN_PARTS 64u                                                    // partials the scatter's own pass writes (its grid); the remaining slots are zeroed by it
 __device__ __forceinline__ uint32_t level_absmax(const uint32_t *__restrict__ parts, uint32_t level) {      // positive floats order like their bit patterns
-#ifdef NGP_PROBE_BWD_NARROW
-	uint4 q; { const uint32_t *pp = parts + level * ABSMAX_PARTS + 4u * (threadIdx.x & 63u); const unsigned long long a = ld64_narrow(pp), b = ld64_narrow(pp + 2); q.x = (uint32_t)a; q.y = (uint32_t)(a >> 32); q.z = (uint32_t)b; q.w = (uint32_t)(b >> 32); }
-#else
 	const uint4 q = reinterpret_cast<const uint4 *>(parts + level * ABSMAX_PARTS)[threadIdx.x & 63u];         // four partials per lane + a wavefront reduction (called by full wavefronts, at kernel entry)
-#endif
 	uint32_t m = max(max(q.x, q.y), max(q.z, q.w));
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
@@ -479,13 +462,8 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_records_runs(uint32_t n, co
 		if (first + RUN_K <= lim && stride == 3) {
 			const float4 *p4 = reinterpret_cast<const float4 *>(pos + (size_t)first * 3);   // 24 floats, 16-byte aligned (first % 8 == 0)
 			float4 v[6];
-#ifdef NGP_PROBE_BWD_NARROW
-#pragma unroll
-			for (int r = 0; r < 12; ++r) { const unsigned long long q = ld64_narrow(reinterpret_cast<const char *>(p4) + 8 * r); memcpy(reinterpret_cast<char *>(v) + 8 * r, &q, 8); }
-#else
 #pragma unroll
 			for (int r = 0; r < 6; ++r) v[r] = p4[r];
-#endif
 			const float *f = reinterpret_cast<const float *>(v);
 #pragma unroll
 			for (uint32_t k = 0; k < RUN_K; ++k) { px[k][0] = f[3 * k]; px[k][1] = f[3 * k + 1]; px[k][2] = f[3 * k + 2]; }
@@ -847,13 +825,8 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const flo
 		if (first + RUN_K <= lim && stride == 3) {
 			const float4 *p4 = reinterpret_cast<const float4 *>(pos + (size_t)first * 3);   // 24 floats, 16-byte aligned (first % 8 == 0)
 			float4 v[6];
-#ifdef NGP_PROBE_BWD_NARROW
-#pragma unroll
-			for (int r = 0; r < 12; ++r) { const unsigned long long q = ld64_narrow(reinterpret_cast<const char *>(p4) + 8 * r); memcpy(reinterpret_cast<char *>(v) + 8 * r, &q, 8); }
-#else
 #pragma unroll
 			for (int r = 0; r < 6; ++r) v[r] = p4[r];
-#endif
 			const float *f = reinterpret_cast<const float *>(v);
 #pragma unroll
 			for (uint32_t k = 0; k < RUN_K; ++k) { px[k][0] = f[3 * k]; px[k][1] = f[3 * k + 1]; px[k][2] = f[3 * k + 2]; }
@@ -1009,7 +982,7 @@ __device__ __forceinline__ void gather_flat(const Rec *__restrict__ recs, const 
 					uint2 e = map[f >> shift];
 					uint32_t w = e.x >> 23; e.x &= 0x7fffffu;
 					while (f >= e.x) e = seg[++w];                          // (rarely: f lies up to 2^shift - 1 records behind the mapped one; empty segments end where they begin: skipped)
-					if (!(probe & 2u)) x[b] = load_record(recs + e.y + f);
+					if (!(probe & 2u)) x[b] = recs[e.y + f];
 				}
 			}
 #pragma unroll
