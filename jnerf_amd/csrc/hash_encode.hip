@@ -1114,6 +1114,11 @@ static HashBwdPath hash_bwd_path(const LevelTable &lt, int dtype, int grad_dtype
 	}
 	return regions ? HB_REGIONS : HB_PERCORNER;
 }
+// test hook (tests/test_host_cpu.py): the routing decision for a 16-byte aligned gradient buffer - 0 = global float atomics, 1 = per-corner lists, 2 = record regions
+NGP_API int ngp_x_hash_bwd_path(const uint32_t *level_table_host, int dtype, int grad_dtype) {
+	static float aligned_dummy[4] __attribute__((aligned(16)));
+	return (int)hash_bwd_path(load_table(level_table_host), dtype, grad_dtype, aligned_dummy);
+}
 // workspace = cursors u32[N_ZEROED] | abs-max partials u32[16 * NGP_ABSMAX_PARTS], spill count | { per-corner: record values | record indices | spill list }
 //                                                                                                 { regions: spill list | edge records | their bin offsets | run records | offsets }
 struct WsLayout { uint64_t cursors, absmax, rec_val, rec_idx, spill, pair_rec, pair_off, run_rec, run_off, total; uint32_t cap, spill_cap, n_binned, n_pair, n_run, pair_s; };

@@ -446,3 +446,38 @@ def test_ngp_comp_config_builds_its_datasets(scene, tmp_path):
     test = build_from_cfg(cfg.dataset.test, DATASETS)
     assert test.have_img is False and test.n_images == 2 and test.resolution == [800, 800] and test.image_data.shape == (2, 800 * 800, 4) and float(test.image_data.abs().max()) == 0.0
     get_cfg().clear()
+
+
+def test_hash_backward_routing_by_level_table_and_dtype():
+    """(r5) csrc/hash_encode.hip: hash_bwd_path - which of the three scatters a workspace call takes is decided by the level table and the dtypes alone (that is what lets the
+    workspace be sized for the path): every table GridEncode builds -> record regions for fp32 dL/dy, per-corner lists for fp16; a level beyond 2^19 entries or a hashed
+    table that is not a power of two -> the reference's global float atomics (the one fallback), whatever the dtypes."""
+    import ctypes as C
+    from jnerf_amd import _lib, ops
+    lib = _lib.lib()
+    lib.ngp_x_hash_bwd_path.restype = C.c_int
+    F32, F16 = _lib.F32, _lib.F16
+    path = lambda t, a, b: lib.ngp_x_hash_bwd_path(np.ascontiguousarray(t, dtype=np.uint32).ctypes.data_as(C.c_void_p), a, b)
+    for aabb in (1, 2, 4, 5, 8, 16):
+        t, _, _ = ops.level_table(aabb)
+        assert path(t, F32, F32) == 2 and path(t, F16, F32) == 1 and path(t, F16, F16) == 1, aabb
+        assert ops.hash_bwd_workspace_bytes(t, 1 << 16, torch_dtype(F32)) < ops.hash_bwd_workspace_bytes(t, 1 << 16, torch_dtype(F16))
+    # aabb_scale >= 32: the finest level has resolution >= 2^16, the reference's uint32 stride loop (HashEncode.h:82-91) overflows on it and indexes it as "dense" - neither
+    # a run level nor edge-capable, so the whole call takes the per-corner lists (exact, just not the region path)
+    for aabb in (32, 128):
+        t, _, _ = ops.level_table(aabb)
+        assert path(t, F32, F32) == 1, aabb
+    t, _, _ = ops.level_table(1)
+    big = np.array(t, dtype=np.uint32).copy().reshape(16, 4)
+    big[15, 1] = 1 << 20                                             # a level of 2^20 entries: the bins end at 2^19
+    assert path(big, F32, F32) == 0 and path(big, F16, F32) == 0
+    odd = np.array(t, dtype=np.uint32).copy().reshape(16, 4)
+    odd[15, 1] = (1 << 19) - 8                                       # hashed (res^3 > size) but not a power of two: the record kernels' mask arithmetic does not apply
+    assert path(odd, F32, F32) == 0
+    assert ops.hash_bwd_workspace_bytes(big, 1 << 16, torch_dtype(F32)) == 0       # the fallback needs no workspace
+
+
+def torch_dtype(code):
+    import torch
+    from jnerf_amd import _lib
+    return torch.float16 if code == _lib.F16 else torch.float32
