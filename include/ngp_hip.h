@@ -173,7 +173,8 @@ int ngp_composite_bwd(void *stream, uint32_t n_rays, uint32_t n_elems, const voi
                       const uint32_t *numsteps_compacted, const float *loss_grad, const float *rgb_ray, const float *density_grid_mean,
                       int cascades, void *dLdout, int zero_first);
 /* (r5) ngp_composite_fwd_huber followed by ngp_composite_bwd (zero_first = 0) as ONE launch - what the native training step issues; same arguments, bit-identical rgb,
- * loss, loss_grad and dLdout.  n_elems: rows of net / dLdout (the sample capacity of the batch: selects the lanes-per-ray variant like ngp_composite_bwd does). */
+ * loss, loss_grad and dLdout.  n_elems: rows of net / dLdout (the sample capacity of the batch: selects the lanes-per-ray variant like ngp_composite_bwd does).  (r6) For
+ * arguments on which the two split launches would pick DIFFERENT variants (n_elems != 2^18 with a ray count between their thresholds) the call issues those two launches. */
 int ngp_composite_train(void *stream, uint32_t n_rays, uint32_t n_elems, const void *net, int dtype, const float *coords, const uint32_t *numsteps, const uint32_t *numsteps_compacted,
                         const float *bg, int cascades, float *rgb_out, const float *target, float huber_delta, float *loss, float *loss_grad, const float *density_grid_mean,
                         void *dLdout);

@@ -1033,10 +1033,23 @@ __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, B
 	}
 	for (uint32_t e = threadIdx.x; e < n_local; e += ACC2_WG) { iacc[2 * e] = 0ull; iacc[2 * e + 1] = 0ull; }
 	__syncthreads();
+#ifdef NGP_PROBE_ACC_U32_CARRY
+	// diagnosis build (tools/probe_acc_carry.sh): the 64-bit sum as two 32-bit LDS atomics with carry instead of ds_add_u64 - the low word's returning add
+	// tells the one thread whose add wrapped it, which adds the carry to the high word; adds commute, so the final sum is the same integer.  Same results, slower; never the product.
+	auto add64 = [&](unsigned long long *p, unsigned long long v) {
+		uint32_t *w = reinterpret_cast<uint32_t *>(p);
+		const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+		const uint32_t old = __hip_atomic_fetch_add(w, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		const uint32_t up = hi + (uint32_t)((uint32_t)(old + lo) < old);
+		if (up) __hip_atomic_fetch_add(w + 1, up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+#else
+	auto add64 = [&](unsigned long long *p, unsigned long long v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+#endif
 	auto add_fixed = [&](uint32_t local, long long ix, long long iy) {
 		if ((ix | iy) == 0) return;
-		__hip_atomic_fetch_add(&iacc[2 * local], (unsigned long long)ix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		__hip_atomic_fetch_add(&iacc[2 * local + 1], (unsigned long long)iy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		add64(&iacc[2 * local], (unsigned long long)ix);
+		add64(&iacc[2 * local + 1], (unsigned long long)iy);
 	};
 	if (is_pair) {
 		gather_flat(prec, poff, ord, ap.pair_regions, ap.pair_region_records, PAIR_OFFS, bin, tables, ap.probe, row0, [&](const PairRec &r) {

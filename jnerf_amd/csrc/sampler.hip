@@ -1076,9 +1076,16 @@ NGP_API int ngp_composite_train(void *stream, uint32_t n_rays, uint32_t n_elems,
 	if (n_rays == 0) return 0;
 	hipStream_t s = (hipStream_t)stream;
 	const bool wide = (uint64_t)n_rays * 24u <= (uint64_t)n_elems;          // >= 24 samples per ray on average: a wavefront per ray (see composite_fwd_impl)
+	const HuberArgs hub{target, delta, loss, loss_grad};
+	// (r6) the split forward picks its lanes per ray from the ray count alone (it has no n_elems), the backward from n_rays and n_elems.  One launch has one
+	// width, and the width sets the order of the per-lane partial sums: where the two launches would disagree (n_elems != 2^18 and a ray count between the two
+	// thresholds) the call IS the two launches, so "bit-identical to ngp_composite_fwd_huber + ngp_composite_bwd" holds for every argument.
+	if (wide != ((uint64_t)n_rays * 24u <= (1u << 18))) {
+		const int e = composite_fwd_impl(stream, n_rays, net, dtype, coords, numsteps, numsteps_c, bg, cascades, rgb_out, hub);
+		return e ? e : ngp_composite_bwd(stream, n_rays, n_elems, net, dtype, coords, numsteps_c, loss_grad, rgb_out, density_grid_mean, cascades, dout, 0);
+	}
 	const uint32_t cg = wide ? CG_INFER : CG_TRAIN;
 	const dim3 grid(div_up(n_rays, 256u / cg)), block(256);
-	const HuberArgs hub{target, delta, loss, loss_grad};
 #define CT_GO(T, W) NGP_LAUNCH((k_composite_train<T, W>), grid, block, 0, s, n_rays, (const T *)net, coords, numsteps, numsteps_c, bg, cascades, rgb_out, hub, density_grid_mean, (T *)dout)
 	if (dtype == NGP_F32) { if (wide) CT_GO(float, CG_INFER); else CT_GO(float, CG_TRAIN); }
 	else { if (wide) CT_GO(__half, CG_INFER); else CT_GO(__half, CG_TRAIN); }

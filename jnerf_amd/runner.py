@@ -118,6 +118,7 @@ class Runner:
         """end of a training run (Runner.train; collective under data parallelism): drain + the FINAL poll of the split kernels' range flag - synchronous, agreed on by all ranks"""
         self.drain()
         self._poll_field32_range(final=True)
+        self._collective_polls = False                      # from here on (Runner.test on rank 0 alone) a poll after a rendered image acts locally again
 
     def __del__(self):
         try:
@@ -162,12 +163,25 @@ class Runner:
         anyway - every 16th step, after every rendered image.  Near the limit: this process continues on the exact-product fp32-MFMA kernels (nothing has overflowed
         yet, results unchanged up to fp32 rounding).  Beyond it: the launches since the last poll produced infinities - an error, never a silent one."""
         m = self.model
-        if not (torch.cuda.is_available() and getattr(m, "fused", False) and getattr(m, "fused_dtype", None) == torch.float32) or getattr(self, "_field32_exact", False):
+        if not (torch.cuda.is_available() and getattr(m, "fused", False) and getattr(m, "fused_dtype", None) == torch.float32):
+            return
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        exact = getattr(self, "_field32_exact", False)
+        if exact and (local or not multi):  # (r6, ADVICE r5) with peers a collective poll is joined whatever this rank's own state: a rank that stopped polling would leave them in the all-reduce
             return
         from . import ops
-        flag = ops.field32_range_check(reset=True, synchronize=bool(final))
-        if not local:                       # (after a rendered image: rank 0 may be rendering alone - Runner.test - so that poll acts on this rank's flag only)
+        flag = 0 if exact else ops.field32_range_check(reset=True, synchronize=bool(final))
+        if local and multi and getattr(self, "_collective_polls", False):
+            # (r6, ADVICE r5) a rendered image INSIDE the training loop (val_img runs on every rank): the read above also consumed bits raised by training launches, and
+            # acting on them here - switching kernels or raising on this rank alone - is the divergence _agree_on_range_flag exists to prevent.  The bits join the carry
+            # and the next collective poll decides for everyone.  (Runner.test after training - rank 0 alone, no collective in reach - keeps the local behaviour.)
+            self._range_flag_carry = getattr(self, "_range_flag_carry", 0) | int(flag)
+            return
+        if not local:
             flag = self._agree_on_range_flag(flag, final)
+            if exact:
+                return
         if flag & 2:
             raise RuntimeError("fp32 field network: an operand left the range of the split-operand kernels (|feature| > 255 or |activation| > 4094) - the results since the "
                                "last check contain infinities.  Re-run with NGP_FIELD32_FWD=mfma32 NGP_FIELD32_BWD=2 (exact-product kernels, no operand range).")
@@ -248,6 +262,7 @@ class Runner:
                 self._grid_event.record(main)            # side streams must not read the bitfield before this refresh has finished
                 self._grid_valid = True
         cfg.m_training_step = i
+        self._collective_polls = True                    # until finish(): see _poll_field32_range(local=True)
         if i % 16 == 0 and i:
             self._poll_field32_range()
         if self._fast:

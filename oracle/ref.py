@@ -11,10 +11,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _DIR = os.path.join(_HERE, "_ref")
 _LIBS = {}
 NAMES = ["hash", "sh", "march_constdt", "march_cone", "compact", "calc_rgb", "grid_mark", "grid_gen", "grid_splat", "grid_ema", "grid_bitfield", "pcg32"]
+# NERF_CASCADES is a constant of the reference's generated prelude (density_grid_sampler.py:56-60, 96-116): one build per value. 5 is the default, 7 what aabb_scale 64 selects.
+NAMES_C7 = ["march_constdt_c7", "march_cone_c7", "compact_c7", "calc_rgb_c7", "grid_gen_c7", "grid_bitfield_c7"]
 
 
 def available():
-    return all(os.path.exists(os.path.join(_DIR, f"libref_{n}.so")) for n in NAMES)
+    return all(os.path.exists(os.path.join(_DIR, f"libref_{n}.so")) for n in NAMES + NAMES_C7)
+
+
+def _cs(cascades):
+    assert cascades in (5, 7), "oracle/ref_shim/Makefile builds NERF_CASCADES = 5 and 7"
+    return "" if cascades == 5 else "_c7"
 
 
 def build(reference="/root/reference"):
@@ -97,7 +104,7 @@ def sh(d, dtype=np.float32):
     return out
 
 
-def march(rays_o, rays_d, bitfield, aabb, rng_state, max_samples, metadata, img_ids, xforms, cone_angle=1.0 / 256, near=0.2, const_dt=True):
+def march(rays_o, rays_d, bitfield, aabb, rng_state, max_samples, metadata, img_ids, xforms, cone_angle=1.0 / 256, near=0.2, const_dt=True, cascades=5):
     rays_o, rays_d = _c(rays_o, np.float32), _c(rays_d, np.float32)
     n = rays_o.shape[0]
     coords = np.zeros((max_samples, 7), np.float32)
@@ -105,49 +112,49 @@ def march(rays_o, rays_d, bitfield, aabb, rng_state, max_samples, metadata, img_
     counters = np.zeros(2, np.uint32)
     ray_idx = np.zeros(n, np.int32)
     name = "march_constdt" if const_dt else "march_cone"
-    getattr(_l(name), "ref_" + name)(C.c_uint32(n), C.c_float(aabb[0]), C.c_float(aabb[1]), C.c_uint32(max_samples), _p(rays_o), _p(rays_d),
+    getattr(_l(name + _cs(cascades)), "ref_" + name)(C.c_uint32(n), C.c_float(aabb[0]), C.c_float(aabb[1]), C.c_uint32(max_samples), _p(rays_o), _p(rays_d),
                                      _p(_c(bitfield, np.uint8)), C.c_float(cone_angle), _p(_c(metadata, np.float32)), _p(_c(img_ids, np.uint32)),
                                      _p(counters), _p(ray_idx), _p(numsteps), _p(coords), _p(_c(xforms, np.float32)), C.c_float(near), _p(rng_state))
     return coords, numsteps, counters, ray_idx
 
 
-def compact(net, coords_in, numsteps_in, cap, aabb):
+def compact(net, coords_in, numsteps_in, cap, aabb, cascades=5):
     net = np.ascontiguousarray(net)
     n = numsteps_in.shape[0]
     coords_out = np.zeros((cap, 7), np.float32)
     numsteps_out = np.zeros((n, 2), np.uint32)
     counter = np.zeros(1, np.uint32)
     rays_counter = np.zeros(1, np.uint32)
-    getattr(_l("compact"), "ref_compact_" + _sfx(net))(C.c_uint32(n), C.c_float(aabb[0]), C.c_float(aabb[1]), C.c_uint32(cap), _p(net), _p(_c(coords_in, np.float32)),
+    getattr(_l("compact" + _cs(cascades)), "ref_compact_" + _sfx(net))(C.c_uint32(n), C.c_float(aabb[0]), C.c_float(aabb[1]), C.c_uint32(cap), _p(net), _p(_c(coords_in, np.float32)),
                                                        _p(coords_out), _p(_c(numsteps_in, np.uint32)), _p(counter), _p(numsteps_out), _p(rays_counter))
     return coords_out, numsteps_out, counter
 
 
-def rgb_fwd(net, coords, numsteps, numsteps_c, bg, aabb):
+def rgb_fwd(net, coords, numsteps, numsteps_c, bg, aabb, cascades=5):
     net = np.ascontiguousarray(net)
     n = numsteps.shape[0]
     rgb = np.zeros((n, 3), np.float32)
-    getattr(_l("calc_rgb"), "ref_rgb_fwd_" + _sfx(net))(C.c_uint32(n), C.c_float(aabb[0]), C.c_float(aabb[1]), _p(net), _p(_c(coords, np.float32)), _p(_c(numsteps, np.uint32)),
+    getattr(_l("calc_rgb" + _cs(cascades)), "ref_rgb_fwd_" + _sfx(net))(C.c_uint32(n), C.c_float(aabb[0]), C.c_float(aabb[1]), _p(net), _p(_c(coords, np.float32)), _p(_c(numsteps, np.uint32)),
                                                          _p(rgb), _p(_c(numsteps_c, np.uint32)), _p(_c(bg, np.float32)))
     return rgb
 
 
-def rgb_bwd(net, coords, numsteps_c, loss_grad, rgb_ray, mean, aabb):
+def rgb_bwd(net, coords, numsteps_c, loss_grad, rgb_ray, mean, aabb, cascades=5):
     net = np.ascontiguousarray(net)
     n = numsteps_c.shape[0]
     dout = np.zeros_like(net)
     m = np.array([mean], np.float32)
-    getattr(_l("calc_rgb"), "ref_rgb_bwd_" + _sfx(net))(C.c_uint32(n), C.c_uint32(net.shape[0]), C.c_float(aabb[0]), C.c_float(aabb[1]), _p(dout), _p(net),
+    getattr(_l("calc_rgb" + _cs(cascades)), "ref_rgb_bwd_" + _sfx(net))(C.c_uint32(n), C.c_uint32(net.shape[0]), C.c_float(aabb[0]), C.c_float(aabb[1]), _p(dout), _p(net),
                                                          _p(_c(numsteps_c, np.uint32)), _p(_c(coords, np.float32)), _p(_c(loss_grad, np.float32)), _p(_c(rgb_ray, np.float32)), _p(m))
     return dout
 
 
-def rgb_inference(net, coords, numsteps, aabb):
+def rgb_inference(net, coords, numsteps, aabb, cascades=5):
     net = np.ascontiguousarray(net)
     n = numsteps.shape[0]
     rgb = np.zeros((n, 3), np.float32)
     alpha = np.zeros((n, 1), np.float32)
-    getattr(_l("calc_rgb"), "ref_rgb_inf_" + _sfx(net))(C.c_uint32(n), C.c_float(aabb[0]), C.c_float(aabb[1]), _p(net), _p(_c(coords, np.float32)), _p(_c(numsteps, np.uint32)), _p(rgb), _p(alpha))
+    getattr(_l("calc_rgb" + _cs(cascades)), "ref_rgb_inf_" + _sfx(net))(C.c_uint32(n), C.c_float(aabb[0]), C.c_float(aabb[1]), _p(net), _p(_c(coords, np.float32)), _p(_c(numsteps, np.uint32)), _p(rgb), _p(alpha))
     return rgb, alpha
 
 
@@ -158,10 +165,10 @@ def grid_mark(n_elements, focal, xforms, W, H):
     return grid
 
 
-def grid_gen(n, rng_state, step, aabb, grid, n_cascades, thresh):
+def grid_gen(n, rng_state, step, aabb, grid, n_cascades, thresh, cascades=5):
     pos = np.zeros((n, 3), np.float32)
     idx = np.zeros(n, np.uint32)
-    _l("grid_gen").ref_grid_gen(C.c_uint32(n), _p(rng_state), C.c_uint32(step), C.c_float(aabb[0]), C.c_float(aabb[1]), _p(_c(grid, np.float32)), _p(pos), _p(idx),
+    _l("grid_gen" + _cs(cascades)).ref_grid_gen(C.c_uint32(n), _p(rng_state), C.c_uint32(step), C.c_float(aabb[0]), C.c_float(aabb[1]), _p(_c(grid, np.float32)), _p(pos), _p(idx),
                                 C.c_uint32(n_cascades), C.c_float(thresh))
     return pos, idx
 
@@ -178,8 +185,7 @@ def grid_ema(grid, grid_tmp, decay=0.95):
 
 
 def grid_bitfield(grid, cascades=5):
-    assert cascades == 5
     mean = np.zeros(1, np.float32)
     bitfield = np.zeros(128 ** 3 * cascades // 8, np.uint8)
-    _l("grid_bitfield").ref_grid_bitfield(_p(_c(grid, np.float32)), _p(mean), _p(bitfield))
+    _l("grid_bitfield" + _cs(cascades)).ref_grid_bitfield(_p(_c(grid, np.float32)), _p(mean), _p(bitfield))
     return bitfield, mean

@@ -7,7 +7,7 @@ import numpy as np
 import synth
 
 _G = None
-CASES = ["case_pcg32", "case_hash", "case_hash_dydx", "case_sh", "case_march_lego", "case_march_fox", "case_grid"]
+CASES = ["case_pcg32", "case_hash", "case_hash_dydx", "case_sh", "case_march_lego", "case_march_fox", "case_grid", "case_hash_wide", "case_march_seven_cascades", "case_grid_seven_cascades"]
 
 
 def load():
@@ -156,3 +156,89 @@ def case_grid(I, g, exact):
         close(mean, [exact_mean], atol=0, rtol=1e-5, what="grid mean vs fp64")
         bf_ref, _ = O.grid_update_bitfield(ema)
         assert np.array_equal(bf, bf_ref)
+
+
+_GW = None
+
+
+def load_wide():
+    """tests/golden/golden_wide_v1.npz (minted from oracle/_ref by tests/golden/make_golden_wide.py): aabb_scale 8 .. 128 and NERF_CASCADES = 7"""
+    global _GW
+    if _GW is None:
+        _GW = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_wide_v1.npz")))
+    return _GW
+
+
+def case_hash_wide(I, g, exact):
+    """hash encode at aabb_scale 8 / 32 / 64 / 128 (HashEncode.h:68-94: from 32 on the uint32 stride of grid_index wraps on the finest levels)"""
+    g = load_wide()
+    x, dy = g["hash_x"], g["hash_dy"]
+    for s in (8, 32, 64, 128):
+        table, offsets, n_params = I.level_table(s)
+        assert np.array_equal(offsets, g[f"hash_offsets_s{s}"])
+        for dt, nm in ((np.float32, "f32"), (np.float16, "f16")):
+            grid = synth.table(n_params, dt, amp=2.0)
+            out = I.hash_encode_fwd(x, grid, table)
+            close(out, g[f"hash_fwd_s{s}_{nm}"], atol=4e-3 if dt == np.float16 else 3e-5, what=f"hash fwd s{s} {nm}")
+            grad = I.hash_encode_bwd(x[:64], dy[:64].astype(dt), table, n_params)
+            idx, val = g[f"hash_bwd_idx_s{s}_{nm}"], g[f"hash_bwd_val_s{s}_{nm}"]
+            nz = np.flatnonzero(grad)
+            assert len(np.setxor1d(nz, idx)) <= max(4, len(idx) // 2000), f"s{s} {nm}: scatter touched different table entries"
+            close(grad[idx], val, atol=2e-4 if dt == np.float16 else 2e-7, rtol=2e-2 if dt == np.float16 else 1e-4, what=f"hash bwd s{s} {nm}")
+        _, dydx = I.hash_encode_fwd_dydx(x[:64], synth.table(n_params, np.float32, amp=2.0), table)
+        assert np.array_equal(dydx, g[f"hash_dydx_s{s}"]), f"dy_dx s{s}"
+
+
+def case_march_seven_cascades(I, g, exact):
+    """NERF_CASCADES = 7, box (-31.5, 32.5), cone stepping (density_grid_sampler.py:56-60; ray_sampler.h, compacted_coord.h, calc_rgb.h built with that constant)"""
+    from oracle import oracle as O
+    sys_path_golden()
+    import make_golden_wide as MW
+    g = load_wide()
+    xf, focal, meta, img, o, d, bits = MW.c7_scene()
+    assert np.array_equal(o, g["c7_o"]) and np.array_equal(d, g["c7_d"]) and np.array_equal(sha(bits), g["c7_bits_sha"]), "the scene generator changed: re-mint the fixture"
+    rng = O.PCG32(1337)
+    coords, ns, cnt, ridx = I.march_rays(o, d, bits, MW.AABB, rng, MW.N_RAYS * 1024, const_dt=False, cascades=MW.CASC)
+    M = int(cnt[1])
+    assert np.array_equal(ns, g["c7_numsteps"]) and np.array_equal(cnt, g["c7_counters"]) and np.array_equal(rng.st, g["c7_rng_end"])
+    assert np.array_equal(coords[:M], g["c7_coords"]), "sample records differ"
+    assert np.array_equal(ridx, g["c7_rayidx"]) and not coords[M:].any()
+    cap = M * 2 // 3
+    cc, nc, ccnt = I.compact_coords(coords[:M], ns, cap)
+    assert np.array_equal(nc, g["c7_compact_numsteps"]) and np.array_equal(ccnt, g["c7_compact_counter"])
+    net, bg, G, netfull = g["c7_net"], g["c7_bg"], g["c7_G"], g["c7_netfull"]
+    for dt, dn in ((np.float32, "f32"), (np.float16, "f16")):
+        f = I.composite_fwd(net.astype(dt), cc, ns, nc, bg, cascades=MW.CASC)
+        b = I.composite_bwd(net.astype(dt), cc, nc, G, g[f"c7_fwd_{dn}"], 0.001, cascades=MW.CASC)
+        ri, ra = I.composite_inference(netfull.astype(dt), coords[:M], ns, cascades=MW.CASC)
+        if exact:
+            assert np.array_equal(f, g[f"c7_fwd_{dn}"]) and np.array_equal(b, g[f"c7_bwd_{dn}"])
+            assert np.array_equal(ri, g[f"c7_inf_{dn}"]) and np.array_equal(ra, g[f"c7_alpha_{dn}"])
+        else:
+            close(f, g[f"c7_fwd_{dn}"], atol=2e-5, rtol=1e-5, what="composite fwd")
+            close(b, g[f"c7_bwd_{dn}"], atol=2e-6 if dt == np.float32 else 2e-4, rtol=1e-4 if dt == np.float32 else 4e-3, what="composite bwd")
+            close(ri, g[f"c7_inf_{dn}"], atol=2e-5, rtol=1e-5, what="composite inference")
+            close(ra, g[f"c7_alpha_{dn}"], atol=2e-5, what="alpha")
+
+
+def case_grid_seven_cascades(I, g, exact):
+    from oracle import oracle as O
+    sys_path_golden()
+    import make_golden_wide as MW
+    g = load_wide()
+    n_el = MW.CASC * 128 ** 3
+    grid = MW.c7_grid()
+    rng = O.PCG32(1337)
+    pos, idx = I.grid_generate_samples(4096, rng, 3, MW.AABB, grid, MW.CASC, 0.01)
+    assert np.array_equal(idx, g["c7_grid_gen_idx"]) and np.array_equal(pos, g["c7_grid_gen_pos"]) and np.array_equal(rng.st, g["c7_grid_gen_rng_end"])
+    bf, mean = I.grid_update_bitfield(grid, MW.CASC)
+    close(mean, g["c7_grid_mean"], atol=0, rtol=0 if exact else 1e-5, what="grid mean")
+    assert mean[0] > 0.011                                # the threshold is min(0.01, mean) = 0.01 whatever the mean's last bit: the bitfield is exact for every implementation
+    assert np.array_equal(sha(bf), g["c7_grid_bitfield_sha"])
+
+
+def sys_path_golden():
+    import sys
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if p not in sys.path:
+        sys.path.insert(0, p)

@@ -149,3 +149,63 @@ def test_range_flag_is_agreed_on_by_all_ranks(tmp_path):
     a, b = np.load(tmp_path / "f0.npy"), np.load(tmp_path / "f1.npy")
     assert np.array_equal(a, b), (a, b)
     assert a.tolist() == [0, 0, 1, 0, 2, 0], a      # raised at polls 1 and 3 on rank 1 -> agreed on at polls 2 and 4; nothing is pending at the final poll
+
+
+def _local_poll_worker(rank, world, port, out_dir):
+    """Runner._poll_field32_range on two ranks over gloo with the device flag stubbed: rank 1's flag shows bit 0 at a poll that follows a rendered image INSIDE the training loop"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jnerf_amd import ops
+    from jnerf_amd.runner import Runner
+    torch.cuda.is_available = lambda: True          # the poll is a no-op without a GPU; nothing below touches one (the two ops it calls are stubbed)
+
+    class _S:
+        device = torch.device("cpu")
+
+    class _M:
+        fused, fused_dtype = True, torch.float32
+    r = Runner.__new__(Runner)
+    r.sampler, r.model = _S(), _M()
+    device_flag = [0]
+    selected = []
+
+    def check(reset=True, synchronize=True):
+        v = device_flag[0]
+        if reset:
+            device_flag[0] = 0
+        return v
+    ops.field32_range_check, ops.field32_select = check, lambda exact: selected.append(bool(exact))
+    trace = []
+
+    def poll(**kw):
+        Runner._poll_field32_range(r, **kw)
+        trace.append(int(bool(getattr(r, "_field32_exact", False))))
+    r._collective_polls = True                      # what train_step sets
+    poll()                                          # step 16
+    if rank == 1:
+        device_flag[0] = 1                          # a training launch came within 4x of the range ...
+    poll(local=True)                                # ... and val_img's poll is the one that reads it: must NOT switch this rank alone
+    poll()                                          # step 32: the bit travels
+    poll()                                          # step 48: both ranks act on it
+    poll(local=True)                                # a later rendered image
+    poll()                                          # step 64: a rank on the exact kernels still joins the collective
+    Runner._poll_field32_range(r, final=True); trace.append(int(bool(getattr(r, "_field32_exact", False))))
+    np.save(os.path.join(out_dir, f"l{rank}.npy"), np.asarray(trace + [len(selected)]))
+    dist.destroy_process_group()
+
+
+def test_poll_after_a_rendered_image_inside_training_never_acts_alone(tmp_path):
+    """(r6) val_img runs on every rank inside the loop; its poll read the flag with reset and acted locally - one rank on the exact kernels, returning early
+    from every later poll while its peer waits in the all-reduce.  Now the bits join the carry and the next collective poll decides: both ranks switch at the same poll, both
+    keep polling, nobody hangs (a hang = the join timeout below)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_local_poll_worker, args=(rk, 2, port, str(tmp_path))) for rk in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, p.exitcode
+    a, b = np.load(tmp_path / "l0.npy"), np.load(tmp_path / "l1.npy")
+    assert np.array_equal(a, b), (a, b)
+    assert a.tolist() == [0, 0, 0, 1, 1, 1, 1, 1], a      # switched once, at the poll after the bit was reduced, on BOTH ranks

@@ -35,7 +35,7 @@ def test_hip_marcher_matches_golden_with_either_count_pass(H, case, count_pass):
     getattr(GC, case)(H, GC.load(), exact=False)
 
 
-@pytest.mark.parametrize("aabb_scale", [1, 4])
+@pytest.mark.parametrize("aabb_scale", [1, 4, 8, 32, 64, 128])     # >= 32: grid_index's uint32 stride wraps on the finest levels (HashEncode.h:82-91)
 def test_hash_fwd_fp32_bit_exact_vs_oracle(H, aabb_scale):
     from jnerf_amd import ops
     table, offsets, n_params = O.level_table(aabb_scale)
@@ -53,7 +53,7 @@ def test_hash_fwd_fp32_bit_exact_vs_oracle(H, aabb_scale):
     assert H.hash_encode_fwd(x[:0], grid, table).shape == (0, 32)    # empty input
 
 
-@pytest.mark.parametrize("aabb_scale", [1, 4])
+@pytest.mark.parametrize("aabb_scale", [1, 4, 64])
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
 def test_hash_fwd_dydx_and_input_gradient(H, aabb_scale, dtype):
     """encoder dL/dx: ngp_hash_encode_fwd_dydx == kernel_grid's dy_dx branch (bit-exact vs the oracle, which is bit-exact vs oracle/_ref),
@@ -135,7 +135,7 @@ def test_hash_bwd_vs_oracle(H, dtype, grad_dtype):
     GC.close(H.N(g).astype(np.float64) / 2, ref, what="hash bwd workspace accumulate", atol=tol["atol"] * 2, rtol=tol["rtol"] * 2)
 
 
-@pytest.mark.parametrize("aabb_scale", [1, 2, 16, 23.4])
+@pytest.mark.parametrize("aabb_scale", [1, 2, 16, 23.4, 32, 64, 128])
 def test_hash_bwd_workspace_other_level_tables(H, aabb_scale):
     """the record kernels must index a level the way the level is laid out.  aabb_scale 23.4 has a DENSE level with res 80 = 512000 entries
     that round 1's size-only predicate binned with the XOR hash; 2 and 16 (colmap2nerf's usual value) have large dense levels (dense levels are dealt to the
@@ -520,7 +520,7 @@ def test_composite_fwd_huber_equals_the_two_calls(H, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
-@pytest.mark.parametrize("n_rays,cap", [(12000, 1 << 16), (600, 1 << 16)])       # 16 lanes per ray (many short rays) | a wavefront per ray (few long ones): both variants
+@pytest.mark.parametrize("n_rays,cap", [(12000, 1 << 16), (600, 1 << 16), (4000, 1 << 16)])       # 16 lanes per ray (many short rays) | a wavefront per ray (few long ones) | (r6) the split launches disagree
 def test_composite_train_equals_the_two_launches(H, dtype, n_rays, cap):
     """(r5) ngp_composite_train - forward + Huber + backward of the compositing in ONE launch, what the native training step issues - against ngp_composite_fwd_huber followed
     by ngp_composite_bwd: rgb, loss, loss gradient and dL/dout are the same BITS (the fused kernel evaluates the same expressions; a ray's colour and loss gradient stay in
@@ -536,7 +536,9 @@ def test_composite_train_equals_the_two_launches(H, dtype, n_rays, cap):
     T = H.T
     tnet, tc, tns, tnsc, tbg, ttar = T(net), T(coords), T(ns.view(np.int32)), T(nsc.view(np.int32)), T(bg), T(target)
     n_elems = coords.shape[0]
-    assert (n_rays * 24 <= n_elems) == (n_rays == 600) and (n_rays * 24 <= (1 << 18)) == (n_rays == 600)     # all three launches pick the same lanes-per-ray variant, and the two shapes are the two variants
+    # 12000 / 600 rays: all three launches pick the same lanes-per-ray variant, and the two shapes are the two variants.  4000 rays with a sample capacity other than 2^18
+    # (ADVICE r5): the split forward (ray count against 2^18) takes a wavefront per ray, the backward (against n_elems) 16 lanes - the fused call must still return their bits
+    assert (n_rays * 24 <= n_elems) == (n_rays == 600) and (n_rays * 24 <= (1 << 18)) == (n_rays in (600, 4000))
     for mean in (0.5, 0.001):
         gm = torch.full((1,), mean, device="cuda")
         rgb = torch.empty((n_rays, 3), device="cuda"); loss = torch.empty_like(rgb); lg = torch.empty_like(rgb)

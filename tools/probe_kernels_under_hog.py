@@ -69,6 +69,9 @@ def st_adam():
 
 stages = [("k_hash_fwd", st_hash_fwd), ("k_field32_fwd_split", st_field_fwd), ("k_composite_train", st_composite), ("k_field32_bwd_split", st_field_bwd), ("k_reduce_slabs", st_reduce),
           ("hash backward (runs2 + pairs + accumulate2)", st_hash_bwd), ("marcher (wave count + scans + write)", st_march), ("k_adam_ema", st_adam)]
+only = os.environ.get("PROBE_STAGES")              # comma-separated substrings of the stage names: run only those
+if only:
+    stages = [st for st in stages if any(k in st[0] for k in only.split(","))]
 t0 = time.time()
 for name, fn in stages:
     try:
