@@ -7,7 +7,9 @@ mkdir -p build
 pids=()
 for f in *.hip; do
   o=build/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ ngp_common.h -nt "$o" ] || [ hash_common.h -nt "$o" ] || [ ../../include/ngp_hip.h -nt "$o" ]; then
+  stale=0
+  for h in *.h ../../include/ngp_hip.h; do [ "$h" -nt "$o" ] && stale=1; done
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
     /opt/rocm/bin/hipcc $FLAGS -c "$f" -o "$o" $EXTRA &
     pids+=($!)
   fi

@@ -16,6 +16,7 @@
 //    rows, five staging phases that reuse one 66-KiB region), one fp32 slab per workgroup, summed by ngp_reduce_slabs (deterministic, no atomics).
 #include "ngp_common.h"
 #include "field_split.h"
+#include "mlp_tail.h"
 #include <stdlib.h>
 #include <map>
 #include <mutex>
@@ -23,27 +24,8 @@
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-#define NF32_FWD 40
-#define NF32_BWD 36
 #define NGP_FIELD32_BWD_DEFAULT 3       // 3 = split fp16 operands (field_split.hip): 109 us in the training step vs 139 us for 2 = two free-running groups on fp32 MFMAs (+4.8 % it/s, A/B on one box)
-#define NF32_ALL (NF32_FWD + NF32_BWD)          // fp32 fragments; the packed buffer continues with the split fp16 fragments (field_split.h: forward + transposed): NGP_PACKED32_WEIGHT_FLOATS = NF32_ALL * 256 + NSPLIT_HALVES / 2
-static_assert(NGP_PACKED32_WEIGHT_FLOATS == NF32_ALL * 256 + NSPLIT_HALVES / 2, "packed fp32 weight buffer layout");
-
-// value j (0..3) of weight fragment f for lane (s = lane&15: row of the A tile, g = lane>>4: k index of the MFMA).  fp32 packs, (out,in) row-major:
-// wd: W0 @0 [64][32], W1 @2048 [16][64];  wc: V0 @0 [64][32], V1 @2048 [64][64], V2 @6144 [16][64]   (ngp_network.py:21-29)
-__device__ __forceinline__ float frag_value32(const float *__restrict__ wd, const float *__restrict__ wc, int f, int s, int g, int j) {
-	if (f < 8) { const int u = f >> 1, kq = f & 1; return wd[(16 * u + s) * 32 + 8 * g + 4 * kq + j]; }                         // L0: lane group g holds features 8g..8g+7
-	if (f < 12) { const int kq = f - 8; return wd[2048 + s * 64 + 16 * kq + 4 * g + j]; }                                        // L1
-	if (f < 20) { const int u = (f - 12) >> 1, kq = (f - 12) & 1; return wc[(16 * u + s) * 32 + 16 * kq + 4 * g + j]; }           // L2: input = [density(16) | SH(16)]
-	if (f < 36) { const int u = (f - 20) >> 2, kq = (f - 20) & 3; return wc[2048 + (16 * u + s) * 64 + 16 * kq + 4 * g + j]; }    // L3
-	if (f < 40) { const int kq = f - 36; return wc[6144 + s * 64 + 16 * kq + 4 * g + j]; }                                       // L4
-	f -= 40;                                                                                                                   // backward: A = W^T
-	if (f < 4) return wc[6144 + (4 * g + j) * 64 + 16 * f + s];                                                                 // dG1 = V2^T dO
-	if (f < 20) { const int u = (f - 4) >> 2, t = (f - 4) & 3; return wc[2048 + (16 * t + 4 * g + j) * 64 + 16 * u + s]; }       // dG0 = V1^T dG1
-	if (f < 24) { const int t = f - 20; return wc[(16 * t + 4 * g + j) * 32 + s]; }                                             // dD  = (V0^T dG0)[0:16]
-	if (f < 28) { const int u = f - 24; return wd[2048 + (4 * g + j) * 64 + 16 * u + s]; }                                      // dH  = W1^T dD
-	{ const int u = (f - 28) >> 2, t = (f - 28) & 3; return wd[(16 * t + 4 * g + j) * 32 + 16 * u + s]; }                        // dF  = W0^T dH
-}
+// NF32_FWD / NF32_BWD / NF32_ALL and frag_value32 (the fp32 fragment layout): mlp_tail.h, shared with the hash backward's record kernels that carry the MLP tail (r6)
 __global__ __launch_bounds__(256) void k_pack_frags32(const float *__restrict__ wd, const float *__restrict__ wc, float *__restrict__ out, int n_frags) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= n_frags * 256) return;
@@ -525,28 +507,7 @@ __global__ __launch_bounds__(512, 2) void k_field32_bwd_2g(uint32_t n, const flo
 __global__ __launch_bounds__(1024) void k_mlp32_sweep_pack(float *__restrict__ pack, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, AdamConsts c,
                                                            float *__restrict__ packed_out) {
 	__shared__ float w[10240];
-	// one workgroup, ten elements per thread: all forty loads of a thread are issued before the first use (a loop of dependent load -> update -> store round trips
-	// made this launch 15 us long for 160 KB of traffic)
-	float P[10], M[10], V[10], G[10];
-#pragma unroll
-	for (int k = 0; k < 10; ++k) { const int i = threadIdx.x + 1024 * k; P[k] = pack[i]; M[k] = m[i]; V[k] = v[i]; G[k] = grad[i]; }
-#pragma unroll
-	for (int k = 0; k < 10; ++k) {
-		const int i = threadIdx.x + 1024 * k;
-		float E = P[k];
-		adam_ema_update<true>(P[k], M[k], V[k], E, G[k], c);
-		pack[i] = P[k]; m[i] = M[k]; v[i] = V[k]; w[i] = P[k];
-	}
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < NF32_ALL / 4; ++k) {                  // 19 rounds of 1024 fragment values: the gathers from LDS are independent, the stores coalesced
-		const int idx = threadIdx.x + 1024 * k;
-		const int f = idx >> 8, lane = (idx >> 2) & 63, j = idx & 3;
-		packed_out[idx] = frag_value32(w, w + 3072, f, lane & 15, lane >> 4, j);
-	}
-	_Float16 *split_out = reinterpret_cast<_Float16 *>(packed_out + NF32_ALL * 256);      // the forward kernel's split fp16 fragments of the same updated weights
-#pragma unroll
-	for (int k = 0; k < NSPLIT_HALVES / 1024; ++k) { const int idx = threadIdx.x + 1024 * k; split_out[idx] = split_frag_half(w, w + 3072, idx); }
+	tail_mlp32_sweep_pack_1024(pack, grad, m, v, c, packed_out, w);       // (mlp_tail.h: the same job rides in k_bin_pairs' grid on the single-GPU training path)
 }
 int ngp_mlp32_sweep_pack(void *stream, float *pack, const float *grad, float *m, float *v, float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, float *packed_out) {
 	NGP_REQUIRE(pack && grad && m && v && packed_out && step >= 1, NGP_E_ARG, "ngp_mlp32_sweep_pack: bad arguments");

@@ -254,8 +254,8 @@ __device__ __forceinline__ floatx4 fma4(floatx4 acc, floatx4 v, float s) {
 	return acc;
 }
 
-// PROBE (timing experiments only, tools/probe_split_bwd.py; results are wrong for PROBE != 0): 1 = no staging stores, 2 = no weight-gradient loads / MFMAs,
-// 3 = neither (chain + barriers only), 4 = no barriers either
+// PROBE (timing experiments only, a -DNGP_PROBE_SPLIT=n build, tools/probe_split_bwd.py; results are wrong for PROBE != 0): 1 = no staging stores, 2 = no weight-gradient
+// loads / MFMAs, 3 = neither (chain + barriers only), 4 = no barriers either
 template <int LAYOUT, int PROBE>
 __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                               const _Float16 *__restrict__ packed, const float *__restrict__ dout,
@@ -486,11 +486,13 @@ int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layou
 	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_split<L, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd(split): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
 	NGP_LAUNCH((k_field32_bwd_split<L, P>), grid, block, shmem, s, n, feat, dir, dir_stride, p, dout, dfeat, slabs, n_valid, am); } while (0)
-	static const int probe = [] {
-		const char *e = getenv("NGP_SPLIT_PROBE"); const int v = e ? atoi(e) : 0;
-		if (v) fprintf(stderr, "libngp_hip: NGP_SPLIT_PROBE=%d - timing probe of the split backward: parts of the kernel are compiled out, ITS RESULTS ARE WRONG\n", v);
-		return v; }();
-#define GO(L) do { if (probe == 1) GOP(L, 1); else if (probe == 2) GOP(L, 2); else if (probe == 3) GOP(L, 3); else if (probe == 4) GOP(L, 4); else GOP(L, 0); } while (0)
+	// (r6) the timing probes (PROBE != 0: parts of the kernel compiled out, RESULTS WRONG) are a compile-time build - EXTRA=-DNGP_PROBE_SPLIT=1..4 bash csrc/build.sh,
+	// tools/probe_split_bwd.py - no longer an environment variable a user could set on the product binary
+#ifdef NGP_PROBE_SPLIT
+#define GO(L) GOP(L, NGP_PROBE_SPLIT)
+#else
+#define GO(L) GOP(L, 0)
+#endif
 	if (layout == NGP_LAYOUT_SOA) GO(NGP_LAYOUT_SOA); else GO(NGP_LAYOUT_AOS);
 #undef GO
 #undef GOP

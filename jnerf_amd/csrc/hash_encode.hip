@@ -26,6 +26,7 @@
 #pragma clang fp contract(off)
 
 #include "hash_common.h"
+#include "mlp_tail.h"
 
 template <typename T, int LAYOUT>
 __device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, const LevelTable &lt,
@@ -699,13 +700,20 @@ __host__ __device__ static inline uint32_t pair_region_records() { return PAIR_S
 template <typename T, int LAYOUT, uint32_t S>
 __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
                                                  const uint32_t *__restrict__ absmax_bits, PairRec *__restrict__ prec, uint16_t *__restrict__ poff,
-                                                 uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill, const uint32_t *__restrict__ n_valid,
-                                                 uint32_t probe /* timing experiment (NGP_PAIR_PROBE; results wrong unless 0): 1 = no record stores */) {
+                                                 uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill, const uint32_t *__restrict__ n_valid, TailJobs tj) {
 	using P = typename Pair<T>::type;
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
+	uint32_t po = blockIdx.y;
+	if (tj.do_sweep) {                                                                        // (r6, mlp_tail.h) row 0 of the grid - dispatched first - carries the MLP pack's Adam sweep + fragment packing: one workgroup
+		if (po == 0u) {
+			if constexpr (S == 1024u) { if (blockIdx.x == 0u) tail_mlp32_sweep_pack_1024(tj.pack, tj.reduce_out, tj.m, tj.v, tj.c, tj.packed_out, reinterpret_cast<float *>(bin_smem)); }
+			return;
+		}
+		po -= 1u;
+	}
 	PairRec *stage = reinterpret_cast<PairRec *>(bin_smem);                                   // [PAIR_STAGE_RECORDS] records, grouped by bin
 	uint32_t *cnt = bin_smem + PAIR_STAGE_RECORDS * 4u, *loff = cnt + PAIR_BINS;             // loff[PAIR_BINS] = total
-	const uint32_t po = blockIdx.y, hl = sel.hl[po], level = bp.level[hl];
+	const uint32_t hl = sel.hl[po], level = bp.level[hl];
 	const uint32_t mask = lt.v[4 * level + 1] - 1u;
 	const bool split = lt.v[4 * level + 2] > PAIR_RES_MAX;                                    // (uniform; the host launches S = 512 when any level of the launch is split)
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
@@ -778,7 +786,9 @@ __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__rest
 	__syncthreads();
 	const uint32_t total = loff[PAIR_BINS];
 	PairRec *out = prec + region * pair_region_records();
-	if (probe & 1u) { if (total == 0x7fffffffu) out[0] = stage[0]; return; }
+#ifdef NGP_PROBE_SCATTER                                                                      // timing experiment (tools/probe_scatter.py builds it): no record stores - results WRONG
+	if (total != 0x7fffffffu) return;
+#endif
 	for (uint32_t p = threadIdx.x; p < total; p += S) out[p] = stage[p];
 }
 
@@ -798,12 +808,19 @@ __host__ __device__ __forceinline__ uint32_t entry2_of(uint32_t bin, uint32_t lo
 template <typename T, int LAYOUT, int OCC>
 __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
                                                          const uint32_t *__restrict__ absmax_bits, RunRec *__restrict__ rrec, uint16_t *__restrict__ roff,
-                                                         const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */,
-                                                         uint32_t probe /* timing experiments (results wrong): 1 = the histogram atomics spread over lane-distinct addresses, 2 = no global record stores */) {
+                                                         const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */, TailJobs tj) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
+	uint32_t ro = blockIdx.y;
+	if (tj.do_reduce) {                                                                    // (r6, mlp_tail.h) row 0 of the grid - dispatched first - carries the MLP weight-gradient slab reduction
+		if (ro == 0u) {
+			for (uint32_t unit = blockIdx.x; unit * TAIL_REDUCE_COLS < tj.width; unit += gridDim.x) { tail_reduce_slabs_256(tj, reinterpret_cast<float *>(bin_smem), unit); __syncthreads(); }
+			return;
+		}
+		ro -= 1u;
+	}
 	RunRec *stage_rec = reinterpret_cast<RunRec *>(bin_smem);                              // [stage]
 	uint32_t *cnt = bin_smem + stage * 3u, *loff = cnt + PAIR_BINS, *cnt2 = loff + PAIR_BINS + 2u;   // loff[PAIR_BINS] = total
-	const uint32_t ro = blockIdx.y, hl = sel.hl[ro], level = bp.level[hl];
+	const uint32_t hl = sel.hl[ro], level = bp.level[hl];
 	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const bool dense = level_is_dense(size, res), il = size < BIN_LEVEL_MAX;
@@ -876,8 +893,7 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const flo
 		}
 		if (open) flush();
 	};
-	const uint32_t spread = (probe & 1u) ? threadIdx.x : 0u;
-	sweep([&](uint32_t e, float, float) { atomicAdd(&cnt[(bin2_of(e, il) + spread) & (PAIR_BINS - 1u)], 1u); });
+	sweep([&](uint32_t e, float, float) { atomicAdd(&cnt[bin2_of(e, il)], 1u); });
 	__syncthreads();
 	if (threadIdx.x < 64u) {                                                    // wave 0, two bins per lane: exclusive prefix = the region's bin offsets
 		const uint32_t b0 = 2u * threadIdx.x, c0 = cnt[b0], c1 = cnt[b0 + 1u];
@@ -892,13 +908,15 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const flo
 	__syncthreads();
 	RunRec *out = rrec + region * run2_region_records();
 	sweep([&](uint32_t e, float x, float y) {
-		const uint32_t bin = (bin2_of(e, il) + spread) & (PAIR_BINS - 1u), p = loff[bin] + atomicAdd(&cnt2[bin], 1u);
+		const uint32_t bin = bin2_of(e, il), p = loff[bin] + atomicAdd(&cnt2[bin], 1u);
 		const RunRec r{x, y, local2_of(e, il)};
-		if (p < stage) stage_rec[p] = r; else if (!(probe & 2u)) out[p] = r;     // beyond the staging area (scattered positions only): straight to its place in the region
+		if (p < stage) stage_rec[p] = r; else out[p] = r;                      // beyond the staging area (scattered positions only): straight to its place in the region
 	});
 	__syncthreads();
 	const uint32_t total = min(loff[PAIR_BINS], stage);
-	if (probe & 2u) return;
+#ifdef NGP_PROBE_SCATTER                                                                  // timing experiment: no record stores from the staging area - results WRONG
+	if (total != 0x7fffffffu) return;
+#endif
 	for (uint32_t p = threadIdx.x; p < total; p += RUN_WG) out[p] = stage_rec[p];
 }
 
@@ -1216,7 +1234,9 @@ static int hash_bwd_set_lds() {
 static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host,
                          void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes,
                          hipEvent_t after_coarse = nullptr /* data parallel, overlapped exchange: recorded behind the accumulate launch of the run-combined (coarse) levels, which then is a launch of its own */,
-                         bool absmax_done = false /* the abs-max partials, zeroed cursors and spill count are already in the workspace (written by the field backward kernel, ngp_hash_bwd_absmax_slots) */) {
+                         bool absmax_done = false /* the abs-max partials, zeroed cursors and spill count are already in the workspace (written by the field backward kernel, ngp_hash_bwd_absmax_slots) */,
+                         const TailJobs *tail = nullptr /* (r6) jobs that may ride in the record launches (mlp_tail.h) */, int *tail_taken = nullptr /* set to 1 when they did */) {
+	if (tail_taken) *tail_taken = 0;
 	NGP_REQUIRE(grad && level_table_host && (n == 0 || (pos && dLdy)), NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_bwd: bad dtype %d", dtype);
 	NGP_REQUIRE(grad_dtype == NGP_F32 || (grad_dtype == NGP_F16 && dtype == NGP_F16), NGP_E_DTYPE, "ngp_hash_encode_bwd: bad grad dtype %d for dtype %d", grad_dtype, dtype);
@@ -1265,9 +1285,13 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	SpillEntry *spill = (SpillEntry *)(ws + wl.spill);
 	const int ow = zero_first ? 1 : 0;
 	bool coarse_marked = false;
-	const uint32_t run_probe = [] { const char *e = getenv("NGP_RUN_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();     // timing probes (tools/probe_scatter.py): parts of a kernel skipped, results wrong
-	const uint32_t pair_probe = [] { const char *e = getenv("NGP_PAIR_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
-	const uint32_t acc_probe = [] { const char *e = getenv("NGP_ACC_PROBE"); return e ? (uint32_t)atoi(e) : 0u; }();
+	// (r6) the timing probes of tools/probe_scatter.py - parts of a kernel skipped, results WRONG - are compile-time builds now (-DNGP_PROBE_SCATTER: no record stores;
+	// -DNGP_PROBE_ACC=1|2: accumulate's records loaded but not processed | not loaded), no longer environment variables a user could set on the product binary
+#ifdef NGP_PROBE_ACC
+	const uint32_t acc_probe = NGP_PROBE_ACC;
+#else
+	const uint32_t acc_probe = 0u;
+#endif
 #define ABSMAX(T, L) do { if (!absmax_done) NGP_LAUNCH((k_level_absmax<T, L>), dim3(ABSMAX_OWN_PARTS, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid, cursors, spill_count); } while (0)   /* also zeroes the cursors and the spill count */
 	if (regions) {
 		// fp32 -> fp32: run records + edge records in regions, no global atomics, ONE accumulate kernel - two launches of it when the data-parallel exchange wants the coarse levels first
@@ -1276,9 +1300,16 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		RunRec *run_rec = (RunRec *)(ws + wl.run_rec);
 		uint16_t *run_off = (uint16_t *)(ws + wl.run_off);
 		const uint32_t pair_s = wl.pair_s;
-#define RGO(L) NGP_LAUNCH((k_bin_runs2<float, L, 5>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run2_stage_bytes(RUN2_STAGE), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, run_rec, run_off, n_valid, RUN2_STAGE, run_probe)
+		// (r6) the MLP tail rides along when both record kernels run, with 1024-thread edge workgroups (the sweep's shape): the slab reduction as row 0 of k_bin_runs2's grid,
+		// the pack's sweep as row 0 of k_bin_pairs' - k_bin_runs2 precedes k_bin_pairs in the stream, so the sweep reads the finished sums
+		TailJobs tj_run = no_tail_jobs(), tj_pair = no_tail_jobs();
+		if (tail && tail->do_reduce && tail->do_sweep && n_runs && n_pair && pair_s == 1024u && n > 0 && tail->width <= 10240u) {
+			tj_run = *tail; tj_run.do_sweep = 0; tj_pair = *tail; tj_pair.do_reduce = 0;
+			if (tail_taken) *tail_taken = 1;
+		}
+#define RGO(L) NGP_LAUNCH((k_bin_runs2<float, L, 5>), dim3(div_up(n, RUN_WG * RUN_K), n_runs + (tj_run.do_reduce ? 1u : 0u)), dim3(RUN_WG), run2_stage_bytes(RUN2_STAGE), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, run_rec, run_off, n_valid, RUN2_STAGE, tj_run)
 // (k_bin_pairs depends on the abs-max pass like k_bin_runs2 does, not on k_bin_runs2: both are plain in-order launches - the any-order launch of round 4 lost its A/B and raced with the abs-max pass when there was no run level)
-#define PGO(L, S) NGP_LAUNCH((k_bin_pairs<float, L, S>), dim3(div_up(n, S), n_pair), dim3(S), pair_stage_bytes(), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_pair, (const uint32_t *)absmax, pair_rec, pair_off, spill_count, spill, n_valid, pair_probe)
+#define PGO(L, S) NGP_LAUNCH((k_bin_pairs<float, L, S>), dim3(div_up(n, S), n_pair + (tj_pair.do_sweep ? 1u : 0u)), dim3(S), pair_stage_bytes(), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_pair, (const uint32_t *)absmax, pair_rec, pair_off, spill_count, spill, n_valid, tj_pair)
 #define RECORDS(L) do { ABSMAX(float, L); if (n_runs) RGO(L); if (n_pair) { if (pair_s == 512u) PGO(L, 512u); else PGO(L, 1024u); } } while (0)
 		if (in_layout == NGP_LAYOUT_SOA) RECORDS(NGP_LAYOUT_SOA); else RECORDS(NGP_LAYOUT_AOS);
 #undef RECORDS
@@ -1326,8 +1357,10 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 
 // the workspace path with the data-parallel marker and the fused abs-max (csrc/train_step.hip); not part of the public ABI
 int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host, void *grad, uint64_t n_params, int dtype,
-                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse, int absmax_done) {
-	return hash_bwd_impl(stream, n, pos, pos_stride, dLdy, level_table_host, grad, n_params, dtype, grad_dtype, in_layout, zero_first, n_valid, workspace, workspace_bytes, after_coarse, absmax_done != 0);
+                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse, int absmax_done,
+                                  const TailJobs *tail, int *tail_taken) {
+	return hash_bwd_impl(stream, n, pos, pos_stride, dLdy, level_table_host, grad, n_params, dtype, grad_dtype, in_layout, zero_first, n_valid, workspace, workspace_bytes, after_coarse, absmax_done != 0,
+	                     tail, tail_taken);
 }
 // mirrors the routing of hash_bwd_impl: the slots are handed out only when that call will read them (grad: the gradient buffer the call will be given)
 AbsmaxOut ngp_hash_bwd_absmax_slots(const uint32_t *level_table_host, uint32_t n, int dtype, int grad_dtype, void *workspace, uint64_t workspace_bytes, const void *grad) {

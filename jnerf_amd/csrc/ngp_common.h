@@ -25,8 +25,11 @@ struct NgpProfScope { int id; hipStream_t s; hipEvent_t a, b; NgpProfScope(int i
 	hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
 
 // internal cross-file entry points (not exported)
+struct TailJobs;
+// tail (may be null) / tail_taken: jobs the call may carry in its record launches; *tail_taken says whether it did (else the caller launches them itself)
 int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host, void *grad, uint64_t n_params, int dtype,
-                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse, int absmax_done);
+                                  int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse, int absmax_done,
+                                  const TailJobs *tail, int *tail_taken);
 // Largest |dL/dfeature| per level, the scale of the hash scatter's fixed-point accumulation.  NGP_ABSMAX_PARTS partial maxima per level (bit patterns of
 // non-negative floats, 0 = none); the consumers take the maximum.  Written either by the scatter's own abs-max pass or - training path, r3 - by the field backward
 // kernel's epilogue (one partial per workgroup: no extra pass over the 33 MB of feature gradients, one launch less); that kernel then also zeroes the scatter's
@@ -48,6 +51,8 @@ int ngp_field32_pack_split(void *stream, const float *wd, const float *wc, void 
 int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const void *split_frags, const float *dout, float *dfeat,
                           float *slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am);
 int ngp_field32_fwd_split(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const void *split_frags, float *out, const uint32_t *n_valid, int density_only);
+int ngp_adam_ema_step_flag(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
+                           float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad, float grad_mul, uint32_t *flag, uint32_t flag_value);
 int ngp_dp_reduce(void *comm, hipStream_t s, const NgpDpPlan *plan, void *grad, int dtype, uint32_t first_bucket, uint32_t last_bucket, float *tail_f32, float *extra_f32, uint64_t extra_count);
 
 struct LevelTable { uint32_t v[64]; };   // [16][4] = offset, size, res, scale bits — passed by value (256 B of kernarg)
@@ -142,6 +147,14 @@ __device__ __forceinline__ void adam_ema_update(float &p, float &m, float &v, fl
 	if (EMA) { pi = ((1 - c.ema_decay) * pi + c.ema_decay * e * c.debias_old) * c.debias_new; e = pi; }
 	p = pi;
 }
+
+// (r6) Small jobs that RIDE in the grid of the hash backward's record kernels instead of being launches of their own (mlp_tail.h; all null / zero: nothing rides).
+// reduce: reduce_out[col] = sum over the MLP weight-gradient slabs, k_reduce_slabs' order, overwrite.  sweep: k_mlp32_sweep_pack's job on (pack, grad = reduce_out, m, v).
+struct TailJobs {
+	const float *slabs; uint32_t n_slabs, width; float *reduce_out;
+	float *pack, *m, *v, *packed_out; AdamConsts c;
+	int do_reduce, do_sweep;
+};
 
 // sampler constants (density_grid_sampler.py:35-39, 96-116)
 #define NGP_GRIDSIZE 128u

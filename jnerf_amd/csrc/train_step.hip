@@ -2,6 +2,7 @@
 // No kernels here - every stage is one of the library's own entry points, called in the order jnerf_amd/fastpath.py calls them; the point is to
 // cross the Python/ctypes boundary once per iteration instead of eleven times (the host had become the pacing side at ~0.45 ms per iteration).
 #include "ngp_common.h"
+#include "mlp_tail.h"
 #include <stdlib.h>
 #include <mutex>
 #include <utility>
@@ -131,11 +132,15 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		std::lock_guard<std::mutex> lk(g_mu);
 		if (g_boundary.first) { hipEventRecord(g_boundary.second, hs); g_pending.push_back(g_boundary); g_boundary = {nullptr, nullptr}; }
 	}
-#define STAGE(id, call) do { Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
+	// (ABI 4) signal_flag: stored when the stream reaches the launch of stage signal_stage - by a one-thread launch in front of it (any stage: the form experiments use), or,
+	// NGP_STAGE_ADAM on one GPU, by the first workgroup of the table's sweep itself (no launch: the product's form)
+	const bool signal = a->signal_flag != nullptr && do_bwd;
+#define STAGE(id, call) do { if (signal && a->signal_stage == (id) && (rc = ngp_flag_signal(stream, a->signal_flag, a->signal_value))) return rc; Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
 	const int T = a->dtype, ow = a->grad_overwrite != 0;
 	if (do_bwd && a->wait_flag && (rc = ngp_flag_wait(stream, a->wait_flag, a->wait_value, a->wait_status))) return rc;      // the batch's hand-over from the sampling stream
 	// the flat fp32 weight pack among the optimiser tensors (fp32 network): its sweep also writes the next iteration's MFMA fragments (ngp_mlp32_sweep_pack)
 	int t_pack = -1;
+	bool t_pack_swept = false;                                   // (r6) the pack's sweep rode in the hash backward's launches
 	if (T == NGP_F32) for (int t = 0; t < a->n_opt; ++t)
 		if (a->p[t] == (float *)a->wd && a->numel[t] == 10240 && (const float *)a->wc == (const float *)a->wd + 3072 && a->ema[t] == a->p[t] && !a->p_half[t] && a->g[t] == a->wgrad_flat && ow) t_pack = t;
 	// fp16 network: the two weight packs (density MLP 3072, colour MLP 7168 elements) whose gradients tile the flat weight-gradient buffer - swept by the slab reduction
@@ -179,7 +184,20 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		STAGE(NGP_STAGE_FIELD_BWD, ngp_field32_bwd_am(stream, a->n, (const float *)a->feat, lay, dirs, 7, (const float *)a->packed_weights, nullptr, (const float *)a->dout, (float *)a->dfeat,
 		                                               a->wgrad_slabs, a->n_slabs, a->n_valid, &am));
 	}
-	if (t_mlp16[0] >= 0) {      // fp16 configuration, single GPU: the slab reduction also sweeps the two weight packs (their gradient is the sum it has just formed)
+	// (r6) fp32 configuration, single GPU, backward and sweep in one call: the slab reduction and the pack's sweep + fragment packing RIDE in the hash backward's two record
+	// launches (mlp_tail.h) instead of being two small launches in front of / behind it - when the scatter takes the path that has both (it says so: tail_taken)
+	TailJobs tail = no_tail_jobs();
+	int tail_taken = 0;
+	const bool want_tail = T == NGP_F32 && t_pack >= 0 && do_sweep && !dp && !host_sharded && a->wgrad_flat && !getenv("NGP_NO_TAIL_RIDE");
+	if (want_tail) {
+		tail.slabs = a->wgrad_slabs; tail.n_slabs = a->n_slabs; tail.width = 10240u; tail.reduce_out = a->wgrad_flat;
+		tail.pack = a->p[t_pack]; tail.m = a->m[t_pack]; tail.v = a->v[t_pack]; tail.packed_out = (float *)a->packed_weights;
+		tail.c = adam_consts(a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, 1.0f);
+		tail.do_reduce = 1; tail.do_sweep = 1;
+	}
+	if (want_tail) {
+		// (the reduction follows the scatter call below if that call did not carry it)
+	} else if (t_mlp16[0] >= 0) {      // fp16 configuration, single GPU: the slab reduction also sweeps the two weight packs (their gradient is the sum it has just formed)
 		const float *pk[2][5]; uint32_t begin[2], count[2];
 		for (int k = 0; k < 2; ++k) {
 			const int t = t_mlp16[k];
@@ -191,7 +209,9 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, ow ? 0 : 1));
 	}
 	STAGE(NGP_STAGE_HASH_BWD, ngp_hash_encode_bwd_ws_marked(stream, a->n, a->pos, 3, a->dfeat, a->level_table_host, a->table_grad, a->n_params, T, NGP_F32, NGP_LAYOUT_SOA, ow ? 1 : 0, a->n_valid,
-	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr, am.parts != nullptr));
+	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr, am.parts != nullptr, want_tail ? &tail : nullptr, &tail_taken));
+	if (want_tail && !tail_taken) { STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, 0)); }
+	if (tail_taken) t_pack_swept = true;
 	}
 	// ---- exchange step (data parallel): every rank ends up with the summed gradient of its shard of the table, of the tail and of the MLP pack
 	const bool wire = dp && a->grad_wire != nullptr;
@@ -217,6 +237,7 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 			if ((rc = ngp_dp_reduce(a->comm, hs, pl, gbuf, gdt, 0, pl->n_buckets - 1, a->table_grad, a->wgrad_flat, 10240))) return rc;
 		}
 	}
+	bool signalled = false;
 	if (do_sweep) {
 		int largest = 0;
 		for (int t = 1; t < a->n_opt; ++t) if (a->numel[t] > a->numel[largest]) largest = t;
@@ -229,11 +250,17 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 			} else if (t == t_mlp16[0] || t == t_mlp16[1]) {
 				continue;                                        // already swept by ngp_reduce_slabs_sweep
 			} else if (t == t_pack) {
+				if (t_pack_swept) continue;
 				if ((rc = ngp_mlp32_sweep_pack(stream, a->p[t], a->g[t], a->m[t], a->v[t], a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, (float *)a->packed_weights))) return rc;
-			} else if ((rc = ngp_adam_ema_step(stream, a->numel[t], a->p[t], a->g[t], NGP_F32, a->m[t], a->v[t], a->ema[t], a->p_half[t], a->lr, a->beta0, a->beta1, a->eps,
-			                                   a->step, a->ema_decay, ow ? 0 : 1))) return rc;
+			} else {
+				const bool sig_here = signal && a->signal_stage == NGP_STAGE_ADAM && t == largest;
+				if ((rc = ngp_adam_ema_step_flag(stream, a->numel[t], a->p[t], a->g[t], NGP_F32, a->m[t], a->v[t], a->ema[t], a->p_half[t], a->lr, a->beta0, a->beta1, a->eps,
+				                                 a->step, a->ema_decay, ow ? 0 : 1, 1.0f, sig_here ? a->signal_flag : nullptr, a->signal_value))) return rc;
+				if (sig_here) signalled = true;
+			}
 		}
 	}
+	if (signal && a->signal_stage == NGP_STAGE_ADAM && !signalled && (rc = ngp_flag_signal(stream, a->signal_flag, a->signal_value))) return rc;      // (sharded / deferred sweeps: never leave a waiter behind)
 	if (dp) {                                                    // everyone gets everyone's updated shard of what the kernels read
 		const int t = a->dp_table;
 		void *bufs[2]; int dts[2]; int nb = 0;

@@ -17,11 +17,16 @@ export PROBE_STAGES="hash backward"
 probe() { cp /tmp/libngp_$1.so jnerf_amd/csrc/libngp_hip.so; python tools/probe_kernels_under_hog.py $REPS 2>&1 | grep -v "^(" | sed "s/^/[$1, $2] /"; }
 probe product alone
 probe carry alone
-python bench.py --steps 200000 --warmup 8 --burn-in 32 --config lego --images 4 --res 64 --no-psnr --no-kernel-events --no-fox --no-neus --no-spheres --no-cpu-baseline --no-lego-gate > /tmp/hog.out 2> /tmp/hog.err &
-HOG=$!; sleep 15
+# the neighbour trains from a COPY of the tree: the probes below swap jnerf_amd/csrc/libngp_hip.so, and a process that has the old file mapped dies with it (r06a: the hog segfaulted at the first swap)
+rm -rf /tmp/hogrepo && mkdir -p /tmp/hogrepo && cp -r bench.py jnerf_amd jnerf tests oracle projects tools include __graft_entry__.py /tmp/hogrepo/ 2>/dev/null
+(cd /tmp/hogrepo && cp /tmp/libngp_product.so jnerf_amd/csrc/libngp_hip.so)
+python /tmp/hogrepo/bench.py --steps 200000 --warmup 8 --burn-in 32 --config lego --images 4 --res 64 --no-psnr --no-kernel-events --no-fox --no-neus --no-spheres --no-cpu-baseline --no-lego-gate > /tmp/hog.out 2> /tmp/hog.err &
+HOG=$!; sleep 20
 probe product "beside a training process"
+kill -0 $HOG 2>/dev/null && echo "(neighbour alive after the first swap)" || echo "(NEIGHBOUR DIED - the 'beside' lines are not valid)"
 probe carry "beside a training process"
 probe product "beside a training process, second pass"
 probe carry "beside a training process, second pass"
+kill -0 $HOG 2>/dev/null && echo "(neighbour alive at the end)" || echo "(NEIGHBOUR DIED - the 'beside' lines are not valid)"
 kill $HOG 2>/dev/null; wait $HOG 2>/dev/null
 cp /tmp/libngp_product.so jnerf_amd/csrc/libngp_hip.so

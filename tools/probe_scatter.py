@@ -1,4 +1,4 @@
-"""Hash-grid backward of the ngp_base.py (lego, fp32) configuration on a REAL training batch, under the timing probes of csrc/hash_encode.hip: per-kernel
+"""Hash-grid backward of the ngp_base.py (lego, fp32) configuration on a REAL training batch (of the product build, or of a -DNGP_PROBE_* timing build of csrc/hash_encode.hip): per-kernel
 HIP-event times (csrc/prof.hip); the product path twice (bit-reproducibility).  Run through gpurun.
 usage: python tools/probe_scatter.py [steps] [scene] [lego|fox]      (fox: the fp16 / aabb_scale 4 / cone-stepping configuration)"""
 import os
@@ -71,12 +71,11 @@ def main():
         return g
 
     ref = variant("product path (fp32: record regions | fp16: per-corner lists)", {})
-    # timing probes (results wrong by design): where the stage's time goes
-    variant("accumulate: records loaded, not processed (NGP_ACC_PROBE=1)", {"NGP_ACC_PROBE": "1"})
-    variant("accumulate: records not loaded (NGP_ACC_PROBE=2)", {"NGP_ACC_PROBE": "2"})
-    if not fox:
-        variant("run kernel: probe 2 (NGP_RUN_PROBE=2)", {"NGP_RUN_PROBE": "2"})
-        variant("edge kernel: probe 2 (NGP_PAIR_PROBE=2)", {"NGP_PAIR_PROBE": "2"})
+    # (r6) the timing probes - parts of a kernel skipped, results wrong by design - are compile-time builds now, not environment switches of the product binary:
+    #   EXTRA=-DNGP_PROBE_SCATTER bash jnerf_amd/csrc/build.sh     record kernels without their record stores
+    #   EXTRA=-DNGP_PROBE_ACC=1 (2)                                accumulate: records loaded but not processed (not loaded)
+    # run this script once per build; PROBE_BUILD_LABEL names the build in the output
+    print("build:", os.environ.get("PROBE_BUILD_LABEL", "product"))
     variant("product path again", {}, ref)
 
 if __name__ == "__main__":

@@ -1,4 +1,4 @@
-"""Times ngp_field32_bwd on a synthetic 2^18-sample batch under the variant / probe switches of the environment (NGP_FIELD32_BWD, NGP_SPLIT_PROBE): where the
+"""Times ngp_field32_bwd on a synthetic 2^18-sample batch under the variant switch of the environment (NGP_FIELD32_BWD) - and, for a library built with EXTRA=-DNGP_PROBE_SPLIT=1..4 bash jnerf_amd/csrc/build.sh (parts of the split backward compiled out, results wrong: r6 moved the probes out of the product binary), with that part missing: where the
 split-operand backward's time goes.  One process per setting (the switches are read once); see tools/gpu_r3_u.sh.  Run through gpurun."""
 import os
 import sys
@@ -27,7 +27,7 @@ def main():
     for _ in range(30):
         fn()
     b.record(); torch.cuda.synchronize()
-    print(f"NGP_FIELD32_BWD={os.environ.get('NGP_FIELD32_BWD', '-')} NGP_SPLIT_PROBE={os.environ.get('NGP_SPLIT_PROBE', '-')}: {a.elapsed_time(b) / 30 * 1e3:7.1f} us")
+    print(f"NGP_FIELD32_BWD={os.environ.get('NGP_FIELD32_BWD', '-')} build={os.environ.get('PROBE_BUILD_LABEL', 'product')}: {a.elapsed_time(b) / 30 * 1e3:7.1f} us")
 
 
 if __name__ == "__main__":
