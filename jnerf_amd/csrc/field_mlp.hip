@@ -20,6 +20,7 @@
 //    summed by ngp_reduce_slabs (no atomics, deterministic).
 //  * Features arrive level-major ([16][n] pairs) from the XCD-aware hash kernel: every wave load is four 64-B segments.
 #include "ngp_common.h"
+#include "mlp_tail.h"
 #include <stdlib.h>
 #include <map>
 #include <mutex>
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs(const float *__restrict__
 // update of the parameter that column is the gradient of (optim.hip: adam_ema_update, the same function on the same values: the gradient a separate sweep would load
 // back is the sum this thread just stored).  The weight gradients tile one flat buffer (3072 of the density MLP's pack, then 7168 of the colour MLP's), each pack with its
 // own fp32 master, moments, EMA state and fp16 shadow.  Replaces three launches (k_reduce_slabs + two 3 k / 7 k-element k_adam_ema: 8 + 5 + 5 us of an iteration).
-struct PackSweep { float *p, *m, *v, *ema; __half *p_half; uint32_t begin, count; };     // columns [begin, begin + count) of the flat gradient
+// (struct PackSweep: ngp_common.h - the same job also rides in the hash backward's run-record launch on the single-GPU training path, mlp_tail.h)
 __global__ __launch_bounds__(1024) void k_reduce_slabs_sweep(const float *__restrict__ slabs, uint32_t n_slabs, uint32_t width, float *__restrict__ out, PackSweep a, PackSweep b, AdamConsts c) {
 	__shared__ float part[16][65];
 	const uint32_t col = blockIdx.x * 64u + (threadIdx.x & 63u), grp = threadIdx.x >> 6;
@@ -385,17 +386,7 @@ __global__ __launch_bounds__(1024) void k_reduce_slabs_sweep(const float *__rest
 #pragma unroll
 		for (int g = 0; g < 16; ++g) t += part[g][threadIdx.x];
 		out[col] = t;                                                      // (overwrite: the fused tail only runs with grad_overwrite)
-		const PackSweep &w = col >= b.begin ? b : a;
-		if (col >= w.begin && col - w.begin < w.count) {
-			const uint32_t e = col - w.begin;
-			float P = w.p[e], M = w.m[e], V = w.v[e], E = 0.f;
-			const bool has_ema = w.ema != nullptr, alias = w.ema == w.p;
-			if (has_ema) E = alias ? P : w.ema[e];
-			if (has_ema) adam_ema_update<true>(P, M, V, E, t, c); else adam_ema_update<false>(P, M, V, E, t, c);
-			w.p[e] = P; w.m[e] = M; w.v[e] = V;
-			if (has_ema && !alias) w.ema[e] = E;
-			if (w.p_half) w.p_half[e] = __float2half_rn(P);
-		}
+		pack_sweep_column(a, b, c, col, t);
 	}
 }
 

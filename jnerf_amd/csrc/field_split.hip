@@ -248,6 +248,57 @@ __device__ __forceinline__ floatx4 wgrad3(const _Float16 *stage, int row_a, int 
 	}
 	return combine(acc, 1.0f);
 }
+// ---- (r6) the transposed staging image.  The image above is [neuron row][sample column]: a lane owns ONE sample and eight neurons of every operand, so it writes eight 2-byte
+// stores per operand half - 240 ds_write_b16 per lane and trip, 26 of the kernel's 120 us (profiles/r05a_split_probe.txt).  Here the image is [sample row][neuron]: a lane's four
+// consecutive neurons are ONE 8-byte store (60 per lane and trip), and the weight-gradient phases read it back through the hardware transpose read (ds_read_b64_tr_b16:
+// sixteen lanes fetch a [4 samples][16 neurons] block, lane i receives neuron i's four samples) - the same operand in the same k slots as before, so the results are the
+// same bits.  Rows are 256 bytes (128 neurons), no padding: 2 planes x 128 x 256 B = 64 KiB; the chunk index (four neurons = 8 bytes) is XORed with a function of the row so
+// that both access patterns spread over the banks: stores (16 lanes = 16 consecutive rows, one chunk) need f mod 16 distinct over 16 rows, transpose reads (16 lanes = 4 rows
+// x 4 chunks, two such groups 8 rows apart per cycle) need c ^ f distinct over the 32 (tools/microbench_trstage.hip measures both against the linear image).
+#define TPLANE (SROWS * 128)
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ int tr_f(int s) { return ((s & 3) << 2) | ((s >> 2) & 3) | (((s >> 3) & 1) << 4); }
+__device__ __forceinline__ int tr_off(int plane, int s, int c) { return plane * TPLANE + s * 128 + ((c ^ tr_f(s)) << 2); }      // halves
+struct alignas(8) H4 { _Float16 v[4]; };
+__device__ __forceinline__ void st_chunk(_Float16 *stage, int s, int c, const half8 &h, const half8 &m, int hi) {               // slots 4 hi .. 4 hi + 3 of both halves of an operand
+	H4 a, b;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) { a.v[j] = h[4 * hi + j]; b.v[j] = m[4 * hi + j]; }
+	*reinterpret_cast<H4 *>(stage + tr_off(0, s, c)) = a; *reinterpret_cast<H4 *>(stage + tr_off(1, s, c)) = b;
+}
+// the lane's eight slots of two k64 half-fragments (neurons nrow0 .. nrow0 + 63) / of one k64 or k32 fragment / the low four slots, as the row `s` of both planes
+__device__ __forceinline__ void st_rows64_T(_Float16 *stage, int nrow0, int s, int g, const B2 &lo, const B2 &hi) {
+	st_chunk(stage, s, (nrow0 >> 2) + g, lo.h, lo.m, 0); st_chunk(stage, s, (nrow0 >> 2) + 4 + g, lo.h, lo.m, 1);                  // sp_k64(0, g, j): 4g + j | 16 + 4g + (j - 4)
+	st_chunk(stage, s, (nrow0 >> 2) + 8 + g, hi.h, hi.m, 0); st_chunk(stage, s, (nrow0 >> 2) + 12 + g, hi.h, hi.m, 1);            // sp_k64(1, g, j): 32 + ...
+}
+__device__ __forceinline__ void st_rows32_T(_Float16 *stage, int nrow0, int s, int g, const B2 &v, bool k32_order) {
+	if (k32_order) { st_chunk(stage, s, (nrow0 >> 2) + 2 * g, v.h, v.m, 0); st_chunk(stage, s, (nrow0 >> 2) + 2 * g + 1, v.h, v.m, 1); }       // sp_k32(g, j) = 8g + j
+	else { st_chunk(stage, s, (nrow0 >> 2) + g, v.h, v.m, 0); st_chunk(stage, s, (nrow0 >> 2) + 4 + g, v.h, v.m, 1); }
+}
+__device__ __forceinline__ void st_rows16_T(_Float16 *stage, int nrow0, int s, int g, const B2 &v) { st_chunk(stage, s, (nrow0 >> 2) + g, v.h, v.m, 0); }
+__device__ __forceinline__ half8 ld_tr8(const _Float16 *stage, int plane, int nrow, int o, int s0) {          // neuron nrow + o, samples s0 .. s0 + 7 (s0 a multiple of 8)
+	const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(stage + tr_off(plane, s0 + (o >> 2), (nrow >> 2) + (o & 3))));
+	const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(stage + tr_off(plane, s0 + 4 + (o >> 2), (nrow >> 2) + (o & 3))));
+	typedef short short8v __attribute__((ext_vector_type(8)));
+	short8v r;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) { r[j] = a[j]; r[4 + j] = b[j]; }
+	return __builtin_bit_cast(half8, r);
+}
+__device__ __forceinline__ floatx4 wgrad3_T(const _Float16 *stage, int row_a, int row_b, int o, int g, int c0, int c1) {
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	Acc acc = {z, z};
+#pragma unroll 2
+	for (int c = c0; c < c1; c += 32) {
+		const int s0 = c + 8 * g;
+		const half8 ah = ld_tr8(stage, 0, row_a, o, s0), am = ld_tr8(stage, 1, row_a, o, s0);
+		const half8 bh = ld_tr8(stage, 0, row_b, o, s0), bm = ld_tr8(stage, 1, row_b, o, s0);
+		acc.main = MFMA16(ah, bh, acc.main);
+		acc.corr = MFMA16(ah, bm, acc.corr);
+		acc.corr = MFMA16(am, bh, acc.corr);
+	}
+	return combine(acc, 1.0f);
+}
 __device__ __forceinline__ floatx4 fma4(floatx4 acc, floatx4 v, float s) {
 #pragma unroll
 	for (int k = 0; k < 4; ++k) acc[k] += v[k] * s;
@@ -256,10 +307,11 @@ __device__ __forceinline__ floatx4 fma4(floatx4 acc, floatx4 v, float s) {
 
 // PROBE (timing experiments only, a -DNGP_PROBE_SPLIT=n build, tools/probe_split_bwd.py; results are wrong for PROBE != 0): 1 = no staging stores, 2 = no weight-gradient
 // loads / MFMAs, 3 = neither (chain + barriers only), 4 = no barriers either
-template <int LAYOUT, int PROBE>
+template <int LAYOUT, int PROBE, bool TR /* (r6) the transposed staging image: 8-byte stores + transpose reads */>
 __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                               const _Float16 *__restrict__ packed, const float *__restrict__ dout,
                                                               float *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
+#define WG3(...) (TR ? wgrad3_T(__VA_ARGS__) : wgrad3(__VA_ARGS__))
 	extern __shared__ __attribute__((aligned(16))) _Float16 smem_split[];
 	__shared__ float smax[8];
 	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // running max |dL/dfeature| of levels 8t + 2g + pr over this lane's samples (absmax_epilogue)
@@ -351,29 +403,29 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 		if (g == 0) { dov[0] = cur.go[0] * sigma; dov[1] = cur.go[1] * sigma; dov[2] = cur.go[2] * sigma; }
 		const B2 dO = split8(dov);
 		// phase C2: V2 = dO x G1 (W1 / V2: each tile's samples split between waves w and w + 4)
-		if (PROBE != 1 && PROBE < 3) st_rows16_2(stage, 0, col, g, dO);
-		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 16, col, g, g10, g11);
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows16_T(stage, 0, col, g, dO) : st_rows16_2(stage, 0, col, g, dO));
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows64_T(stage, 16, col, g, g10, g11) : st_rows64_2(stage, 16, col, g, g10, g11));
 		if (PROBE < 4) __syncthreads();
-		if (PROBE < 2) aV2 = fma4(aV2, wgrad3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
+		if (PROBE < 2) aV2 = fma4(aV2, WG3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
 #pragma unroll
 		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, t, lane, dO, a); c[t] = combine(a, 1.0f); }
 		const B2 dG1lo = split_masked(c[0], c[1], mg10), dG1hi = split_masked(c[2], c[3], mg11);
 		if (PROBE < 4) __syncthreads();
 		// phase A: V1 = dG1 x G0
-		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 0, col, g, dG1lo, dG1hi);
-		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 64, col, g, g00, g01);
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows64_T(stage, 0, col, g, dG1lo, dG1hi) : st_rows64_2(stage, 0, col, g, dG1lo, dG1hi));
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows64_T(stage, 64, col, g, g00, g01) : st_rows64_2(stage, 64, col, g, g00, g01));
 		if (PROBE < 4) __syncthreads();
-		if (PROBE < 2) aV1[0] = fma4(aV1[0], wgrad3(stage, 16 * to, 64 + 16 * ti0, o, g, 0, SBT), uH);
-		if (PROBE < 2) aV1[1] = fma4(aV1[1], wgrad3(stage, 16 * to, 64 + 16 * (ti0 + 1), o, g, 0, SBT), uH);
+		if (PROBE < 2) aV1[0] = fma4(aV1[0], WG3(stage, 16 * to, 64 + 16 * ti0, o, g, 0, SBT), uH);
+		if (PROBE < 2) aV1[1] = fma4(aV1[1], WG3(stage, 16 * to, 64 + 16 * (ti0 + 1), o, g, 0, SBT), uH);
 #pragma unroll
 		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 4 + 2 * t, lane, dG1lo, a); mma3<MS>(wb, 5 + 2 * t, lane, dG1hi, a); c[t] = combine(a, 1.0f); }
 		const B2 dG0lo = split_masked(c[0], c[1], mg00), dG0hi = split_masked(c[2], c[3], mg01);
 		if (PROBE < 4) __syncthreads();
 		// phase B2: V0 = dG0 x [density | SH]
-		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 0, col, g, dG0lo, dG0hi);
-		if (PROBE != 1 && PROBE < 3) st_rows32_2(stage, 64, col, g, b2, false);
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows64_T(stage, 0, col, g, dG0lo, dG0hi) : st_rows64_2(stage, 0, col, g, dG0lo, dG0hi));
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows32_T(stage, 64, col, g, b2, false) : st_rows32_2(stage, 64, col, g, b2, false));
 		if (PROBE < 4) __syncthreads();
-		if (PROBE < 2) aV0 = fma4(aV0, wgrad3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uH);
+		if (PROBE < 2) aV0 = fma4(aV0, WG3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uH);
 		floatx4 dD;
 		{ Acc a = {z, z}; mma3<MS>(wb, 12, lane, dG0lo, a); mma3<MS>(wb, 13, lane, dG0hi, a); dD = combine(a, 1.0f); }
 		if (g == 0) dD[0] += cur.go[3] * sigma;                                      // out[:,3] = den[:,0]  (ngp_network.py:83)
@@ -381,19 +433,19 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 		const B2 dDf = split8(ddv);
 		if (PROBE < 4) __syncthreads();
 		// phase C1: W1 = dD x H
-		if (PROBE != 1 && PROBE < 3) st_rows16_2(stage, 0, col, g, dDf);
-		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 16, col, g, h0, h1);
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows16_T(stage, 0, col, g, dDf) : st_rows16_2(stage, 0, col, g, dDf));
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows64_T(stage, 16, col, g, h0, h1) : st_rows64_2(stage, 16, col, g, h0, h1));
 		if (PROBE < 4) __syncthreads();
-		if (PROBE < 2) aW1 = fma4(aW1, wgrad3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
+		if (PROBE < 2) aW1 = fma4(aW1, WG3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
 #pragma unroll
 		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 14 + t, lane, dDf, a); c[t] = combine(a, 1.0f); }
 		const B2 dHlo = split_masked(c[0], c[1], mh0), dHhi = split_masked(c[2], c[3], mh1);
 		if (PROBE < 4) __syncthreads();
 		// phase B1: W0 = dH x features
-		if (PROBE != 1 && PROBE < 3) st_rows64_2(stage, 0, col, g, dHlo, dHhi);
-		if (PROBE != 1 && PROBE < 3) st_rows32_2(stage, 64, col, g, b0, true);
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows64_T(stage, 0, col, g, dHlo, dHhi) : st_rows64_2(stage, 0, col, g, dHlo, dHhi));
+		if (PROBE != 1 && PROBE < 3) (TR ? st_rows32_T(stage, 64, col, g, b0, true) : st_rows32_2(stage, 64, col, g, b0, true));
 		if (PROBE < 4) __syncthreads();
-		if (PROBE < 2) aW0 = fma4(aW0, wgrad3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uF);
+		if (PROBE < 2) aW0 = fma4(aW0, WG3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uF);
 		floatx4 dF[2];
 #pragma unroll
 		for (int t = 0; t < 2; ++t) { Acc a = {z, z}; mma3<MS>(wb, 18 + 2 * t, lane, dHlo, a); mma3<MS>(wb, 19 + 2 * t, lane, dHhi, a); dF[t] = combine(a, inv_sigma); }
@@ -438,6 +490,7 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 	if (am.parts) { __syncthreads(); absmax_epilogue(am, lmax, reinterpret_cast<float *>(stage), 8); }
 }
 
+#undef WG3
 // bit 0: an operand of a split forward came within 4x of fp16's largest finite value since the last reset; bit 1: one left the range (infinities in that launch's
 // results) or a split backward stored a non-finite feature gradient.  A 4-byte read-back through the null stream; it does not wait for other streams' kernels - a launch
 // that has not reported yet reports at the next check.  reset clears EXACTLY the bits that were read, atomically on the device (r5, ADVICE r4: a read followed by a
@@ -481,11 +534,13 @@ int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layou
 	const size_t shmem = ngp_field32_bwd_split_shmem();
 	const dim3 grid(n_slabs), block(512);
 	const _Float16 *p = (const _Float16 *)split_frags;
-#define GOP(L, P) do { \
+	static const bool tr = [] { const char *e = getenv("NGP_SPLIT_TRSTAGE"); return !(e && e[0] == '0'); }();      // A/B hook: NGP_SPLIT_TRSTAGE=0 = rounds 3-5's [neuron][sample] staging image
+#define GOPT(L, P, T) do { \
 	static bool attr_set = false; \
-	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_split<L, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field32_bwd_split<L, P, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field32_bwd(split): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	NGP_LAUNCH((k_field32_bwd_split<L, P>), grid, block, shmem, s, n, feat, dir, dir_stride, p, dout, dfeat, slabs, n_valid, am); } while (0)
+	NGP_LAUNCH((k_field32_bwd_split<L, P, T>), grid, block, shmem, s, n, feat, dir, dir_stride, p, dout, dfeat, slabs, n_valid, am); } while (0)
+#define GOP(L, P) do { if (tr) GOPT(L, P, true); else GOPT(L, P, false); } while (0)
 	// (r6) the timing probes (PROBE != 0: parts of the kernel compiled out, RESULTS WRONG) are a compile-time build - EXTRA=-DNGP_PROBE_SPLIT=1..4 bash csrc/build.sh,
 	// tools/probe_split_bwd.py - no longer an environment variable a user could set on the product binary
 #ifdef NGP_PROBE_SPLIT
@@ -496,6 +551,7 @@ int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layou
 	if (layout == NGP_LAYOUT_SOA) GO(NGP_LAYOUT_SOA); else GO(NGP_LAYOUT_AOS);
 #undef GO
 #undef GOP
+#undef GOPT
 	NGP_LAUNCH_CHECK("ngp_field32_bwd(split)");
 	return 0;
 }

@@ -17,8 +17,9 @@
 //    contribution computed once, written as a record for the bin its entry lives in, summed per bin in 64-bit integer LDS accumulators, coarse levels with per-thread run
 //    combining; bit-reproducible.  fp32 dL/dy (ngp_base.py), round 4: record REGIONS - no global atomic of any kind, one 16-byte record per cell edge on the fine levels, one
 //    accumulate kernel for all levels (k_bin_runs2 / k_bin_pairs / k_bin_accumulate2).  fp16 dL/dy (ngp_fox.py): round 2/3's per-corner record lists with cursor
-//    reservations (k_bin_records_runs / k_bin_records / k_bin_accumulate).  Without a workspace: an owner-computes scan (a workgroup owns a slice of a level in LDS and
-//    filters the sample stream).  NGP_HASH_BWD_ATOMICS=1 or a non-power-of-two hashed table: the reference's scheme, one global float atomic per corner.
+//    reservations (k_bin_records_runs / k_bin_records / k_bin_accumulate).  Without a workspace, with NGP_HASH_BWD_ATOMICS=1, or for a table the bins cannot take (a level
+//    beyond 2^19 entries, a hashed table that is not a power of two): the reference's scheme, one global float atomic per corner (k_hash_bwd) - the ONE fallback since the
+//    owner-computes scan of rounds 1-2 was deleted in round 5.
 #include "ngp_common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -116,6 +117,48 @@ __device__ __forceinline__ void hash_fwd_body(uint32_t n, const float *__restric
 	}
 }
 
+// (r6) fp32 table, two LANES per (sample, level): lane pair (2p, 2p + 1) = the cell's x = g and x = g + 1 faces, four 8-byte gathers each.  The forward gather is bound by
+// the number of distinct cache lines a wavefront's load instruction names (~one line per clock through the CU's texture path: 33.5 M lines of a 2^18-sample batch = 54 us of
+// the kernel's 65), and the two x-neighbours of a cell edge are adjacent 8-byte entries - always on a dense level, and on a hashed one whenever x is even
+// ((x + 1) ^ h == (x ^ h) ^ 1) - i.e. ONE line.  One lane loading both (the 16-byte pair loads of rounds 1-4) needed a three-way branch that serialised the loads; two
+// adjacent lanes loading one each in the SAME instruction are merged by the address coalescer with no branch at all: 6 lines per (sample, hashed level) on average instead
+// of 8.  Bit-exact: the lanes swap halves (lane 2p ends up with every corner's first component, lane 2p + 1 with the second) and each sums its component's eight terms in the
+// reference's order, k = x + 2 y + 4 z.
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void k_hash_fwd_x2(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ table, LevelTable lt,
+                                                     T *__restrict__ out, uint32_t nblk, const uint32_t *__restrict__ n_valid) {
+	using P = typename Pair<T>::type;
+	uint32_t level, chunk; block_to_level_chunk(nblk, level, chunk);
+	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
+	const uint32_t off = lt.v[4 * level], size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
+	const float scale = __uint_as_float(lt.v[4 * level + 3]);
+	const bool dense = level_is_dense(size, res);
+	const P *tab = reinterpret_cast<const P *>(table) + off;
+	const uint32_t xc = threadIdx.x & 1u;
+	// (both lanes of a pair take the same trips, so the swap below always has its partner)
+	for (uint32_t i = chunk * 128u + (threadIdx.x >> 1); i < lim; i += nblk * 128u) {
+		const Corner c = locate(pos, stride, i, scale);
+		const uint32_t gx = c.g[0] + xc;
+		P v[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) v[j] = tab[grid_index(size, res, dense, gx, c.g[1] + (j & 1u), c.g[2] + (j >> 1))];      // j = (y corner, z corner); all four gathers issued before the first use
+		float acc = 0.f;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) {
+			const float wy = (j & 1u) ? c.w[1] : 1 - c.w[1], wz = (j >> 1) ? c.w[2] : 1 - c.w[2];
+			const float w0 = ((1 - c.w[0]) * wy) * wz, w1 = (c.w[0] * wy) * wz;          // the reference's x, y, z multiplication order
+			const float2 f = to_f2(v[j]);
+			const float own = xc ? f.y : f.x, give = xc ? f.x : f.y;
+			const float got = __shfl_xor(give, 1);                                      // the partner's value of MY component
+			acc += w0 * (xc ? got : own);                                                // corner k = 2 j     (x = g)
+			acc += w1 * (xc ? own : got);                                                // corner k = 2 j + 1 (x = g + 1)
+		}
+		const size_t o = (LAYOUT == NGP_LAYOUT_SOA ? (size_t)level * n + i : (size_t)i * 16 + level) * 2u + xc;
+		if (sizeof(T) == 4) reinterpret_cast<float *>(out)[o] = acc;
+		else reinterpret_cast<__half *>(out)[o] = __float2half_rn(acc);
+	}
+}
+
 template <typename T, typename G, int LAYOUT>
 __global__ __launch_bounds__(256) void k_hash_bwd(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt,
                                                   G *__restrict__ grad, uint32_t nblk, const uint32_t *__restrict__ n_valid) {
@@ -159,10 +202,21 @@ NGP_API int ngp_hash_encode_fwd(void *stream, uint32_t n, const float *pos, uint
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_fwd: bad dtype %d", dtype);
 	if (n == 0) return 0;
 	NGP_REQUIRE(pos_stride >= 3, NGP_E_ARG, "ngp_hash_encode_fwd: pos stride %u < 3", pos_stride);
-	const uint32_t nblk = min(div_up(n, 256), 2048u);         // chunks per level in flight (k_hash_fwd strides over the rest)
 	const dim3 block(256);
 	const LevelTable lt = load_table(level_table_host);
 	hipStream_t s = (hipStream_t)stream;
+	// A/B hook NGP_HASH_FWD_X2: bit 0 = two lanes per (sample, level) for the fp32 table (default on), bit 1 = for the fp16 table (default off: its 8-byte pair loads stay)
+	static const int x2 = [] { const char *e = getenv("NGP_HASH_FWD_X2"); return e ? atoi(e) : 1; }();
+	if ((dtype == NGP_F32 && (x2 & 1)) || (dtype == NGP_F16 && (x2 & 2))) {            // two lanes per (sample, level): 128 samples per workgroup
+		const uint32_t nblk2 = min(div_up(n, 128), 4096u);
+#define GO2(T, L) NGP_LAUNCH((k_hash_fwd_x2<T, L>), dim3(16 * nblk2), block, 0, s, n, pos, pos_stride, (const T *)table, lt, (T *)out, nblk2, n_valid)
+		if (dtype == NGP_F32) { if (out_layout == NGP_LAYOUT_SOA) GO2(float, NGP_LAYOUT_SOA); else GO2(float, NGP_LAYOUT_AOS); }
+		else { if (out_layout == NGP_LAYOUT_SOA) GO2(__half, NGP_LAYOUT_SOA); else GO2(__half, NGP_LAYOUT_AOS); }
+#undef GO2
+		NGP_LAUNCH_CHECK("ngp_hash_encode_fwd");
+		return 0;
+	}
+	const uint32_t nblk = min(div_up(n, 256), 2048u);         // chunks per level in flight (k_hash_fwd strides over the rest)
 	const dim3 grid(16 * nblk);
 #define GO(T, L) NGP_LAUNCH((k_hash_fwd<T, L>), grid, block, 0, s, n, pos, pos_stride, (const T *)table, lt, (T *)out, nblk, n_valid)
 	if (dtype == NGP_F32) { if (out_layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
@@ -190,7 +244,8 @@ NGP_API int ngp_hash_encode_fwd_dydx(void *stream, uint32_t n, const float *pos,
 	NGP_LAUNCH_CHECK("ngp_hash_encode_fwd_dydx");
 	return 0;
 }
-// method: 0 = owner-computes LDS scatter (default), 1 = one global atomic per corner (the reference's scheme).  NGP_HASH_BWD_ATOMICS=1 selects 1.
+// method: 0 = by what the caller hands over (a workspace: the binned scatter; none: global atomics), 1 = one global atomic per corner whatever is handed over
+// (the reference's scheme; NGP_HASH_BWD_ATOMICS=1)
 static int hash_bwd_method() {
 	static int m = -1;
 	if (m < 0) { const char *e = getenv("NGP_HASH_BWD_ATOMICS"); m = (e && e[0] == '1') ? 1 : 0; }
@@ -199,8 +254,8 @@ static int hash_bwd_method() {
 
 
 // ---------------------------------------------------------------------------------------------------------------- binned scatter (every level of up to 2^19 entries)
-// The owner-computes scan above redoes every sample's index arithmetic once per slice owner (32x per level, ~220 instructions each) — it is
-// VALU-bound at ~0.45 ms per 2^18-sample batch.  With a workspace the levels take this two-phase path instead:
+// (Rounds 1-2 scattered through an owner-computes scan - every slice owner re-deriving every sample's indices, VALU-bound at ~0.45 ms per 2^18-sample batch; deleted in
+// round 5.)  With a workspace the levels take this two-phase path:
 //   A  records: the eight (entry, weight*gradient) contributions of a (sample, level) are computed ONCE and appended to the record list of the bin the
 //      entry lives in (64 bins per level).  Slots are handed out by an LDS histogram per workgroup plus ONE global integer atomic per
 //      (workgroup, bin) — ~10^5 global atomics per batch instead of 3*10^7.
@@ -441,13 +496,21 @@ template <typename T, int LAYOUT, int OCC /* waves per SIMD the register budget 
 __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_records_runs(uint32_t n, const float *__restrict__ pos, uint32_t stride, const T *__restrict__ dLdy, LevelTable lt, BinPlan bp, LevelSel sel,
                                                            const uint32_t *__restrict__ absmax_bits, uint32_t *__restrict__ cursors, void *__restrict__ rec_val,
                                                            uint16_t *__restrict__ rec_idx, uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill,
-                                                           const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */) {
+                                                           const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */, TailJobs tj) {
 	using P = typename Pair<T>::type;
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
+	uint32_t by = blockIdx.y;
+	if (tj.do_reduce) {                                                                   // (r6, mlp_tail.h) row 0 of the grid - dispatched first - carries the MLP weight-gradient slab reduction (+ the two packs' sweep)
+		if (by == 0u) {
+			for (uint32_t unit = blockIdx.x; unit * TAIL_REDUCE_COLS < tj.width; unit += gridDim.x) { tail_reduce_slabs_256(tj, reinterpret_cast<float *>(bin_smem), unit); __syncthreads(); }
+			return;
+		}
+		by -= 1u;
+	}
 	float2 *stage_val = reinterpret_cast<float2 *>(bin_smem);                             // [stage]
 	uint32_t *stage_idx = bin_smem + stage * 2u;                                          // [stage] level-wide entry indices
 	uint32_t *cnt = stage_idx + stage, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL, *cnt2 = loff + BINS_PER_LEVEL;
-	const uint32_t hl = sel.hl[blockIdx.y], level = bp.level[hl], sub = blockIdx.x % CUR_SUBS;
+	const uint32_t hl = sel.hl[by], level = bp.level[hl], sub = blockIdx.x % CUR_SUBS;
 	const uint32_t size = lt.v[4 * level + 1], res = lt.v[4 * level + 2];
 	const float scale = __uint_as_float(lt.v[4 * level + 3]);
 	const bool dense = level_is_dense(size, res), il = size < BIN_LEVEL_MAX;
@@ -1245,6 +1308,13 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	const LevelTable lt = load_table(level_table_host);
 	const HashBwdPath path = workspace ? hash_bwd_path(lt, dtype, grad_dtype, grad) : HB_ATOMICS;
 	const WsLayout wl = ws_layout(lt, n, path);
+	// (r6) the routing looks at the gradient pointer's alignment, the sizing function cannot: an fp32 call with an unaligned gradient used to land on the per-corner path,
+	// which needs three times the bytes ngp_hash_bwd_workspace_bytes_for returned - and the capacity error below then named the wrong size.  The workspace path takes aligned
+	// gradients only (every buffer torch or hipMalloc hands out is; a view into a flat parameter buffer at an odd offset is the caller's to avoid).
+	NGP_REQUIRE(!workspace || ((uintptr_t)grad & 15u) == 0, NGP_E_ALIGN, "ngp_hash_encode_bwd: with a workspace the gradient buffer must be 16-byte aligned");
+	// (r6) the spill lists are sized for the worst case up to a cap; beyond it entries would be DROPPED - a silently wrong gradient.  Refuse such a batch up front.
+	if (path == HB_REGIONS) NGP_REQUIRE((uint64_t)wl.n_pair * 8u * n <= (1ull << 27), NGP_E_CAPACITY, "ngp_hash_encode_bwd: %u samples exceed the workspace path's spill capacity (%llu per call for this level table): split the batch", n, (unsigned long long)((1ull << 27) / (8u * (wl.n_pair ? wl.n_pair : 1u))));
+	if (path == HB_PERCORNER) NGP_REQUIRE(n <= (1u << 25) / (wl.n_binned ? wl.n_binned : 1u), NGP_E_CAPACITY, "ngp_hash_encode_bwd: %u samples exceed the workspace path's spill capacity (%u per call for this level table): split the batch", n, (1u << 25) / (wl.n_binned ? wl.n_binned : 1u));
 	// (r5) a workspace that is too small for the path its dtypes take is an ERROR - rounds 2-4 dropped silently to a slower path
 	NGP_REQUIRE(path == HB_ATOMICS || workspace_bytes >= wl.total, NGP_E_CAPACITY, "ngp_hash_encode_bwd: workspace of %llu bytes, ngp_hash_bwd_workspace_bytes_for(n = %u) = %llu",
 	            (unsigned long long)workspace_bytes, n, (unsigned long long)wl.total);
@@ -1332,10 +1402,13 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		// per-corner record lists (fp16 dL/dy): 6-byte fp16 records for the fine levels, fp32 run records for the coarse ones
 		void *rec_val = (void *)(ws + wl.rec_val);
 		uint16_t *rec_idx = (uint16_t *)(ws + wl.rec_idx);
+		// (r6) fp16 configuration: the slab reduction that also sweeps the two MLP packs (k_reduce_slabs_sweep's job) rides as row 0 of the run-record launch
+		TailJobs tj_pc = no_tail_jobs();
+		if (tail && tail->do_reduce && tail->do_sweep16 && !tail->do_sweep && n_runs && n > 0) { tj_pc = *tail; if (tail_taken) *tail_taken = 1; }
 #define GO(T, G, L) do { \
 	using RV_ = typename RecVal<T>::type; \
 	ABSMAX(T, L); \
-	if (n_runs) NGP_LAUNCH((k_bin_records_runs<T, L, 4>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(RUN_STAGE), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, RUN_STAGE); \
+	if (n_runs) NGP_LAUNCH((k_bin_records_runs<T, L, 4>), dim3(div_up(n, RUN_WG * RUN_K), n_runs + (tj_pc.do_reduce ? 1u : 0u)), dim3(RUN_WG), run_stage_bytes(RUN_STAGE), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, RUN_STAGE, tj_pc); \
 	if (n_fine) NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, BIN_WG), n_fine), dim3(BIN_WG), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_fine, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid); \
 	if (sizeof(RV_) == 8 && !(after_coarse && n_runs && n_fine)) {   /* fp32 records, one type: one accumulate launch over all their levels */ \
 		if (n_all) NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_all * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \

@@ -34,6 +34,21 @@ static inline TailJobs no_tail_jobs() { TailJobs t; memset(&t, 0, sizeof(t)); re
 #define TAIL_REDUCE_COLS 64u
 #define TAIL_REDUCE_LDS_FLOATS (16u * 65u)
 
+// Adam + EMA of the parameter that column `col` of the flat weight gradient belongs to (its gradient: the column sum t); fp16 configuration, two packs with their fp16 shadows
+__device__ __forceinline__ void pack_sweep_column(const PackSweep &a, const PackSweep &b, const AdamConsts &c, uint32_t col, float t) {
+	const PackSweep &w = col >= b.begin ? b : a;
+	if (col >= w.begin && col - w.begin < w.count) {
+		const uint32_t e = col - w.begin;
+		float P = w.p[e], M = w.m[e], V = w.v[e], E = 0.f;
+		const bool has_ema = w.ema != nullptr, alias = w.ema == w.p;
+		if (has_ema) E = alias ? P : w.ema[e];
+		if (has_ema) adam_ema_update<true>(P, M, V, E, t, c); else adam_ema_update<false>(P, M, V, E, t, c);
+		w.p[e] = P; w.m[e] = M; w.v[e] = V;
+		if (has_ema && !alias) w.ema[e] = E;
+		if (w.p_half) w.p_half[e] = __float2half_rn(P);
+	}
+}
+
 // the slab reduction for columns [64 unit, 64 unit + 64) by ONE 256-thread workgroup: thread = (column, quarter q); partial sums of slab groups q, q + 4, q + 8, q + 12 of
 // k_reduce_slabs' sixteen (independent chains: four loads in flight), then the sixteen partials in its order.  lds: TAIL_REDUCE_LDS_FLOATS floats.
 __device__ __forceinline__ void tail_reduce_slabs_256(const TailJobs &tj, float *lds, uint32_t unit) {
@@ -54,6 +69,7 @@ __device__ __forceinline__ void tail_reduce_slabs_256(const TailJobs &tj, float 
 #pragma unroll
 		for (int g = 0; g < 16; ++g) t += part[g][lc];
 		tj.reduce_out[col] = t;
+		if (tj.do_sweep16) pack_sweep_column(tj.a16, tj.b16, tj.c, col, t);          // fp16 configuration: k_reduce_slabs_sweep's second half
 	}
 }
 

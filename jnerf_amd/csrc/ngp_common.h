@@ -150,10 +150,14 @@ __device__ __forceinline__ void adam_ema_update(float &p, float &m, float &v, fl
 
 // (r6) Small jobs that RIDE in the grid of the hash backward's record kernels instead of being launches of their own (mlp_tail.h; all null / zero: nothing rides).
 // reduce: reduce_out[col] = sum over the MLP weight-gradient slabs, k_reduce_slabs' order, overwrite.  sweep: k_mlp32_sweep_pack's job on (pack, grad = reduce_out, m, v).
+//         sweep16 (fp16 configuration): k_reduce_slabs_sweep's job - the thread that holds a column's sum also applies Adam + EMA to the parameter it is the gradient of
+//         (two packs a / b whose gradients tile reduce_out).
+struct PackSweep { float *p, *m, *v, *ema; __half *p_half; uint32_t begin, count; };     // columns [begin, begin + count) of the flat gradient
 struct TailJobs {
 	const float *slabs; uint32_t n_slabs, width; float *reduce_out;
 	float *pack, *m, *v, *packed_out; AdamConsts c;
-	int do_reduce, do_sweep;
+	PackSweep a16, b16;
+	int do_reduce, do_sweep, do_sweep16;
 };
 
 // sampler constants (density_grid_sampler.py:35-39, 96-116)

@@ -66,13 +66,13 @@ __global__ void k_flag_wait(const uint32_t *flag, uint32_t value, uint32_t *stat
 }
 NGP_API int ngp_flag_signal(void *stream, uint32_t *flag, uint32_t value) {
 	NGP_REQUIRE(flag, NGP_E_ARG, "ngp_flag_signal: null flag");
-	NGP_LAUNCH(k_flag_signal, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value);
+	hipLaunchKernelGGL(k_flag_signal, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value);      // (not through NGP_LAUNCH: a hand-over is not a kernel of the path - the per-kernel event brackets of csrc/prof.hip skip it)
 	NGP_LAUNCH_CHECK("ngp_flag_signal");
 	return 0;
 }
 NGP_API int ngp_flag_wait(void *stream, const uint32_t *flag, uint32_t value, uint32_t *status) {
 	NGP_REQUIRE(flag, NGP_E_ARG, "ngp_flag_wait: null flag");
-	NGP_LAUNCH(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, status);
+	hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, status);  // (likewise: its duration is the time it WAITS)
 	NGP_LAUNCH_CHECK("ngp_flag_wait");
 	return 0;
 }
@@ -135,7 +135,8 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	// (ABI 4) signal_flag: stored when the stream reaches the launch of stage signal_stage - by a one-thread launch in front of it (any stage: the form experiments use), or,
 	// NGP_STAGE_ADAM on one GPU, by the first workgroup of the table's sweep itself (no launch: the product's form)
 	const bool signal = a->signal_flag != nullptr && do_bwd;
-#define STAGE(id, call) do { if (signal && a->signal_stage == (id) && (rc = ngp_flag_signal(stream, a->signal_flag, a->signal_value))) return rc; Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
+	bool signalled = false;                                      // (a stage that is not launched in this configuration - a slab reduction that rides in another launch - must not leave a waiter behind: see the end of the call)
+#define STAGE(id, call) do { if (signal && !signalled && a->signal_stage == (id)) { if ((rc = ngp_flag_signal(stream, a->signal_flag, a->signal_value))) return rc; signalled = true; } Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
 	const int T = a->dtype, ow = a->grad_overwrite != 0;
 	if (do_bwd && a->wait_flag && (rc = ngp_flag_wait(stream, a->wait_flag, a->wait_value, a->wait_status))) return rc;      // the batch's hand-over from the sampling stream
 	// the flat fp32 weight pack among the optimiser tensors (fp32 network): its sweep also writes the next iteration's MFMA fragments (ngp_mlp32_sweep_pack)
@@ -195,23 +196,39 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		tail.c = adam_consts(a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, 1.0f);
 		tail.do_reduce = 1; tail.do_sweep = 1;
 	}
-	if (want_tail) {
-		// (the reduction follows the scatter call below if that call did not carry it)
-	} else if (t_mlp16[0] >= 0) {      // fp16 configuration, single GPU: the slab reduction also sweeps the two weight packs (their gradient is the sum it has just formed)
-		const float *pk[2][5]; uint32_t begin[2], count[2];
+	// fp16 configuration, single GPU: the slab reduction also sweeps the two weight packs (their gradient is the sum it has just formed) - and rides the same way
+	const float *pk16[2][5]; uint32_t begin16[2], count16[2];
+	const bool want_tail16 = t_mlp16[0] >= 0 && !getenv("NGP_NO_TAIL_RIDE");
+	if (t_mlp16[0] >= 0) {
 		for (int k = 0; k < 2; ++k) {
 			const int t = t_mlp16[k];
-			pk[k][0] = a->p[t]; pk[k][1] = a->m[t]; pk[k][2] = a->v[t]; pk[k][3] = a->ema[t]; pk[k][4] = (const float *)a->p_half[t];
-			begin[k] = (uint32_t)(a->g[t] - a->wgrad_flat); count[k] = (uint32_t)a->numel[t];
+			pk16[k][0] = a->p[t]; pk16[k][1] = a->m[t]; pk16[k][2] = a->v[t]; pk16[k][3] = a->ema[t]; pk16[k][4] = (const float *)a->p_half[t];
+			begin16[k] = (uint32_t)(a->g[t] - a->wgrad_flat); count16[k] = (uint32_t)a->numel[t];
 		}
-		STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs_sweep(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, pk, begin, count, a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay));
+	}
+	if (want_tail16) {
+		tail.slabs = a->wgrad_slabs; tail.n_slabs = a->n_slabs; tail.width = 10240u; tail.reduce_out = a->wgrad_flat;
+		for (int k = 0; k < 2; ++k) {
+			PackSweep &w = k ? tail.b16 : tail.a16;
+			w = PackSweep{(float *)pk16[k][0], (float *)pk16[k][1], (float *)pk16[k][2], (float *)pk16[k][3], (__half *)pk16[k][4], begin16[k], count16[k]};
+		}
+		tail.c = adam_consts(a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, 1.0f);
+		tail.do_reduce = 1; tail.do_sweep16 = 1;
+	}
+	if (want_tail || want_tail16) {
+		// (the reduction follows the scatter call below if that call did not carry it)
+	} else if (t_mlp16[0] >= 0) {
+		STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs_sweep(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, pk16, begin16, count16, a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay));
 	} else {
 		STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, ow ? 0 : 1));
 	}
 	STAGE(NGP_STAGE_HASH_BWD, ngp_hash_encode_bwd_ws_marked(stream, a->n, a->pos, 3, a->dfeat, a->level_table_host, a->table_grad, a->n_params, T, NGP_F32, NGP_LAYOUT_SOA, ow ? 1 : 0, a->n_valid,
-	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr, am.parts != nullptr, want_tail ? &tail : nullptr, &tail_taken));
+	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr, am.parts != nullptr, (want_tail || want_tail16) ? &tail : nullptr, &tail_taken));
 	if (want_tail && !tail_taken) { STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, 0)); }
-	if (tail_taken) t_pack_swept = true;
+	if (want_tail16 && !tail_taken) {
+		STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs_sweep(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, pk16, begin16, count16, a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay));
+	}
+	if (tail_taken && want_tail) t_pack_swept = true;
 	}
 	// ---- exchange step (data parallel): every rank ends up with the summed gradient of its shard of the table, of the tail and of the MLP pack
 	const bool wire = dp && a->grad_wire != nullptr;
@@ -237,7 +254,6 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 			if ((rc = ngp_dp_reduce(a->comm, hs, pl, gbuf, gdt, 0, pl->n_buckets - 1, a->table_grad, a->wgrad_flat, 10240))) return rc;
 		}
 	}
-	bool signalled = false;
 	if (do_sweep) {
 		int largest = 0;
 		for (int t = 1; t < a->n_opt; ++t) if (a->numel[t] > a->numel[largest]) largest = t;
@@ -260,7 +276,7 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 			}
 		}
 	}
-	if (signal && a->signal_stage == NGP_STAGE_ADAM && !signalled && (rc = ngp_flag_signal(stream, a->signal_flag, a->signal_value))) return rc;      // (sharded / deferred sweeps: never leave a waiter behind)
+	if (signal && !signalled && (rc = ngp_flag_signal(stream, a->signal_flag, a->signal_value))) return rc;      // (the stage was not launched - sharded / deferred sweeps, a riding slab reduction: never leave a waiter behind)
 	if (dp) {                                                    // everyone gets everyone's updated shard of what the kernels read
 		const int t = a->dp_table;
 		void *bufs[2]; int dts[2]; int nb = 0;

@@ -58,7 +58,7 @@ class Runner:
         self._queue, self._sides, self._done_steps, self._fast, self._rays_event = {}, [], set(), None, None
         self.pipeline_depth = int(cfg.pipeline_depth or 2)          # batches marched ahead of the one being trained on
         # stage of the native step beside which the sampling streams start a batch's kernels (None / "none": wherever the host enqueues them); see train_step
-        mb = cfg.march_beside if cfg.march_beside is not None else "adam_ema"
+        mb = cfg.march_beside if cfg.march_beside is not None else "none"
         self._march_beside = None if mb in (False, "none", "") else str(mb)
         self._phase_flag = None
         self.done_period = int(cfg.pipeline_done_period or 4)       # the training stream records a `done` checkpoint every this many steps (train_step)

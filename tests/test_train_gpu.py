@@ -567,12 +567,12 @@ def test_fused_launches_of_the_native_step_change_no_bit(fp16, monkeypatch):
     for a, b in zip(fused, split):
         assert torch.equal(a, b)
     assert any(float(t.abs().max()) > 0 for t in fused)
-    if not fp16:
-        # (r6) fp32 configuration: by default the slab reduction and the pack's sweep + fragment packing RIDE in the hash backward's two record launches (csrc/mlp_tail.h);
-        # NGP_NO_TAIL_RIDE leaves them as the two launches of round 3-5 (k_reduce_slabs, k_mlp32_sweep_pack) - same bits again
-        monkeypatch.delenv("NGP_SPLIT_COMPOSITE", raising=False); monkeypatch.delenv("NGP_NO_FUSED_MLP_TAIL", raising=False)
-        monkeypatch.setenv("NGP_NO_TAIL_RIDE", "1")
-        own, l_own = run()
-        assert torch.equal(l_fused, l_own)
-        for a, b in zip(fused, own):
-            assert torch.equal(a, b)
+    # (r6) by default the MLP tail RIDES in the hash backward's record launches (csrc/mlp_tail.h) - fp32 configuration: the slab reduction in k_bin_runs2's grid, the pack's
+    # sweep + fragment packing in k_bin_pairs'; fp16 configuration: the reduction that also sweeps the two packs in k_bin_records_runs'.  NGP_NO_TAIL_RIDE leaves them as the
+    # launches of rounds 3-5 (k_reduce_slabs + k_mlp32_sweep_pack | k_reduce_slabs_sweep) - same bits again
+    monkeypatch.delenv("NGP_SPLIT_COMPOSITE", raising=False); monkeypatch.delenv("NGP_NO_FUSED_MLP_TAIL", raising=False)
+    monkeypatch.setenv("NGP_NO_TAIL_RIDE", "1")
+    own, l_own = run()
+    assert torch.equal(l_fused, l_own)
+    for a, b in zip(fused, own):
+        assert torch.equal(a, b)
