@@ -221,7 +221,7 @@ def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
 
 
 # kernel variants: same algorithmic bytes / flops as the kernel they replace
-KERNEL_VARIANTS = {"k_field32_bwd_2g": "k_field32_bwd", "k_hash_fwd_dydx": "k_hash_fwd",
+KERNEL_VARIANTS = {"k_field32_bwd_2g": "k_field32_bwd", "k_hash_fwd_dydx": "k_hash_fwd", "k_hash_fwd_x2": "k_hash_fwd",
                    "k_field32_fwd_split": "k_field32_fwd", "k_field32_bwd_split": "k_field32_bwd"}
 # kernels that do fp32-accurate work on the fp16 matrix cores (split operands, three v_mfma_f32_16x16x32_f16 per product sum, csrc/field_split.hip): the algorithmic
 # FLOPs are SURVEY.md §8(d)'s, the pipe they run on peaks at 2.5 PFLOP/s dense, and they execute 3x the products

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NGP_ABI_VERSION 4
+#define NGP_ABI_VERSION 3
 enum { NGP_F32 = 0, NGP_F16 = 1 };
 enum { NGP_E_ARG = -1, NGP_E_DTYPE = -2, NGP_E_ALIGN = -3, NGP_E_CAPACITY = -4 };
 /* feature-tensor layouts between the encoder and the MLP */
@@ -321,11 +321,6 @@ typedef struct NgpTrainStep {
 	/* wait_flag != NULL: the call starts with ngp_flag_wait(stream, wait_flag, wait_value, wait_status) - the batch was produced on another stream that ended it with
 	 * ngp_flag_signal (cheaper than an event hand-over between two HIP streams, see below) */
 	const uint32_t *wait_flag; uint32_t *wait_status; uint32_t wait_value; uint32_t pad4;
-	/* (ABI 4) signal_flag != NULL: when `stream` reaches the launch of stage `signal_stage` (NGP_STAGE_*) the call stores signal_value to *signal_flag (device u32; like
-	 * ngp_flag_signal).  A sampling stream that starts its next batch with ngp_flag_wait on that flag thereby runs its marcher BESIDE a chosen part of the iteration instead of
-	 * wherever the host happened to enqueue it (r6: the marcher landed on the LDS-bound k_bin_accumulate2 in three steps of four and made it 70 -> 112 us;
-	 * profiles/r06a_lego_timeline.txt).  NGP_STAGE_ADAM: stored by the first workgroup of the table's sweep itself - no launch of its own. */
-	uint32_t *signal_flag; uint32_t signal_value; int32_t signal_stage;
 } NgpTrainStep;
 enum { NGP_PHASE_ALL = 0, NGP_PHASE_BACKWARD = 1, NGP_PHASE_SWEEP = 2 };
 enum { NGP_STAGE_PACK = 0, NGP_STAGE_HASH_FWD, NGP_STAGE_FIELD_FWD, NGP_STAGE_COMPOSITE_FWD, NGP_STAGE_COMPOSITE_BWD, NGP_STAGE_FIELD_BWD, NGP_STAGE_REDUCE_SLABS,

@@ -29,8 +29,7 @@ class NgpTrainStep(C.Structure):
                 ("p", _vp * 4), ("g", _vp * 4), ("m", _vp * 4), ("v", _vp * 4), ("ema", _vp * 4), ("p_half", _vp * 4), ("numel", _u64 * 4),
                 ("timed_stage", _i32), ("grad_overwrite", _i32),
                 ("phase", _i32), ("dp_overlap", _i32), ("dp_table", _i32), ("dp_gather_master", _i32), ("comm", _vp), ("dp", _vp), ("grad_wire", _vp), ("wire_scale", _f32), ("frags_fresh", _i32),
-                ("wait_flag", _vp), ("wait_status", _vp), ("wait_value", _u32), ("pad4", _u32),
-                ("signal_flag", _vp), ("signal_value", _u32), ("signal_stage", _i32)]
+                ("wait_flag", _vp), ("wait_status", _vp), ("wait_value", _u32), ("pad4", _u32)]
 
 
 PHASE_ALL, PHASE_BACKWARD, PHASE_SWEEP = 0, 1, 2      # NGP_PHASE_*
@@ -139,7 +138,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_lib, name)       # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
-        if _lib.ngp_abi_version() != 4:
+        if _lib.ngp_abi_version() != 3:
             raise RuntimeError("libngp_hip.so ABI version mismatch")
     return _lib
 

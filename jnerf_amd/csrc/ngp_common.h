@@ -51,8 +51,6 @@ int ngp_field32_pack_split(void *stream, const float *wd, const float *wc, void 
 int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const void *split_frags, const float *dout, float *dfeat,
                           float *slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am);
 int ngp_field32_fwd_split(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const void *split_frags, float *out, const uint32_t *n_valid, int density_only);
-int ngp_adam_ema_step_flag(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
-                           float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad, float grad_mul, uint32_t *flag, uint32_t flag_value);
 int ngp_dp_reduce(void *comm, hipStream_t s, const NgpDpPlan *plan, void *grad, int dtype, uint32_t first_bucket, uint32_t last_bucket, float *tail_f32, float *extra_f32, uint64_t extra_count);
 
 struct LevelTable { uint32_t v[64]; };   // [16][4] = offset, size, res, scale bits — passed by value (256 B of kernarg)

@@ -11,8 +11,7 @@
 
 template <typename G, int EMA /*0 none, 1 separate buffer, 2 the EMA state IS the parameter (v == p at every step boundary)*/, bool HALF, bool ZERO>
 __global__ __launch_bounds__(256) void k_adam_ema(uint64_t n4, float4 *__restrict__ p, G *__restrict__ g, float4 *__restrict__ m, float4 *__restrict__ v, float4 *__restrict__ ema,
-                                                  uint2 *__restrict__ p_half, AdamConsts c, uint32_t *__restrict__ flag, uint32_t flag_value) {
-	if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (r6) "the sweep has begun": NgpTrainStep.signal_flag
+                                                  uint2 *__restrict__ p_half, AdamConsts c) {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
 		float gi[4];
 		if (sizeof(G) == 4) { float4 t = reinterpret_cast<float4 *>(g)[i]; gi[0] = t.x; gi[1] = t.y; gi[2] = t.z; gi[3] = t.w; if (ZERO) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -68,15 +67,8 @@ NGP_API int ngp_adam_ema_step(void *stream, uint64_t n, float *p, void *g, int g
                               float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad) {
 	return ngp_adam_ema_step_scaled(stream, n, p, g, g_dtype, m, v, ema, p_half, lr, beta0, beta1, eps, step, ema_decay, zero_grad, 1.0f);
 }
-// the sweep with a device flag stored by its first workgroup (csrc/train_step.hip: NgpTrainStep.signal_flag at NGP_STAGE_ADAM); not part of the public ABI
-int ngp_adam_ema_step_flag(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
-                           float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad, float grad_mul, uint32_t *flag, uint32_t flag_value);
 NGP_API int ngp_adam_ema_step_scaled(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
                                      float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad, float grad_mul) {
-	return ngp_adam_ema_step_flag(stream, n, p, g, g_dtype, m, v, ema, p_half, lr, beta0, beta1, eps, step, ema_decay, zero_grad, grad_mul, nullptr, 0u);
-}
-int ngp_adam_ema_step_flag(void *stream, uint64_t n, float *p, void *g, int g_dtype, float *m, float *v, float *ema, void *p_half,
-                           float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, int zero_grad, float grad_mul, uint32_t *flag, uint32_t flag_value) {
 	NGP_REQUIRE(p && g && m && v && step >= 1, NGP_E_ARG, "ngp_adam_ema_step: bad arguments");
 	NGP_REQUIRE(grad_mul == 1.0f || g_dtype == NGP_F16, NGP_E_ARG, "ngp_adam_ema_step: a gradient multiplier is only applied to fp16 (communication) gradients");
 	NGP_REQUIRE(g_dtype == NGP_F32 || g_dtype == NGP_F16, NGP_E_DTYPE, "ngp_adam_ema_step: bad gradient dtype %d", g_dtype);
@@ -87,7 +79,7 @@ int ngp_adam_ema_step_flag(void *stream, uint64_t n, float *p, void *g, int g_dt
 	const uint64_t n4 = n / 4;
 	uint32_t blocks = (uint32_t)((n4 + 255) / 256); if (blocks > 2048 * 4) blocks = 2048 * 4;
 	hipStream_t s = (hipStream_t)stream;
-#define GO(G, E, H, Z) NGP_LAUNCH((k_adam_ema<G, E, H, Z>), dim3(blocks), dim3(256), 0, s, n4, (float4 *)p, (G *)g, (float4 *)m, (float4 *)v, (float4 *)ema, (uint2 *)p_half, c, flag, flag_value)
+#define GO(G, E, H, Z) NGP_LAUNCH((k_adam_ema<G, E, H, Z>), dim3(blocks), dim3(256), 0, s, n4, (float4 *)p, (G *)g, (float4 *)m, (float4 *)v, (float4 *)ema, (uint2 *)p_half, c)
 #define GO_Z(G, E, H) do { if (zero_grad) GO(G, E, H, true); else GO(G, E, H, false); } while (0)
 #define GO_H(G, E) do { if (p_half) GO_Z(G, E, true); else GO_Z(G, E, false); } while (0)
 #define GO_E(G) do { if (ema == p) GO_H(G, 2); else if (ema) GO_H(G, 1); else GO_H(G, 0); } while (0)

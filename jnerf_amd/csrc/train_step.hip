@@ -132,11 +132,7 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		std::lock_guard<std::mutex> lk(g_mu);
 		if (g_boundary.first) { hipEventRecord(g_boundary.second, hs); g_pending.push_back(g_boundary); g_boundary = {nullptr, nullptr}; }
 	}
-	// (ABI 4) signal_flag: stored when the stream reaches the launch of stage signal_stage - by a one-thread launch in front of it (any stage: the form experiments use), or,
-	// NGP_STAGE_ADAM on one GPU, by the first workgroup of the table's sweep itself (no launch: the product's form)
-	const bool signal = a->signal_flag != nullptr && do_bwd;
-	bool signalled = false;                                      // (a stage that is not launched in this configuration - a slab reduction that rides in another launch - must not leave a waiter behind: see the end of the call)
-#define STAGE(id, call) do { if (signal && !signalled && a->signal_stage == (id)) { if ((rc = ngp_flag_signal(stream, a->signal_flag, a->signal_value))) return rc; signalled = true; } Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
+#define STAGE(id, call) do { Bracket br(hs, a->timed_stage == (id)); rc = (call); } while (0); if (rc) return rc
 	const int T = a->dtype, ow = a->grad_overwrite != 0;
 	if (do_bwd && a->wait_flag && (rc = ngp_flag_wait(stream, a->wait_flag, a->wait_value, a->wait_status))) return rc;      // the batch's hand-over from the sampling stream
 	// the flat fp32 weight pack among the optimiser tensors (fp32 network): its sweep also writes the next iteration's MFMA fragments (ngp_mlp32_sweep_pack)
@@ -268,15 +264,10 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 			} else if (t == t_pack) {
 				if (t_pack_swept) continue;
 				if ((rc = ngp_mlp32_sweep_pack(stream, a->p[t], a->g[t], a->m[t], a->v[t], a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, (float *)a->packed_weights))) return rc;
-			} else {
-				const bool sig_here = signal && a->signal_stage == NGP_STAGE_ADAM && t == largest;
-				if ((rc = ngp_adam_ema_step_flag(stream, a->numel[t], a->p[t], a->g[t], NGP_F32, a->m[t], a->v[t], a->ema[t], a->p_half[t], a->lr, a->beta0, a->beta1, a->eps,
-				                                 a->step, a->ema_decay, ow ? 0 : 1, 1.0f, sig_here ? a->signal_flag : nullptr, a->signal_value))) return rc;
-				if (sig_here) signalled = true;
-			}
+			} else if ((rc = ngp_adam_ema_step(stream, a->numel[t], a->p[t], a->g[t], NGP_F32, a->m[t], a->v[t], a->ema[t], a->p_half[t], a->lr, a->beta0, a->beta1, a->eps,
+			                                   a->step, a->ema_decay, ow ? 0 : 1))) return rc;
 		}
 	}
-	if (signal && !signalled && (rc = ngp_flag_signal(stream, a->signal_flag, a->signal_value))) return rc;      // (the stage was not launched - sharded / deferred sweeps, a riding slab reduction: never leave a waiter behind)
 	if (dp) {                                                    // everyone gets everyone's updated shard of what the kernels read
 		const int t = a->dp_table;
 		void *bufs[2]; int dts[2]; int nb = 0;

@@ -164,11 +164,6 @@ class FusedTrainStep:
             a.wait_flag, a.wait_value, a.wait_status = fl[0].data_ptr(), fl[1] & 0xFFFFFFFF, fl[2].data_ptr()
         else:
             a.wait_flag, a.wait_value, a.wait_status = None, 0, None
-        pf = getattr(r, "_phase_flag", None)           # (r6) where the sampling streams place their marchers: Runner.train_step waits for this step's signal
-        if pf is not None and r._march_beside is not None and not self._dp_host_collective:
-            a.signal_flag, a.signal_value, a.signal_stage = pf.data_ptr(), (int(b["step"]) + 1) & 0xFFFFFFFF, L.STAGES[r._march_beside]
-        else:
-            a.signal_flag, a.signal_value, a.signal_stage = None, 0, -1
         a.table, a.wd, a.wc = table.data_ptr(), wd.data_ptr(), wc.data_ptr()
         a.rgb, a.loss, a.loss_grad = rgb.data_ptr(), loss.data_ptr(), lgrad.data_ptr()
         if self._dp_host_collective:

@@ -57,10 +57,6 @@ class Runner:
         self.pipeline = cfg.pipeline_sampling is not False      # `pipeline_sampling = False` in the config restores the strictly sequential loop
         self._queue, self._sides, self._done_steps, self._fast, self._rays_event = {}, [], set(), None, None
         self.pipeline_depth = int(cfg.pipeline_depth or 2)          # batches marched ahead of the one being trained on
-        # stage of the native step beside which the sampling streams start a batch's kernels (None / "none": wherever the host enqueues them); see train_step
-        mb = cfg.march_beside if cfg.march_beside is not None else "none"
-        self._march_beside = None if mb in (False, "none", "") else str(mb)
-        self._phase_flag = None
         self.done_period = int(cfg.pipeline_done_period or 4)       # the training stream records a `done` checkpoint every this many steps (train_step)
         n_sets = len(getattr(self.sampler, "_sets", ())) or 3
         assert n_sets >= self.pipeline_depth + self.done_period - 1, (
@@ -115,9 +111,6 @@ class Runner:
         self._queue.clear()
         if getattr(self, "_flags", None) is not None and int(self._flags[-1].item()) != 0:
             raise RuntimeError("a batch hand-over timed out on the GPU (ngp_flag_wait waited 2 s for a sampling stream): the results of this run are not valid")
-        if getattr(self, "_phase_flag", None) is not None and int(self._phase_flag[1].item()) != 0:
-            self._phase_flag[1] = 0
-            print("[jnerf_amd] a sampling stream waited 2 s for the training stream's `march_beside` signal and went on without it (results unaffected: the signal only places the marcher in time)", flush=True)
         if hasattr(self.sampler, "finish_batch_rays_update"):
             self.sampler.finish_batch_rays_update()
 
@@ -269,8 +262,6 @@ class Runner:
                 self._grid_event.record(main)            # side streams must not read the bitfield before this refresh has finished
                 self._grid_valid = True
         cfg.m_training_step = i
-        if self._phase_flag is None and self._march_beside is not None and self.pipeline and main is not None:
-            self._phase_flag = torch.zeros(2, dtype=torch.int32, device=self.sampler.device)          # [0]: step (+ 1) whose `march_beside` stage the training stream has reached; [1]: status of the waits
         self._collective_polls = True                    # until finish(): see _poll_field32_range(local=True)
         if i % 16 == 0 and i:
             self._poll_field32_range()
@@ -331,12 +322,6 @@ class Runner:
             if cur_state is None:
                 cur_state = self.sampler.export_batch_state()
             with torch.cuda.stream(side):
-                if self._phase_flag is not None and self._fast and self._fast.native and not self._fast._dp_host_collective:
-                    # (r6) placement of the marcher: this batch's kernels start when the TRAINING stream reaches stage `march_beside` of the step being issued now (step i) -
-                    # ngp_train_step stores i + 1 to the flag there (NgpTrainStep.signal_flag), one spinning wavefront waits for it here.  Without it the marcher starts whenever
-                    # the host enqueues it, which on MI355X put it beside the LDS-bound k_bin_accumulate2 in three steps of four (70 -> 112 us, profiles/r06a_lego_timeline.txt)
-                    from . import ops as _ops
-                    _ops.flag_wait(self._phase_flag[0:1], i + 1, self._phase_flag[1:2])
                 nb = self._make_batch(k, self._ray_bufs[k % n_sets] if self._ray_bufs is not None else None)
                 if cfg.flag_handover is True:
                     from . import ops as _ops

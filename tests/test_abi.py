@@ -18,7 +18,7 @@ def declared_symbols():
 
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.lib()
-    assert lib.ngp_abi_version() == 4
+    assert lib.ngp_abi_version() == 3
     syms = declared_symbols()
     assert len(syms) >= 31
     exported = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()

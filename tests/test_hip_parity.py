@@ -19,7 +19,7 @@ def H():
 
 def test_extension_loaded_and_mfma_layout(H):
     from jnerf_amd import ops, _lib
-    assert _lib.lib().ngp_abi_version() == 4
+    assert _lib.lib().ngp_abi_version() == 3
     bad, magic = ops.selftest_mfma()
     assert magic == 0xC0FFEE, "self-test kernel did not run"
     assert bad == 0, f"MFMA fragment layout assumption violated for {bad} elements"
