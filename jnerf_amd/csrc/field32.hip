@@ -505,14 +505,47 @@ __global__ __launch_bounds__(512, 2) void k_field32_bwd_2g(uint32_t n, const flo
 // Adam+EMA sweep of the flat weight pack (10240 floats, EMA aliasing the parameter like k_adam_ema<float, 2>) and the MFMA fragments of the UPDATED weights for the
 // next iteration, one single-workgroup launch instead of k_adam_ema (pack) + next step's k_pack_frags32: two launches and their boundaries less per iteration.
 __global__ __launch_bounds__(1024) void k_mlp32_sweep_pack(float *__restrict__ pack, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, AdamConsts c,
-                                                           float *__restrict__ packed_out) {
+                                                           float *__restrict__ packed_out, const uint16_t *__restrict__ table) {
 	__shared__ float w[10240];
-	tail_mlp32_sweep_pack_1024(pack, grad, m, v, c, packed_out, w);       // (mlp_tail.h: the same job rides in k_bin_pairs' grid on the single-GPU training path)
+	tail_mlp32_sweep_pack_1024(pack, grad, m, v, c, packed_out, w, table);       // (mlp_tail.h: the same job rides in k_bin_pairs' grid on the single-GPU training path)
+}
+// the slot -> weight table: the layout functions evaluated on a ramp (weight i holds the value i + 1, exact in fp32; a constant-zero slot reads 0)
+__global__ void k_pack_table_ramp(float *ramp) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < 10240) ramp[i] = (float)(i + 1); }
+__global__ void k_pack_table_build(const float *__restrict__ ramp, uint16_t *__restrict__ table) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx < PACK_TABLE_32) {
+		const int f = idx >> 8, lane = (idx >> 2) & 63, j = idx & 3;
+		table[idx] = (uint16_t)frag_value32(ramp, ramp + 3072, f, lane & 15, lane >> 4, j);
+	} else if (idx < PACK_TABLE_32 + PACK_TABLE_SPLIT) {
+		const int r = idx - PACK_TABLE_32, f = r >> 9, lane = (r >> 3) & 63, j = r & 7;
+		table[idx] = (uint16_t)split_frag_weight(ramp, ramp + 3072, f, lane & 15, lane >> 4, j);
+	}
+}
+const uint16_t *ngp_mlp32_pack_table(void *stream) {
+	static std::mutex mu;
+	static uint16_t *tab[64] = {nullptr};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+	std::lock_guard<std::mutex> lk(mu);
+	if (tab[dev]) return tab[dev];
+	float *ramp = nullptr; uint16_t *t = nullptr;
+	const uint32_t n = PACK_TABLE_32 + PACK_TABLE_SPLIT;
+	if (hipMalloc((void **)&ramp, 10240 * sizeof(float)) != hipSuccess || hipMalloc((void **)&t, n * sizeof(uint16_t)) != hipSuccess) { ngp_set_error("ngp_mlp32_pack_table: hipMalloc failed"); if (ramp) (void)hipFree(ramp); return nullptr; }
+	hipStream_t s = (hipStream_t)stream;
+	hipLaunchKernelGGL(k_pack_table_ramp, dim3(40), dim3(256), 0, s, ramp);
+	hipLaunchKernelGGL(k_pack_table_build, dim3(div_up(n, 256)), dim3(256), 0, s, (const float *)ramp, t);
+	// built once per device: wait for it, so that every stream may use the table from here on, and release the ramp
+	if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { ngp_set_error("ngp_mlp32_pack_table: building the table failed"); (void)hipFree(ramp); (void)hipFree(t); return nullptr; }
+	(void)hipFree(ramp);
+	tab[dev] = t;
+	return t;
 }
 int ngp_mlp32_sweep_pack(void *stream, float *pack, const float *grad, float *m, float *v, float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, float *packed_out) {
 	NGP_REQUIRE(pack && grad && m && v && packed_out && step >= 1, NGP_E_ARG, "ngp_mlp32_sweep_pack: bad arguments");
+	const uint16_t *table = ngp_mlp32_pack_table(stream);
+	if (!table) return NGP_E_ARG;
 	const AdamConsts c = adam_consts(lr, beta0, beta1, eps, step, ema_decay, 1.0f);
-	NGP_LAUNCH(k_mlp32_sweep_pack, dim3(1), dim3(1024), 0, (hipStream_t)stream, pack, grad, m, v, c, packed_out);
+	NGP_LAUNCH(k_mlp32_sweep_pack, dim3(1), dim3(1024), 0, (hipStream_t)stream, pack, grad, m, v, c, packed_out, table);
 	NGP_LAUNCH_CHECK("ngp_mlp32_sweep_pack");
 	return 0;
 }

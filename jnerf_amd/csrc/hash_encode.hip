@@ -531,8 +531,17 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_records_runs(uint32_t n, co
 			const float *f = reinterpret_cast<const float *>(v);
 #pragma unroll
 			for (uint32_t k = 0; k < RUN_K; ++k) { px[k][0] = f[3 * k]; px[k][1] = f[3 * k + 1]; px[k][2] = f[3 * k + 2]; }
+			if (LAYOUT == NGP_LAYOUT_SOA && sizeof(P) == 8 && (n & 1u) == 0u) {       // (r6) level-major fp32 gradients: the thread's eight pairs are 64 contiguous, 16-byte aligned bytes - four loads instead of eight
+				const float4 *g4 = reinterpret_cast<const float4 *>(dy + (size_t)level * n + first);
+				float4 u[4];
 #pragma unroll
-			for (uint32_t k = 0; k < RUN_K; ++k) gk[k] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + first + k] : dy[(size_t)(first + k) * 16 + level]);
+				for (int r = 0; r < 4; ++r) u[r] = g4[r];
+#pragma unroll
+				for (int r = 0; r < 4; ++r) { gk[2 * r] = make_float2(u[r].x, u[r].y); gk[2 * r + 1] = make_float2(u[r].z, u[r].w); }
+			} else {
+#pragma unroll
+				for (uint32_t k = 0; k < RUN_K; ++k) gk[k] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + first + k] : dy[(size_t)(first + k) * 16 + level]);
+			}
 		} else {
 #pragma unroll
 			for (uint32_t k = 0; k < RUN_K; ++k) {
@@ -769,7 +778,7 @@ __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__rest
 	uint32_t po = blockIdx.y;
 	if (tj.do_sweep) {                                                                        // (r6, mlp_tail.h) row 0 of the grid - dispatched first - carries the MLP pack's Adam sweep + fragment packing: one workgroup
 		if (po == 0u) {
-			if constexpr (S == 1024u) { if (blockIdx.x == 0u) tail_mlp32_sweep_pack_1024(tj.pack, tj.reduce_out, tj.m, tj.v, tj.c, tj.packed_out, reinterpret_cast<float *>(bin_smem)); }
+			if constexpr (S == 1024u) { if (blockIdx.x == 0u) tail_mlp32_sweep_pack_1024(tj.pack, tj.reduce_out, tj.m, tj.v, tj.c, tj.packed_out, reinterpret_cast<float *>(bin_smem), tj.pack_table); }
 			return;
 		}
 		po -= 1u;
@@ -910,8 +919,17 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const flo
 			const float *f = reinterpret_cast<const float *>(v);
 #pragma unroll
 			for (uint32_t k = 0; k < RUN_K; ++k) { px[k][0] = f[3 * k]; px[k][1] = f[3 * k + 1]; px[k][2] = f[3 * k + 2]; }
+			if (LAYOUT == NGP_LAYOUT_SOA && sizeof(P) == 8 && (n & 1u) == 0u) {       // (r6) level-major fp32 gradients: the thread's eight pairs are 64 contiguous, 16-byte aligned bytes - four loads instead of eight
+				const float4 *g4 = reinterpret_cast<const float4 *>(dy + (size_t)level * n + first);
+				float4 u[4];
 #pragma unroll
-			for (uint32_t k = 0; k < RUN_K; ++k) gk[k] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + first + k] : dy[(size_t)(first + k) * 16 + level]);
+				for (int r = 0; r < 4; ++r) u[r] = g4[r];
+#pragma unroll
+				for (int r = 0; r < 4; ++r) { gk[2 * r] = make_float2(u[r].x, u[r].y); gk[2 * r + 1] = make_float2(u[r].z, u[r].w); }
+			} else {
+#pragma unroll
+				for (uint32_t k = 0; k < RUN_K; ++k) gk[k] = to_f2(LAYOUT == NGP_LAYOUT_SOA ? dy[(size_t)level * n + first + k] : dy[(size_t)(first + k) * 16 + level]);
+			}
 		} else {
 #pragma unroll
 			for (uint32_t k = 0; k < RUN_K; ++k) {
@@ -1373,7 +1391,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		// (r6) the MLP tail rides along when both record kernels run, with 1024-thread edge workgroups (the sweep's shape): the slab reduction as row 0 of k_bin_runs2's grid,
 		// the pack's sweep as row 0 of k_bin_pairs' - k_bin_runs2 precedes k_bin_pairs in the stream, so the sweep reads the finished sums
 		TailJobs tj_run = no_tail_jobs(), tj_pair = no_tail_jobs();
-		if (tail && tail->do_reduce && tail->do_sweep && n_runs && n_pair && pair_s == 1024u && n > 0 && tail->width <= 10240u) {
+		if (tail && tail->do_reduce && tail->do_sweep && tail->pack_table && n_runs && n_pair && pair_s == 1024u && n > 0 && tail->width <= 10240u) {
 			tj_run = *tail; tj_run.do_sweep = 0; tj_pair = *tail; tj_pair.do_reduce = 0;
 			if (tail_taken) *tail_taken = 1;
 		}

@@ -73,9 +73,11 @@ __device__ __forceinline__ void tail_reduce_slabs_256(const TailJobs &tj, float 
 	}
 }
 
-// k_mlp32_sweep_pack's job by ONE 1024-thread workgroup; w: 10240 floats of LDS
+#define PACK_TABLE_32 (NF32_ALL * 256)
+#define PACK_TABLE_SPLIT (NSPLIT_FRAGS * 512)
+// k_mlp32_sweep_pack's job by ONE 1024-thread workgroup; w: 10240 floats of LDS; table: ngp_mlp32_pack_table()
 __device__ __forceinline__ void tail_mlp32_sweep_pack_1024(float *__restrict__ pack, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, const AdamConsts &c,
-                                                           float *__restrict__ packed_out, float *w) {
+                                                           float *__restrict__ packed_out, float *w, const uint16_t *__restrict__ table) {
 	// ten elements per thread: all forty loads of a thread are issued before the first use (a loop of dependent load -> update -> store round trips made this 15 us long for 160 KB of traffic)
 	float P[10], M[10], V[10], G[10];
 #pragma unroll
@@ -88,13 +90,21 @@ __device__ __forceinline__ void tail_mlp32_sweep_pack_1024(float *__restrict__ p
 		pack[i] = P[k]; m[i] = M[k]; v[i] = V[k]; w[i] = P[k];
 	}
 	__syncthreads();
+	// (r6) the fragments of the UPDATED weights, gathered through the slot -> weight table: the index arithmetic of frag_value32 / split_frag_weight (~60 instructions per
+	// slot, 105 k slots) made this ONE workgroup VALU-bound - 12 us alone, ~25 us beside the record workgroups it now shares a CU with
 #pragma unroll
-	for (int k = 0; k < NF32_ALL / 4; ++k) {                  // 19 rounds of 1024 fragment values: the gathers from LDS are independent, the stores coalesced
+	for (int k = 0; k < PACK_TABLE_32 / 1024; ++k) {          // 19 rounds: table loads and stores coalesced, the LDS gathers independent
 		const int idx = threadIdx.x + 1024 * k;
-		const int f = idx >> 8, lane = (idx >> 2) & 63, j = idx & 3;
-		packed_out[idx] = frag_value32(w, w + 3072, f, lane & 15, lane >> 4, j);
+		const uint32_t src = table[idx];
+		packed_out[idx] = src ? w[src - 1u] : 0.f;
 	}
-	_Float16 *split_out = reinterpret_cast<_Float16 *>(packed_out + NF32_ALL * 256);      // the forward kernel's split fp16 fragments of the same updated weights
+	_Float16 *split_out = reinterpret_cast<_Float16 *>(packed_out + NF32_ALL * 256);      // the split fp16 fragments (field_split.h): h part, then the m part
 #pragma unroll
-	for (int k = 0; k < NSPLIT_HALVES / 1024; ++k) { const int idx = threadIdx.x + 1024 * k; split_out[idx] = split_frag_half(w, w + 3072, idx); }
+	for (int k = 0; k < PACK_TABLE_SPLIT / 1024; ++k) {       // 21 rounds: one gather serves a slot's h and m half
+		const int r = threadIdx.x + 1024 * k;
+		const uint32_t src = table[PACK_TABLE_32 + r];
+		const float wv = src ? w[src - 1u] : 0.f;
+		const _Float16 h = (_Float16)wv;
+		split_out[r] = h; split_out[PACK_TABLE_SPLIT + r] = (_Float16)((wv - (float)h) * SPLIT_SCALE);
+	}
 }

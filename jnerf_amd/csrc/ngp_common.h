@@ -46,6 +46,10 @@ int ngp_field_bwd_am(void *stream, uint32_t n, const void *feat, int layout, con
                      const void *dLdout, int out_dtype, void *dLdfeat, float *wgrad_slabs, uint32_t n_slabs, const uint32_t *n_valid, const AbsmaxOut *am);
 // fused tail of the fp32 step: Adam+EMA of the flat 10240-float weight pack (EMA aliasing the parameter) AND the MFMA fragments of the updated weights, one launch
 int ngp_mlp32_sweep_pack(void *stream, float *pack, const float *grad, float *m, float *v, float lr, float beta0, float beta1, float eps, uint32_t step, float ema_decay, float *packed_out);
+// (r6) device table u16[NF32_ALL * 256 + NSPLIT_FRAGS * 512]: for every slot of the fp32 fragments, then of the split fp16 fragments (one entry for a slot's h AND m half), the
+// index + 1 of the weight of the flat 10240-float pack it holds (0: a constant zero).  Built once per device from the layout functions themselves (frag_value32 /
+// split_frag_weight evaluated on a ramp), so the sweep's packing is a table-driven gather instead of ~60 instructions of index arithmetic per slot.  nullptr on failure.
+const uint16_t *ngp_mlp32_pack_table(void *stream);
 // fp32 field forward on split fp16 operands (field_split.hip): the split fragments live behind the NF32_ALL fp32 fragments of the packed weight buffer
 int ngp_field32_pack_split(void *stream, const float *wd, const float *wc, void *out_halves, int n_frags);
 int ngp_field32_bwd_split(void *stream, uint32_t n, const float *feat, int layout, const float *dir, uint32_t dir_stride, const void *split_frags, const float *dout, float *dfeat,
@@ -154,6 +158,7 @@ struct PackSweep { float *p, *m, *v, *ema; __half *p_half; uint32_t begin, count
 struct TailJobs {
 	const float *slabs; uint32_t n_slabs, width; float *reduce_out;
 	float *pack, *m, *v, *packed_out; AdamConsts c;
+	const uint16_t *pack_table;                                          // ngp_mlp32_pack_table(): source weight (+ 1; 0 = a constant zero) of every fragment slot
 	PackSweep a16, b16;
 	int do_reduce, do_sweep, do_sweep16;
 };

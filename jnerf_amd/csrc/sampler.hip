@@ -930,14 +930,19 @@ __global__ __launch_bounds__(256) void k_composite_train(uint32_t n_rays, const 
 		return;
 	}
 	// ---- forward: k_composite_fwd<T, false, CG>
+	// (r6) the kernel's duration is its longest ray's (up to 1024 samples = 16 rounds of 64, forward and again backward): every round's loads are issued one round AHEAD,
+	// so a round costs max(load, arithmetic) instead of their sum.  Same values, same arithmetic, same order - only the loads move.
 	float T_ = 1.f, ray[3] = {0.f, 0.f, 0.f};
+	float on[4] = {0.f, 0.f, 0.f, 0.f}, wn = 0.f;                       // the next round's network outputs and warped dt of this lane's sample
+	auto fetch = [&](uint32_t c0) { if (c0 + lane < ns) { const size_t s = (size_t)base + c0 + lane; load4<T>(net + s * 4, on); wn = coords[s * 7 + 3]; } };
+	fetch(0);
 	for (uint32_t c0 = 0; c0 < ns; c0 += CG) {
 		const uint32_t m = min(CG, ns - c0);
 		float rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f;
+		const float o[4] = {on[0], on[1], on[2], on[3]}, wdt = wn;
+		if (c0 + CG < ns) fetch(c0 + CG);
 		if (lane < m) {
-			const size_t s = (size_t)base + c0 + lane;
-			float o[4]; load4<T>(net + s * 4, o);
-			const float dt = unwarp_dt(coords[s * 7 + 3], cascades);
+			const float dt = unwarp_dt(wdt, cascades);
 			const float density = __expf(o[3]);
 			alpha = 1.f - __expf(-density * dt);
 #pragma unroll
@@ -973,15 +978,18 @@ __global__ __launch_bounds__(256) void k_composite_train(uint32_t n_rays, const 
 	const float l1 = *density_grid_mean < 0.01f ? 1e-4f : 0.0f;
 	T_ = 1.f;
 	float ray2[3] = {0.f, 0.f, 0.f};
+	if (ns > CG) fetch(0);                                              // (a ray of one round still holds its values from the forward: on / wn were not overwritten)
 	for (uint32_t c0 = 0; c0 < ns; c0 += CG) {
 		const uint32_t m = min(CG, ns - c0);
 		const size_t s = (size_t)base + c0 + lane;
 		float o[4] = {0.f, 0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f}, alpha = 0.f, dt = 0.f;
+		const float oc[4] = {on[0], on[1], on[2], on[3]}, wdt = wn;
+		if (c0 + CG < ns) fetch(c0 + CG);
 		if (lane < m) {
-			load4<T>(net + s * 4, o);
+			o[0] = oc[0]; o[1] = oc[1]; o[2] = oc[2]; o[3] = oc[3];
 #pragma unroll
 			for (int c = 0; c < 3; ++c) rgb[c] = logistic(o[c]);
-			dt = unwarp_dt(coords[s * 7 + 3], cascades);
+			dt = unwarp_dt(wdt, cascades);
 			const float density = __expf(o[3]);
 			alpha = 1.f - __expf(-density * dt);
 		}

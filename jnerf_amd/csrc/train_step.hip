@@ -190,6 +190,7 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 		tail.slabs = a->wgrad_slabs; tail.n_slabs = a->n_slabs; tail.width = 10240u; tail.reduce_out = a->wgrad_flat;
 		tail.pack = a->p[t_pack]; tail.m = a->m[t_pack]; tail.v = a->v[t_pack]; tail.packed_out = (float *)a->packed_weights;
 		tail.c = adam_consts(a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, 1.0f);
+		tail.pack_table = ngp_mlp32_pack_table(stream);
 		tail.do_reduce = 1; tail.do_sweep = 1;
 	}
 	// fp16 configuration, single GPU: the slab reduction also sweeps the two weight packs (their gradient is the sum it has just formed) - and rides the same way
