@@ -310,6 +310,7 @@ def main():
     ap.add_argument("--dp-overlap", action="store_true", help="data parallel: two gradient buckets, the coarse levels' reduce-scatter on the library's communication stream under the fine levels' accumulate")
     ap.add_argument("--dp-host-sharded", action="store_true", help="(tests, --backend gloo) the sharded sweep without RCCL: the host sums the gradient and gathers the updated shards")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
+    ap.add_argument("--no-second-scaling", action="store_true", help="--gpus > 1: skip the second timed region in the OTHER scaling mode (extra.dp.other_scaling)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -516,6 +517,7 @@ def main():
         torch.cuda.synchronize(); tr = time.perf_counter() - tr0
         extra["render_Msamples_per_s"] = round(n_s / tr / 1e6, 2)
         extra["render_ms_per_%dx%d_view" % (res, res)] = round(tr / 4 * 1e3, 2)
+    dp_exchange_used = getattr(getattr(runner, "_fast", None), "dp_exchange", None)
     if use_dist:
         extra["dist_backend"] = dist.get_backend()
         # data-parallel invariant: every rank must hold bit-identical parameters (identical summed gradients + a deterministic sweep)
@@ -533,6 +535,41 @@ def main():
                        "overlap": bool(args.dp_overlap), "n_ranks_seen": _dpm.n_ranks_seen() if in_lib else dist.get_world_size(),
                        "dp_exchange": getattr(getattr(runner, "_fast", None), "dp_exchange", None), "grad_wire": "fp16 x 2^14" if getattr(getattr(runner, "_fast", None), "_grad_wire", None) is not None else "fp32",
                        "scaling_curve": "this line is ONE point; no multi-GPU scaling curve has been measured by the authors (one-GPU boxes only)"}
+    if use_dist and world > 1 and not args.no_second_scaling:
+        # (r6) SURVEY.md 8(e) makes STRONG scaling (one 2^18-sample iteration split over the ranks: the same optimisation trajectory at every N) the primary
+        # multi-GPU figure, the driver's contract line is weak scaling: one run prints both.  A second, shorter timed region in the other mode, on every rank (collective);
+        # `value` above is untouched by it.
+        other = "strong" if args.scaling == "weak" else "weak"
+        try:
+            runner = None
+            torch.cuda.empty_cache()
+            share2 = world if other == "strong" else 1
+            ngp_cfg(scene=scene, fp16=fp16, aabb_scale=aabb_scale, const_dt=const_dt, n_images=n_images, W=res, H=res, device=f"cuda:{local_rank}", rank=rank, world_size=world,
+                    target_batch_size=(1 << 18) // share2, n_rays_per_batch=4096 // share2, dp_force_collectives=bool(args.force_dist), dp_overlap=bool(args.dp_overlap), dp_host_sharded=bool(args.dp_host_sharded),
+                    **json.loads(os.environ.get("BENCH_EXTRA_CFG", "{}")))
+            torch.manual_seed(1234 + rank)
+            r2 = Runner()
+            with r2.training_stream():
+                st2 = 0
+                for _ in range(min(args.burn_in, 256) + min(args.warmup, 16)):
+                    r2.train_step(st2); st2 += 1
+                barrier()
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    l2 = r2.train_step(st2); st2 += 1
+                barrier()
+                dt2 = time.perf_counter() - t2
+                r2.finish()
+            tm2 = torch.tensor([dt2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+            dt2 = float(tm2.item())
+            extra["dp"]["other_scaling"] = {"scaling": other, "value": round((world if other == "weak" else 1) * args.steps / dt2, 2), "unit": "iters/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                                            "samples_per_iter_per_gpu": (1 << 18) // share2, "burn_in_steps": min(args.burn_in, 256), "steps": args.steps, "loss": round(float(l2.mean().item()), 6)}
+            r2 = None
+            torch.cuda.empty_cache()
+        except Exception as e:        # (deterministic failures hit every rank alike; the contract line must survive them)
+            extra["dp"]["other_scaling"] = {"scaling": other, "error": repr(e)[:300]}
+        runner = None
     if rank == 0 and not use_dist and lego and scene != "spheres" and not args.no_spheres:
         del runner
         runner = None
@@ -567,7 +604,7 @@ def main():
                                                                                                           "the data set is not on the box and cannot be fetched)" if scene == "bricks" else "") +
                                        f", random-init weights, {args.burn_in}-step burn-in before warm-up", "scene": scene,
                            "samples_per_iter_per_gpu": (1 << 18) // share, "parallelism": f"ray-batch dp{world} ({args.scaling} scaling)" if world > 1 else "single",
-                           **({"dp_exchange": getattr(getattr(runner, "_fast", None), "dp_exchange", None)} if use_dist else {})},
+                           **({"dp_exchange": dp_exchange_used} if use_dist else {})},
                 "roofline": roof, "cpu_baseline": None if (args.no_cpu_baseline or use_dist) else cpu_baseline(aabb_scale, fp16, const_dt), "extra": extra}
         print(json.dumps(line), flush=True)
     if use_dist:

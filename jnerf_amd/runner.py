@@ -92,7 +92,9 @@ class Runner:
         if not torch.cuda.is_available() or self.cfg.train_on_default_stream:
             return contextlib.nullcontext()
         if self._train_stream is None:
-            self._train_stream = torch.cuda.Stream()
+            # (probe knob `train_stream_priority`: -1 = the higher of the device's two levels, so that freed wave slots / LDS go to the training stream's workgroups before
+            # the sampling streams' - measured in round 2 (worse) and again in round 6)
+            self._train_stream = torch.cuda.Stream(priority=int(self.cfg.train_stream_priority or 0))
 
         @contextlib.contextmanager
         def ctx():

@@ -152,6 +152,11 @@ def test_two_ranks_data_parallel_on_one_gpu(scaling):
     assert d["config"]["samples_per_iter_per_gpu"] == ((1 << 18) if scaling == "weak" else (1 << 17))       # strong: ONE 2^18-sample iteration split over the ranks
     assert d["extra"]["replicas_identical"] is True           # both ranks hold bit-identical parameters after 60 data-parallel steps
     assert d["extra"]["native_step"] is True                  # data parallel keeps the one-call native step (here: two phases around gloo's all-reduce)
+    # (r6) one run prints both scaling modes: the contract line in the requested one, a second timed region in the other
+    o = d["extra"]["dp"]["other_scaling"]
+    assert "error" not in o, o
+    assert o["scaling"] == ("strong" if scaling == "weak" else "weak") and o["value"] > 0 and np.isfinite(o["loss"])
+    assert o["samples_per_iter_per_gpu"] == ((1 << 17) if scaling == "weak" else (1 << 18))
 
 
 @pytest.mark.parametrize("world,n_buckets,half", [(2, 1, False), (2, 2, False), (3, 2, True), (8, 1, True), (8, 2, False)])
