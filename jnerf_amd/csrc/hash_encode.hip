@@ -499,14 +499,8 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_records_runs(uint32_t n, co
                                                            const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */, TailJobs tj) {
 	using P = typename Pair<T>::type;
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
-	uint32_t by = blockIdx.y;
-	if (tj.do_reduce) {                                                                   // (r6, mlp_tail.h) row 0 of the grid - dispatched first - carries the MLP weight-gradient slab reduction (+ the two packs' sweep)
-		if (by == 0u) {
-			for (uint32_t unit = blockIdx.x; unit * TAIL_REDUCE_COLS < tj.width; unit += gridDim.x) { tail_reduce_slabs_256(tj, reinterpret_cast<float *>(bin_smem), unit); __syncthreads(); }
-			return;
-		}
-		by -= 1u;
-	}
+	const uint32_t by = blockIdx.y;
+	if (tj.do_reduce) tail_reduce_share(tj, reinterpret_cast<float *>(bin_smem), by * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);      // (r6, mlp_tail.h) this workgroup's 8 columns of the MLP weight-gradient slabs (+ the two packs' sweep)
 	float2 *stage_val = reinterpret_cast<float2 *>(bin_smem);                             // [stage]
 	uint32_t *stage_idx = bin_smem + stage * 2u;                                          // [stage] level-wide entry indices
 	uint32_t *cnt = stage_idx + stage, *base = cnt + BINS_PER_LEVEL, *loff = base + BINS_PER_LEVEL, *cnt2 = loff + BINS_PER_LEVEL;
@@ -775,14 +769,8 @@ __global__ __launch_bounds__(S) void k_bin_pairs(uint32_t n, const float *__rest
                                                  uint32_t *__restrict__ spill_count, SpillEntry *__restrict__ spill, const uint32_t *__restrict__ n_valid, TailJobs tj) {
 	using P = typename Pair<T>::type;
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
-	uint32_t po = blockIdx.y;
-	if (tj.do_sweep) {                                                                        // (r6, mlp_tail.h) row 0 of the grid - dispatched first - carries the MLP pack's Adam sweep + fragment packing: one workgroup
-		if (po == 0u) {
-			if constexpr (S == 1024u) { if (blockIdx.x == 0u) tail_mlp32_sweep_pack_1024(tj.pack, tj.reduce_out, tj.m, tj.v, tj.c, tj.packed_out, reinterpret_cast<float *>(bin_smem), tj.pack_table); }
-			return;
-		}
-		po -= 1u;
-	}
+	const uint32_t po = blockIdx.y;
+	if (tj.do_sweep) tail_pack_share(tj, po * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);      // (r6, mlp_tail.h) this workgroup's 32 slots of the MLP fragment buffer, from the pack the run kernel's launch has swept
 	PairRec *stage = reinterpret_cast<PairRec *>(bin_smem);                                   // [PAIR_STAGE_RECORDS] records, grouped by bin
 	uint32_t *cnt = bin_smem + PAIR_STAGE_RECORDS * 4u, *loff = cnt + PAIR_BINS;             // loff[PAIR_BINS] = total
 	const uint32_t hl = sel.hl[po], level = bp.level[hl];
@@ -882,14 +870,8 @@ __global__ __launch_bounds__(RUN_WG, OCC) void k_bin_runs2(uint32_t n, const flo
                                                          const uint32_t *__restrict__ absmax_bits, RunRec *__restrict__ rrec, uint16_t *__restrict__ roff,
                                                          const uint32_t *__restrict__ n_valid, uint32_t stage /* records of LDS staging */, TailJobs tj) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t bin_smem[];
-	uint32_t ro = blockIdx.y;
-	if (tj.do_reduce) {                                                                    // (r6, mlp_tail.h) row 0 of the grid - dispatched first - carries the MLP weight-gradient slab reduction
-		if (ro == 0u) {
-			for (uint32_t unit = blockIdx.x; unit * TAIL_REDUCE_COLS < tj.width; unit += gridDim.x) { tail_reduce_slabs_256(tj, reinterpret_cast<float *>(bin_smem), unit); __syncthreads(); }
-			return;
-		}
-		ro -= 1u;
-	}
+	const uint32_t ro = blockIdx.y;
+	if (tj.do_reduce) tail_reduce_share(tj, reinterpret_cast<float *>(bin_smem), ro * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);      // (r6, mlp_tail.h) this workgroup's 8 columns of the MLP weight-gradient slabs (+ their parameters' sweep)
 	RunRec *stage_rec = reinterpret_cast<RunRec *>(bin_smem);                              // [stage]
 	uint32_t *cnt = bin_smem + stage * 3u, *loff = cnt + PAIR_BINS, *cnt2 = loff + PAIR_BINS + 2u;   // loff[PAIR_BINS] = total
 	const uint32_t hl = sel.hl[ro], level = bp.level[hl];
@@ -1388,16 +1370,16 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 		RunRec *run_rec = (RunRec *)(ws + wl.run_rec);
 		uint16_t *run_off = (uint16_t *)(ws + wl.run_off);
 		const uint32_t pair_s = wl.pair_s;
-		// (r6) the MLP tail rides along when both record kernels run, with 1024-thread edge workgroups (the sweep's shape): the slab reduction as row 0 of k_bin_runs2's grid,
-		// the pack's sweep as row 0 of k_bin_pairs' - k_bin_runs2 precedes k_bin_pairs in the stream, so the sweep reads the finished sums
+		// (r6) the MLP tail rides along when both record kernels run: every workgroup of k_bin_runs2 reduces its share of the slabs and sweeps those parameters, every workgroup
+		// of k_bin_pairs - the next launch in the stream, so it reads the swept pack - gathers its share of the fragment buffer (mlp_tail.h)
 		TailJobs tj_run = no_tail_jobs(), tj_pair = no_tail_jobs();
-		if (tail && tail->do_reduce && tail->do_sweep && tail->pack_table && n_runs && n_pair && pair_s == 1024u && n > 0 && tail->width <= 10240u) {
-			tj_run = *tail; tj_run.do_sweep = 0; tj_pair = *tail; tj_pair.do_reduce = 0;
+		if (tail && tail->do_reduce && tail->do_sweep && tail->pack_table && n_runs && n_pair && n > 0) {
+			tj_run = *tail; tj_pair = *tail; tj_pair.do_reduce = 0;
 			if (tail_taken) *tail_taken = 1;
 		}
-#define RGO(L) NGP_LAUNCH((k_bin_runs2<float, L, 5>), dim3(div_up(n, RUN_WG * RUN_K), n_runs + (tj_run.do_reduce ? 1u : 0u)), dim3(RUN_WG), run2_stage_bytes(RUN2_STAGE), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, run_rec, run_off, n_valid, RUN2_STAGE, tj_run)
+#define RGO(L) NGP_LAUNCH((k_bin_runs2<float, L, 5>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run2_stage_bytes(RUN2_STAGE), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, run_rec, run_off, n_valid, RUN2_STAGE, tj_run)
 // (k_bin_pairs depends on the abs-max pass like k_bin_runs2 does, not on k_bin_runs2: both are plain in-order launches - the any-order launch of round 4 lost its A/B and raced with the abs-max pass when there was no run level)
-#define PGO(L, S) NGP_LAUNCH((k_bin_pairs<float, L, S>), dim3(div_up(n, S), n_pair + (tj_pair.do_sweep ? 1u : 0u)), dim3(S), pair_stage_bytes(), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_pair, (const uint32_t *)absmax, pair_rec, pair_off, spill_count, spill, n_valid, tj_pair)
+#define PGO(L, S) NGP_LAUNCH((k_bin_pairs<float, L, S>), dim3(div_up(n, S), n_pair), dim3(S), pair_stage_bytes(), s, n, pos, pos_stride, (const float *)dLdy, lt, bp, sel_pair, (const uint32_t *)absmax, pair_rec, pair_off, spill_count, spill, n_valid, tj_pair)
 #define RECORDS(L) do { ABSMAX(float, L); if (n_runs) RGO(L); if (n_pair) { if (pair_s == 512u) PGO(L, 512u); else PGO(L, 1024u); } } while (0)
 		if (in_layout == NGP_LAYOUT_SOA) RECORDS(NGP_LAYOUT_SOA); else RECORDS(NGP_LAYOUT_AOS);
 #undef RECORDS
@@ -1426,7 +1408,7 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 #define GO(T, G, L) do { \
 	using RV_ = typename RecVal<T>::type; \
 	ABSMAX(T, L); \
-	if (n_runs) NGP_LAUNCH((k_bin_records_runs<T, L, 4>), dim3(div_up(n, RUN_WG * RUN_K), n_runs + (tj_pc.do_reduce ? 1u : 0u)), dim3(RUN_WG), run_stage_bytes(RUN_STAGE), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, RUN_STAGE, tj_pc); \
+	if (n_runs) NGP_LAUNCH((k_bin_records_runs<T, L, 4>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(RUN_STAGE), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, RUN_STAGE, tj_pc); \
 	if (n_fine) NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, BIN_WG), n_fine), dim3(BIN_WG), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_fine, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid); \
 	if (sizeof(RV_) == 8 && !(after_coarse && n_runs && n_fine)) {   /* fp32 records, one type: one accumulate launch over all their levels */ \
 		if (n_all) NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_all * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \

@@ -1,9 +1,15 @@
 // (r6) The two small launches at the end of the fp32 configuration's backward - the slab reduction of the MLP weight gradients (k_reduce_slabs: 160 workgroups, ~10 us)
 // and the Adam + EMA sweep of the 10240-float weight pack with the fragment packing (k_mlp32_sweep_pack: ONE workgroup, ~12 us) - as device functions, so that they can
-// RIDE in the grid of a launch that is in the stream anyway: kernel boundaries are at the hardware's floor (1.2 us), so the only way left to shorten the main stream is
-// fewer and fuller launches.  Both jobs are tiny grids that leave the chip idle; as extra workgroups of the hash backward's record kernels (k_bin_runs2: 256 threads,
-// 26 KB of LDS; k_bin_pairs: 1024 threads, 66 KB) they run beside ~1300 latency-bound workgroups instead of in front of them.  Same arithmetic in the same order as the
-// standalone kernels (which remain: other precisions, data parallel, level tables without both record kernels) - bit-identical results.
+// RIDE in launches that are in the stream anyway: kernel boundaries are at the hardware's floor (1.2 us), so the only way left to shorten the main stream is fewer and fuller
+// launches.  First form (profiles/r06b_ab_lines.txt: +2.6 % it/s): an extra ROW of workgroups in front of the hash backward's two record kernels.  But those kernels are
+// tuned to be exactly resident (k_bin_runs2: 1280 workgroups = 5 per CU), so 128 extra workgroups of ~15 us pushed 128 real ones into a second round (41 -> 52 us alone), and
+// the single sweep-and-pack workgroup sharing a CU with record workgroups ran 2-3x its stand-alone time (k_bin_pairs 27 -> 42 us: profiles/r06d_lego_timeline.txt).  Second
+// form (this file): the jobs are DISTRIBUTED over the record workgroups themselves -
+//   every workgroup of the run kernel reduces 8 columns of the slabs (k_reduce_slabs' order: 16 partial sums over slabs k, k + 16, ..., then their sum in order) and the
+//   thread that holds a column's sum applies Adam + EMA to the parameter it is the gradient of (fp32: the flat pack; fp16: the two packs and their shadows);
+//   every workgroup of the edge kernel - the NEXT launch, so every parameter is updated - gathers 32 slots of the fragment buffer through the slot -> weight table.
+// One dependent load round at the top of each workgroup instead of rows of foreign workgroups.  Same arithmetic in the same order as the stand-alone kernels (which
+// remain: data parallel, level tables without both record kernels, the per-stage API) - bit-identical results.
 #pragma once
 #include "ngp_common.h"
 #include "field_split.h"
@@ -31,8 +37,6 @@ __device__ __forceinline__ float frag_value32(const float *__restrict__ wd, cons
 }
 
 static inline TailJobs no_tail_jobs() { TailJobs t; memset(&t, 0, sizeof(t)); return t; }
-#define TAIL_REDUCE_COLS 64u
-#define TAIL_REDUCE_LDS_FLOATS (16u * 65u)
 
 // Adam + EMA of the parameter that column `col` of the flat weight gradient belongs to (its gradient: the column sum t); fp16 configuration, two packs with their fp16 shadows
 __device__ __forceinline__ void pack_sweep_column(const PackSweep &a, const PackSweep &b, const AdamConsts &c, uint32_t col, float t) {
@@ -49,28 +53,47 @@ __device__ __forceinline__ void pack_sweep_column(const PackSweep &a, const Pack
 	}
 }
 
-// the slab reduction for columns [64 unit, 64 unit + 64) by ONE 256-thread workgroup: thread = (column, quarter q); partial sums of slab groups q, q + 4, q + 8, q + 12 of
-// k_reduce_slabs' sixteen (independent chains: four loads in flight), then the sixteen partials in its order.  lds: TAIL_REDUCE_LDS_FLOATS floats.
-__device__ __forceinline__ void tail_reduce_slabs_256(const TailJobs &tj, float *lds, uint32_t unit) {
-	float (*part)[65] = reinterpret_cast<float (*)[65]>(lds);
-	const uint32_t lc = threadIdx.x & 63u, q = threadIdx.x >> 6, col = unit * TAIL_REDUCE_COLS + lc;
-	float s[4] = {0.f, 0.f, 0.f, 0.f};
-	if (col < tj.width) {
-		for (uint32_t k0 = 0; k0 < tj.n_slabs; k0 += 16u) {
+// Adam + EMA of element `col` of the flat fp32 weight pack (EMA aliasing the parameter): k_mlp32_sweep_pack's update of that element
+__device__ __forceinline__ void pack32_sweep_column(const TailJobs &tj, uint32_t col, float t) {
+	float P = tj.pack[col], M = tj.m[col], V = tj.v[col], E = P;
+	adam_ema_update<true>(P, M, V, E, t, tj.c);
+	tj.pack[col] = P; tj.m[col] = M; tj.v[col] = V;
+}
+// the slab reduction for columns [8 unit, 8 unit + 8) by the first 128 threads of a workgroup (any size >= 128): thread = (column c, slab group q of k_reduce_slabs' sixteen);
+// a group's slabs q, q + 16, ... are loaded together and added in order, then the sixteen partials in order - k_reduce_slabs' sums bit for bit.  The thread that ends up with a
+// column's sum stores it and (do_sweep / do_sweep16) updates the parameter it is the gradient of.  lds: TAIL_REDUCE_LDS_FLOATS floats; contains one __syncthreads().
+#define TAIL_REDUCE_COLS 8u
+#define TAIL_REDUCE_LDS_FLOATS (16u * 9u)
+__device__ __forceinline__ void tail_reduce_cols8(const TailJobs &tj, float *lds, uint32_t unit) {
+	float (*part)[9] = reinterpret_cast<float (*)[9]>(lds);
+	const uint32_t c = threadIdx.x & 7u, q = (threadIdx.x >> 3) & 15u, col = unit * TAIL_REDUCE_COLS + c;
+	if (threadIdx.x < 128u) {
+		float s = 0.f;
+		if (col < tj.width) {
+			for (uint32_t k0 = q; k0 < tj.n_slabs; k0 += 256u) {          // sixteen loads in flight, added in slab order
+				float v[16];
 #pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) { const uint32_t k = k0 + q + 4u * u; if (k < tj.n_slabs) s[u] += tj.slabs[(size_t)k * tj.width + col]; }
+				for (uint32_t j = 0; j < 16; ++j) { const uint32_t k = k0 + 16u * j; v[j] = k < tj.n_slabs ? tj.slabs[(size_t)k * tj.width + col] : 0.f; }
+#pragma unroll
+				for (uint32_t j = 0; j < 16; ++j) if (k0 + 16u * j < tj.n_slabs) s += v[j];
+			}
 		}
+		part[q][c] = s;
 	}
-#pragma unroll
-	for (uint32_t u = 0; u < 4; ++u) part[q + 4u * u][lc] = s[u];
 	__syncthreads();
-	if (q == 0 && col < tj.width) {
+	if (threadIdx.x < 8u && col < tj.width) {
 		float t = 0.f;
 #pragma unroll
-		for (int g = 0; g < 16; ++g) t += part[g][lc];
+		for (int g = 0; g < 16; ++g) t += part[g][c];
 		tj.reduce_out[col] = t;
 		if (tj.do_sweep16) pack_sweep_column(tj.a16, tj.b16, tj.c, col, t);          // fp16 configuration: k_reduce_slabs_sweep's second half
+		if (tj.do_sweep) pack32_sweep_column(tj, col, t);                            // fp32 configuration: k_mlp32_sweep_pack's first half
 	}
+}
+// every workgroup of a launch with `n_wg` workgroups, this one being number `wg`: its share of the reduction.  Call at the top of the kernel, before its own LDS use, by ALL threads.
+__device__ __forceinline__ void tail_reduce_share(const TailJobs &tj, float *lds, uint32_t wg, uint32_t n_wg) {
+	const uint32_t n_units = (tj.width + TAIL_REDUCE_COLS - 1u) / TAIL_REDUCE_COLS;
+	for (uint32_t unit = wg; unit < n_units; unit += n_wg) { tail_reduce_cols8(tj, lds, unit); __syncthreads(); }
 }
 
 #define PACK_TABLE_32 (NF32_ALL * 256)
@@ -108,3 +131,23 @@ __device__ __forceinline__ void tail_mlp32_sweep_pack_1024(float *__restrict__ p
 		split_out[r] = h; split_out[PACK_TABLE_SPLIT + r] = (_Float16)((wv - (float)h) * SPLIT_SCALE);
 	}
 }
+
+// k_mlp32_sweep_pack's second half, distributed: 32 slots of the fragment buffer per unit, gathered from the UPDATED pack in memory (the launch before this one swept it).
+#define TAIL_PACK_SLOTS 32u
+__device__ __forceinline__ void tail_pack_share(const TailJobs &tj, uint32_t wg, uint32_t n_wg) {
+	if (threadIdx.x >= TAIL_PACK_SLOTS) return;
+	const uint32_t n_units = (PACK_TABLE_32 + PACK_TABLE_SPLIT) / TAIL_PACK_SLOTS;
+	_Float16 *split_out = reinterpret_cast<_Float16 *>(tj.packed_out + NF32_ALL * 256);
+	for (uint32_t unit = wg; unit < n_units; unit += n_wg) {
+		const uint32_t idx = unit * TAIL_PACK_SLOTS + threadIdx.x;
+		const uint32_t src = tj.pack_table[idx];
+		const float wv = src ? tj.pack[src - 1u] : 0.f;
+		if (idx < PACK_TABLE_32) tj.packed_out[idx] = wv;
+		else {
+			const uint32_t r = idx - PACK_TABLE_32;
+			const _Float16 h = (_Float16)wv;
+			split_out[r] = h; split_out[PACK_TABLE_SPLIT + r] = (_Float16)((wv - (float)h) * SPLIT_SCALE);
+		}
+	}
+}
+static_assert((PACK_TABLE_32 + PACK_TABLE_SPLIT) % TAIL_PACK_SLOTS == 0 && PACK_TABLE_32 % TAIL_PACK_SLOTS == 0, "whole units of fragment slots");

@@ -284,7 +284,11 @@ class Runner:
             # (probe knobs, tools/gpu_r3_g.sh: HIP multiplexes streams onto a few hardware queues in creation order, and which streams end up together moves the
             # iteration time by +-4 % - `pipeline_dummy_streams` unused streams created first shift that mapping, `pipeline_side_streams` = 1 marches on one stream)
             self._dummy_streams = [torch.cuda.Stream() for _ in range(int(cfg.pipeline_dummy_streams or 0))]
-            self._sides = [torch.cuda.Stream(priority=int(cfg.pipeline_side_priority or 0)) for _ in range(int(cfg.pipeline_side_streams or 2))]
+            # (r6) ONE sampling stream by default: rounds 2-5 marched on two (two marchers may then run at once, and beside any kernel of the step).  With the step at ~0.52 ms a
+            # batch's ray generation + marching (~0.2 ms) still fits the step on one stream, consecutive marchers never overlap each other, and the training stream's kernels
+            # keep more of the chip: +5.1 % it/s in three A/B pairs of one call (profiles/r06f_ab_lines.txt: 1929 / 1929 / 1938 vs 1834 / 1837 / 1841).
+            n_side = int(cfg.pipeline_side_streams or os.environ.get("NGP_PIPELINE_SIDE_STREAMS") or 1)
+            self._sides = [torch.cuda.Stream(priority=int(cfg.pipeline_side_priority or 0)) for _ in range(n_side)]
             self._ready = [torch.cuda.Event() for _ in range(n_sets)]            # persistent events, re-recorded (no create/destroy per step)
             self._done = [torch.cuda.Event() for _ in range(n_sets // P + 2)]
             self._grid_event, self._grid_valid = torch.cuda.Event(), False
