@@ -344,14 +344,14 @@ __global__ __launch_bounds__(64) void k_march_wave(uint32_t n_rays, MarchParams 
 				occ = bitfield[idx / 8 + (NGP_GRIDSIZE * NGP_GRIDSIZE * NGP_GRIDSIZE * mip) / 8] & (1 << (idx % 8));
 				if (!occ) {                                              // next_voxel_target with the per-ray constants (same expressions: x / 2^k == x * 2^-k exactly)
 					const uint32_t res = NGP_GRIDSIZE >> mip;
-					const float resf = (float)res, inv_res = 1.0f / resf;
+					const float resf = (float)res, inv_res = scalbnf(1.0f, (int)mip - 7);      // 1 / res, exactly: res = 128 >> mip is a power of two
 					float t3[3];
 #pragma unroll
 					for (int k = 0; k < 3; ++k) { const float q = resf * pos[k]; t3[k] = (floorf(q + 0.5f + hs[k]) - q) * idir[k]; }
 					const float tt = fminf(fminf(t3[0], t3[1]), t3[2]);
 					target = tl[w] + fmaxf(tt * inv_res, 0.0f);
 					// the skip lands on the first candidate m > self with !(t_m < target): estimate from the local step, settle with LDS probes (NC = beyond this round)
-					const float est = (target - tl[w]) / dt;
+					const float est = (target - tl[w]) * __frcp_rn(dt);                        // (only where the search below STARTS: it settles on the same candidate from any start)
 					uint32_t g = self + 1u;
 					if (est > 1.0f) g = est >= (float)NC ? NC : self + (uint32_t)est;
 					if (g > NC) g = NC;
