@@ -186,7 +186,7 @@ def cpu_baseline(aabb_scale, fp16, const_dt, n_samples=1 << 18, n_rays=4096, n_m
 
 
 # ---------------------------------------------------------------------------------------------------------------- roofline bookkeeping
-def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
+def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10, run_param_frac=0.1):
     """ALGORITHMIC bytes (and flops) per launch of every hot-path kernel: per-unit figure x units one launch processes.
     n = samples in the batch, P = hash-table parameters, R = rays in the batch, n_refresh = points of one occupancy-grid refresh launch, n_runs = levels with
     res <= 300 (k_bin_records_runs; the other 16 - n_runs go through k_bin_records), T = bytes per table / feature element."""
@@ -201,6 +201,10 @@ def alg_bytes_table(n, P, R, n_refresh, fp16, n_runs=10):
         # hash backward: the stage's necessary traffic is pos 12 + dL/dy 32*T + 128 scattered fp32 updates (4 B each as one write); attributed to the kernels that do each part
         "k_level_absmax": n * 32 * T, "k_bin_records": n * (12 + 32 * T) * (16 - n_runs) / 16, "k_bin_records_runs": n * (12 + 32 * T) * n_runs / 16, "k_bin_accumulate": n * 16 * 8 * 2 * 4,
         "k_bin_pairs": n * (12 + 32 * T) * (16 - n_runs) / 16, "k_bin_runs2": n * (12 + 32 * T) * n_runs / 16, "k_bin_accumulate2": n * 16 * 8 * 2 * 4,
+        "k_bin_accumulate2_adam": n * 16 * 8 * 2 * 4 + P * 24,        # (r6) the accumulate with the table's sweep riding: + read p, m, v, write p, m, v; the gradient never exists in HBM
+        # (r6) per-corner path (fp16 configuration), two launches: run levels (fp32 records; run_param_frac of the parameters) | fine levels (fp16 records); + the 2-byte shadow
+        "k_bin_accumulate_adam_f32rec": n * 8 * 2 * 4 * n_runs + P * run_param_frac * (24 + (2 if fp16 else 0)),
+        "k_bin_accumulate_adam_f16rec": n * 8 * 2 * 4 * (16 - n_runs) + P * (1 - run_param_frac) * (24 + (2 if fp16 else 0)),
         "k_reduce_slabs": 10240 * 4, "k_reduce_slabs_sweep": 10240 * (4 + 30), "k_pack_frags": 21504 * 2 * 2,
         # sampling: ray in (24 B) + one 28-byte record and one 12-byte position out per sample
         "k_march_count": R * 24 + n * 4, "k_march_wave": R * 24 + n * 4, "k_mscan_totals": R * 4, "k_mscan_ok": R * 4, "k_mscan_final": R * 20, "k_march_write_cached": n * (4 + 40),
@@ -230,8 +234,10 @@ SPLIT_FP16_KERNELS = ("k_field32_fwd_split", "k_field32_bwd_split")
 EXECUTED_FLOPS_PER_SAMPLE = {"k_field_fwd": 20480.0, "k_field_bwd": 61440.0, "k_field32_fwd": 20480.0, "k_field32_bwd": 61440.0, "k_field32_bwd_2g": 59392.0,
                              "k_field32_fwd_split": 3 * 20480.0, "k_field32_bwd_split": 3 * 59392.0}
 # the hash-backward stage's kernels: round 3's per-corner records (the fp16 configuration still) | round 4's region records of the fp32 configuration
-HASH_BWD_STAGE = ("k_level_absmax", "k_bin_records_runs", "k_bin_records", "k_bin_accumulate", "k_bin_runs2", "k_bin_pairs", "k_bin_accumulate2")
-HASH_BWD_ACC = ("k_bin_accumulate", "k_bin_accumulate2")
+HASH_BWD_STAGE = ("k_level_absmax", "k_bin_records_runs", "k_bin_records", "k_bin_accumulate", "k_bin_runs2", "k_bin_pairs", "k_bin_accumulate2", "k_bin_accumulate2_adam",
+                  "k_bin_accumulate_adam_f32rec", "k_bin_accumulate_adam_f16rec")
+HASH_BWD_ACC = ("k_bin_accumulate", "k_bin_accumulate2", "k_bin_accumulate2_adam")        # kernels of the stage that are launched more than once per step (per-launch average x launches)
+HASH_BWD_RIDE = ("k_bin_accumulate2_adam", "k_bin_accumulate_adam_f32rec", "k_bin_accumulate_adam_f16rec")
 
 
 
@@ -426,8 +432,10 @@ def main():
     # ---- roofline of the dominant kernel: live HIP-event durations over the timed region, algorithmic bytes per launch
     P = runner.model.pos_encoder.n_params
     n_refresh = 128 ** 3 * (runner.sampler.max_cascade + 1) // 2
-    n_runs = int((runner.model.pos_encoder.level_table.reshape(16, 4)[:, 2] <= 300).sum())
-    alg, flops = alg_bytes_table(mean_valid, P, mean_rays, n_refresh, fp16, n_runs)
+    _lt = runner.model.pos_encoder.level_table.reshape(16, 4)
+    n_runs = int((_lt[:, 2] <= 300).sum())
+    run_param_frac = float(_lt[_lt[:, 2] <= 300, 1].sum()) / max(float(_lt[:, 1].sum()), 1.0)
+    alg, flops = alg_bytes_table(mean_valid, P, mean_rays, n_refresh, fp16, n_runs, run_param_frac)
     roof = None
     # (the committed counter passes describe the BENCH workload: default image count and resolution - a run with --images / --res is another workload and gets no traffic figure)
     pmc, traffic_source = pmc_lookup(args.config, scene) if not (args.images or args.res) else ({}, None)
@@ -453,13 +461,16 @@ def main():
         # the hash-backward STAGE is four launches under four kernel names (abs-max, two record passes, accumulate): one roofline for the stage, from the probe steps
         stage = None
         st_kernels = [k for k in HASH_BWD_STAGE if k in probe_ms]      # (k_level_absmax is absent when the field backward kernel's epilogue computes the maxima)
-        if any(k in st_kernels for k in HASH_BWD_ACC):
+        if any(k in st_kernels for k in HASH_BWD_ACC + HASH_BWD_RIDE):
             st_ms = sum(max(sum(batch_class(probe_ms[k])) / len(batch_class(probe_ms[k])) - ev_overhead, 0.0) * (len(probe_ms[k]) / probe if k in HASH_BWD_ACC else 1.0) for k in st_kernels)
             T_ = 2 if fp16 else 4
             st_bytes = mean_valid * (12 + 32 * T_ + 128 * 2 * T_)                  # pos + dL/dy + 128 scattered table-element updates per sample (588 | 1164 B)
+            rides = any(k in st_kernels for k in HASH_BWD_RIDE)                     # (r6) the table's Adam + EMA sweep is done by the stage's accumulate kernel(s): its bytes belong to the stage
+            if rides:
+                st_bytes += P * (26 if fp16 else 24)
             st_traffic = [pmc.get(k, {}).get("hbm_bytes_per_launch") for k in st_kernels]
             st_traffic = None if (not st_traffic or any(x is None for x in st_traffic)) else int(sum(st_traffic))
-            stage = {"name": "hash_backward", "kernels": st_kernels, "ms": round(st_ms, 4), "alg_bytes": int(st_bytes), "achieved": round(st_bytes / (st_ms * 1e-3) / 1e9, 1),
+            stage = {"name": "hash_backward+table_sweep" if rides else "hash_backward", "kernels": st_kernels, "ms": round(st_ms, 4), "alg_bytes": int(st_bytes), "achieved": round(st_bytes / (st_ms * 1e-3) / 1e9, 1),
                      "peak": 8000.0, "unit": "GB/s", "frac": round(st_bytes / (st_ms * 1e-3) / 8e12, 4),
                      # counter bytes of the stage's launches (this round's --pmc passes) over its algorithmic bytes: > 1 = records written and read back, re-reads
                      "traffic": st_traffic, "traffic_ratio": None if st_traffic is None else round(st_traffic / st_bytes, 3)}

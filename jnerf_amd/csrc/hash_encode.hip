@@ -618,10 +618,16 @@ __device__ __forceinline__ void rec_to_fixed(__half2 v, float, long long &ix, lo
 }
 __device__ __forceinline__ void rec_to_fixed(float2 v, float s32, long long &ix, long long &iy) { ix = __float2ll_rn(v.x * s32); iy = __float2ll_rn(v.y * s32); }
 
-template <typename G, typename RV>
+// (r6) ADAM: the table's Adam + EMA sweep rides here as it does in k_bin_accumulate2 below (see there): the eight entries a thread would store the gradient of get
+// optim.hip's update instead - fp32 master, both moments and, when the table has one, the fp16 shadow the gathers read.
+__device__ __forceinline__ void adam_ride_update(float &p, float &m, float &v, float g, const AdamRide &ar) {
+	float e = p;
+	if (ar.ema) adam_ema_update<true>(p, m, v, e, g, ar.c); else adam_ema_update<false>(p, m, v, e, g, ar.c);
+}
+template <typename G, typename RV, bool ADAM>
 __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan bp, LevelSel sel, const uint32_t *__restrict__ absmax_bits, const uint32_t *__restrict__ cursors,
                                                          void *__restrict__ rec_val_base, uint16_t *__restrict__ rec_idx_base, const uint32_t *__restrict__ spill_count,
-                                                         const SpillEntry *__restrict__ spill, G *__restrict__ grad, int overwrite) {
+                                                         const SpillEntry *__restrict__ spill, G *__restrict__ grad, int overwrite, AdamRide ar) {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long iacc[];   // [BIN_ENTRIES][2] 64-bit fixed point
 	using GP = typename Pair<G>::type;
 	constexpr bool F32 = sizeof(RV) == 8;
@@ -646,8 +652,20 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 	const SubLists sl = sub_lists(cursors + (hl * BINS_PER_LEVEL + bin) * CUR_SUBS, bp.cap, K);
 	const uint32_t count = sl.gstart[CUR_SUBS] * K + sl.tstart[CUR_SUBS];
 	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level];
+	float2 *P2 = nullptr, *M2 = nullptr, *V2 = nullptr; __half2 *H2 = nullptr;     // ADAM: the level's parameters, moments and fp16 shadow as pairs
+	if (ADAM) {
+		P2 = reinterpret_cast<float2 *>(ar.p) + lt.v[4 * level]; M2 = reinterpret_cast<float2 *>(ar.m) + lt.v[4 * level]; V2 = reinterpret_cast<float2 *>(ar.v) + lt.v[4 * level];
+		if (ar.p_half) H2 = reinterpret_cast<__half2 *>(ar.p_half) + lt.v[4 * level];
+	}
+	auto sweep_store = [&](uint32_t t, float2 p, float2 m, float2 v, float gx, float gy) {
+		adam_ride_update(p.x, m.x, v.x, gx, ar); adam_ride_update(p.y, m.y, v.y, gy, ar);
+		P2[t] = p; M2[t] = m; V2[t] = v;
+		if (H2) H2[t] = __floats2half2_rn(p.x, p.y);
+	};
 	if (s32 == 0.f || count == 0) {                                      // nothing to add: an accumulating destination is left alone, an overwritten one gets its zeros
-		if (overwrite) {
+		if (ADAM) {                                                         // ... and the sweep sees a zero gradient
+			for (uint32_t e = threadIdx.x; e < n_local; e += 1024) { const uint32_t t = entry_of(bin, e, il); if (t < size) sweep_store(t, P2[t], M2[t], V2[t], 0.f, 0.f); }
+		} else if (overwrite) {
 			GP zv; from_f2(zv, make_float2(0.f, 0.f));
 			for (uint32_t e = threadIdx.x; e < n_local; e += 1024) { const uint32_t t = entry_of(bin, e, il); if (t < size) dst[t] = zv; }
 		}
@@ -706,6 +724,24 @@ __global__ __launch_bounds__(1024) void k_bin_accumulate(LevelTable lt, BinPlan 
 		}
 	}
 	__syncthreads();
+	if (ADAM) {
+		static_assert(BIN_ENTRIES == 8u * 1024u, "eight entries per thread");
+		float2 rp[8], rm[8], rv[8];                                         // this thread's eight entries (the write-out's own assignment): all loads first
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k) {
+			const uint32_t e = threadIdx.x + k * 1024, t = e < n_local ? entry_of(bin, e, il) : ~0u;
+			rp[k] = rm[k] = rv[k] = make_float2(0.f, 0.f);
+			if (t < size) { rp[k] = P2[t]; rm[k] = M2[t]; rv[k] = V2[t]; }
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k) {
+			const uint32_t e = threadIdx.x + k * 1024, t = e < n_local ? entry_of(bin, e, il) : ~0u;
+			if (!(t < size)) continue;
+			const long long sx = (long long)iacc[2 * e], sy = (long long)iacc[2 * e + 1];
+			sweep_store(t, rp[k], rm[k], rv[k], (float)sx * inv, (float)sy * inv);
+		}
+		return;
+	}
 	for (uint32_t e0 = 0; e0 < n_local; e0 += 8u * 1024u) {                // (a full bin: one trip, all eight read-modify-write loads in flight)
 		GP oldv[8]; uint32_t tgt[8];
 #pragma unroll
@@ -1025,7 +1061,7 @@ __device__ __forceinline__ uint2 segment_row(const uint16_t *__restrict__ offs, 
 	const uint32_t q0 = (bin & 1u) ? o >> 16 : o & 0xffffu, q1 = (bin & 1u) ? o2 & 0xffffu : o >> 16;
 	return make_uint2(q1 - q0, (uint32_t)(region * region_records) + q0);
 }
-template <typename Rec, typename F>
+template <uint32_t B /* records in flight per thread */, typename Rec, typename F>
 __device__ __forceinline__ void gather_flat(const Rec *__restrict__ recs, const uint16_t *__restrict__ offs, uint32_t level_ord, uint32_t n_regions, uint32_t region_records,
                                             uint32_t offs_per_region, uint32_t bin, uint32_t *__restrict__ lds, uint32_t probe /* timing experiments: 1 = records loaded, not processed; 2 = not loaded */,
                                             uint2 row0 /* segment_row(..., 0), loaded by the caller ahead of time */, F process) {
@@ -1053,7 +1089,6 @@ __device__ __forceinline__ void gather_flat(const Rec *__restrict__ recs, const 
 		if (T >> 23) { T = (1u << 23) - 1u; }                               // (cannot happen below 8 M records per bin; keeps the packed entries well-formed)
 		if (len) { const uint32_t G = 1u << shift; for (uint32_t g = (p0 + G - 1u) >> shift; (g << shift) < p0 + len; ++g) map[g] = make_uint2((p0 + len) | (threadIdx.x << 23), st - p0); }   // (T < 2^23: 8 M records of one bin)
 		__syncthreads();
-		constexpr uint32_t B = 8;
 		for (uint32_t f0 = threadIdx.x; f0 < T; f0 += ACC2_WG * B) {
 			Rec x[B];
 #pragma unroll
@@ -1074,10 +1109,16 @@ __device__ __forceinline__ void gather_flat(const Rec *__restrict__ recs, const 
 	if (sink == 0x9e3779b9u) lds[0] = sink;                                 // (keeps the probe's loads alive)
 }
 
-template <typename G>
+// (r6) The table's Adam + EMA sweep can RIDE in this kernel (ADAM = true, fp32 table on one GPU with backward and sweep in one ngp_train_step call): a unit owns its
+// 4096 entries exclusively and holds their finished gradient sums in LDS, so the thread that would store a gradient pair applies optim.hip's adam_ema_update to the
+// parameter instead - the same arithmetic on the same float, hence the same bits as the separate k_adam_ema launch (test_fused_launches_of_the_native_step_change_no_bit).
+// The gradient itself is never written (48.8 MB out + 48.8 MB back in per iteration saved, one launch less), and the sweep's HBM streams run beside the other resident
+// workgroups' LDS-atomic phases: 103 us for both jobs against 70 + 49 us as two launches (+3.7 % it/s, profiles/r06l_ab_variants.txt).  Requesting the unit's p, m, v
+// BEFORE the record gather (48 registers per thread held across it, six to eight records in flight) was measured too and is slower than loading them here: 110 - 114 us.
+template <typename G, bool ADAM>
 __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, BinPlan bp, LevelSel sel_pair, LevelSel sel_run, Acc2Plan ap, const uint32_t *__restrict__ absmax_bits,
                                                                const PairRec *__restrict__ prec, const uint16_t *__restrict__ poff, const RunRec *__restrict__ rrec, const uint16_t *__restrict__ roff,
-                                                               const uint32_t *__restrict__ spill_count, const SpillEntry *__restrict__ spill, G *__restrict__ grad, int overwrite) {
+                                                               const uint32_t *__restrict__ spill_count, const SpillEntry *__restrict__ spill, G *__restrict__ grad, int overwrite, AdamRide ar) {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long iacc[];   // [PAIR_BIN_ENTRIES][2] 64-bit fixed point
 	using GP = typename Pair<G>::type;
 	uint32_t *tables = reinterpret_cast<uint32_t *>(iacc + 2u * PAIR_BIN_ENTRIES);        // gather_flat's segment tables, behind the accumulators
@@ -1105,8 +1146,19 @@ __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, B
 	const float inv = s32 > 0.f ? 1.0f / s32 : 0.f;
 	const uint32_t ns = is_pair ? min(*spill_count, bp.spill_cap) : 0u;
 	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level];
+	constexpr uint32_t ACC2_B = 8u;                                        // records in flight per thread
+	float2 *P2 = nullptr, *M2 = nullptr, *V2 = nullptr;                  // ADAM: the level's parameters and moments as pairs
+	if (ADAM) { P2 = reinterpret_cast<float2 *>(ar.p) + lt.v[4 * level]; M2 = reinterpret_cast<float2 *>(ar.m) + lt.v[4 * level]; V2 = reinterpret_cast<float2 *>(ar.v) + lt.v[4 * level]; }
 	if (s32 == 0.f) {                                                     // the level has no gradient: an accumulating destination is left alone, an overwritten one gets its zeros
-		if (overwrite) {
+		if (ADAM) {                                                         // ... and the sweep sees a zero gradient (the moments decay, the parameter follows them)
+			for (uint32_t e = threadIdx.x; e < n_local; e += ACC2_WG) {
+				const uint32_t t = entry2_of(bin, e, il);
+				if (t >= size) continue;
+				float2 p = P2[t], m = M2[t], v = V2[t];
+				adam_ride_update(p.x, m.x, v.x, 0.f, ar); adam_ride_update(p.y, m.y, v.y, 0.f, ar);
+				P2[t] = p; M2[t] = m; V2[t] = v;
+			}
+		} else if (overwrite) {
 			GP zv; from_f2(zv, make_float2(0.f, 0.f));
 			for (uint32_t e = threadIdx.x; e < n_local; e += ACC2_WG) { const uint32_t t = entry2_of(bin, e, il); if (t < size) dst[t] = zv; }
 		}
@@ -1133,7 +1185,7 @@ __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, B
 		add64(&iacc[2 * local + 1], (unsigned long long)iy);
 	};
 	if (is_pair) {
-		gather_flat(prec, poff, ord, ap.pair_regions, ap.pair_region_records, PAIR_OFFS, bin, tables, ap.probe, row0, [&](const PairRec &r) {
+		gather_flat<ACC2_B>(prec, poff, ord, ap.pair_regions, ap.pair_region_records, PAIR_OFFS, bin, tables, ap.probe, row0, [&](const PairRec &r) {
 			const float w0 = 1 - r.fx;
 			add_fixed(r.loc & (PAIR_BIN_ENTRIES - 1u), fixed_rn(r.a * w0, s32), fixed_rn(r.b * w0, s32));
 			add_fixed((r.loc >> PAIR_BIN_BITS) & (PAIR_BIN_ENTRIES - 1u), fixed_rn(r.a * r.fx, s32), fixed_rn(r.b * r.fx, s32));
@@ -1144,12 +1196,46 @@ __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, B
 			if ((se.key >> 19) == hl && (e >> PAIR_BIN_BITS) == bin) add_fixed(e & (PAIR_BIN_ENTRIES - 1u), __float2ll_rn(se.x * s32), __float2ll_rn(se.y * s32));
 		}
 	} else {
-		gather_flat(rrec, roff, ord, ap.run_regions, ap.run_region_records, RUN2_OFFS, bin, tables, ap.probe, row0, [&](const RunRec &r) {
+		gather_flat<ACC2_B>(rrec, roff, ord, ap.run_regions, ap.run_region_records, RUN2_OFFS, bin, tables, ap.probe, row0, [&](const RunRec &r) {
 			add_fixed(r.loc, fixed_rn(r.x, s32), fixed_rn(r.y, s32));
 		});
 	}
 	__syncthreads();
-	if (!il) {                                                            // a full bin: contiguous, two entries (16 bytes of fp32 gradient) per thread and trip
+	if (ADAM) {                                                           // the sweep instead of the gradient store: same entries per thread as below; all of a thread's loads first
+		static_assert(PAIR_BIN_ENTRIES == 8u * ACC2_WG, "eight entries per thread");
+		if (!il) {
+			float4 *Pq = reinterpret_cast<float4 *>(P2 + (bin << PAIR_BIN_BITS)), *Mq = reinterpret_cast<float4 *>(M2 + (bin << PAIR_BIN_BITS)), *Vq = reinterpret_cast<float4 *>(V2 + (bin << PAIR_BIN_BITS));
+			float4 rp[4], rm[4], rv[4];
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k) { const uint32_t q = threadIdx.x + k * ACC2_WG; rp[k] = Pq[q]; rm[k] = Mq[q]; rv[k] = Vq[q]; }
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k) {
+				const uint32_t q = threadIdx.x + k * ACC2_WG, e = 2u * q;
+				const long long s0 = (long long)iacc[2 * e], s1 = (long long)iacc[2 * e + 1], s2 = (long long)iacc[2 * e + 2], s3 = (long long)iacc[2 * e + 3];
+				float4 p = rp[k], m = rm[k], v = rv[k];
+				adam_ride_update(p.x, m.x, v.x, (float)s0 * inv, ar); adam_ride_update(p.y, m.y, v.y, (float)s1 * inv, ar);
+				adam_ride_update(p.z, m.z, v.z, (float)s2 * inv, ar); adam_ride_update(p.w, m.w, v.w, (float)s3 * inv, ar);
+				Pq[q] = p; Mq[q] = m; Vq[q] = v;
+			}
+		} else {
+			float2 rp[8], rm[8], rv[8];
+#pragma unroll
+			for (uint32_t k = 0; k < 8u; ++k) {
+				const uint32_t e = threadIdx.x + k * ACC2_WG, t = entry2_of(bin, e, il);
+				rp[k] = rm[k] = rv[k] = make_float2(0.f, 0.f);
+				if (e < n_local && t < size) { rp[k] = P2[t]; rm[k] = M2[t]; rv[k] = V2[t]; }
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < 8u; ++k) {
+				const uint32_t e = threadIdx.x + k * ACC2_WG, t = entry2_of(bin, e, il);
+				if (!(e < n_local && t < size)) continue;
+				const long long sx = (long long)iacc[2 * e], sy = (long long)iacc[2 * e + 1];
+				float2 p = rp[k], m = rm[k], v = rv[k];
+				adam_ride_update(p.x, m.x, v.x, (float)sx * inv, ar); adam_ride_update(p.y, m.y, v.y, (float)sy * inv, ar);
+				P2[t] = p; M2[t] = m; V2[t] = v;
+			}
+		}
+	} else if (!il) {                                                     // a full bin: contiguous, two entries (16 bytes of fp32 gradient) per thread and trip
 		GP *d = dst + (bin << PAIR_BIN_BITS);
 		for (uint32_t e = 2u * threadIdx.x; e < PAIR_BIN_ENTRIES; e += 2u * ACC2_WG) {
 			const long long s0 = (long long)iacc[2 * e], s1 = (long long)iacc[2 * e + 1], s2 = (long long)iacc[2 * e + 2], s3 = (long long)iacc[2 * e + 3];
@@ -1176,6 +1262,10 @@ __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, B
 	}
 	}
 }
+// the accumulate with the table's sweep riding, under its own name for NGP_LAUNCH's brackets (bench.py tells the two apart; rocprof shows the template arguments)
+#define k_bin_accumulate2_adam (k_bin_accumulate2<float, true>)
+#define k_bin_accumulate_adam_f32rec (k_bin_accumulate<float, float2, true>)
+#define k_bin_accumulate_adam_f16rec (k_bin_accumulate<float, __half2, true>)
 
 // Which levels can take the binned path: up to 2^19 entries, and indexed the way the record kernels index (dense, or the XOR hash masked by a power of two).
 // (aabb_scale 23.4 has a DENSE level with res 80 = 512000 entries - round 1 binned it with the XOR hash by looking at the size alone.)
@@ -1287,8 +1377,10 @@ static int hash_bwd_set_lds() {
 	SET((k_bin_pairs<float, NGP_LAYOUT_SOA, 1024u>), pair_stage_bytes()); SET((k_bin_pairs<float, NGP_LAYOUT_AOS, 1024u>), pair_stage_bytes());
 	SET((k_bin_runs2<float, NGP_LAYOUT_SOA, 5>), run2_stage_bytes(RUN2_STAGE)); SET((k_bin_runs2<float, NGP_LAYOUT_AOS, 5>), run2_stage_bytes(RUN2_STAGE));
 #undef SET_T
-	SET((k_bin_accumulate2<float>), PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA);
-	SET((k_bin_accumulate<float, float2>), BIN_ENTRIES * 16); SET((k_bin_accumulate<float, __half2>), BIN_ENTRIES * 16); SET((k_bin_accumulate<__half, float2>), BIN_ENTRIES * 16); SET((k_bin_accumulate<__half, __half2>), BIN_ENTRIES * 16);
+	SET((k_bin_accumulate2<float, false>), PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA);
+	SET((k_bin_accumulate2<float, true>), PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA);
+	SET((k_bin_accumulate<float, float2, false>), BIN_ENTRIES * 16); SET((k_bin_accumulate<float, __half2, false>), BIN_ENTRIES * 16); SET((k_bin_accumulate<__half, float2, false>), BIN_ENTRIES * 16); SET((k_bin_accumulate<__half, __half2, false>), BIN_ENTRIES * 16);
+	SET((k_bin_accumulate<float, float2, true>), BIN_ENTRIES * 16); SET((k_bin_accumulate<float, __half2, true>), BIN_ENTRIES * 16);
 #undef SET
 	if (!rc) done[dev] = true;
 	return rc;
@@ -1298,8 +1390,10 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
                          void *grad, uint64_t n_params, int dtype, int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes,
                          hipEvent_t after_coarse = nullptr /* data parallel, overlapped exchange: recorded behind the accumulate launch of the run-combined (coarse) levels, which then is a launch of its own */,
                          bool absmax_done = false /* the abs-max partials, zeroed cursors and spill count are already in the workspace (written by the field backward kernel, ngp_hash_bwd_absmax_slots) */,
-                         const TailJobs *tail = nullptr /* (r6) jobs that may ride in the record launches (mlp_tail.h) */, int *tail_taken = nullptr /* set to 1 when they did */) {
+                         const TailJobs *tail = nullptr /* (r6) jobs that may ride in the record launches (mlp_tail.h) */, int *tail_taken = nullptr /* set to 1 when they did */,
+                         const AdamRide *adam = nullptr /* (r6) the table's Adam + EMA sweep, applied by the accumulate kernel INSTEAD of storing the gradient */, int *adam_taken = nullptr /* set to 1 when it was */) {
 	if (tail_taken) *tail_taken = 0;
+	if (adam_taken) *adam_taken = 0;
 	NGP_REQUIRE(grad && level_table_host && (n == 0 || (pos && dLdy)), NGP_E_ARG, "ngp_hash_encode_bwd: null pointer");
 	NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_E_DTYPE, "ngp_hash_encode_bwd: bad dtype %d", dtype);
 	NGP_REQUIRE(grad_dtype == NGP_F32 || (grad_dtype == NGP_F16 && dtype == NGP_F16), NGP_E_DTYPE, "ngp_hash_encode_bwd: bad grad dtype %d for dtype %d", grad_dtype, dtype);
@@ -1362,6 +1456,17 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 #else
 	const uint32_t acc_probe = 0u;
 #endif
+	// (r6) the table's sweep rides in the accumulate launches when together they OVERWRITE the whole table: every level is a unit level on the workspace paths, so that is
+	// "the levels tile [0, n_params) without gaps" (every table GridEncode builds), an fp32 gradient (the sweep's input) and no data-parallel exchange between the two
+	// (after_coarse); anything else leaves the sweep to the caller.  The fp32 region kernel has no shadow to write.
+	bool ride = adam && adam->p && adam->m && adam->v && ow && !after_coarse && grad_dtype == NGP_F32 && (((uintptr_t)adam->p | (uintptr_t)adam->m | (uintptr_t)adam->v) & 15u) == 0 &&
+	            (((uintptr_t)adam->p_half) & 7u) == 0 && !(regions && adam->p_half);
+	if (ride) {
+		uint64_t covered = 0;
+		for (int l = 0; l < 16; ++l) { if ((uint64_t)lt.v[4 * l] * 2u != covered || (lt.v[4 * l] & 1u)) ride = false; covered += (uint64_t)lt.v[4 * l + 1] * 2u; }
+		if (covered != n_params) ride = false;
+	}
+	const AdamRide no_ride{nullptr, nullptr, nullptr, nullptr, AdamConsts{}, 0};
 #define ABSMAX(T, L) do { if (!absmax_done) NGP_LAUNCH((k_level_absmax<T, L>), dim3(ABSMAX_OWN_PARTS, 16), dim3(256), 0, s, n, (const T *)dLdy, absmax, n_valid, cursors, spill_count); } while (0)   /* also zeroes the cursors and the spill count */
 	if (regions) {
 		// fp32 -> fp32: run records + edge records in regions, no global atomics, ONE accumulate kernel - two launches of it when the data-parallel exchange wants the coarse levels first
@@ -1393,11 +1498,17 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 			ap.probe = acc_probe;
 			const uint32_t n_units = (ap.n_pair + ap.n_run) * PAIR_BINS;
 			if (!n_units) return;
-			NGP_LAUNCH((k_bin_accumulate2<float>), dim3(n_units), dim3(ACC2_WG), PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA, s, lt, bp, sel_pair, sel_runs, ap, (const uint32_t *)absmax, (const PairRec *)pair_rec,
-			           (const uint16_t *)pair_off, (const RunRec *)run_rec, (const uint16_t *)run_off, (const uint32_t *)spill_count, (const SpillEntry *)spill, (float *)grad, ow);
+			if (ride) {
+				NGP_LAUNCH(k_bin_accumulate2_adam, dim3(n_units), dim3(ACC2_WG), PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA, s, lt, bp, sel_pair, sel_runs, ap, (const uint32_t *)absmax, (const PairRec *)pair_rec,
+				           (const uint16_t *)pair_off, (const RunRec *)run_rec, (const uint16_t *)run_off, (const uint32_t *)spill_count, (const SpillEntry *)spill, (float *)nullptr, 1, *adam);
+				return;
+			}
+			NGP_LAUNCH((k_bin_accumulate2<float, false>), dim3(n_units), dim3(ACC2_WG), PAIR_BIN_ENTRIES * 16u + ACC2_LDS_EXTRA, s, lt, bp, sel_pair, sel_runs, ap, (const uint32_t *)absmax, (const PairRec *)pair_rec,
+			           (const uint16_t *)pair_off, (const RunRec *)run_rec, (const uint16_t *)run_off, (const uint32_t *)spill_count, (const SpillEntry *)spill, (float *)grad, ow, no_ride);
 		};
 		if (after_coarse && n_runs && n_pair) { accumulate(true, false); (void)hipEventRecord(after_coarse, s); coarse_marked = true; accumulate(false, true); }
 		else accumulate(true, true);
+		if (ride && adam_taken) *adam_taken = 1;
 	} else {
 		// per-corner record lists (fp16 dL/dy): 6-byte fp16 records for the fine levels, fp32 run records for the coarse ones
 		void *rec_val = (void *)(ws + wl.rec_val);
@@ -1410,12 +1521,20 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 	ABSMAX(T, L); \
 	if (n_runs) NGP_LAUNCH((k_bin_records_runs<T, L, 4>), dim3(div_up(n, RUN_WG * RUN_K), n_runs), dim3(RUN_WG), run_stage_bytes(RUN_STAGE), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_runs, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid, RUN_STAGE, tj_pc); \
 	if (n_fine) NGP_LAUNCH((k_bin_records<T, L>), dim3(div_up(n, BIN_WG), n_fine), dim3(BIN_WG), bin_stage_bytes<T>(), s, n, pos, pos_stride, (const T *)dLdy, lt, bp, sel_fine, (const uint32_t *)absmax, cursors, rec_val, rec_idx, spill_count, spill, n_valid); \
-	if (sizeof(RV_) == 8 && !(after_coarse && n_runs && n_fine)) {   /* fp32 records, one type: one accumulate launch over all their levels */ \
-		if (n_all) NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_all * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
+	if (ride && sizeof(G) == 4) {                                    /* (r6) the table's sweep rides: same launches, the update in place of the gradient store */ \
+		if (sizeof(RV_) == 8) { \
+			if (n_all) NGP_LAUNCH(k_bin_accumulate_adam_f32rec, dim3(n_all * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (float *)nullptr, 1, *adam); \
+		} else { \
+			if (n_runs) NGP_LAUNCH(k_bin_accumulate_adam_f32rec, dim3(n_runs * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_runs, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (float *)nullptr, 1, *adam); \
+			if (n_fine) NGP_LAUNCH(k_bin_accumulate_adam_f16rec, dim3(n_fine * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_fine, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (float *)nullptr, 1, *adam); \
+		} \
+		if (adam_taken) *adam_taken = 1; \
+	} else if (sizeof(RV_) == 8 && !(after_coarse && n_runs && n_fine)) {   /* fp32 records, one type: one accumulate launch over all their levels */ \
+		if (n_all) NGP_LAUNCH((k_bin_accumulate<G, float2, false>), dim3(n_all * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_all, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow, no_ride); \
 	} else { \
-		if (n_runs) { NGP_LAUNCH((k_bin_accumulate<G, float2>), dim3(n_runs * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_runs, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
+		if (n_runs) { NGP_LAUNCH((k_bin_accumulate<G, float2, false>), dim3(n_runs * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_runs, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow, no_ride); \
 			if (after_coarse && n_fine) { (void)hipEventRecord(after_coarse, s); coarse_marked = true; } } \
-		if (n_fine) NGP_LAUNCH((k_bin_accumulate<G, RV_>), dim3(n_fine * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_fine, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow); \
+		if (n_fine) NGP_LAUNCH((k_bin_accumulate<G, RV_, false>), dim3(n_fine * BINS_PER_LEVEL), dim3(1024), BIN_ENTRIES * 16, s, lt, bp, sel_fine, (const uint32_t *)absmax, (const uint32_t *)cursors, rec_val, rec_idx, (const uint32_t *)spill_count, (const SpillEntry *)spill, (G *)grad, ow, no_ride); \
 	} } while (0)
 		if (dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(float, float, NGP_LAYOUT_SOA); else GO(float, float, NGP_LAYOUT_AOS); }
 		else if (grad_dtype == NGP_F32) { if (in_layout == NGP_LAYOUT_SOA) GO(__half, float, NGP_LAYOUT_SOA); else GO(__half, float, NGP_LAYOUT_AOS); }
@@ -1431,9 +1550,9 @@ static int hash_bwd_impl(void *stream, uint32_t n, const float *pos, uint32_t po
 // the workspace path with the data-parallel marker and the fused abs-max (csrc/train_step.hip); not part of the public ABI
 int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host, void *grad, uint64_t n_params, int dtype,
                                   int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse, int absmax_done,
-                                  const TailJobs *tail, int *tail_taken) {
+                                  const TailJobs *tail, int *tail_taken, const AdamRide *adam, int *adam_taken) {
 	return hash_bwd_impl(stream, n, pos, pos_stride, dLdy, level_table_host, grad, n_params, dtype, grad_dtype, in_layout, zero_first, n_valid, workspace, workspace_bytes, after_coarse, absmax_done != 0,
-	                     tail, tail_taken);
+	                     tail, tail_taken, adam, adam_taken);
 }
 // mirrors the routing of hash_bwd_impl: the slots are handed out only when that call will read them (grad: the gradient buffer the call will be given)
 AbsmaxOut ngp_hash_bwd_absmax_slots(const uint32_t *level_table_host, uint32_t n, int dtype, int grad_dtype, void *workspace, uint64_t workspace_bytes, const void *grad) {

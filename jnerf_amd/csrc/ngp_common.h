@@ -26,10 +26,12 @@ struct NgpProfScope { int id; hipStream_t s; hipEvent_t a, b; NgpProfScope(int i
 
 // internal cross-file entry points (not exported)
 struct TailJobs;
+struct AdamRide;
 // tail (may be null) / tail_taken: jobs the call may carry in its record launches; *tail_taken says whether it did (else the caller launches them itself)
+// adam (may be null) / adam_taken: the table's sweep, applied by the accumulate kernel in place of the gradient store; *adam_taken says whether it was (the gradient buffer is NOT written then)
 int ngp_hash_encode_bwd_ws_marked(void *stream, uint32_t n, const float *pos, uint32_t pos_stride, const void *dLdy, const uint32_t *level_table_host, void *grad, uint64_t n_params, int dtype,
                                   int grad_dtype, int in_layout, int zero_first, const uint32_t *n_valid, void *workspace, uint64_t workspace_bytes, hipEvent_t after_coarse, int absmax_done,
-                                  const TailJobs *tail, int *tail_taken);
+                                  const TailJobs *tail, int *tail_taken, const AdamRide *adam, int *adam_taken);
 // Largest |dL/dfeature| per level, the scale of the hash scatter's fixed-point accumulation.  NGP_ABSMAX_PARTS partial maxima per level (bit patterns of
 // non-negative floats, 0 = none); the consumers take the maximum.  Written either by the scatter's own abs-max pass or - training path, r3 - by the field backward
 // kernel's epilogue (one partial per workgroup: no extra pass over the 33 MB of feature gradients, one launch less); that kernel then also zeroes the scatter's
@@ -149,6 +151,9 @@ __device__ __forceinline__ void adam_ema_update(float &p, float &m, float &v, fl
 	if (EMA) { pi = ((1 - c.ema_decay) * pi + c.ema_decay * e * c.debias_old) * c.debias_new; e = pi; }
 	p = pi;
 }
+
+// (r6) The hash table's Adam + EMA sweep as a rider of the hash backward's accumulate kernel (hash_encode.hip: k_bin_accumulate2_adam).
+struct AdamRide { float *p, *m, *v; __half *p_half /* the fp16 shadow the gathers read (fp16 configuration), or null */; AdamConsts c; int ema /* 0: none, else the EMA state IS the parameter (k_adam_ema's EMA == 2) */; };
 
 // (r6) Small jobs that RIDE in the grid of the hash backward's record kernels instead of being launches of their own (mlp_tail.h; all null / zero: nothing rides).
 // reduce: reduce_out[col] = sum over the MLP weight-gradient slabs, k_reduce_slabs' order, overwrite.  sweep: k_mlp32_sweep_pack's job on (pack, grad = reduce_out, m, v).

@@ -138,6 +138,7 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	// the flat fp32 weight pack among the optimiser tensors (fp32 network): its sweep also writes the next iteration's MFMA fragments (ngp_mlp32_sweep_pack)
 	int t_pack = -1;
 	bool t_pack_swept = false;                                   // (r6) the pack's sweep rode in the hash backward's launches
+	int t_table = -1;                                            // (r6) the hash table among the optimiser tensors, when ITS sweep rode in the accumulate kernel
 	if (T == NGP_F32) for (int t = 0; t < a->n_opt; ++t)
 		if (a->p[t] == (float *)a->wd && a->numel[t] == 10240 && (const float *)a->wc == (const float *)a->wd + 3072 && a->ema[t] == a->p[t] && !a->p_half[t] && a->g[t] == a->wgrad_flat && ow) t_pack = t;
 	// fp16 network: the two weight packs (density MLP 3072, colour MLP 7168 elements) whose gradients tile the flat weight-gradient buffer - swept by the slab reduction
@@ -219,8 +220,24 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 	} else {
 		STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, ow ? 0 : 1));
 	}
+	// (r6) single GPU, backward and sweep in one call: the TABLE's sweep rides in the accumulate kernel(s), which apply Adam + EMA to each entry in place of storing its
+	// gradient (k_bin_accumulate2_adam | k_bin_accumulate_adam_*; the call says whether its path could: adam_taken) - table_grad is not written in such a call
+	AdamRide ride{nullptr, nullptr, nullptr, nullptr, AdamConsts{}, 0};
+	if (do_sweep && !dp && !host_sharded && ow && !getenv("NGP_NO_ADAM_RIDE")) {
+		// the hash table among the optimiser tensors: fp32 configuration - the master IS what the gathers read; fp16 configuration - they read its fp16 shadow
+		for (int t = 0; t < a->n_opt; ++t)
+			if (a->g[t] == a->table_grad && a->numel[t] == a->n_params && (!a->ema[t] || a->ema[t] == a->p[t]) &&
+			    (T == NGP_F32 ? (a->p[t] == (float *)a->table && !a->p_half[t]) : (a->p_half[t] == a->table))) t_table = t;
+		if (t_table >= 0) {
+			ride.p = a->p[t_table]; ride.m = a->m[t_table]; ride.v = a->v[t_table]; ride.p_half = (__half *)a->p_half[t_table]; ride.ema = a->ema[t_table] ? 1 : 0;
+			ride.c = adam_consts(a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay, 1.0f);
+		}
+	}
+	int adam_taken = 0;
 	STAGE(NGP_STAGE_HASH_BWD, ngp_hash_encode_bwd_ws_marked(stream, a->n, a->pos, 3, a->dfeat, a->level_table_host, a->table_grad, a->n_params, T, NGP_F32, NGP_LAYOUT_SOA, ow ? 1 : 0, a->n_valid,
-	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr, am.parts != nullptr, (want_tail || want_tail16) ? &tail : nullptr, &tail_taken));
+	                                                        a->hash_workspace, a->hash_workspace_bytes, overlap ? side->coarse : nullptr, am.parts != nullptr, (want_tail || want_tail16) ? &tail : nullptr, &tail_taken,
+	                                                        t_table >= 0 ? &ride : nullptr, &adam_taken));
+	if (!adam_taken) t_table = -1;
 	if (want_tail && !tail_taken) { STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, 0)); }
 	if (want_tail16 && !tail_taken) {
 		STAGE(NGP_STAGE_REDUCE_SLABS, ngp_reduce_slabs_sweep(stream, a->wgrad_slabs, a->n_slabs, 10240, a->wgrad_flat, pk16, begin16, count16, a->lr, a->beta0, a->beta1, a->eps, a->step, a->ema_decay));
@@ -260,6 +277,8 @@ NGP_API int ngp_train_step(void *stream, const NgpTrainStep *a) {
 				const NgpDpPlan *pl = a->dp;
 				for (uint32_t b = 0; b < pl->n_buckets; ++b) if ((rc = sweep_range(stream, a, t, pl->shard_begin[b], pl->shard_count[b], wire, 0))) return rc;
 				if ((rc = sweep_range(stream, a, t, pl->tail_begin, pl->tail_count, false, 0))) return rc;
+			} else if (t == t_table) {
+				continue;                                        // swept by the accumulate kernel(s) of the hash backward
 			} else if (t == t_mlp16[0] || t == t_mlp16[1]) {
 				continue;                                        // already swept by ngp_reduce_slabs_sweep
 			} else if (t == t_pack) {

@@ -310,8 +310,9 @@ def test_bench_contract_small():
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["kernel"] in rf["ms_per_step_by_kernel"] and rf["launches_timed"] >= 8
     assert rf["ms_per_step_by_kernel"][rf["kernel"]] == max(rf["ms_per_step_by_kernel"].values())
-    assert {"k_hash_fwd_x2", "k_adam_ema", "k_composite_train"} <= set(d["extra"]["probe_kernels"])      # (r5: compositing forward + Huber + backward are one launch in the native step; r6: the fp32 gather runs two lanes per (sample, level))
-    assert not ({"k_reduce_slabs", "k_mlp32_sweep_pack"} & set(d["extra"]["probe_kernels"]))                # (r6: the MLP tail rides in the hash backward's record launches)
+    assert {"k_hash_fwd_x2", "k_bin_accumulate2_adam", "k_composite_train"} <= set(d["extra"]["probe_kernels"])      # (r5: compositing forward + Huber + backward are one launch in the native step; r6: the fp32 gather runs two lanes per (sample, level))
+    assert not ({"k_reduce_slabs", "k_mlp32_sweep_pack", "k_adam_ema", "k_bin_accumulate2"} & set(d["extra"]["probe_kernels"]))   # (r6: the MLP tail rides in the hash backward's record launches, the table's sweep in its accumulate kernel)
+    assert rf["stage"]["name"] == "hash_backward+table_sweep" and "k_bin_accumulate2_adam" in rf["stage"]["kernels"]
     assert any(k.startswith("k_march") for k in d["extra"]["probe_kernels"])
     # (r5) no fraction above 1 is printable: split-operand kernels are scored on the fp16 pipe they issue on; the whole-step HBM fraction is in the line;
     # `traffic` is null unless this round's counter pass of this scene is committed (this tiny scene has none)
@@ -581,4 +582,12 @@ def test_fused_launches_of_the_native_step_change_no_bit(fp16, monkeypatch):
     own, l_own = run()
     assert torch.equal(l_fused, l_own)
     for a, b in zip(fused, own):
+        assert torch.equal(a, b)
+    # (r6) fp32 configuration: the hash table's Adam + EMA sweep rides in the accumulate kernel (k_bin_accumulate2_adam applies the update where it would store the gradient,
+    # which then is never written).  NGP_NO_ADAM_RIDE leaves the gradient store + the k_adam_ema launch - same bits in the table, its moments and everything downstream
+    monkeypatch.delenv("NGP_NO_TAIL_RIDE", raising=False)
+    monkeypatch.setenv("NGP_NO_ADAM_RIDE", "1")
+    swept, l_swept = run()
+    assert torch.equal(l_fused, l_swept)
+    for a, b in zip(fused, swept):
         assert torch.equal(a, b)
