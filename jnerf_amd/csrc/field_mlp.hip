@@ -211,18 +211,55 @@ __device__ __forceinline__ void st_rows64(_Float16 *stage, int row0, int col, in
 }
 __device__ __forceinline__ half8 ld_rows(const _Float16 *stage, int row, int col) { return *reinterpret_cast<const half8 *>(stage + row * RS + col); }
 
+// ---- (r6) the transposed staging image (field_split.hip's, one plane): [sample row][neuron], 512-byte rows (256 neuron slots, 192 used).  A lane's four consecutive neurons
+// are ONE 8-byte store (30 per lane and trip instead of 120 ds_write_b16), and the weight-gradient phases read the operands back through the hardware transpose read
+// (ds_read_b64_tr_b16: sixteen lanes fetch a [4 samples][16 neurons] block, lane i receives neuron i's four samples) - the same values in the same k slots of the same
+// MFMAs, so the same bits.  The chunk index (four neurons = 8 bytes) is XORed with a function of the row so that both access patterns spread over the banks
+// (tools/microbench_trstage.hip: the analysis and the measurement behind the function).
+#define FT_ROW 256
+typedef short ft_short4 __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ int ft_f(int s) { return ((s & 3) << 2) | ((s >> 2) & 3) | (((s >> 3) & 1) << 4); }
+__device__ __forceinline__ int ft_off(int s, int c) { return s * FT_ROW + ((c ^ ft_f(s)) << 2); }                          // halves; c = chunk of four neurons, 0..63
+struct alignas(8) FtH4 { _Float16 v[4]; };
+__device__ __forceinline__ void st_chunk_T(_Float16 *stage, int s, int c, const half8 &h, int hi) {                        // slots 4 hi .. 4 hi + 3 of an operand
+	FtH4 a;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) a.v[j] = h[4 * hi + j];
+	*reinterpret_cast<FtH4 *>(stage + ft_off(s, c)) = a;
+}
+// the lane's eight slots of two k64 half-fragments (neurons nrow0 .. nrow0 + 63) / of one k32- or k64(0)-ordered fragment / the low four slots, as row `s`
+__device__ __forceinline__ void st_rows64_T(_Float16 *stage, int nrow0, int s, int g, const half8 &lo, const half8 &hi) {
+	st_chunk_T(stage, s, (nrow0 >> 2) + g, lo, 0); st_chunk_T(stage, s, (nrow0 >> 2) + 4 + g, lo, 1);                          // k64(0, g, j): 4g + j | 16 + 4g + (j - 4)
+	st_chunk_T(stage, s, (nrow0 >> 2) + 8 + g, hi, 0); st_chunk_T(stage, s, (nrow0 >> 2) + 12 + g, hi, 1);                    // k64(1, g, j): 32 + ...
+}
+__device__ __forceinline__ void st_rows32_T(_Float16 *stage, int nrow0, int s, int g, const half8 &v, bool k32_order) {
+	if (k32_order) { st_chunk_T(stage, s, (nrow0 >> 2) + 2 * g, v, 0); st_chunk_T(stage, s, (nrow0 >> 2) + 2 * g + 1, v, 1); }   // k32(g, j) = 8g + j
+	else { st_chunk_T(stage, s, (nrow0 >> 2) + g, v, 0); st_chunk_T(stage, s, (nrow0 >> 2) + 4 + g, v, 1); }
+}
+__device__ __forceinline__ void st_rows16_T(_Float16 *stage, int nrow0, int s, int g, const half8 &v) { st_chunk_T(stage, s, (nrow0 >> 2) + g, v, 0); }
+__device__ __forceinline__ half8 ld_rows_T(const _Float16 *stage, int nrow, int o, int s0) {      // neuron nrow + o (nrow a multiple of 4), samples s0 .. s0 + 7 (s0 a multiple of 8)
+	const ft_short4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ft_short4 *)(stage + ft_off(s0 + (o >> 2), (nrow >> 2) + (o & 3))));
+	const ft_short4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ft_short4 *)(stage + ft_off(s0 + 4 + (o >> 2), (nrow >> 2) + (o & 3))));
+	typedef short ft_short8 __attribute__((ext_vector_type(8)));
+	ft_short8 r;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) { r[j] = a[j]; r[4 + j] = b[j]; }
+	return __builtin_bit_cast(half8, r);
+}
+
 template <typename T> __device__ __forceinline__ void load_dout(const T *p, float o[4]);
 template <> __device__ __forceinline__ void load_dout<float>(const float *p, float o[4]) { float4 v = *reinterpret_cast<const float4 *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 template <> __device__ __forceinline__ void load_dout<__half>(const __half *p, float o[4]) { half4 v = *reinterpret_cast<const half4 *>(p); o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
 
-template <typename T, int LAYOUT>
+template <typename T, int LAYOUT, bool TR /* (r6) the transposed staging image: 8-byte stores + transpose reads */>
 __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                       const _Float16 *__restrict__ packed, const T *__restrict__ dout,
                                                       _Float16 *__restrict__ dfeat, float *__restrict__ slabs, const uint32_t *__restrict__ n_valid, AbsmaxOut am) {
 	float lmax[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // running max |dL/dfeature| (of the fp16 values as stored) of levels 8t + 2g + pr over this lane's samples (absmax_epilogue)
 	extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
 	_Float16 *wl = smem;                                         // 42 fragments
-	_Float16 *stage = smem + (N_FWD_FRAGS + N_BWD_FRAGS) * 512;  // [N_ROWS][RS]
+	_Float16 *stage = smem + (N_FWD_FRAGS + N_BWD_FRAGS) * 512;  // [N_ROWS][RS] | TR: [BT][FT_ROW]
+#define LDR(nrow, cs) (TR ? ld_rows_T(stage, (nrow), o, (cs)) : ld_rows(stage, (nrow) + o, (cs)))
 	stage_weights(wl, packed, N_FWD_FRAGS + N_BWD_FRAGS);
 	const _Float16 *wb = wl + N_FWD_FRAGS * 512;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
@@ -295,41 +332,51 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 		// ---- weight gradients: dW[o][i] += sum_s dY[s][o] X[s][i]   (A = dY^T rows o, B = X columns i, k = sample), three staging phases
 		const int col = 16 * w + s, o = lane & 15;
 		// phase A
-		st_rows64(stage, 0, col, g, dG1lo, dG1hi);
-		st_rows64(stage, 64, col, g, st.g0[0], st.g0[1]);
+		if (TR) { st_rows64_T(stage, 0, col, g, dG1lo, dG1hi); st_rows64_T(stage, 64, col, g, st.g0[0], st.g0[1]); }
+		else { st_rows64(stage, 0, col, g, dG1lo, dG1hi); st_rows64(stage, 64, col, g, st.g0[0], st.g0[1]); }
 		__syncthreads();
-#pragma unroll
+#pragma unroll 2
 		for (int kb = 0; kb < BT / 32; ++kb) {
 			const int cs = 32 * kb + 8 * g;
-			const half8 a_dg1 = ld_rows(stage, 16 * to + o, cs);
-			aV1[0] = MFMA(a_dg1, ld_rows(stage, 64 + 16 * ti0 + o, cs), aV1[0]);
-			aV1[1] = MFMA(a_dg1, ld_rows(stage, 64 + 16 * (ti0 + 1) + o, cs), aV1[1]);
+			const half8 a_dg1 = LDR(16 * to, cs);
+			aV1[0] = MFMA(a_dg1, LDR(64 + 16 * ti0, cs), aV1[0]);
+			aV1[1] = MFMA(a_dg1, LDR(64 + 16 * (ti0 + 1), cs), aV1[1]);
 		}
 		__syncthreads();
 		// phase B
-		st_rows64(stage, 0, col, g, dHlo, dHhi);
-		st_rows64(stage, 96, col, g, dG0lo, dG0hi);
+		if (TR) {
+			st_rows64_T(stage, 0, col, g, dHlo, dHhi); st_rows64_T(stage, 96, col, g, dG0lo, dG0hi);
+			st_rows32_T(stage, 64, col, g, st.feat, true); st_rows32_T(stage, 160, col, g, st.in2, false);
+		} else {
+			st_rows64(stage, 0, col, g, dHlo, dHhi);
+			st_rows64(stage, 96, col, g, dG0lo, dG0hi);
 #pragma unroll
-		for (int j = 0; j < 8; ++j) { stage[(64 + k32(g, j)) * RS + col] = st.feat[j]; stage[(160 + k64(0, g, j)) * RS + col] = st.in2[j]; }
+			for (int j = 0; j < 8; ++j) { stage[(64 + k32(g, j)) * RS + col] = st.feat[j]; stage[(160 + k64(0, g, j)) * RS + col] = st.in2[j]; }
+		}
 		__syncthreads();
-#pragma unroll
+#pragma unroll 2
 		for (int kb = 0; kb < BT / 32; ++kb) {
 			const int cs = 32 * kb + 8 * g;
-			aW0 = MFMA(ld_rows(stage, 16 * to + o, cs), ld_rows(stage, 64 + 16 * tj + o, cs), aW0);
-			aV0 = MFMA(ld_rows(stage, 96 + 16 * to + o, cs), ld_rows(stage, 160 + 16 * tj + o, cs), aV0);
+			aW0 = MFMA(LDR(16 * to, cs), LDR(64 + 16 * tj, cs), aW0);
+			aV0 = MFMA(LDR(96 + 16 * to, cs), LDR(160 + 16 * tj, cs), aV0);
 		}
 		__syncthreads();
 		// phase C
+		if (TR) {
+			st_rows16_T(stage, 0, col, g, dDf); st_rows16_T(stage, 80, col, g, dO);
+			st_rows64_T(stage, 16, col, g, st.hfrag[0], st.hfrag[1]); st_rows64_T(stage, 96, col, g, st.g1[0], st.g1[1]);
+		} else {
 #pragma unroll
-		for (int j = 0; j < 4; ++j) { stage[(4 * g + j) * RS + col] = dDf[j]; stage[(80 + 4 * g + j) * RS + col] = dO[j]; }
-		st_rows64(stage, 16, col, g, st.hfrag[0], st.hfrag[1]);
-		st_rows64(stage, 96, col, g, st.g1[0], st.g1[1]);
+			for (int j = 0; j < 4; ++j) { stage[(4 * g + j) * RS + col] = dDf[j]; stage[(80 + 4 * g + j) * RS + col] = dO[j]; }
+			st_rows64(stage, 16, col, g, st.hfrag[0], st.hfrag[1]);
+			st_rows64(stage, 96, col, g, st.g1[0], st.g1[1]);
+		}
 		__syncthreads();
-#pragma unroll
+#pragma unroll 2
 		for (int kb = 0; kb < BT / 32; ++kb) {
 			const int cs = 32 * kb + 8 * g;
-			if (w < 4) aX = MFMA(ld_rows(stage, o, cs), ld_rows(stage, 16 + 16 * w + o, cs), aX);               // W1: dD^T x H tile w
-			else aX = MFMA(ld_rows(stage, 80 + o, cs), ld_rows(stage, 96 + 16 * (w - 4) + o, cs), aX);           // V2: dO^T x G1 tile w-4
+			if (w < 4) aX = MFMA(LDR(0, cs), LDR(16 + 16 * w, cs), aX);               // W1: dD^T x H tile w
+			else aX = MFMA(LDR(80, cs), LDR(96 + 16 * (w - 4), cs), aX);              // V2: dO^T x G1 tile w-4
 		}
 		__syncthreads();
 		if (more) cur = nxt;
@@ -348,6 +395,7 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 		else slab[3072 + 6144 + ro * 64 + 16 * (w - 4) + ci] = aX[r];
 	}
 	if (am.parts) absmax_epilogue(am, lmax, reinterpret_cast<float *>(stage), 8);      // (the trip loop ends with a barrier: the staging region is free)
+#undef LDR
 }
 
 // (r5) The free-running-groups variant of this kernel (k_field_bwd_g, NGP_FIELD_BWD_GROUPS = 2 | 3 | 4: round 3) is gone: alone it ran 61 -> 50 us, in the training step it
@@ -505,18 +553,21 @@ int ngp_field_bwd_am(void *stream, uint32_t n, const void *feat, int layout, con
 	NGP_REQUIRE(dir && dLdout && dLdfeat && wgrad_slabs && dir_stride >= 3, NGP_E_ARG, "ngp_field_bwd: null pointer");
 	NGP_REQUIRE((int)n_slabs == ngp_field_bwd_slabs(n), NGP_E_ARG, "ngp_field_bwd: n_slabs %u != ngp_field_bwd_slabs(%u)", n_slabs, n);
 	if (n == 0) return 0;
-	const size_t shmem = ((N_FWD_FRAGS + N_BWD_FRAGS) * 512 + N_ROWS * RS) * sizeof(_Float16);
+	static const bool tr = [] { const char *e = getenv("NGP_FIELD_TRSTAGE"); return !(e && e[0] == '0'); }();      // A/B hook: NGP_FIELD_TRSTAGE=0 = rounds 1-5's [neuron][sample] staging image (same bits)
+	const size_t shmem = ((N_FWD_FRAGS + N_BWD_FRAGS) * 512 + (tr ? BT * FT_ROW : N_ROWS * RS)) * sizeof(_Float16);
 	const dim3 grid(n_slabs), block(512);
 	hipStream_t s = (hipStream_t)stream;
 	const _Float16 *packed = pack_weights("ngp_field_bwd", s, wd, wc, N_FWD_FRAGS + N_BWD_FRAGS, layout_flags); if (!packed) return NGP_E_ARG;
-#define GO(T, L) do { \
+#define GOT(T, L, R) do { \
 	static bool attr_set = false; \
-	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field_bwd<T, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+	if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void *)k_field_bwd<T, L, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
 		if (e != hipSuccess) { ngp_set_error("ngp_field_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } attr_set = true; } \
-	NGP_LAUNCH((k_field_bwd<T, L>), grid, block, shmem, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid, am); } while (0)
+	NGP_LAUNCH((k_field_bwd<T, L, R>), grid, block, shmem, s, n, (const _Float16 *)feat, dir, dir_stride, packed, (const T *)dLdout, (_Float16 *)dLdfeat, wgrad_slabs, n_valid, am); } while (0)
+#define GO(T, L) do { if (tr) GOT(T, L, true); else GOT(T, L, false); } while (0)
 	if (out_dtype == NGP_F32) { if (layout == NGP_LAYOUT_SOA) GO(float, NGP_LAYOUT_SOA); else GO(float, NGP_LAYOUT_AOS); }
 	else { if (layout == NGP_LAYOUT_SOA) GO(__half, NGP_LAYOUT_SOA); else GO(__half, NGP_LAYOUT_AOS); }
 #undef GO
+#undef GOT
 	NGP_LAUNCH_CHECK("ngp_field_bwd");
 	return 0;
 }

@@ -1061,6 +1061,12 @@ __device__ __forceinline__ uint2 segment_row(const uint16_t *__restrict__ offs, 
 	const uint32_t q0 = (bin & 1u) ? o >> 16 : o & 0xffffu, q1 = (bin & 1u) ? o2 & 0xffffu : o >> 16;
 	return make_uint2(q1 - q0, (uint32_t)(region * region_records) + q0);
 }
+template <typename Rec> __device__ __forceinline__ Rec nt_ld_rec(const Rec *p) {
+	uint32_t w[sizeof(Rec) / 4];
+#pragma unroll
+	for (uint32_t k = 0; k < sizeof(Rec) / 4; ++k) w[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p) + k);
+	Rec r; __builtin_memcpy(&r, w, sizeof(Rec)); return r;
+}
 template <uint32_t B /* records in flight per thread */, typename Rec, typename F>
 __device__ __forceinline__ void gather_flat(const Rec *__restrict__ recs, const uint16_t *__restrict__ offs, uint32_t level_ord, uint32_t n_regions, uint32_t region_records,
                                             uint32_t offs_per_region, uint32_t bin, uint32_t *__restrict__ lds, uint32_t probe /* timing experiments: 1 = records loaded, not processed; 2 = not loaded */,
@@ -1098,7 +1104,11 @@ __device__ __forceinline__ void gather_flat(const Rec *__restrict__ recs, const 
 					uint2 e = map[f >> shift];
 					uint32_t w = e.x >> 23; e.x &= 0x7fffffu;
 					while (f >= e.x) e = seg[++w];                          // (rarely: f lies up to 2^shift - 1 records behind the mapped one; empty segments end where they begin: skipped)
+#ifndef ACC2_NO_NT
+					if (!(probe & 2u)) x[b] = nt_ld_rec(recs + e.y + f);
+#else
 					if (!(probe & 2u)) x[b] = recs[e.y + f];
+#endif
 				}
 			}
 #pragma unroll
@@ -1115,6 +1125,18 @@ __device__ __forceinline__ void gather_flat(const Rec *__restrict__ recs, const 
 // The gradient itself is never written (48.8 MB out + 48.8 MB back in per iteration saved, one launch less), and the sweep's HBM streams run beside the other resident
 // workgroups' LDS-atomic phases: 103 us for both jobs against 70 + 49 us as two launches (+3.7 % it/s, profiles/r06l_ab_variants.txt).  Requesting the unit's p, m, v
 // BEFORE the record gather (48 registers per thread held across it, six to eight records in flight) was measured too and is slower than loading them here: 110 - 114 us.
+// the moments and the records are touched once per iteration: as non-temporal accesses they leave the caches to the table the next forward gathers from
+// (profiles/r06m_ab_variants.txt: every kernel of the step 0-2 us shorter, +0.2 % it/s - inside the noise of a pair, consistent over both; -DACC2_NO_NT builds the plain accesses)
+typedef float f4v_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_ld4(const float4 *p) { const f4v_nt v = __builtin_nontemporal_load(reinterpret_cast<const f4v_nt *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void nt_st4(float4 *p, float4 v) { const f4v_nt t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<f4v_nt *>(p)); }
+#ifndef ACC2_NO_NT
+#define MV_LD(ptr) nt_ld4(ptr)
+#define MV_ST(ptr, val) nt_st4((ptr), (val))
+#else
+#define MV_LD(ptr) (*(ptr))
+#define MV_ST(ptr, val) (*(ptr) = (val))
+#endif
 template <typename G, bool ADAM>
 __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, BinPlan bp, LevelSel sel_pair, LevelSel sel_run, Acc2Plan ap, const uint32_t *__restrict__ absmax_bits,
                                                                const PairRec *__restrict__ prec, const uint16_t *__restrict__ poff, const RunRec *__restrict__ rrec, const uint16_t *__restrict__ roff,
@@ -1207,7 +1229,7 @@ __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, B
 			float4 *Pq = reinterpret_cast<float4 *>(P2 + (bin << PAIR_BIN_BITS)), *Mq = reinterpret_cast<float4 *>(M2 + (bin << PAIR_BIN_BITS)), *Vq = reinterpret_cast<float4 *>(V2 + (bin << PAIR_BIN_BITS));
 			float4 rp[4], rm[4], rv[4];
 #pragma unroll
-			for (uint32_t k = 0; k < 4u; ++k) { const uint32_t q = threadIdx.x + k * ACC2_WG; rp[k] = Pq[q]; rm[k] = Mq[q]; rv[k] = Vq[q]; }
+			for (uint32_t k = 0; k < 4u; ++k) { const uint32_t q = threadIdx.x + k * ACC2_WG; rp[k] = Pq[q]; rm[k] = MV_LD(Mq + q); rv[k] = MV_LD(Vq + q); }
 #pragma unroll
 			for (uint32_t k = 0; k < 4u; ++k) {
 				const uint32_t q = threadIdx.x + k * ACC2_WG, e = 2u * q;
@@ -1215,7 +1237,7 @@ __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, B
 				float4 p = rp[k], m = rm[k], v = rv[k];
 				adam_ride_update(p.x, m.x, v.x, (float)s0 * inv, ar); adam_ride_update(p.y, m.y, v.y, (float)s1 * inv, ar);
 				adam_ride_update(p.z, m.z, v.z, (float)s2 * inv, ar); adam_ride_update(p.w, m.w, v.w, (float)s3 * inv, ar);
-				Pq[q] = p; Mq[q] = m; Vq[q] = v;
+				Pq[q] = p; MV_ST(Mq + q, m); MV_ST(Vq + q, v);
 			}
 		} else {
 			float2 rp[8], rm[8], rv[8];

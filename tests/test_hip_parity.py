@@ -361,6 +361,44 @@ def test_field32_bwd_vs_oracle(H, n):
         assert not dw[3072 + 6144 + 3 * 64:].any()       # padded rows of the last layer stay zero
 
 
+_STAGING_SCRIPT = r"""
+import hashlib, sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from jnerf_amd import ops
+import synth
+n = 8192 + 17
+rng = np.random.default_rng(10)
+feat = (rng.normal(size=(n, 32)) * 0.5)
+d = synth.unit_dirs01(n, seed=11)
+wd, wc = synth.mlp_weights(12)
+dout = (np.random.default_rng(20).normal(size=(n, 4)) * 1e-2)
+T = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).cuda()
+for name, fn, dt in (("fp16", ops.field_bwd, np.float16), ("fp32", ops.field32_bwd, np.float32)):
+    for layout in (ops.LAYOUT_AOS, ops.LAYOUT_SOA):
+        f = feat if layout == ops.LAYOUT_AOS else feat.reshape(n, 16, 2).transpose(1, 0, 2)
+        dfeat, slabs = fn(T(f, dt), T(d, np.float32), T(wd, dt), T(wc, dt), T(dout, dt), layout=layout)
+        torch.cuda.synchronize()
+        print(name, layout, hashlib.sha256(dfeat.cpu().numpy().tobytes()).hexdigest(), hashlib.sha256(slabs.cpu().numpy().tobytes()).hexdigest(), float(slabs.abs().sum()))
+"""
+
+
+def test_field_backward_staging_images_give_the_same_bits():
+    """(r6) The weight-gradient operands of both field backward kernels are staged as a [sample][neuron] LDS image (8-byte stores) and read back through the hardware transpose
+    read (ds_read_b64_tr_b16); rounds 1-5 staged [neuron][sample] with 2-byte stores.  Same operands in the same k slots of the same MFMAs: feature gradients and the
+    weight-gradient slabs must be bit-identical (the switches are read once per process: one subprocess each)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _STAGING_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
+    outs = []
+    for v in ("1", "0"):
+        env = dict(os.environ, NGP_FIELD_TRSTAGE=v, NGP_SPLIT_TRSTAGE=v)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith(("fp16", "fp32"))])
+    assert len(outs[0]) == 4 and outs[0] == outs[1], (outs[0], outs[1])
+    assert all(float(l.split()[-1]) > 0 for l in outs[0])
+
+
 @pytest.fixture(params=["serial", "coop"])
 def count_pass(request):
     """ngp_march_rays_compacted picks its count pass by samples per ray (thread-per-ray serial traversal | wave-cooperative evaluation of the ray's fixed t sequence);
