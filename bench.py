@@ -241,7 +241,7 @@ HASH_BWD_RIDE = ("k_bin_accumulate2_adam", "k_bin_accumulate_adam_f32rec", "k_bi
 
 
 
-PMC_ROUND = "r05"          # the round whose counter passes describe THIS tree's kernels (profiles/<round>_pmc.json)
+PMC_ROUND = "r06z"          # the round whose counter passes describe THIS tree's kernels (profiles/<round>_pmc.json)
 
 
 def pmc_lookup(config, scene):

@@ -303,6 +303,10 @@ typedef struct NgpTrainStep {
 	/* != 0: the gradient buffers are OVERWRITTEN by this step's backward (hash scatter with zero_first, slab reduction without accumulation) and the sweep does
 	 * not zero them afterwards - 4 B/parameter less traffic than accumulate-then-zero.  0: gradients are accumulated into and zeroed by the sweep. */
 	int32_t grad_overwrite;
+	/* (r6, no layout change) With grad_overwrite != 0, phase NGP_PHASE_ALL, run_optimizer != 0 and no communicator / plan (one GPU), the hash table's sweep is applied by
+	 * the hash backward's accumulate kernel(s) in place of the gradient store (same update on the same values - bit-identical parameters and moments): the contents of
+	 * table_grad after such a call are UNSPECIFIED (the reference's optimizer.step(loss) exposes no gradient either).  A caller that wants the table's gradient runs
+	 * NGP_PHASE_BACKWARD (complete in table_grad) and NGP_PHASE_SWEEP, or sets NGP_NO_ADAM_RIDE=1 in the environment (A/B hook). */
 	/* ---- (ABI 2) phases and data parallelism.  phase: NGP_PHASE_ALL = the whole iteration; NGP_PHASE_BACKWARD = everything up to and including the hash
 	 * scatter (gradients complete in table_grad / wgrad_flat, no sweep); NGP_PHASE_SWEEP = only the Adam+EMA sweeps.  A host that owns its own collective (gloo
 	 * in the two-ranks-on-one-GPU tests, Jittor's MPI hooks) calls BACKWARD, reduces the two gradient buffers, calls SWEEP.

@@ -19,7 +19,8 @@
 //    accumulate kernel for all levels (k_bin_runs2 / k_bin_pairs / k_bin_accumulate2).  fp16 dL/dy (ngp_fox.py): round 2/3's per-corner record lists with cursor
 //    reservations (k_bin_records_runs / k_bin_records / k_bin_accumulate).  Without a workspace, with NGP_HASH_BWD_ATOMICS=1, or for a table the bins cannot take (a level
 //    beyond 2^19 entries, a hashed table that is not a power of two): the reference's scheme, one global float atomic per corner (k_hash_bwd) - the ONE fallback since the
-//    owner-computes scan of rounds 1-2 was deleted in round 5.
+//    owner-computes scan of rounds 1-2 was deleted in round 5.  (r6) On the single-GPU training path the accumulate kernels of both workspace designs also apply the
+//    table's Adam + EMA sweep in place of the gradient store (AdamRide: k_bin_accumulate2<float, true>, k_bin_accumulate<float, RV, true>).
 #include "ngp_common.h"
 #include <stdlib.h>
 #include <string.h>

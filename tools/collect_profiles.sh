@@ -9,10 +9,10 @@
 set -u
 WHAT=${1:-all}
 CFGS=${2:-"lego fox"}
-TAG=${TAG:-r05}
+TAG=${TAG:-r06z}
 R=$PWD
 mkdir -p $R/gpurun_out
-BASE="python $R/bench.py --no-cpu-baseline --no-psnr --no-fox --no-neus --no-spheres"
+BASE="python $R/bench.py --no-cpu-baseline --no-psnr --no-fox --no-neus --no-spheres --no-lego-gate"
 PMC="--burn-in 64 --steps 16 --warmup 16"
 INC_RE="k_(hash|bin|field|adam|march|mscan|composite|grid|occ|generate|reduce|mlp32|pack|level|bitfield|refresh)"
 scene_of() { [ $1 = lego ] && echo bricks || echo spheres; }
@@ -25,6 +25,14 @@ for cfg in $CFGS; do
   KT=$(find /tmp/pf_$cfg -name "*.db" | head -1)
   (cd $R && python tools/rocprof_summary.py "$KT" gpurun_out/${TAG}_${cfg}_kernel_trace.md "bench.py --config $cfg (N=1, 1024 burn-in + 64 warm-up + 200 timed steps), rocprofv3 --kernel-trace --stats" 200 && python tools/rocprof_gaps.py "$KT" 128 > gpurun_out/${TAG}_${cfg}_timeline.txt)
 done
+fi
+# (r6) the real-fox leg (bench.py's extra.fox: ngp_fox.py on data/fox) under the kernel trace
+if [ $WHAT = all ] || [ $WHAT = trace ] || [ $WHAT = realfox ]; then
+  rm -rf /tmp/pf_realfox && mkdir -p /tmp/pf_realfox
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pf_realfox -o kt -- python $R/tools/fox_leg.py 200 > /tmp/pf_realfox/log 2>&1
+  grep "^fox_leg" /tmp/pf_realfox/log | tail -1 > $R/gpurun_out/${TAG}_realfox_wall.txt
+  KT=$(find /tmp/pf_realfox -name "*.db" | head -1)
+  (cd $R && python tools/rocprof_summary.py "$KT" gpurun_out/${TAG}_realfox_kernel_trace.md "python tools/fox_leg.py 200 (ngp_fox.py on data/fox: 1024 burn-in + 200 timed steps), rocprofv3 --kernel-trace --stats" 200 && python tools/rocprof_gaps.py "$KT" 128 > gpurun_out/${TAG}_realfox_timeline.txt)
 fi
 if [ $WHAT = all ] || [ $WHAT = pmc ]; then
 for cfg in $CFGS; do
