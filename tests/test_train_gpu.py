@@ -321,7 +321,8 @@ def test_bench_contract_small():
     assert st["alg_bytes"] > 0 and 0.0 < st["frac_hbm"] <= 1.0 and abs(st["GBps"] - st["alg_bytes"] / (d["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * st["GBps"] + 0.1
     assert rf["traffic"] is None and rf["traffic_source"] is None
     for k, row in d["extra"]["probe_kernels"].items():
-        assert row["frac_hbm"] <= 1.0 and row.get("frac_mfma", 0.0) <= 1.0, (k, row)
+        assert (row["frac_hbm"] is None and row.get("served_from_cache") and row["avg_launch_ms"] < 0.02) or row["frac_hbm"] <= 1.0, (k, row)      # (only a few-microsecond kernel on cache-resident data may exceed HBM's rate; it then carries no fraction)
+        assert row.get("frac_mfma", 0.0) <= 1.0, (k, row)
 
 
 def test_render_survives_sample_capacity_overflow():
