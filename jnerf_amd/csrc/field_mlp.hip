@@ -217,6 +217,13 @@ __device__ __forceinline__ half8 ld_rows(const _Float16 *stage, int row, int col
 // MFMAs, so the same bits.  The chunk index (four neurons = 8 bytes) is XORed with a function of the row so that both access patterns spread over the banks
 // (tools/microbench_trstage.hip: the analysis and the measurement behind the function).
 #define FT_ROW 256
+// Unrolling of the weight-gradient loops (four k steps per phase).  Fully unrolled, the transposed image's reads (two per operand) pushed the kernel to 256 VGPRs + scratch;
+// unrolled by two it needs 242 - and a 512-thread workgroup at 2 x 242 registers per SIMD lane leaves room for ONE 24-register wavefront of another kernel, so on the
+// sparse many-ray batches whose serial marcher (k_march_count, 300 us) holds two wavefronts on many SIMDs the workgroups had to wait for CUs to drain (90 us in the
+// procedural-fox trace against 45 us alone, profiles/r06z_fox_kernel_trace.md).  Not unrolled: 226.
+#ifndef FIELD_WG_UNROLL
+#define FIELD_WG_UNROLL 1
+#endif
 typedef short ft_short4 __attribute__((__vector_size__(4 * sizeof(short))));
 __device__ __forceinline__ int ft_f(int s) { return ((s & 3) << 2) | ((s >> 2) & 3) | (((s >> 3) & 1) << 4); }
 __device__ __forceinline__ int ft_off(int s, int c) { return s * FT_ROW + ((c ^ ft_f(s)) << 2); }                          // halves; c = chunk of four neurons, 0..63
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 		if (TR) { st_rows64_T(stage, 0, col, g, dG1lo, dG1hi); st_rows64_T(stage, 64, col, g, st.g0[0], st.g0[1]); }
 		else { st_rows64(stage, 0, col, g, dG1lo, dG1hi); st_rows64(stage, 64, col, g, st.g0[0], st.g0[1]); }
 		__syncthreads();
-#pragma unroll 2
+#pragma unroll FIELD_WG_UNROLL
 		for (int kb = 0; kb < BT / 32; ++kb) {
 			const int cs = 32 * kb + 8 * g;
 			const half8 a_dg1 = LDR(16 * to, cs);
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 			for (int j = 0; j < 8; ++j) { stage[(64 + k32(g, j)) * RS + col] = st.feat[j]; stage[(160 + k64(0, g, j)) * RS + col] = st.in2[j]; }
 		}
 		__syncthreads();
-#pragma unroll 2
+#pragma unroll FIELD_WG_UNROLL
 		for (int kb = 0; kb < BT / 32; ++kb) {
 			const int cs = 32 * kb + 8 * g;
 			aW0 = MFMA(LDR(16 * to, cs), LDR(64 + 16 * tj, cs), aW0);
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 			st_rows64(stage, 96, col, g, st.g1[0], st.g1[1]);
 		}
 		__syncthreads();
-#pragma unroll 2
+#pragma unroll FIELD_WG_UNROLL
 		for (int kb = 0; kb < BT / 32; ++kb) {
 			const int cs = 32 * kb + 8 * g;
 			if (w < 4) aX = MFMA(LDR(0, cs), LDR(16 + 16 * w, cs), aX);               // W1: dD^T x H tile w

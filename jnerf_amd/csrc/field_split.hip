@@ -45,7 +45,13 @@ struct B2 { half8 h, m; };
 __device__ __forceinline__ B2 split8(const float v[8]) {
 	B2 r;
 #pragma unroll
-	for (int k = 0; k < 8; ++k) { const _Float16 h = (_Float16)v[k]; r.h[k] = h; r.m[k] = (_Float16)((v[k] - (float)h) * SPLIT_SCALE); }
+	for (int k = 0; k < 8; ++k) {
+		const _Float16 h = (_Float16)v[k]; r.h[k] = h;
+		// (v - h) 2^11 as ONE fused multiply-add on the fp16 h and the pre-scaled v: v - h is exact in fp32 and so is every factor of two, so this is the same number as
+		// the subtract-then-multiply of rounds 3-5, bit for bit - but the compiler can issue it as v_fma_mixlo / mixhi_f16 (fp16 operand in, fp16 result out: no separate
+		// conversion of h back to fp32, no separate conversion of the residual)
+		r.m[k] = (_Float16)__builtin_fmaf((float)h, -SPLIT_SCALE, v[k] * SPLIT_SCALE);
+	}
 	return r;
 }
 __device__ __forceinline__ B2 split_relu(floatx4 a, floatx4 b) {
