@@ -446,7 +446,7 @@ def main():
         nbytes = float(alg.get(dom, 0.0))
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch: rocprofv3 cannot run inside this process, so this is a LOOK-UP in the committed --pmc FETCH_SIZE / WRITE_SIZE passes of this round's tree
-        # (tools/collect_profiles.sh -> profiles/r05_pmc.json).  Only a pass of THIS round, THIS configuration and THIS scene counts: anything else is
+        # (tools/collect_profiles.sh -> profiles/<PMC_ROUND>_pmc.json).  Only a pass of THIS round, THIS configuration and THIS scene counts: anything else is
         # another kernel generation or another workload, and `traffic` is null.
         counters = pmc.get(dom, {})
         traffic = counters.get("hbm_bytes_per_launch")
