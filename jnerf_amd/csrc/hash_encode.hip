@@ -1223,14 +1223,26 @@ __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, B
 			add_fixed(r.loc, fixed_rn(r.x, s32), fixed_rn(r.y, s32));
 		});
 	}
+#ifdef ACC2_PMV_BEFORE_BARRIER
+	// (A/B build) a full bin's p, m, v requested by each thread as soon as IT has processed its records - the loads then travel while the workgroup waits at the barrier for its
+	// slowest wavefront - instead of after the barrier
+	float4 rp[4], rm[4], rv[4];
+	if (ADAM && !il) {
+		const float4 *Pq = reinterpret_cast<const float4 *>(P2 + (bin << PAIR_BIN_BITS)), *Mq = reinterpret_cast<const float4 *>(M2 + (bin << PAIR_BIN_BITS)), *Vq = reinterpret_cast<const float4 *>(V2 + (bin << PAIR_BIN_BITS));
+#pragma unroll
+		for (uint32_t k = 0; k < 4u; ++k) { const uint32_t q = threadIdx.x + k * ACC2_WG; rp[k] = Pq[q]; rm[k] = MV_LD(Mq + q); rv[k] = MV_LD(Vq + q); }
+	}
+#endif
 	__syncthreads();
 	if (ADAM) {                                                           // the sweep instead of the gradient store: same entries per thread as below; all of a thread's loads first
 		static_assert(PAIR_BIN_ENTRIES == 8u * ACC2_WG, "eight entries per thread");
 		if (!il) {
 			float4 *Pq = reinterpret_cast<float4 *>(P2 + (bin << PAIR_BIN_BITS)), *Mq = reinterpret_cast<float4 *>(M2 + (bin << PAIR_BIN_BITS)), *Vq = reinterpret_cast<float4 *>(V2 + (bin << PAIR_BIN_BITS));
+#ifndef ACC2_PMV_BEFORE_BARRIER
 			float4 rp[4], rm[4], rv[4];
 #pragma unroll
 			for (uint32_t k = 0; k < 4u; ++k) { const uint32_t q = threadIdx.x + k * ACC2_WG; rp[k] = Pq[q]; rm[k] = MV_LD(Mq + q); rv[k] = MV_LD(Vq + q); }
+#endif
 #pragma unroll
 			for (uint32_t k = 0; k < 4u; ++k) {
 				const uint32_t q = threadIdx.x + k * ACC2_WG, e = 2u * q;
