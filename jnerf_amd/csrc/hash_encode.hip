@@ -1169,7 +1169,10 @@ __global__ __launch_bounds__(ACC2_WG, 4) void k_bin_accumulate2(LevelTable lt, B
 	const float inv = s32 > 0.f ? 1.0f / s32 : 0.f;
 	const uint32_t ns = is_pair ? min(*spill_count, bp.spill_cap) : 0u;
 	GP *dst = reinterpret_cast<GP *>(grad) + lt.v[4 * level];
-	constexpr uint32_t ACC2_B = 8u;                                        // records in flight per thread
+#ifndef ACC2_RECORDS_IN_FLIGHT
+#define ACC2_RECORDS_IN_FLIGHT 8u
+#endif
+	constexpr uint32_t ACC2_B = ACC2_RECORDS_IN_FLIGHT;                    // records in flight per thread
 	float2 *P2 = nullptr, *M2 = nullptr, *V2 = nullptr;                  // ADAM: the level's parameters and moments as pairs
 	if (ADAM) { P2 = reinterpret_cast<float2 *>(ar.p) + lt.v[4 * level]; M2 = reinterpret_cast<float2 *>(ar.m) + lt.v[4 * level]; V2 = reinterpret_cast<float2 *>(ar.v) + lt.v[4 * level]; }
 	if (s32 == 0.f) {                                                     // the level has no gradient: an accumulating destination is left alone, an overwritten one gets its zeros
