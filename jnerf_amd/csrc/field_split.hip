@@ -291,14 +291,37 @@ __device__ __forceinline__ half8 ld_tr8(const _Float16 *stage, int plane, int nr
 	for (int j = 0; j < 4; ++j) { r[j] = a[j]; r[4 + j] = b[j]; }
 	return __builtin_bit_cast(half8, r);
 }
+// (r6b) The staging region starts 84 KiB into the workgroup's LDS and a DS instruction's immediate offset is 16 bits: left to the compiler, every transpose read's address was
+// "lane part + 0x15000 + block" with the constant beyond the immediate's reach - one v_add_u32 per read, 20 per loop iteration.  Here the four lane-dependent addresses of a
+// tile (operand a | b, sample rows +0 | +4 of the first step, plane 0) are formed once, made opaque to constant re-association, and every other block of the tile is an
+// immediate behind one of them: a step = 32 sample rows = 8 KiB, plane 1 = 32 KiB, at most 0xE000.  (tr_f depends on the row's low four bits only, which a step keeps.)
+typedef __attribute__((address_space(3))) short4v lds_short4v;
+__device__ __forceinline__ uint32_t tr_lane_addr(const _Float16 *stage, int s, int c) {
+	uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const _Float16 *)(stage + tr_off(0, s, c));
+	asm("" : "+v"(a));
+	return a;
+}
+__device__ __forceinline__ half8 ld_tr8_at(uint32_t a0, uint32_t a4, uint32_t byte_off) {           // samples s .. s + 3 (a0) and s + 4 .. s + 7 (a4) of one neuron
+	const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v *)(a0 + byte_off));
+	const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v *)(a4 + byte_off));
+	typedef short short8v __attribute__((ext_vector_type(8)));
+	short8v r;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) { r[j] = a[j]; r[4 + j] = b[j]; }
+	return __builtin_bit_cast(half8, r);
+}
 __device__ __forceinline__ floatx4 wgrad3_T(const _Float16 *stage, int row_a, int row_b, int o, int g, int c0, int c1) {
 	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
 	Acc acc = {z, z};
+	const int s0 = c0 + 8 * g + (o >> 2);
+	const uint32_t a0 = tr_lane_addr(stage, s0, (row_a >> 2) + (o & 3)), a4 = tr_lane_addr(stage, s0 + 4, (row_a >> 2) + (o & 3));
+	const uint32_t b0 = tr_lane_addr(stage, s0, (row_b >> 2) + (o & 3)), b4 = tr_lane_addr(stage, s0 + 4, (row_b >> 2) + (o & 3));
+	constexpr uint32_t P1 = TPLANE * 2, STEP = 32 * 128 * 2;                                          // bytes
 #pragma unroll 2
 	for (int c = c0; c < c1; c += 32) {
-		const int s0 = c + 8 * g;
-		const half8 ah = ld_tr8(stage, 0, row_a, o, s0), am = ld_tr8(stage, 1, row_a, o, s0);
-		const half8 bh = ld_tr8(stage, 0, row_b, o, s0), bm = ld_tr8(stage, 1, row_b, o, s0);
+		const uint32_t off = (uint32_t)((c - c0) >> 5) * STEP;
+		const half8 ah = ld_tr8_at(a0, a4, off), am = ld_tr8_at(a0, a4, off + P1);
+		const half8 bh = ld_tr8_at(b0, b4, off), bm = ld_tr8_at(b0, b4, off + P1);
 		acc.main = MFMA16(ah, bh, acc.main);
 		acc.corr = MFMA16(ah, bm, acc.corr);
 		acc.corr = MFMA16(am, bh, acc.corr);
