@@ -68,18 +68,26 @@ __device__ __forceinline__ void stage_weights(_Float16 *lds, const _Float16 *__r
 }
 __device__ __forceinline__ half8 ld_frag(const _Float16 *lds, int f, int lane) { return *reinterpret_cast<const half8 *>(lds + f * 512 + lane * 8); }
 
+// (r6b) packed register arithmetic, written out: two accumulator values are ONE v_cvt_pk_f16_f32, and the ReLU is one v_pk_max_f16 on the pair - rounding is monotone and
+// keeps the sign, so max(fp16(x), 0) is fp16(max(x, 0)).  (Left to the compiler an activation was two v_max_f32 - one to quiet a NaN the matrix instruction might have
+// produced - and a scalar conversion, then a re-packing permute: 3.5 vector instructions per value, 1 now.)
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half2v cvt_pk(float a, float b) { return __builtin_convertvector((float2v){a, b}, half2v); }
+__device__ __forceinline__ half8 join4(half2v a, half2v b, half2v c, half2v d) {
+	return __builtin_bit_cast(half8, (uint4v){__builtin_bit_cast(unsigned int, a), __builtin_bit_cast(unsigned int, b), __builtin_bit_cast(unsigned int, c), __builtin_bit_cast(unsigned int, d)});
+}
 __device__ __forceinline__ half8 pack_relu(floatx4 a, floatx4 b) {
-	half8 r;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) { r[k] = (_Float16)fmaxf(a[k], 0.f); r[4 + k] = (_Float16)fmaxf(b[k], 0.f); }
-	return r;
+	const half2v z = {(_Float16)0, (_Float16)0};
+	return join4(__builtin_elementwise_max(cvt_pk(a[0], a[1]), z), __builtin_elementwise_max(cvt_pk(a[2], a[3]), z),
+	             __builtin_elementwise_max(cvt_pk(b[0], b[1]), z), __builtin_elementwise_max(cvt_pk(b[2], b[3]), z));
 }
 // relu'(pre-activation) * grad; the mask is taken from the fp32 accumulator (bit k of `mask` <-> slot k), not from the rounded fp16 activation
 __device__ __forceinline__ half8 pack_masked(floatx4 a, floatx4 b, uint32_t mask) {
-	half8 r;
+	floatx4 va, vb;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) { r[k] = (mask >> k) & 1u ? (_Float16)a[k] : (_Float16)0; r[4 + k] = (mask >> (4 + k)) & 1u ? (_Float16)b[k] : (_Float16)0; }
-	return r;
+	for (int k = 0; k < 4; ++k) { va[k] = (mask >> k) & 1u ? a[k] : 0.f; vb[k] = (mask >> (4 + k)) & 1u ? b[k] : 0.f; }
+	return join4(cvt_pk(va[0], va[1]), cvt_pk(va[2], va[3]), cvt_pk(vb[0], vb[1]), cvt_pk(vb[2], vb[3]));
 }
 __device__ __forceinline__ uint32_t relu_mask(floatx4 a, floatx4 b) {
 	uint32_t m = 0;
@@ -158,7 +166,7 @@ template <> __device__ __forceinline__ void store_out1<float>(float *p, float a)
 template <> __device__ __forceinline__ void store_out1<__half>(__half *p, float a) { *p = __float2half(a); }
 
 template <typename T, int LAYOUT, bool DENSITY_ONLY>
-__global__ __launch_bounds__(256) void k_field_fwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+__global__ __launch_bounds__(256, 2) void k_field_fwd(uint32_t n, const _Float16 *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                    const _Float16 *__restrict__ packed, T *__restrict__ out,
                                                    const uint32_t *__restrict__ n_valid) {
 	__shared__ __attribute__((aligned(16))) _Float16 wl[N_FWD_FRAGS * 512];
@@ -244,15 +252,29 @@ __device__ __forceinline__ void st_rows32_T(_Float16 *stage, int nrow0, int s, i
 	else { st_chunk_T(stage, s, (nrow0 >> 2) + g, v, 0); st_chunk_T(stage, s, (nrow0 >> 2) + 4 + g, v, 1); }
 }
 __device__ __forceinline__ void st_rows16_T(_Float16 *stage, int nrow0, int s, int g, const half8 &v) { st_chunk_T(stage, s, (nrow0 >> 2) + g, v, 0); }
-__device__ __forceinline__ half8 ld_rows_T(const _Float16 *stage, int nrow, int o, int s0) {      // neuron nrow + o (nrow a multiple of 4), samples s0 .. s0 + 7 (s0 a multiple of 8)
-	const ft_short4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ft_short4 *)(stage + ft_off(s0 + (o >> 2), (nrow >> 2) + (o & 3))));
-	const ft_short4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ft_short4 *)(stage + ft_off(s0 + 4 + (o >> 2), (nrow >> 2) + (o & 3))));
+// (r6b) An operand's transpose reads as immediates behind two lane-dependent addresses (sample rows +0 | +4 of the first k step) that are formed once per phase and made
+// opaque to the compiler's constant re-association: the staging image lies 42 KiB into the workgroup's LDS and spans 64 KiB, so "lane part + region base + step" mostly
+// exceeds a DS instruction's 16-bit immediate and every read had its own shift and three-operand add.  A k step is 32 sample rows = 16 KiB; ft_f depends on the row's low
+// four bits only, which a step keeps.
+struct TrAddr { uint32_t a0, a4; };
+__device__ __forceinline__ TrAddr ft_lane_addr(const _Float16 *stage, int nrow, int o, int s0) {    // neuron nrow + o (nrow a multiple of 4), samples s0 .. s0 + 7 (s0 a multiple of 8)
+	TrAddr r;
+	r.a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const _Float16 *)(stage + ft_off(s0 + (o >> 2), (nrow >> 2) + (o & 3)));
+	r.a4 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const _Float16 *)(stage + ft_off(s0 + 4 + (o >> 2), (nrow >> 2) + (o & 3)));
+	asm("" : "+v"(r.a0)); asm("" : "+v"(r.a4));
+	return r;
+}
+__device__ __forceinline__ half8 ld_rows_T_at(TrAddr t, uint32_t byte_off) {
+	typedef __attribute__((address_space(3))) ft_short4 lds_ft_short4;
+	const ft_short4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ft_short4 *)(uintptr_t)(t.a0 + byte_off));
+	const ft_short4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ft_short4 *)(uintptr_t)(t.a4 + byte_off));
 	typedef short ft_short8 __attribute__((ext_vector_type(8)));
 	ft_short8 r;
 #pragma unroll
 	for (int j = 0; j < 4; ++j) { r[j] = a[j]; r[4 + j] = b[j]; }
 	return __builtin_bit_cast(half8, r);
 }
+#define FT_KSTEP (32 * FT_ROW * 2)                                                               // bytes per k step
 
 template <typename T> __device__ __forceinline__ void load_dout(const T *p, float o[4]);
 template <> __device__ __forceinline__ void load_dout<float>(const float *p, float o[4]) { float4 v = *reinterpret_cast<const float4 *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 	extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
 	_Float16 *wl = smem;                                         // 42 fragments
 	_Float16 *stage = smem + (N_FWD_FRAGS + N_BWD_FRAGS) * 512;  // [N_ROWS][RS] | TR: [BT][FT_ROW]
-#define LDR(nrow, cs) (TR ? ld_rows_T(stage, (nrow), o, (cs)) : ld_rows(stage, (nrow) + o, (cs)))
+#define LDR(nrow, cs) ld_rows(stage, (nrow) + o, (cs))
 	stage_weights(wl, packed, N_FWD_FRAGS + N_BWD_FRAGS);
 	const _Float16 *wb = wl + N_FWD_FRAGS * 512;
 	uint32_t lim = n; if (n_valid) { uint32_t nv = *n_valid; lim = nv < n ? nv : n; }
@@ -342,12 +364,22 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 		if (TR) { st_rows64_T(stage, 0, col, g, dG1lo, dG1hi); st_rows64_T(stage, 64, col, g, st.g0[0], st.g0[1]); }
 		else { st_rows64(stage, 0, col, g, dG1lo, dG1hi); st_rows64(stage, 64, col, g, st.g0[0], st.g0[1]); }
 		__syncthreads();
+		if (TR) {
+			const TrAddr ta = ft_lane_addr(stage, 16 * to, o, 8 * g), tb0 = ft_lane_addr(stage, 64 + 16 * ti0, o, 8 * g), tb1 = ft_lane_addr(stage, 64 + 16 * (ti0 + 1), o, 8 * g);
 #pragma unroll FIELD_WG_UNROLL
-		for (int kb = 0; kb < BT / 32; ++kb) {
-			const int cs = 32 * kb + 8 * g;
-			const half8 a_dg1 = LDR(16 * to, cs);
-			aV1[0] = MFMA(a_dg1, LDR(64 + 16 * ti0, cs), aV1[0]);
-			aV1[1] = MFMA(a_dg1, LDR(64 + 16 * (ti0 + 1), cs), aV1[1]);
+			for (int kb = 0; kb < BT / 32; ++kb) {
+				const half8 a_dg1 = ld_rows_T_at(ta, kb * FT_KSTEP);
+				aV1[0] = MFMA(a_dg1, ld_rows_T_at(tb0, kb * FT_KSTEP), aV1[0]);
+				aV1[1] = MFMA(a_dg1, ld_rows_T_at(tb1, kb * FT_KSTEP), aV1[1]);
+			}
+		} else {
+#pragma unroll FIELD_WG_UNROLL
+			for (int kb = 0; kb < BT / 32; ++kb) {
+				const int cs = 32 * kb + 8 * g;
+				const half8 a_dg1 = LDR(16 * to, cs);
+				aV1[0] = MFMA(a_dg1, LDR(64 + 16 * ti0, cs), aV1[0]);
+				aV1[1] = MFMA(a_dg1, LDR(64 + 16 * (ti0 + 1), cs), aV1[1]);
+			}
 		}
 		__syncthreads();
 		// phase B
@@ -361,11 +393,21 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 			for (int j = 0; j < 8; ++j) { stage[(64 + k32(g, j)) * RS + col] = st.feat[j]; stage[(160 + k64(0, g, j)) * RS + col] = st.in2[j]; }
 		}
 		__syncthreads();
+		if (TR) {
+			const TrAddr ta = ft_lane_addr(stage, 16 * to, o, 8 * g), tb = ft_lane_addr(stage, 64 + 16 * tj, o, 8 * g);
+			const TrAddr tc = ft_lane_addr(stage, 96 + 16 * to, o, 8 * g), td = ft_lane_addr(stage, 160 + 16 * tj, o, 8 * g);
 #pragma unroll FIELD_WG_UNROLL
-		for (int kb = 0; kb < BT / 32; ++kb) {
-			const int cs = 32 * kb + 8 * g;
-			aW0 = MFMA(LDR(16 * to, cs), LDR(64 + 16 * tj, cs), aW0);
-			aV0 = MFMA(LDR(96 + 16 * to, cs), LDR(160 + 16 * tj, cs), aV0);
+			for (int kb = 0; kb < BT / 32; ++kb) {
+				aW0 = MFMA(ld_rows_T_at(ta, kb * FT_KSTEP), ld_rows_T_at(tb, kb * FT_KSTEP), aW0);
+				aV0 = MFMA(ld_rows_T_at(tc, kb * FT_KSTEP), ld_rows_T_at(td, kb * FT_KSTEP), aV0);
+			}
+		} else {
+#pragma unroll FIELD_WG_UNROLL
+			for (int kb = 0; kb < BT / 32; ++kb) {
+				const int cs = 32 * kb + 8 * g;
+				aW0 = MFMA(LDR(16 * to, cs), LDR(64 + 16 * tj, cs), aW0);
+				aV0 = MFMA(LDR(96 + 16 * to, cs), LDR(160 + 16 * tj, cs), aV0);
+			}
 		}
 		__syncthreads();
 		// phase C
@@ -379,11 +421,17 @@ __global__ __launch_bounds__(512, 1) void k_field_bwd(uint32_t n, const _Float16
 			st_rows64(stage, 96, col, g, st.g1[0], st.g1[1]);
 		}
 		__syncthreads();
+		if (TR) {                                                                     // W1: dD^T x H tile w (waves 0-3) | V2: dO^T x G1 tile w - 4
+			const TrAddr ta = ft_lane_addr(stage, w < 4 ? 0 : 80, o, 8 * g), tb = ft_lane_addr(stage, w < 4 ? 16 + 16 * w : 96 + 16 * (w - 4), o, 8 * g);
 #pragma unroll FIELD_WG_UNROLL
-		for (int kb = 0; kb < BT / 32; ++kb) {
-			const int cs = 32 * kb + 8 * g;
-			if (w < 4) aX = MFMA(LDR(0, cs), LDR(16 + 16 * w, cs), aX);               // W1: dD^T x H tile w
-			else aX = MFMA(LDR(80, cs), LDR(96 + 16 * (w - 4), cs), aX);              // V2: dO^T x G1 tile w-4
+			for (int kb = 0; kb < BT / 32; ++kb) aX = MFMA(ld_rows_T_at(ta, kb * FT_KSTEP), ld_rows_T_at(tb, kb * FT_KSTEP), aX);
+		} else {
+#pragma unroll FIELD_WG_UNROLL
+			for (int kb = 0; kb < BT / 32; ++kb) {
+				const int cs = 32 * kb + 8 * g;
+				if (w < 4) aX = MFMA(LDR(0, cs), LDR(16 + 16 * w, cs), aX);               // W1: dD^T x H tile w
+				else aX = MFMA(LDR(80, cs), LDR(96 + 16 * (w - 4), cs), aX);              // V2: dO^T x G1 tile w-4
+			}
 		}
 		__syncthreads();
 		if (more) cur = nxt;

@@ -42,42 +42,78 @@ int ngp_field32_pack_split(void *stream, const float *wd, const float *wc, void 
 }
 
 struct B2 { half8 h, m; };
-__device__ __forceinline__ B2 split8(const float v[8]) {
-	B2 r;
-#pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		const _Float16 h = (_Float16)v[k]; r.h[k] = h;
-		// (v - h) 2^11 as ONE fused multiply-add on the fp16 h and the pre-scaled v: v - h is exact in fp32 and so is every factor of two, so this is the same number as
-		// the subtract-then-multiply of rounds 3-5, bit for bit - but the compiler can issue it as v_fma_mixlo / mixhi_f16 (fp16 operand in, fp16 result out: no separate
-		// conversion of h back to fp32, no separate conversion of the residual)
-		r.m[k] = (_Float16)__builtin_fmaf((float)h, -SPLIT_SCALE, v[k] * SPLIT_SCALE);
-	}
+// (r6b) Packed register arithmetic, written out.  Left to the compiler the split of eight operands was ~3 vector instructions per operand plus re-packing moves (its SLP pass
+// pairs the residuals' fused multiply-adds into v_pk_fma_f32, which takes no fp16 operand: a conversion of h back to fp32 and a second conversion of the residual per operand,
+// and pairs taken across register-pair boundaries).  Here two operands are: one v_cvt_pk_f16_f32 (h, h'), and one v_fma_mix{lo,hi}_f16 each for m = fp16(fma(h, -2^11, v 2^11))
+// - the fp16 h read in place, the fp16 result written in place - on v 2^11 from a packed multiply.  Same bits as rounds 3-6a (same roundings in the same order).
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2v){a, b}, half2v)); }
+// The residuals are ONE asm statement per operand set, for three reasons the compiler cannot be told otherwise: (1) v_fma_mixhi_f16 must land in the register its mixlo
+// partner wrote; (2) gfx950 wants two wait states between a vector instruction's register write and a matrix instruction that reads it, and the compiler - which inserts
+// them for its own instructions - does not look into asm: the statement ends in s_nop 1 (2 cycles per eight operands); (3) a 16-bit partial write followed at once by a read
+// of the register is a forwarding hazard the compiler also handles only for its own instructions: all low halves first, then all high halves (>= 2 instructions apart).
+// The inputs come from v_cvt_pk_f16_f32 / v_pk_mul_f32 (vector ALU -> vector ALU is interlocked in hardware), never straight from a matrix instruction.
+// slots 0..3 <- a, 4..7 <- b  (wa / wb: the same values times 2^11)
+__device__ __forceinline__ B2 split_x4(floatx4 a, floatx4 b, floatx4 wa, floatx4 wb) {
+	const uint32_t h0 = cvt_pk(a[0], a[1]), h1 = cvt_pk(a[2], a[3]), h2 = cvt_pk(b[0], b[1]), h3 = cvt_pk(b[2], b[3]);
+	uint32_t m0, m1, m2, m3;
+	const float ns = -SPLIT_SCALE;
+	asm("v_fma_mixlo_f16 %0, %4, %16, %8 op_sel_hi:[1,0,0]\n\t"
+	    "v_fma_mixlo_f16 %1, %5, %16, %10 op_sel_hi:[1,0,0]\n\t"
+	    "v_fma_mixlo_f16 %2, %6, %16, %12 op_sel_hi:[1,0,0]\n\t"
+	    "v_fma_mixlo_f16 %3, %7, %16, %14 op_sel_hi:[1,0,0]\n\t"
+	    "v_fma_mixhi_f16 %0, %4, %16, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+	    "v_fma_mixhi_f16 %1, %5, %16, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+	    "v_fma_mixhi_f16 %2, %6, %16, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+	    "v_fma_mixhi_f16 %3, %7, %16, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+	    "s_nop 1"
+	    : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+	    : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wb[0]), "v"(wb[1]), "v"(wb[2]), "v"(wb[3]), "s"(ns));
+	B2 r; r.h = __builtin_bit_cast(half8, (uint4v){h0, h1, h2, h3}); r.m = __builtin_bit_cast(half8, (uint4v){m0, m1, m2, m3});
 	return r;
 }
-__device__ __forceinline__ B2 split_relu(floatx4 a, floatx4 b) {
-	float v[8];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) { v[k] = fmaxf(a[k], 0.f) * HID_PRESCALE; v[4 + k] = fmaxf(b[k], 0.f) * HID_PRESCALE; }
-	return split8(v);
+// slots 0..3 <- a, 4..7 zero
+__device__ __forceinline__ B2 split_x4_low(floatx4 a, floatx4 wa) {
+	const uint32_t h0 = cvt_pk(a[0], a[1]), h1 = cvt_pk(a[2], a[3]);
+	uint32_t m0, m1;
+	const float ns = -SPLIT_SCALE;
+	asm("v_fma_mixlo_f16 %0, %2, %8, %4 op_sel_hi:[1,0,0]\n\t"
+	    "v_fma_mixlo_f16 %1, %3, %8, %6 op_sel_hi:[1,0,0]\n\t"
+	    "s_nop 0\n\t"
+	    "v_fma_mixhi_f16 %0, %2, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+	    "v_fma_mixhi_f16 %1, %3, %8, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+	    "s_nop 1"
+	    : "=&v"(m0), "=&v"(m1)
+	    : "v"(h0), "v"(h1), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "s"(ns));
+	B2 r; r.h = __builtin_bit_cast(half8, (uint4v){h0, h1, 0u, 0u}); r.m = __builtin_bit_cast(half8, (uint4v){m0, m1, 0u, 0u});
+	return r;
 }
-// split8 that also folds the operands' magnitudes into rmax: the h part converted back (it is needed for the residual anyway; an overflowed operand reads as infinity)
+__device__ __forceinline__ B2 split8(const float v[8]) {
+	const floatx4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+	return split_x4(a, b, a * SPLIT_SCALE, b * SPLIT_SCALE);
+}
+// ReLU + prescale + split of two accumulator tiles given RAW (main + corr 2^-11, see combine_raw): operand = max(t, 0) 2^E.  Rounds 3-6a formed ((t S) relu) P with the
+// layer's combine scale S and the next layer's prescale P, two exact multiplications by powers of two; 2^E = S P is the same number (E = -4 behind the first layer: 2^-8 2^4;
+// 0 behind the hidden layers: 2^-4 2^4 - no multiplication at all).
+template <int E>
+__device__ __forceinline__ B2 split_relu_raw(floatx4 ta, floatx4 tb) {
+	const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+	floatx4 va = __builtin_elementwise_max(ta, z), vb = __builtin_elementwise_max(tb, z);
+	const floatx4 wa = va * (SPLIT_SCALE * __builtin_ldexpf(1.0f, E)), wb = vb * (SPLIT_SCALE * __builtin_ldexpf(1.0f, E));
+	if (E != 0) { va = va * __builtin_ldexpf(1.0f, E); vb = vb * __builtin_ldexpf(1.0f, E); }
+	return split_x4(va, vb, wa, wb);
+}
+// the operands' magnitudes folded into rmax: |h| as bit patterns order like the magnitudes (an overflowed operand reads 0x7c00): a packed unsigned 16-bit maximum over the
+// four registers of the h part
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ B2 split8(const float v[8], uint32_t &rmax) {
-	const B2 r = split8(v);
-	// |h| as bit patterns order like the magnitudes (an overflowed operand reads 0x7c00): a packed unsigned 16-bit maximum over the four registers of the h part
+__device__ __forceinline__ void range_fold(const B2 &r, uint32_t &rmax) {
 	const uint4v q = __builtin_bit_cast(uint4v, r.h) & 0x7fff7fffu;
 	ushort2v m = __builtin_bit_cast(ushort2v, rmax);
 #pragma unroll
 	for (int k = 0; k < 4; ++k) m = __builtin_elementwise_max(m, __builtin_bit_cast(ushort2v, q[k]));
 	rmax = __builtin_bit_cast(uint32_t, m);
-	return r;
-}
-__device__ __forceinline__ B2 split_relu(floatx4 a, floatx4 b, uint32_t &rmax) {
-	float v[8];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) { v[k] = fmaxf(a[k], 0.f) * HID_PRESCALE; v[4 + k] = fmaxf(b[k], 0.f) * HID_PRESCALE; }
-	return split8(v, rmax);
 }
 struct Acc { floatx4 main, corr; };
 __device__ __forceinline__ half8 ld_half8(const _Float16 *lds, int f, int lane) { return *reinterpret_cast<const half8 *>(lds + f * 512 + lane * 8); }
@@ -90,12 +126,13 @@ __device__ __forceinline__ void mma3(const _Float16 *wl, int f, int lane, const 
 	acc.corr = MFMA16(ah, b.m, acc.corr);
 	acc.corr = MFMA16(am, b.h, acc.corr);
 }
-__device__ __forceinline__ floatx4 combine(const Acc &a, float scale) {
-	floatx4 r;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) r[k] = (a.main[k] + a.corr[k] * (1.0f / SPLIT_SCALE)) * scale;
-	return r;
+// main + corr 2^-11 as ONE fused multiply-add per register pair (v_pk_fma_f32): the product by a power of two is exact, so this is the separate multiply and add of rounds
+// 3-6a bit for bit; a power-of-two scale on top commutes with the rounding
+__device__ __forceinline__ floatx4 combine_raw(const Acc &a) {
+	const floatx4 k = {1.0f / SPLIT_SCALE, 1.0f / SPLIT_SCALE, 1.0f / SPLIT_SCALE, 1.0f / SPLIT_SCALE};
+	return __builtin_elementwise_fma(a.corr, k, a.main);
 }
+__device__ __forceinline__ floatx4 combine(const Acc &a, float scale) { return combine_raw(a) * scale; }
 
 // degree-4 SH of (2d-1), components 4g..4g+3 (SphericalEncode.h:77-95)
 __device__ __forceinline__ void sh4_split(const float d[3], int g, float o[4]) {
@@ -127,30 +164,30 @@ __device__ __forceinline__ void forward_split(const _Float16 *wl, int lane, cons
 	float fs[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) fs[k] = feat[k] * FEAT_PRESCALE;
-	const B2 b0 = split8(fs, rmax);
+	const B2 b0 = split8(fs); range_fold(b0, rmax);
 	floatx4 c0[4];
 #pragma unroll
-	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, t, lane, b0, a); c0[t] = combine(a, 1.0f / FEAT_PRESCALE); }        // L0: 32 -> 64
-	const B2 h0 = split_relu(c0[0], c0[1], rmax), h1 = split_relu(c0[2], c0[3], rmax);
-	{ Acc a = {z, z}; mma3<MSTRIDE>(wl, 4, lane, h0, a); mma3<MSTRIDE>(wl, 5, lane, h1, a); den = combine(a, 1.0f / HID_PRESCALE); }               // L1: 64 -> 16
+	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, t, lane, b0, a); c0[t] = combine_raw(a); }                                     // L0: 32 -> 64  (raw: x 2^8)
+	const B2 h0 = split_relu_raw<-4>(c0[0], c0[1]), h1 = split_relu_raw<-4>(c0[2], c0[3]); range_fold(h0, rmax); range_fold(h1, rmax);
+	floatx4 dr;                                                                                                                                      // L1: 64 -> 16  (raw: x 2^4)
+	{ Acc a = {z, z}; mma3<MSTRIDE>(wl, 4, lane, h0, a); mma3<MSTRIDE>(wl, 5, lane, h1, a); dr = combine_raw(a); den = dr * (1.0f / HID_PRESCALE); }
 	if (DENSITY_ONLY) return;
-	float in2[8];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) { in2[k] = den[k] * HID_PRESCALE; in2[4 + k] = sh[k] * HID_PRESCALE; }
-	const B2 b2 = split8(in2, rmax);
+	const floatx4 shv = {sh[0], sh[1], sh[2], sh[3]};
+	const floatx4 shs = shv * HID_PRESCALE;
+	const B2 b2 = split_x4(dr, shs, dr * SPLIT_SCALE, shs * SPLIT_SCALE); range_fold(b2, rmax);                                                      // den 2^4 = the raw value
 	floatx4 c2[4];
 #pragma unroll
-	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, 6 + t, lane, b2, a); c2[t] = combine(a, 1.0f / HID_PRESCALE); }                       // L2: [density(16) | SH(16)] -> 64
-	const B2 g00 = split_relu(c2[0], c2[1], rmax), g01 = split_relu(c2[2], c2[3], rmax);
+	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, 6 + t, lane, b2, a); c2[t] = combine_raw(a); }                                  // L2: [density(16) | SH(16)] -> 64
+	const B2 g00 = split_relu_raw<0>(c2[0], c2[1]), g01 = split_relu_raw<0>(c2[2], c2[3]); range_fold(g00, rmax); range_fold(g01, rmax);
 	floatx4 c3[4];
 #pragma unroll
-	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, 10 + 2 * t, lane, g00, a); mma3<MSTRIDE>(wl, 11 + 2 * t, lane, g01, a); c3[t] = combine(a, 1.0f / HID_PRESCALE); }   // L3: 64 -> 64
-	const B2 g10 = split_relu(c3[0], c3[1], rmax), g11 = split_relu(c3[2], c3[3], rmax);
-	{ Acc a = {z, z}; mma3<MSTRIDE>(wl, 18, lane, g10, a); mma3<MSTRIDE>(wl, 19, lane, g11, a); rgb = combine(a, 1.0f / HID_PRESCALE); }                          // L4: 64 -> 16 (3 used)
+	for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MSTRIDE>(wl, 10 + 2 * t, lane, g00, a); mma3<MSTRIDE>(wl, 11 + 2 * t, lane, g01, a); c3[t] = combine_raw(a); }   // L3: 64 -> 64
+	const B2 g10 = split_relu_raw<0>(c3[0], c3[1]), g11 = split_relu_raw<0>(c3[2], c3[3]); range_fold(g10, rmax); range_fold(g11, rmax);
+	{ Acc a = {z, z}; mma3<MSTRIDE>(wl, 18, lane, g10, a); mma3<MSTRIDE>(wl, 19, lane, g11, a); rgb = combine(a, 1.0f / HID_PRESCALE); }             // L4: 64 -> 16 (3 used)
 }
 
 template <int LAYOUT, bool DENSITY_ONLY>
-__global__ __launch_bounds__(256) void k_field32_fwd_split(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
+__global__ __launch_bounds__(256, 2) void k_field32_fwd_split(uint32_t n, const float *__restrict__ feat, const float *__restrict__ dir, uint32_t dir_stride,
                                                            const _Float16 *__restrict__ packed, float *__restrict__ out, const uint32_t *__restrict__ n_valid) {
 	__shared__ __attribute__((aligned(16))) _Float16 wl[2 * NSPLIT_FWD * 512];
 	{	// both parts of the forward fragments this variant reads (density only: layers 0 and 1); the buffer holds NSPLIT_FRAGS fragments per part
@@ -212,10 +249,10 @@ __global__ __launch_bounds__(256) void k_field32_fwd_split(uint32_t n, const flo
                                               // overflows (2^7 was as accurate - powers of two are exact - but left only a 250-fold margin)
 
 __device__ __forceinline__ B2 split_masked(floatx4 a, floatx4 b, uint32_t mask) {           // relu'(pre-activation) * gradient, split
-	float v[8];
+	floatx4 va, vb;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) { v[k] = (mask >> k) & 1u ? a[k] : 0.f; v[4 + k] = (mask >> (4 + k)) & 1u ? b[k] : 0.f; }
-	return split8(v);
+	for (int k = 0; k < 4; ++k) { va[k] = (mask >> k) & 1u ? a[k] : 0.f; vb[k] = (mask >> (4 + k)) & 1u ? b[k] : 0.f; }
+	return split_x4(va, vb, va * SPLIT_SCALE, vb * SPLIT_SCALE);
 }
 __device__ __forceinline__ uint32_t relu_mask8(floatx4 a, floatx4 b) {
 	uint32_t m = 0;
@@ -252,7 +289,7 @@ __device__ __forceinline__ floatx4 wgrad3(const _Float16 *stage, int row_a, int 
 		acc.corr = MFMA16(ah, bm, acc.corr);
 		acc.corr = MFMA16(am, bh, acc.corr);
 	}
-	return combine(acc, 1.0f);
+	return combine_raw(acc);
 }
 // ---- (r6) the transposed staging image.  The image above is [neuron row][sample column]: a lane owns ONE sample and eight neurons of every operand, so it writes eight 2-byte
 // stores per operand half - 240 ds_write_b16 per lane and trip, 26 of the kernel's 120 us (profiles/r05a_split_probe.txt).  Here the image is [sample row][neuron]: a lane's four
@@ -302,8 +339,8 @@ __device__ __forceinline__ uint32_t tr_lane_addr(const _Float16 *stage, int s, i
 	return a;
 }
 __device__ __forceinline__ half8 ld_tr8_at(uint32_t a0, uint32_t a4, uint32_t byte_off) {           // samples s .. s + 3 (a0) and s + 4 .. s + 7 (a4) of one neuron
-	const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v *)(a0 + byte_off));
-	const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v *)(a4 + byte_off));
+	const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v *)(uintptr_t)(a0 + byte_off));
+	const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4v *)(uintptr_t)(a4 + byte_off));
 	typedef short short8v __attribute__((ext_vector_type(8)));
 	short8v r;
 #pragma unroll
@@ -326,7 +363,7 @@ __device__ __forceinline__ floatx4 wgrad3_T(const _Float16 *stage, int row_a, in
 		acc.corr = MFMA16(ah, bm, acc.corr);
 		acc.corr = MFMA16(am, bh, acc.corr);
 	}
-	return combine(acc, 1.0f);
+	return combine_raw(acc);
 }
 __device__ __forceinline__ floatx4 fma4(floatx4 acc, floatx4 v, float s) {
 #pragma unroll
@@ -404,40 +441,38 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 #pragma unroll
 		for (int k = 0; k < 8; ++k) fs[k] = cur.f[k] * FEAT_PRESCALE;
 		const B2 b0 = split8(fs);
-		floatx4 c[4];
+		floatx4 c[4];                                                             // RAW accumulator values from here on (combine_raw; the scales are folded into split_relu_raw)
 #pragma unroll
-		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wl, t, lane, b0, a); c[t] = combine(a, 1.0f / FEAT_PRESCALE); }
-		const B2 h0 = split_relu(c[0], c[1]), h1 = split_relu(c[2], c[3]);
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wl, t, lane, b0, a); c[t] = combine_raw(a); }
+		const B2 h0 = split_relu_raw<-4>(c[0], c[1]), h1 = split_relu_raw<-4>(c[2], c[3]);
 		const uint32_t mh0 = relu_mask8(c[0], c[1]), mh1 = relu_mask8(c[2], c[3]);
-		floatx4 den;
-		{ Acc a = {z, z}; mma3<MS>(wl, 4, lane, h0, a); mma3<MS>(wl, 5, lane, h1, a); den = combine(a, 1.0f / HID_PRESCALE); }
-		float in2[8];
+		floatx4 dr;
+		{ Acc a = {z, z}; mma3<MS>(wl, 4, lane, h0, a); mma3<MS>(wl, 5, lane, h1, a); dr = combine_raw(a); }
+		const floatx4 shs = (floatx4){sh[0], sh[1], sh[2], sh[3]} * HID_PRESCALE;
+		const B2 b2 = split_x4(dr, shs, dr * SPLIT_SCALE, shs * SPLIT_SCALE);
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { in2[k] = den[k] * HID_PRESCALE; in2[4 + k] = sh[k] * HID_PRESCALE; }
-		const B2 b2 = split8(in2);
-#pragma unroll
-		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wl, 6 + t, lane, b2, a); c[t] = combine(a, 1.0f / HID_PRESCALE); }
-		const B2 g00 = split_relu(c[0], c[1]), g01 = split_relu(c[2], c[3]);
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wl, 6 + t, lane, b2, a); c[t] = combine_raw(a); }
+		const B2 g00 = split_relu_raw<0>(c[0], c[1]), g01 = split_relu_raw<0>(c[2], c[3]);
 		const uint32_t mg00 = relu_mask8(c[0], c[1]), mg01 = relu_mask8(c[2], c[3]);
 #pragma unroll
-		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wl, 10 + 2 * t, lane, g00, a); mma3<MS>(wl, 11 + 2 * t, lane, g01, a); c[t] = combine(a, 1.0f / HID_PRESCALE); }
-		const B2 g10 = split_relu(c[0], c[1]), g11 = split_relu(c[2], c[3]);
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wl, 10 + 2 * t, lane, g00, a); mma3<MS>(wl, 11 + 2 * t, lane, g01, a); c[t] = combine_raw(a); }
+		const B2 g10 = split_relu_raw<0>(c[0], c[1]), g11 = split_relu_raw<0>(c[2], c[3]);
 		const uint32_t mg10 = relu_mask8(c[0], c[1]), mg11 = relu_mask8(c[2], c[3]);
 		// ---- dgrad chain on sigma-scaled gradients (register resident, transposed fragments), interleaved with the five weight-gradient phases in the order that
 		// releases registers soonest: a phase runs as soon as its gradient exists, and its activations (only the ReLU masks feed the chain) die with it.
 		// dW[o][i] += sum_s dY[s][o] X[s][i]   (A = dY^T rows o, B = X^T rows i, k = sample); a trip's tiles carry sigma and X's prescale.
 		const int col = 16 * w + s, o = lane & 15;
 		const float uH = inv_sigma * (1.0f / HID_PRESCALE), uF = inv_sigma * (1.0f / FEAT_PRESCALE);
-		float dov[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                       // slots j < 4 <-> output neuron 4g + j; only neurons 0..2 (g == 0) are non-zero
+		floatx4 dov = {0.f, 0.f, 0.f, 0.f};                                              // slots j < 4 <-> output neuron 4g + j; only neurons 0..2 (g == 0) are non-zero
 		if (g == 0) { dov[0] = cur.go[0] * sigma; dov[1] = cur.go[1] * sigma; dov[2] = cur.go[2] * sigma; }
-		const B2 dO = split8(dov);
+		const B2 dO = split_x4_low(dov, dov * SPLIT_SCALE);
 		// phase C2: V2 = dO x G1 (W1 / V2: each tile's samples split between waves w and w + 4)
 		if (PROBE != 1 && PROBE < 3) (TR ? st_rows16_T(stage, 0, col, g, dO) : st_rows16_2(stage, 0, col, g, dO));
 		if (PROBE != 1 && PROBE < 3) (TR ? st_rows64_T(stage, 16, col, g, g10, g11) : st_rows64_2(stage, 16, col, g, g10, g11));
 		if (PROBE < 4) __syncthreads();
 		if (PROBE < 2) aV2 = fma4(aV2, WG3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
 #pragma unroll
-		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, t, lane, dO, a); c[t] = combine(a, 1.0f); }
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, t, lane, dO, a); c[t] = combine_raw(a); }
 		const B2 dG1lo = split_masked(c[0], c[1], mg10), dG1hi = split_masked(c[2], c[3], mg11);
 		if (PROBE < 4) __syncthreads();
 		// phase A: V1 = dG1 x G0
@@ -447,7 +482,7 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 		if (PROBE < 2) aV1[0] = fma4(aV1[0], WG3(stage, 16 * to, 64 + 16 * ti0, o, g, 0, SBT), uH);
 		if (PROBE < 2) aV1[1] = fma4(aV1[1], WG3(stage, 16 * to, 64 + 16 * (ti0 + 1), o, g, 0, SBT), uH);
 #pragma unroll
-		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 4 + 2 * t, lane, dG1lo, a); mma3<MS>(wb, 5 + 2 * t, lane, dG1hi, a); c[t] = combine(a, 1.0f); }
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 4 + 2 * t, lane, dG1lo, a); mma3<MS>(wb, 5 + 2 * t, lane, dG1hi, a); c[t] = combine_raw(a); }
 		const B2 dG0lo = split_masked(c[0], c[1], mg00), dG0hi = split_masked(c[2], c[3], mg01);
 		if (PROBE < 4) __syncthreads();
 		// phase B2: V0 = dG0 x [density | SH]
@@ -456,10 +491,9 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 		if (PROBE < 4) __syncthreads();
 		if (PROBE < 2) aV0 = fma4(aV0, WG3(stage, 16 * to, 64 + 16 * tj, o, g, 0, SBT), uH);
 		floatx4 dD;
-		{ Acc a = {z, z}; mma3<MS>(wb, 12, lane, dG0lo, a); mma3<MS>(wb, 13, lane, dG0hi, a); dD = combine(a, 1.0f); }
+		{ Acc a = {z, z}; mma3<MS>(wb, 12, lane, dG0lo, a); mma3<MS>(wb, 13, lane, dG0hi, a); dD = combine_raw(a); }
 		if (g == 0) dD[0] += cur.go[3] * sigma;                                      // out[:,3] = den[:,0]  (ngp_network.py:83)
-		float ddv[8] = {dD[0], dD[1], dD[2], dD[3], 0.f, 0.f, 0.f, 0.f};
-		const B2 dDf = split8(ddv);
+		const B2 dDf = split_x4_low(dD, dD * SPLIT_SCALE);
 		if (PROBE < 4) __syncthreads();
 		// phase C1: W1 = dD x H
 		if (PROBE != 1 && PROBE < 3) (TR ? st_rows16_T(stage, 0, col, g, dDf) : st_rows16_2(stage, 0, col, g, dDf));
@@ -467,7 +501,7 @@ __global__ __launch_bounds__(512, 1) void k_field32_bwd_split(uint32_t n, const 
 		if (PROBE < 4) __syncthreads();
 		if (PROBE < 2) aW1 = fma4(aW1, WG3(stage, 0, 16 + 16 * tx, o, g, 64 * half, 64 * half + 64), uH);
 #pragma unroll
-		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 14 + t, lane, dDf, a); c[t] = combine(a, 1.0f); }
+		for (int t = 0; t < 4; ++t) { Acc a = {z, z}; mma3<MS>(wb, 14 + t, lane, dDf, a); c[t] = combine_raw(a); }
 		const B2 dHlo = split_masked(c[0], c[1], mh0), dHhi = split_masked(c[2], c[3], mh1);
 		if (PROBE < 4) __syncthreads();
 		// phase B1: W0 = dH x features
