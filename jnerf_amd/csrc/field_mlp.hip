@@ -225,12 +225,14 @@ __device__ __forceinline__ half8 ld_rows(const _Float16 *stage, int row, int col
 // MFMAs, so the same bits.  The chunk index (four neurons = 8 bytes) is XORed with a function of the row so that both access patterns spread over the banks
 // (tools/microbench_trstage.hip: the analysis and the measurement behind the function).
 #define FT_ROW 256
-// Unrolling of the weight-gradient loops (four k steps per phase).  Fully unrolled, the transposed image's reads (two per operand) pushed the kernel to 256 VGPRs + scratch;
-// unrolled by two it needs 242 - and a 512-thread workgroup at 2 x 242 registers per SIMD lane leaves room for ONE 24-register wavefront of another kernel, so on the
-// sparse many-ray batches whose serial marcher (k_march_count, 300 us) holds two wavefronts on many SIMDs the workgroups had to wait for CUs to drain (90 us in the
-// procedural-fox trace against 45 us alone, profiles/r06z_fox_kernel_trace.md).  Not unrolled: 226.
+// Unrolling of the weight-gradient loops (four k steps per phase).  History: fully unrolled, the transposed image's reads (two per operand) pushed round 6a's kernel to
+// 256 VGPRs + scratch; unrolled by two it needed 242 - and a 512-thread workgroup at 2 x 242 registers per SIMD lane leaves room for ONE 24-register wavefront of another
+// kernel, so on the sparse many-ray batches whose serial marcher (k_march_count, 300 us) holds two wavefronts on many SIMDs the workgroups had to wait for CUs to drain
+// (90 us in the procedural-fox trace against 45 us alone, profiles/r06z_fox_kernel_trace.md); not unrolled: 226.  (r6b) With the packed register arithmetic and the reads
+// behind lane bases the kernel needs 194 not unrolled and 202 - 206 FULLY unrolled (no scratch): the default now (419 -> 346 vector instructions per trip);
+// -DFIELD_WG_UNROLL=1 is the earlier form (same bits).
 #ifndef FIELD_WG_UNROLL
-#define FIELD_WG_UNROLL 1
+#define FIELD_WG_UNROLL 4
 #endif
 typedef short ft_short4 __attribute__((__vector_size__(4 * sizeof(short))));
 __device__ __forceinline__ int ft_f(int s) { return ((s & 3) << 2) | ((s >> 2) & 3) | (((s >> 3) & 1) << 4); }

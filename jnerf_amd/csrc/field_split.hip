@@ -332,6 +332,12 @@ __device__ __forceinline__ half8 ld_tr8(const _Float16 *stage, int plane, int nr
 // "lane part + 0x15000 + block" with the constant beyond the immediate's reach - one v_add_u32 per read, 20 per loop iteration.  Here the four lane-dependent addresses of a
 // tile (operand a | b, sample rows +0 | +4 of the first step, plane 0) are formed once, made opaque to constant re-association, and every other block of the tile is an
 // immediate behind one of them: a step = 32 sample rows = 8 KiB, plane 1 = 32 KiB, at most 0xE000.  (tr_f depends on the row's low four bits only, which a step keeps.)
+// Unrolling of the weight-gradient loops (k steps of 32 samples: four per full tile).  Rounds 3-6a ran them unrolled by two - fully unrolled the kernel wanted 290 VGPRs - but with
+// the register arithmetic written out (above) the full unrolling fits the 256 without scratch, loses the loops' accumulator zeroing and counters (746 -> 652 vector instructions
+// per trip) and lets the V1 tile pair share its gradient operand's reads.  -DSPLIT_WG_UNROLL=2 is the earlier form (same bits: the same MFMAs in the same order).
+#ifndef SPLIT_WG_UNROLL
+#define SPLIT_WG_UNROLL 4
+#endif
 typedef __attribute__((address_space(3))) short4v lds_short4v;
 __device__ __forceinline__ uint32_t tr_lane_addr(const _Float16 *stage, int s, int c) {
 	uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const _Float16 *)(stage + tr_off(0, s, c));
@@ -354,7 +360,7 @@ __device__ __forceinline__ floatx4 wgrad3_T(const _Float16 *stage, int row_a, in
 	const uint32_t a0 = tr_lane_addr(stage, s0, (row_a >> 2) + (o & 3)), a4 = tr_lane_addr(stage, s0 + 4, (row_a >> 2) + (o & 3));
 	const uint32_t b0 = tr_lane_addr(stage, s0, (row_b >> 2) + (o & 3)), b4 = tr_lane_addr(stage, s0 + 4, (row_b >> 2) + (o & 3));
 	constexpr uint32_t P1 = TPLANE * 2, STEP = 32 * 128 * 2;                                          // bytes
-#pragma unroll 2
+#pragma unroll SPLIT_WG_UNROLL
 	for (int c = c0; c < c1; c += 32) {
 		const uint32_t off = (uint32_t)((c - c0) >> 5) * STEP;
 		const half8 ah = ld_tr8_at(a0, a4, off), am = ld_tr8_at(a0, a4, off + P1);

@@ -101,3 +101,30 @@ def test_level_table_matches_reference_tables():
         assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2] == b[2]
         c = np.zeros((16, 4), np.uint32)
         assert _lib.lib().ngp_level_table(float(s), c.ctypes.data_as(C.c_void_p)) == a[2] and (c == a[0]).all()
+
+
+@pytest.mark.parametrize("src", ["field_split.hip", "field_mlp.hip"])
+def test_field_kernels_keep_their_register_form(src):
+    """(r6b) The field kernels' matrix instructions must write plain VGPRs - in AGPR form (what the compiler picks for a 256-thread kernel that MAY use 512 registers per
+    lane) every accumulator value costs a v_accvgpr_read before the vector ALU can touch it: 112 of the split forward's 457 vector instructions per tile - and the backward
+    kernels of the step (transposed staging image) must not spill.  Device-only compile with -Rpass-analysis=kernel-resource-usage, as tools/kernel_resources.py; no GPU."""
+    import shutil
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    path = os.path.join(ROOT, "jnerf_amd", "csrc", src)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-fvisibility=hidden",
+           "--cuda-device-only", "-c", path, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+    err = subprocess.run(cmd, capture_output=True, text=True, timeout=600).stderr
+    rows, cur = [], None
+    for line in err.splitlines():
+        m = re.search(r"remark: (?:\S+ )?\s*(Function Name|AGPRs|ScratchSize \[bytes/lane\]): (\S+)", line)
+        if m and m.group(1) == "Function Name":
+            cur = {"name": m.group(2)}; rows.append(cur)
+        elif m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    field = [r for r in rows if "k_field" in r["name"]]
+    assert len(field) >= 8 and any("_bwd" in r["name"] and "Lb1EEv" in r["name"] for r in field), [r["name"] for r in rows]
+    for r in field:
+        assert r["AGPRs"] == 0, r
+        if "_bwd" in r["name"] and "Lb1EEv" in r["name"]:                               # last template argument TR = true: the variants the step launches
+            assert r["ScratchSize [bytes/lane]"] == 0, r

@@ -27,7 +27,7 @@ for cfg in $CFGS; do
 done
 fi
 # (r6) the real-fox leg (bench.py's extra.fox: ngp_fox.py on data/fox) under the kernel trace
-if [ $WHAT = all ] || [ $WHAT = trace ] || [ $WHAT = realfox ]; then
+if [ ${NO_REALFOX:-0} = 0 ] && { [ $WHAT = all ] || [ $WHAT = trace ] || [ $WHAT = realfox ]; }; then
   rm -rf /tmp/pf_realfox && mkdir -p /tmp/pf_realfox
   timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pf_realfox -o kt -- python $R/tools/fox_leg.py 200 > /tmp/pf_realfox/log 2>&1
   grep "^fox_leg" /tmp/pf_realfox/log | tail -1 > $R/gpurun_out/${TAG}_realfox_wall.txt
