@@ -232,7 +232,7 @@ __device__ __forceinline__ half8 ld_rows(const _Float16 *stage, int row, int col
 // behind lane bases the kernel needs 194 not unrolled and 202 - 206 FULLY unrolled (no scratch): the default now (419 -> 346 vector instructions per trip);
 // -DFIELD_WG_UNROLL=1 is the earlier form (same bits).
 #ifndef FIELD_WG_UNROLL
-#define FIELD_WG_UNROLL 4
+#define FIELD_WG_UNROLL 1
 #endif
 typedef short ft_short4 __attribute__((__vector_size__(4 * sizeof(short))));
 __device__ __forceinline__ int ft_f(int s) { return ((s & 3) << 2) | ((s >> 2) & 3) | (((s >> 3) & 1) << 4); }

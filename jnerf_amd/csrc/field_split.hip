@@ -336,7 +336,7 @@ __device__ __forceinline__ half8 ld_tr8(const _Float16 *stage, int plane, int nr
 // the register arithmetic written out (above) the full unrolling fits the 256 without scratch, loses the loops' accumulator zeroing and counters (746 -> 652 vector instructions
 // per trip) and lets the V1 tile pair share its gradient operand's reads.  -DSPLIT_WG_UNROLL=2 is the earlier form (same bits: the same MFMAs in the same order).
 #ifndef SPLIT_WG_UNROLL
-#define SPLIT_WG_UNROLL 4
+#define SPLIT_WG_UNROLL 2
 #endif
 typedef __attribute__((address_space(3))) short4v lds_short4v;
 __device__ __forceinline__ uint32_t tr_lane_addr(const _Float16 *stage, int s, int c) {
