@@ -229,8 +229,8 @@ __device__ __forceinline__ half8 ld_rows(const _Float16 *stage, int row, int col
 // 256 VGPRs + scratch; unrolled by two it needed 242 - and a 512-thread workgroup at 2 x 242 registers per SIMD lane leaves room for ONE 24-register wavefront of another
 // kernel, so on the sparse many-ray batches whose serial marcher (k_march_count, 300 us) holds two wavefronts on many SIMDs the workgroups had to wait for CUs to drain
 // (90 us in the procedural-fox trace against 45 us alone, profiles/r06z_fox_kernel_trace.md); not unrolled: 226.  (r6b) With the packed register arithmetic and the reads
-// behind lane bases the kernel needs 194 not unrolled and 202 - 206 FULLY unrolled (no scratch): the default now (419 -> 346 vector instructions per trip);
-// -DFIELD_WG_UNROLL=1 is the earlier form (same bits).
+// behind lane bases the kernel needs 194 not unrolled and 202 - 206 FULLY unrolled (-DFIELD_WG_UNROLL=4: no scratch, 419 -> 346 vector instructions per trip, same bits);
+// measured together with the split kernel's: not faster (profiles/r06y_ab_unroll.txt), so not unrolled stays - the fewest registers beside the serial marcher.
 #ifndef FIELD_WG_UNROLL
 #define FIELD_WG_UNROLL 1
 #endif

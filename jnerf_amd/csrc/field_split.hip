@@ -332,9 +332,10 @@ __device__ __forceinline__ half8 ld_tr8(const _Float16 *stage, int plane, int nr
 // "lane part + 0x15000 + block" with the constant beyond the immediate's reach - one v_add_u32 per read, 20 per loop iteration.  Here the four lane-dependent addresses of a
 // tile (operand a | b, sample rows +0 | +4 of the first step, plane 0) are formed once, made opaque to constant re-association, and every other block of the tile is an
 // immediate behind one of them: a step = 32 sample rows = 8 KiB, plane 1 = 32 KiB, at most 0xE000.  (tr_f depends on the row's low four bits only, which a step keeps.)
-// Unrolling of the weight-gradient loops (k steps of 32 samples: four per full tile).  Rounds 3-6a ran them unrolled by two - fully unrolled the kernel wanted 290 VGPRs - but with
-// the register arithmetic written out (above) the full unrolling fits the 256 without scratch, loses the loops' accumulator zeroing and counters (746 -> 652 vector instructions
-// per trip) and lets the V1 tile pair share its gradient operand's reads.  -DSPLIT_WG_UNROLL=2 is the earlier form (same bits: the same MFMAs in the same order).
+// Unrolling of the weight-gradient loops (k steps of 32 samples: four per full tile).  Unrolled by two since round 3 - fully unrolled the kernel wanted 290 VGPRs then.  With the
+// register arithmetic written out (above) the full unrolling (-DSPLIT_WG_UNROLL=4) fits the 256 without scratch, loses the loops' accumulator zeroing and counters (746 -> 652
+// vector instructions per trip) and lets the V1 tile pair share its gradient operand's reads: measured, same bits (the same MFMAs in the same order), kernel 83.0 -> 81.9 us, step
+// 2146 vs 2140 it/s (profiles/r06y_ab_unroll.txt) - not faster, so the smaller form stays.
 #ifndef SPLIT_WG_UNROLL
 #define SPLIT_WG_UNROLL 2
 #endif
