@@ -241,7 +241,8 @@ HASH_BWD_RIDE = ("k_bin_accumulate2_adam", "k_bin_accumulate_adam_f32rec", "k_bi
 
 
 
-PMC_ROUND = "r06z"          # the round whose counter passes describe THIS tree's kernels (profiles/<round>_pmc.json)
+PMC_ROUND = "r06z"          # the round whose counter passes describe THIS tree's kernels (profiles/<round>_pmc.json): taken before the last session of round 6, which changed
+                            # only the field kernels' register arithmetic (same loads, stores and matrix instructions; the hash / record / accumulate kernels untouched)
 
 
 def pmc_lookup(config, scene):
@@ -253,7 +254,7 @@ def pmc_lookup(config, scene):
         return {}, None
     if pm.get("_scenes", {}).get(config) != scene or not pm.get(config):
         return {}, None
-    return pm[config], f"profiles/{PMC_ROUND}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{pm.get('_commands', {}).get(config, '?')}`: this tree, this scene; not measured in this run)"
+    return pm[config], f"profiles/{PMC_ROUND}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{pm.get('_commands', {}).get(config, '?')}`: this round's hash / record / accumulate kernels as they are in this tree, this scene; not measured in this run)"
 
 
 def mfma_roofline(k, alg_flops, n, ms, fp16, counters=None):
