@@ -128,3 +128,50 @@ def test_field_kernels_keep_their_register_form(src):
         assert r["AGPRs"] == 0, r
         if "_bwd" in r["name"] and "Lb1EEv" in r["name"]:                               # last template argument TR = true: the variants the step launches
             assert r["ScratchSize [bytes/lane]"] == 0, r
+
+
+def test_asm_written_operands_keep_their_distance_from_matrix_instructions():
+    """(r6b) csrc/field_split.hip writes the residual halves of the split operands with v_fma_mix{lo,hi}_f16 inside asm statements.  gfx950 wants two wait states between a
+    vector instruction's register write and a matrix instruction that reads the register; the compiler inserts them for its own instructions but does not look into asm, so
+    every such statement ends in `s_nop 1`.  This reads the compiler's assembly of every kernel in the file and checks that no v_mfma reads a register less than three issue
+    slots after a v_fma_mix wrote it (s_nop N counts N + 1), and that the statements kept their low-halves-first order (a 16-bit partial write is not read back at once)."""
+    import shutil, tempfile
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    with tempfile.NamedTemporaryFile(suffix=".s") as f:
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-fvisibility=hidden",
+                        "-S", "--cuda-device-only", os.path.join(ROOT, "jnerf_amd", "csrc", "field_split.hip"), "-o", f.name], check=True, capture_output=True, timeout=600)
+        lines = [l.strip() for l in open(f.name)]
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
+    ins = [l for l in lines if l and not l.startswith((".", ";", "_Z")) and not l.endswith(":")]
+    n_mix, n_checked, worst = 0, 0, 99
+    for i, l in enumerate(ins):
+        if l.startswith("v_fma_mixhi_f16"):
+            n_mix += 1
+            dst = l.split(None, 1)[1].split(",")[0].strip()
+            lo = [j for j in range(max(0, i - 8), i) if ins[j].startswith("v_fma_mixlo_f16") and ins[j].split(None, 1)[1].split(",")[0].strip() == dst]
+            assert lo and i - lo[-1] >= 2, (ins[max(0, i - 8):i + 1])
+        if not l.startswith("v_mfma"):
+            continue
+        ops = [t.strip() for t in l.split(None, 1)[1].split(",")]
+        src = set().union(*[regs(t) for t in ops[1:4]])
+        d = 0
+        for j in range(i - 1, max(i - 8, -1), -1):
+            p = ins[j]
+            if p.startswith("s_nop"):
+                d += int(p.split()[1]) + 1
+                continue
+            d += 1
+            if p.startswith("v_fma_mix") and regs(p.split(None, 1)[1].split(",")[0].strip()) & src:
+                n_checked += 1
+                worst = min(worst, d)
+                break
+    assert n_mix >= 100, n_mix                   # the asm statements are there (eight kernels x 30 - 60 operand pairs)
+    assert worst >= 3, worst
